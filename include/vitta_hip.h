@@ -1,0 +1,178 @@
+/*
+ * vitta_hip.h — C ABI of libvitta_hip.so (gfx950 / MI355X).
+ *
+ * The reference (wlin-at/ViTTA) has no FFI layer: its hot path is a chain of stock
+ * PyTorch ops fired from forward hooks.  This header is the boundary one level
+ * below the reference's Python operator protocol; every entry point names the
+ * reference code it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer named d_* is a caller-owned DEVICE pointer (tensor.data_ptr());
+ *     pointers named h_* are host pointers read synchronously during the call;
+ *   - every launch function takes an explicit hipStream_t (passed as void*) and is
+ *     asynchronous; nothing synchronises the device;
+ *   - return value: 0 = ok, <0 = error (see vitta_status_string); never throws,
+ *     never aborts; no global mutable state, re-entrant;
+ *   - all arithmetic is fp32 (the reference is fp32 end to end), partial moments
+ *     are merged with Chan's formula, the tiny cross-block combines run in fp64.
+ */
+#ifndef VITTA_HIP_H_
+#define VITTA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITTA_ABI_VERSION 1
+
+/* status codes */
+#define VITTA_OK 0
+#define VITTA_ERR_INVALID_ARG (-1)
+#define VITTA_ERR_LAUNCH (-2)
+#define VITTA_ERR_ALLOC (-3)
+#define VITTA_ERR_UNSUPPORTED (-4)
+#define VITTA_ERR_WORKSPACE (-5)
+
+/* feature layouts of a hooked norm layer's output */
+#define VITTA_LAYOUT_NCHW 0 /* [outer=N*T][C][inner=H*W]   BatchNorm2d output (norm_stats_utils.py:188-193) */
+#define VITTA_LAYOUT_NHWC 1 /* [outer=N*T*H*W][C][inner=1] LayerNorm output   (norm_stats_utils.py:222-230) */
+
+/* regularisation types of compute_regularization (norm_stats_utils.py:531-542) */
+#define VITTA_REG_L1 0
+#define VITTA_REG_MSE 1
+#define VITTA_REG_KLD 2
+
+/* maximum number of hooked layers in one plan (pointers travel as kernel arguments) */
+#define VITTA_MAX_LAYERS 96
+
+int vitta_abi_version(void);
+const char* vitta_status_string(int status);
+
+/* One hooked layer: static shape information. */
+typedef struct vitta_layer_shape {
+  int64_t outer;  /* NCHW: N*V*T frames ; NHWC: N*V*T'*H*W rows */
+  int32_t C;      /* channels */
+  int64_t inner;  /* NCHW: H*W ; NHWC: 1 */
+  int32_t layout; /* VITTA_LAYOUT_* */
+} vitta_layer_shape;
+
+/* --------------------------------------------------------------------------
+ * Plan: the static part (shapes -> block tables, packed channel offsets) of the
+ * batched multi-layer launches.  Packed per-channel arrays have length
+ * vitta_plan_total_channels(); layer l owns [chan_off(l), chan_off(l)+C_l).
+ * -------------------------------------------------------------------------- */
+typedef struct vitta_plan vitta_plan;
+
+int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
+                      vitta_plan** out_plan);
+void vitta_plan_destroy(vitta_plan* plan);
+int64_t vitta_plan_total_channels(const vitta_plan* plan);
+int64_t vitta_plan_channel_offset(const vitta_plan* plan, int layer);
+size_t vitta_plan_workspace_bytes(const vitta_plan* plan);
+int64_t vitta_plan_num_blocks(const vitta_plan* plan); /* workgroups of the moments launch (both layouts) */
+
+/* --------------------------------------------------------------------------
+ * A1/A2 — per-channel spatio-temporal moments over (N*V, T, H, W).
+ * Replaces CombineNormStatsRegHook_onereg.compute_reg_for_NCTHW's
+ *   permute -> contiguous -> mean((0,2,3,4)) -> permute -> contiguous -> var(1, unbiased=False)
+ * (utils/norm_stats_utils.py:238-243, BN2d branch :188-204, LN branch :222-230) and
+ * ComputeNormStatsHook.compute_stat_for_NCTHW (:92-95).
+ *
+ * Batched form: one launch per layout over all layers of the plan.
+ *   h_x[l]    device pointer of layer l's feature (fp32, contiguous in its layout)
+ *   d_shift   [total_channels] or NULL: per-channel shift k_c (use the source mean);
+ *   d_cnt     [n_layers]        out: element count per channel n_l (as float)
+ *   d_s1      [total_channels]  out: sum_i (x_i - k_c)
+ *   d_s2      [total_channels]  out: sum_i (x_i - k_c)^2
+ * (cnt,s1,s2) are ADDITIVE across data-parallel ranks: one SUM all-reduce over the
+ * three arrays gives the moments of the pooled batch.
+ * -------------------------------------------------------------------------- */
+int vitta_moments_batched_f32(const vitta_plan* plan, const void* const* h_x, const float* d_shift,
+                              float* d_cnt, float* d_s1, float* d_s2, void* d_workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Convert additive sums to (mean, biased var): mean = k + s1/n, var = s2/n - (s1/n)^2. */
+int vitta_moments_to_meanvar_f32(const vitta_plan* plan, const float* d_shift, const float* d_cnt,
+                                 const float* d_s1, const float* d_s2, float* d_mean, float* d_var,
+                                 void* stream);
+
+/* Single-layer conveniences (SURVEY 8b names).  d_mean/d_var: [C].  Workspace from
+ * vitta_moments_workspace_bytes(outer, C, inner, layout). */
+size_t vitta_moments_workspace_bytes(int64_t outer, int32_t C, int64_t inner, int32_t layout);
+int vitta_moments_nchw_f32(const float* d_x, int64_t NT, int32_t C, int64_t HW, float* d_mean,
+                           float* d_var, void* d_workspace, size_t workspace_bytes, void* stream);
+int vitta_moments_nhwc_f32(const float* d_x, int64_t rows, int32_t C, float* d_mean, float* d_var,
+                           void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
+ * A3 + A4 — EMA update and alignment loss, all layers in one launch.
+ * Replaces MovingAverageTensor.update (utils/utils_.py:204-211; avg0 = 0, no bias
+ * correction) and compute_regularization / compute_kld
+ * (utils/norm_stats_utils.py:531-542, :8-16), plus the autograd bookkeeping of A6:
+ *   d_ema_mean/d_ema_var [total_channels] in/out  EMA state (zero-initialised)
+ *   d_src_mean/d_src_var [total_channels]         source statistics
+ *   momentum                                       args.momentum_mvg
+ *   d_layer_loss [n_layers] out  r_feature of every hook
+ *   d_total_loss [1]        out  sum over layers (loss_reg, corpus/basics.py:658-661)
+ *   d_mu   [total_channels] out  batch mean mu_c (needed by the backward)
+ *   d_coef_a,d_coef_b       out  dL/dx[i,c] = a_c + b_c * (x[i,c] - mu_c)
+ * -------------------------------------------------------------------------- */
+int vitta_stat_align_fwd_f32(const vitta_plan* plan, const float* d_shift, const float* d_cnt,
+                             const float* d_s1, const float* d_s2, float* d_ema_mean,
+                             float* d_ema_var, const float* d_src_mean, const float* d_src_var,
+                             float momentum, int reg_type, float* d_layer_loss, float* d_total_loss,
+                             float* d_mu, float* d_coef_a, float* d_coef_b, void* d_workspace,
+                             size_t workspace_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
+ * A6 — backward of A1-A4 w.r.t. the hooked feature:
+ *   gin[i,c] = gout[i,c] + gscale * (a_c + b_c * (x[i,c] - mu_c))
+ * d_gout may be NULL (treated as 0); d_gin may alias d_gout.  d_gscale is a DEVICE
+ * scalar (upstream gradient of loss_reg, e.g. lambda_feature_reg) or NULL (= 1).
+ * d_mu/d_coef_a/d_coef_b point at the layer's [C] slice.
+ * -------------------------------------------------------------------------- */
+int vitta_stat_align_bwd_f32(const float* d_x, const float* d_gout, float* d_gin, int64_t outer,
+                             int32_t C, int64_t inner, int32_t layout, const float* d_mu,
+                             const float* d_coef_a, const float* d_coef_b, const float* d_gscale,
+                             void* stream);
+
+/* --------------------------------------------------------------------------
+ * A5 — prediction-consistency loss and its gradient.
+ * Replaces compute_pred_consis (utils/pred_consistency_utils.py:15-31):
+ *   p_v = softmax(logits[:,v,:]); pbar = mean_v p_v (not detached);
+ *   loss = sum_v sum_{b,k} |p_v - pbar| / V.
+ * d_logits [B,V,K] contiguous; d_loss [1 + B]: [0] = loss, [1..B] = per-video partial sums
+ * (scratch); d_grad [B,V,K] = dloss/dlogits (may be NULL).  2*V*K*4 bytes must fit 48 KB of LDS.
+ * -------------------------------------------------------------------------- */
+int vitta_pred_consis_f32(const float* d_logits, int32_t B, int32_t V, int32_t K, float* d_loss,
+                          float* d_grad, void* stream);
+
+/* --------------------------------------------------------------------------
+ * A9 — TAM (temporal adaptive module) aggregation, fused.
+ * Replaces the tail of TAM.forward (models/tanet_models/temporal_module.py:47-65):
+ *   y = gate * x ; out[n,t,c,:] = sum_{j=0..2} K[n,c,j] * y[n,t+j-1,c,:]  (zero pad in T)
+ * on x [N*T, C, H*W] WITHOUT the two permute+contiguous copies.
+ *   d_x    [N*T, C, HW]   d_gate [N, C, T]   d_kern [N*C, 3]   d_out [N*T, C, HW]
+ * and of F.adaptive_avg_pool2d on the permuted copy (:51):
+ *   d_pool [N, C, T] = mean over HW.
+ * Backward: d_gx (w.r.t. x), d_ggate, d_gkern from d_gout.  d_ggate must have room for
+ * N*C*T*4 floats: the [N,C,T] result followed by an [N,C,T,3] scratch of row dot products.
+ * vitta_tam_pool_bwd adds gpool[n,c,t]/HW to every element of row (n,t,c) of d_gx_accum.
+ * -------------------------------------------------------------------------- */
+int vitta_tam_pool_f32(const float* d_x, int32_t N, int32_t T, int32_t C, int32_t HW,
+                       float* d_pool, void* stream);
+int vitta_tam_agg_fwd_f32(const float* d_x, const float* d_gate, const float* d_kern, int32_t N,
+                          int32_t T, int32_t C, int32_t HW, float* d_out, void* stream);
+int vitta_tam_agg_bwd_f32(const float* d_x, const float* d_gate, const float* d_kern,
+                          const float* d_gout, int32_t N, int32_t T, int32_t C, int32_t HW,
+                          float* d_gx, float* d_ggate, float* d_gkern, void* stream);
+int vitta_tam_pool_bwd_f32(const float* d_gpool, int32_t N, int32_t T, int32_t C, int32_t HW,
+                           float* d_gx_accum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITTA_HIP_H_ */

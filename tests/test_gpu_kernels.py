@@ -1,0 +1,218 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle -- GPU box only."""
+import pytest
+import torch
+
+from oracle import vitta_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+# fp32 tolerances (stated per SURVEY section 7 "Variance numerics")
+RTOL_MEAN, ATOL_MEAN = 1e-5, 1e-6
+RTOL_VAR = 1e-4
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _feat(shape, seed, chan_dim, offset_scale=3.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(shape, generator=g)
+    c = shape[chan_dim]
+    off = torch.randn(c, generator=g) * offset_scale
+    sc = torch.rand(c, generator=g) * 2 + 0.25
+    view = [1] * len(shape)
+    view[chan_dim] = c
+    return x * sc.view(view) + off.view(view)
+
+
+BN2D_SHAPES = [
+    (16, 8, 7, 7),       # plane 392 (vec path, HW odd)
+    (16, 7, 7, 7),       # plane 343 -> scalar path
+    (16, 256, 28, 28),   # C2 layer3.0 conv1/bn1 shape
+    (16, 1024, 14, 14),  # C2 largest hooked tensor
+    (16, 2048, 7, 7),
+    (16, 512, 7, 7),
+    (3, 5, 2, 3),        # tiny ragged
+    (64, 64, 56, 56),    # big HW (one channel spans many chunks)
+]
+
+
+@pytest.mark.parametrize("shape", BN2D_SHAPES)
+def test_moments_nchw_single(shape):
+    from vitta_amd import ops
+    x = _feat(shape, 1, 1)
+    clip = 8 if shape[0] % 8 == 0 else shape[0]
+    m_ref, v_ref = O.moments(x.double(), "bn2d", clip)
+    m, v = ops.moments(x.to(_dev()), "bn2d")
+    torch.testing.assert_close(m.cpu().double(), m_ref, rtol=RTOL_MEAN, atol=ATOL_MEAN)
+    torch.testing.assert_close(v.cpu().double(), v_ref, rtol=RTOL_VAR, atol=1e-7)
+
+
+LN_SHAPES = [(2, 8, 14, 14, 512), (2, 8, 7, 7, 1024), (2, 8, 7, 7, 2048), (4, 4, 7, 7, 16), (1, 2, 3, 3, 6),
+             (2, 4, 7, 7, 96), (1, 3, 5, 5, 7)]
+
+
+@pytest.mark.parametrize("shape", LN_SHAPES)
+def test_moments_nhwc_single(shape):
+    from vitta_amd import ops
+    x = _feat(shape, 2, 4)
+    m_ref, v_ref = O.moments(x.double(), "ln")
+    m, v = ops.moments(x.to(_dev()), "ln")
+    torch.testing.assert_close(m.cpu().double(), m_ref, rtol=RTOL_MEAN, atol=ATOL_MEAN)
+    torch.testing.assert_close(v.cpu().double(), v_ref, rtol=RTOL_VAR, atol=1e-7)
+
+
+def test_moments_large_mean_small_var():
+    """|mean| >> sigma: one-pass sum/sum-of-squares in fp32 would lose the variance."""
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 64, 14, 14, generator=g) * 1e-2 + 100.0
+    m_ref, v_ref = O.moments(x.double(), "bn2d", 8)
+    m, v = ops.moments(x.to(_dev()), "bn2d")
+    torch.testing.assert_close(m.cpu().double(), m_ref, rtol=1e-6, atol=0)
+    torch.testing.assert_close(v.cpu().double(), v_ref, rtol=1e-3, atol=0)
+
+
+def _mixed_plan_inputs():
+    feats = [(_feat((16, 256, 14, 14), 10, 1), "bn2d"), (_feat((16, 512, 7, 7), 11, 1), "bn2d"),
+             (_feat((2, 8, 7, 7, 128), 12, 4), "ln"), (_feat((16, 6, 5, 5), 13, 1), "bn2d"),
+             (_feat((2, 4, 7, 7, 10), 14, 4), "ln")]
+    return feats
+
+
+@pytest.mark.parametrize("with_shift", [False, True])
+def test_moments_batched_mixed_layouts(with_shift):
+    from vitta_amd import ops
+    feats = _mixed_plan_inputs()
+    shapes = [ops.feature_layout(f, k) for f, k in feats]
+    plan = ops.StatPlan(shapes, _dev())
+    dfeats = [f.to(_dev()) for f, _ in feats]
+    refs = [O.moments(f.double(), k, 8) for f, k in feats]
+    shift = None
+    if with_shift:
+        shift = torch.cat([r[0].float() + 0.1 for r in refs]).to(_dev())
+    plan.moments(dfeats, shift)
+    mean, var = plan.mean_var(shift)
+    m_ref = torch.cat([r[0] for r in refs])
+    v_ref = torch.cat([r[1] for r in refs])
+    torch.testing.assert_close(mean.cpu().double(), m_ref, rtol=RTOL_MEAN, atol=ATOL_MEAN)
+    # without a shift the additive form s2/n - (s1/n)^2 cancels in fp32: looser bound there
+    torch.testing.assert_close(var.cpu().double(), v_ref, rtol=RTOL_VAR if with_shift else 2e-3, atol=1e-6)
+    n_ref = torch.tensor([f.numel() / s[1] for (f, _), s in zip(feats, shapes)])
+    torch.testing.assert_close(plan.cnt.cpu(), n_ref.float())
+
+
+@pytest.mark.parametrize("reg_type", ["l1_loss", "mse_loss", "kld"])
+def test_align_three_steps_vs_oracle(reg_type):
+    """EMA recurrence (zero init) + loss + injected gradient over 3 steps, all layers batched."""
+    from vitta_amd import ops
+    momentum = 0.1
+    base = _mixed_plan_inputs()
+    kinds = [k for _, k in base]
+    shapes = [ops.feature_layout(f, k) for f, k in base]
+    plan = ops.StatPlan(shapes, _dev())
+    g = torch.Generator().manual_seed(77)
+    src = []
+    for f, k in base:
+        m, v = O.moments(f, k, 8)
+        src.append((m + 0.3 * torch.randn(m.shape, generator=g), v * (1.0 + 0.5 * torch.rand(v.shape, generator=g))))
+    hooks = [O.StatHookOracle(sm, sv, reg_type, momentum, k, 8) for (sm, sv), k in zip(src, kinds)]
+    src_mean = torch.cat([s[0] for s in src]).to(_dev())
+    src_var = torch.cat([s[1] for s in src]).to(_dev())
+    ema_mean = torch.zeros_like(src_mean)
+    ema_var = torch.zeros_like(src_var)
+    for step in range(3):
+        feats = [(_feat(tuple(f.shape), 100 + 10 * step + i, 1 if k == "bn2d" else 4)) for i, (f, k) in enumerate(base)]
+        leaves = [f.clone().requires_grad_(True) for f in feats]
+        r = [h(x) for h, x in zip(hooks, leaves)]
+        total_ref = sum(r)
+        total_ref.backward()
+        dfeats = [f.to(_dev()) for f in feats]
+        plan.moments(dfeats, src_mean)
+        total, layer = plan.align(src_mean, ema_mean, ema_var, src_mean, src_var, momentum, reg_type)
+        torch.testing.assert_close(layer.cpu(), torch.stack([t.detach() for t in r]), rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(total.cpu()[0], total_ref.detach(), rtol=2e-5, atol=1e-6)
+        for i, h in enumerate(hooks):
+            sl = plan.channel_slice(i)
+            torch.testing.assert_close(ema_mean[sl].cpu(), h.mean_avg.avg.detach(), rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(ema_var[sl].cpu(), h.var_avg.avg.detach(), rtol=1e-4, atol=1e-7)
+            gx = ops.stat_align_bwd(dfeats[i], None, kinds[i], plan.mu[sl], plan.coef_a[sl], plan.coef_b[sl])
+            ref = leaves[i].grad
+            scale = ref.abs().max().item()
+            assert (gx.cpu() - ref).abs().max().item() <= 2e-4 * scale + 1e-12
+
+
+def test_align_bwd_accumulates_and_scales():
+    from vitta_amd import ops
+    x = _feat((16, 32, 7, 7), 3, 1).to(_dev())
+    gout = torch.randn_like(x)
+    mu = torch.randn(32, device=_dev())
+    a = torch.randn(32, device=_dev())
+    b = torch.randn(32, device=_dev())
+    gs = torch.tensor([0.5], device=_dev())
+    ref = gout + 0.5 * (a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1) * (x - mu.view(1, -1, 1, 1)))
+    out = ops.stat_align_bwd(x, gout, "bn2d", mu, a, b, gs)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+    g2 = gout.clone()
+    ops.stat_align_bwd(x, g2, "bn2d", mu, a, b, gs, out=g2)  # in place
+    torch.testing.assert_close(g2, ref, rtol=1e-5, atol=1e-5)
+    xl = _feat((2, 4, 7, 7, 24), 4, 4).to(_dev())
+    gl = torch.randn_like(xl)
+    mu, a, b = (torch.randn(24, device=_dev()) for _ in range(3))
+    refl = gl + (a + b * (xl - mu))
+    torch.testing.assert_close(ops.stat_align_bwd(xl, gl, "ln", mu, a, b), refl, rtol=1e-5, atol=1e-5)
+
+
+def test_feature_moments_autograd():
+    from vitta_amd import ops
+    x = _feat((16, 24, 7, 7), 8, 1)
+    xr = x.clone().requires_grad_(True)
+    m, v = O.moments(xr, "bn2d", 8)
+    wm, wv = torch.randn(24), torch.randn(24)
+    ((m * wm).sum() + (v * wv).sum()).backward()
+    xd = x.to(_dev()).requires_grad_(True)
+    md, vd = ops.FeatureMoments.apply(xd, "bn2d")
+    ((md * wm.to(_dev())).sum() + (vd * wv.to(_dev())).sum()).backward()
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 101), (3, 4, 174), (2, 2, 400), (5, 3, 7)])
+def test_pred_consis(shape):
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(shape, generator=g) * 3
+    zr = z.clone().requires_grad_(True)
+    ref = O.compute_pred_consis(zr)
+    ref.backward()
+    zd = z.to(_dev()).requires_grad_(True)
+    out = ops.pred_consis(zd)
+    out.backward()
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(zd.grad.cpu(), zr.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dims", [(2, 8, 64, 14, 14), (1, 8, 16, 7, 7), (2, 16, 8, 28, 28), (1, 4, 5, 3, 3)])
+def test_tam_kernels(dims):
+    from vitta_amd import ops
+    n, t, c, h, w = dims
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(n * t, c, h, w, generator=g)
+    gate = torch.rand(n, c, t, generator=g)
+    kern = torch.softmax(torch.randn(n * c, 3, generator=g), -1)
+    gout = torch.randn(n * t, c, h, w, generator=g)
+    gp = torch.randn(n, c, t, generator=g)
+    xr, gr, kr = (v.clone().requires_grad_(True) for v in (x, gate, kern))
+    pool_ref = O.tam_pool(xr, t)
+    out_ref = O.tam_aggregate(xr, gr, kr, t)
+    ((out_ref * gout).sum() + (pool_ref * gp).sum()).backward()
+    d = _dev()
+    xd, gd, kd = (v.to(d).requires_grad_(True) for v in (x, gate, kern))
+    pool = ops.TamPool.apply(xd, t)
+    out = ops.TamAggregate.apply(xd, gd, kd, t)
+    ((out * gout.to(d)).sum() + (pool * gp.to(d)).sum()).backward()
+    torch.testing.assert_close(pool.cpu(), pool_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out.cpu(), out_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(kd.grad.cpu(), kr.grad, rtol=1e-4, atol=1e-3)

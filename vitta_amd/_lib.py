@@ -1,0 +1,84 @@
+"""ctypes binding of libvitta_hip.so (the C ABI declared in include/vitta_hip.h).
+
+The product path never falls back: if the shared library is missing or a symbol
+cannot be resolved, `lib()` raises.  Building happens in `vitta_amd.build`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvitta_hip.so")
+
+LAYOUT_NCHW = 0
+LAYOUT_NHWC = 1
+REG_TYPES = {"l1_loss": 0, "mse_loss": 1, "kld": 2}
+MAX_LAYERS = 96
+
+
+class LayerShape(C.Structure):
+    _fields_ = [("outer", C.c_int64), ("C", C.c_int32), ("inner", C.c_int64), ("layout", C.c_int32)]
+
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/vitta_hip.h
+SIGNATURES = {
+    "vitta_abi_version": (C.c_int, []),
+    "vitta_status_string": (C.c_char_p, [C.c_int]),
+    "vitta_plan_create": (C.c_int, [C.POINTER(LayerShape), C.c_int, C.c_int, C.POINTER(_p)]),
+    "vitta_plan_destroy": (None, [_p]),
+    "vitta_plan_total_channels": (_i64, [_p]),
+    "vitta_plan_channel_offset": (_i64, [_p, C.c_int]),
+    "vitta_plan_workspace_bytes": (_sz, [_p]),
+    "vitta_plan_num_blocks": (_i64, [_p]),
+    "vitta_moments_batched_f32": (C.c_int, [_p, C.POINTER(_p), _p, _p, _p, _p, _p, _sz, _p]),
+    "vitta_moments_to_meanvar_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p]),
+    "vitta_moments_workspace_bytes": (_sz, [_i64, _i32, _i64, _i32]),
+    "vitta_moments_nchw_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
+    "vitta_moments_nhwc_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "vitta_stat_align_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, C.c_int,
+                                           _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "vitta_stat_align_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p]),
+    "vitta_pred_consis_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
+    "vitta_tam_pool_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitta_tam_agg_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitta_tam_agg_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "vitta_tam_pool_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+}
+
+_LIB = None
+
+
+class VittaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raise loudly if it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise VittaHipError(
+            f"{LIB_PATH} not found: build it with `python -m vitta_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise VittaHipError(f"libvitta_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = handle
+    return _LIB
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().vitta_status_string(status).decode()
+        raise VittaHipError(f"{what}: {msg} (status {status})")

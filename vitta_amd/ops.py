@@ -1,0 +1,270 @@
+"""Torch-facing wrappers of the C ABI (device memory + streams only; all arithmetic of the
+hooked-statistics path runs in libvitta_hip.so).
+
+Every function here requires CUDA(HIP) tensors and raises if the library is missing -- there
+is no eager fallback for the HIP path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_NCHW, LAYOUT_NHWC, REG_TYPES, check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_cuda_f32(t, name):
+    if not t.is_cuda:
+        raise _lib.VittaHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise _lib.VittaHipError(f"{name} must be float32 (got {t.dtype})")
+
+
+def feature_layout(feature, kind):
+    """(outer, C, inner, layout, flat_feature) of a hooked feature.
+
+    kind 'bn2d': [N*T, C, H, W]  (norm_stats_utils.py:188-193)   -> NCHW, outer = N*T
+    kind 'bn3d': [N, C, T, H, W] (norm_stats_utils.py:195-199)   -> NCHW with inner = T*H*W
+    kind 'ln'  : [N, T, H, W, C] (norm_stats_utils.py:222-230)   -> NHWC, rows = N*T*H*W
+    """
+    if kind == "bn2d":
+        nt, c, h, w = feature.shape
+        return nt, c, h * w, LAYOUT_NCHW
+    if kind == "bn3d":
+        n, c, t, h, w = feature.shape
+        return n, c, t * h * w, LAYOUT_NCHW
+    if kind == "ln":
+        c = feature.shape[-1]
+        return feature.numel() // c, c, 1, LAYOUT_NHWC
+    raise ValueError(f"unknown feature kind {kind}")
+
+
+# ------------------------------------------------------------------------------------------------
+# single-layer moments (drop-in for one hook invocation)
+# ------------------------------------------------------------------------------------------------
+def moments(feature, kind):
+    """Per-channel (mean, biased var) over (N, T, H, W) of one hooked feature; no autograd."""
+    _require_cuda_f32(feature, "feature")
+    x = feature if feature.is_contiguous() else feature.contiguous()
+    outer, c, inner, layout = feature_layout(x, kind)
+    L = lib()
+    ws_bytes = L.vitta_moments_workspace_bytes(outer, c, inner, layout)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    if layout == LAYOUT_NCHW:
+        check(L.vitta_moments_nchw_f32(_p(x), outer, c, inner, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
+              "vitta_moments_nchw_f32")
+    else:
+        check(L.vitta_moments_nhwc_f32(_p(x), outer, c, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
+              "vitta_moments_nhwc_f32")
+    return mean, var
+
+
+def stat_align_bwd(x, gout, kind, mu, coef_a, coef_b, gscale=None, out=None):
+    """gin = gout + gscale * (a_c + b_c (x - mu_c)); `out` may alias gout."""
+    _require_cuda_f32(x, "x")
+    outer, c, inner, layout = feature_layout(x, kind)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().vitta_stat_align_bwd_f32(_p(x), _p(gout), _p(out), outer, c, inner, layout, _p(mu), _p(coef_a),
+                                         _p(coef_b), _p(gscale), _stream()), "vitta_stat_align_bwd_f32")
+    return out
+
+
+class FeatureMoments(torch.autograd.Function):
+    """(mean, var) = moments(feature) with the analytic backward
+    dx = gmean/n + gvar * 2 (x - mean)/n   (autograd of norm_stats_utils.py:242-243)."""
+
+    @staticmethod
+    def forward(ctx, feature, kind):
+        x = feature if feature.is_contiguous() else feature.contiguous()
+        mean, var = moments(x, kind)
+        ctx.kind = kind
+        ctx.save_for_backward(x, mean)
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, gmean, gvar):
+        x, mean = ctx.saved_tensors
+        _, c, _, _ = feature_layout(x, ctx.kind)
+        n = x.numel() // c
+        a = (gmean / n).contiguous()
+        b = (gvar * (2.0 / n)).contiguous()
+        return stat_align_bwd(x, None, ctx.kind, mean, a, b), None
+
+
+# ------------------------------------------------------------------------------------------------
+# prediction consistency
+# ------------------------------------------------------------------------------------------------
+class PredConsis(torch.autograd.Function):
+    """compute_pred_consis (utils/pred_consistency_utils.py:15-31): loss and dloss/dlogits in one launch."""
+
+    @staticmethod
+    def forward(ctx, preds):
+        _require_cuda_f32(preds, "preds")
+        z = preds.contiguous()
+        b, v, k = z.shape
+        loss = torch.empty(1 + b, dtype=torch.float32, device=z.device)
+        grad = torch.empty_like(z)
+        check(lib().vitta_pred_consis_f32(_p(z), b, v, k, _p(loss), _p(grad), _stream()), "vitta_pred_consis_f32")
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g
+
+
+def pred_consis(preds):
+    return PredConsis.apply(preds)
+
+
+# ------------------------------------------------------------------------------------------------
+# batched plan: all hooked layers of one forward in single launches
+# ------------------------------------------------------------------------------------------------
+class StatPlan:
+    """Owns a vitta_plan plus the packed per-channel device buffers of the batched path."""
+
+    def __init__(self, shapes, device, target_blocks=0):
+        # shapes: list of (outer, C, inner, layout)
+        self.device = torch.device(device)
+        self.shapes = [tuple(int(v) for v in s) for s in shapes]
+        n = len(self.shapes)
+        if n == 0 or n > _lib.MAX_LAYERS:
+            raise ValueError(f"number of hooked layers must be in 1..{_lib.MAX_LAYERS}, got {n}")
+        arr = (_lib.LayerShape * n)(*[_lib.LayerShape(*s) for s in self.shapes])
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().vitta_plan_create(arr, n, target_blocks, C.byref(handle)), "vitta_plan_create")
+        self._h = handle
+        L = lib()
+        self.n_layers = n
+        self.total_channels = int(L.vitta_plan_total_channels(self._h))
+        self.offsets = [int(L.vitta_plan_channel_offset(self._h, i)) for i in range(n)]
+        self.ws_bytes = int(L.vitta_plan_workspace_bytes(self._h))
+        self.num_blocks = int(L.vitta_plan_num_blocks(self._h))
+        f = dict(dtype=torch.float32, device=self.device)
+        tc = self.total_channels
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        # additive statistics, packed [cnt(L) | s1(TC) | s2(TC)] so ONE all-reduce covers them
+        self.stats = torch.zeros(n + 2 * tc, **f)
+        self.cnt = self.stats[:n]
+        self.s1 = self.stats[n:n + tc]
+        self.s2 = self.stats[n + tc:]
+        self.mu = torch.zeros(tc, **f)
+        self.coef_a = torch.zeros(tc, **f)
+        self.coef_b = torch.zeros(tc, **f)
+        self.layer_loss = torch.zeros(n, **f)
+        self.total_loss = torch.zeros(1, **f)
+        self._ptr_arr = (C.c_void_p * n)()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().vitta_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def channel_slice(self, layer):
+        o = self.offsets[layer]
+        return slice(o, o + self.shapes[layer][1])
+
+    def moments(self, feats, shift=None):
+        """feats: list of contiguous CUDA fp32 tensors (one per layer) -> fills cnt/s1/s2."""
+        if len(feats) != self.n_layers:
+            raise ValueError("one feature per planned layer expected")
+        for i, t in enumerate(feats):
+            _require_cuda_f32(t, f"feature {i}")
+            if not t.is_contiguous():
+                raise _lib.VittaHipError(f"feature {i} must be contiguous")
+            outer, c, inner, _ = self.shapes[i]
+            if t.numel() != outer * c * inner:
+                raise _lib.VittaHipError(f"feature {i} has {t.numel()} elements, plan expects {outer * c * inner}")
+            self._ptr_arr[i] = t.data_ptr()
+        check(lib().vitta_moments_batched_f32(self._h, self._ptr_arr, _p(shift), _p(self.cnt), _p(self.s1),
+                                              _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
+              "vitta_moments_batched_f32")
+        return self.cnt, self.s1, self.s2
+
+    def mean_var(self, shift=None):
+        mean = torch.empty(self.total_channels, dtype=torch.float32, device=self.device)
+        var = torch.empty_like(mean)
+        check(lib().vitta_moments_to_meanvar_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2),
+                                                 _p(mean), _p(var), _stream()), "vitta_moments_to_meanvar_f32")
+        return mean, var
+
+    def align(self, shift, ema_mean, ema_var, src_mean, src_var, momentum, reg_type):
+        check(lib().vitta_stat_align_fwd_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2),
+                                             _p(ema_mean), _p(ema_var), _p(src_mean), _p(src_var),
+                                             float(momentum), REG_TYPES[reg_type], _p(self.layer_loss),
+                                             _p(self.total_loss), _p(self.mu), _p(self.coef_a), _p(self.coef_b),
+                                             _p(self.ws), self.ws_bytes, _stream()), "vitta_stat_align_fwd_f32")
+        return self.total_loss, self.layer_loss
+
+
+# ------------------------------------------------------------------------------------------------
+# TAM
+# ------------------------------------------------------------------------------------------------
+class TamPool(torch.autograd.Function):
+    """pooled[n,c,t] = mean_hw x[n*T+t, c, :]  (temporal_module.py:47-52 without the permute copy)."""
+
+    @staticmethod
+    def forward(ctx, x, n_segment):
+        _require_cuda_f32(x, "x")
+        x = x.contiguous()
+        nt, c, h, w = x.shape
+        n = nt // n_segment
+        pool = torch.empty(n, c, n_segment, dtype=torch.float32, device=x.device)
+        check(lib().vitta_tam_pool_f32(_p(x), n, n_segment, c, h * w, _p(pool), _stream()), "vitta_tam_pool_f32")
+        ctx.dims = (n, n_segment, c, h, w)
+        return pool
+
+    @staticmethod
+    def backward(ctx, gpool):
+        n, t, c, h, w = ctx.dims
+        gx = torch.zeros(n * t, c, h, w, dtype=torch.float32, device=gpool.device)
+        check(lib().vitta_tam_pool_bwd_f32(_p(gpool.contiguous()), n, t, c, h * w, _p(gx), _stream()),
+              "vitta_tam_pool_bwd_f32")
+        return gx, None
+
+
+class TamAggregate(torch.autograd.Function):
+    """out[n,t,c] = sum_j K[n,c,j] gate[n,c,t+j-1] x[n,t+j-1,c]  (temporal_module.py:56-63, fused)."""
+
+    @staticmethod
+    def forward(ctx, x, gate, kern, n_segment):
+        _require_cuda_f32(x, "x")
+        x = x.contiguous()
+        gate = gate.contiguous()
+        kern = kern.contiguous()
+        nt, c, h, w = x.shape
+        n = nt // n_segment
+        out = torch.empty_like(x)
+        check(lib().vitta_tam_agg_fwd_f32(_p(x), _p(gate), _p(kern), n, n_segment, c, h * w, _p(out), _stream()),
+              "vitta_tam_agg_fwd_f32")
+        ctx.save_for_backward(x, gate, kern)
+        ctx.dims = (n, n_segment, c, h * w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, gate, kern = ctx.saved_tensors
+        n, t, c, hw = ctx.dims
+        gout = gout.contiguous()
+        gx = torch.empty_like(x)
+        ggate_buf = torch.empty(n * c * t * 4, dtype=torch.float32, device=x.device)
+        gkern = torch.empty_like(kern)
+        check(lib().vitta_tam_agg_bwd_f32(_p(x), _p(gate), _p(kern), _p(gout), n, t, c, hw, _p(gx), _p(ggate_buf),
+                                          _p(gkern), _stream()), "vitta_tam_agg_bwd_f32")
+        ggate = ggate_buf[: n * c * t].view_as(gate)
+        return gx, ggate, gkern, None
