@@ -1,0 +1,83 @@
+"""ResNet-50 v1.5 trunk (stride on the 3x3 conv) with torchvision's state_dict key names.
+
+The reference builds its TANet on `torchvision.models.resnet50` (models/tanet_models/tanet.py:129,
+torchvision==0.8.2, NOT vendored in the reference).  This is a from-scratch restatement of that
+published architecture so that `tanet_ucf.pth.tar` style checkpoints load key-for-key:
+    conv1, bn1, layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}, fc
+Parity of the trunk itself is unpinned by the reference; registration ORDER of
+sub-modules is load-bearing because the source statistics are positional (corpus/basics.py:490-498).
+
+Difference from torchvision kept on purpose: no in-place ReLU / `out += identity`.  The hooked BN
+outputs must survive until the backward pass (the stat-loss gradient a_c + b_c (x - mu_c) reads
+them), so nothing downstream may overwrite them.
+"""
+import torch
+import torch.nn as nn
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=False)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class ResNet(nn.Module):
+    def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), num_classes=1000):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=False)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(512 * block.expansion, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        stage = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        stage += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stage)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = torch.flatten(self.avgpool(x), 1)
+        return self.fc(x)
+
+
+def resnet50(pretrained=False, **kw):
+    """`pretrained` is accepted for call-site compatibility (tanet.py:129 passes True); ImageNet
+    weights are never downloaded -- TTA always loads a full checkpoint afterwards."""
+    return ResNet(Bottleneck, (3, 4, 6, 3), **kw)

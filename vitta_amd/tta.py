@@ -1,0 +1,545 @@
+"""The ViTTA driver: online test-time adaptation loop, source-only validation, source-statistics
+producer, model/dataset factories.
+
+Interface mirror of corpus/basics.py:
+    tta_standard :403-747   validate :96-217   compute_statistics :220-307
+    get_model :1447-1493    get_dataset_tanet :1230-1291   get_dataset_videoswin :1191-1228
+Same call signatures, same per-video protocol (adapt on video i -> evaluate video i -> next video
+without resetting the model), same log-line formats.  MI355X-first differences:
+
+* statistics hooks run in the batched engine (one moments launch + one align launch per step, gradient
+  injected during backward) whenever the configuration allows it (stat_reg 'mean_var', moving_avg,
+  before_norm False); otherwise each hook falls back to the stand-alone HIP op;
+* device-agnostic (no hard-coded .cuda()); one process per GPU.  Under torch.distributed (RCCL) the
+  test videos are sharded round-robin over ranks, the packed moments [cnt|s1|s2] are all-reduced once
+  per step before the EMA update and the gradients once before the optimizer step -- R ranks x 1
+  video is exactly the reference run with batch_size = R;
+* no per-video host synchronisation: per-video metrics are read back with a lag (DeferredLog).
+"""
+import copy as cp
+import os.path as osp
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .bns_utils import choose_layers, collect_bn_params, freeze_except_bn
+from .norm_stats import CombineNormStatsRegHook_onereg, ComputeNormStatsHook, StatAlignEngine
+from .pred_consistency import compute_pred_consis
+from .utils_ import AverageMeter, accuracy
+
+# tests may point this at a factory of oracle-backed backends to run the host logic without a GPU;
+# the product default (None) is the HIP backend, which raises on CPU tensors.
+BACKEND_FACTORY = None
+
+NUM_CLASSES = {"ucf101": 101, "hmdb51": 51, "kinetics": 400, "somethingv2": 174, "kth": 6, "u2h": 12, "h2u": 12}
+
+
+class SingleDeviceParallel(nn.Module):
+    """Stand-in for nn.DataParallel(model, device_ids=[0]) (corpus/main_eval.py:61,65): one process
+    drives one GPU, but sub-module names keep the `module.` prefix the checkpoints and the Swin
+    `chosen_blocks` ('module.backbone.layers.2', tta_swin_ucf101.py:40) rely on."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# factories
+# ------------------------------------------------------------------------------------------------
+def get_model(args, num_classes, logger=None):
+    if args.arch == "tanet":
+        from .tanet import TSN
+        return TSN(num_classes, args.clip_length, args.modality, base_model="resnet50", consensus_type="avg",
+                   img_feature_dim=args.img_feature_dim, tam=True, non_local=False, partial_bn=args.partial_bn)
+    if args.arch == "videoswintransformer":
+        from .swin import Recognizer3D
+        return Recognizer3D(num_classes=num_classes, patch_size=args.patch_size, window_size=args.window_size,
+                            drop_path_rate=args.drop_path_rate)
+    raise Exception(f"{args.arch} is not a valid model!")
+
+
+def get_dataset_tanet(args, split="train", dataset_type=None):
+    from . import data
+    return data.build_tanet_dataset(args, split, dataset_type)
+
+
+def get_dataset_videoswin(args, split="train", dataset_type=None):
+    from . import data
+    return data.build_videoswin_dataset(args, split, dataset_type)
+
+
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+def _loader(dataset, args):
+    workers = 0 if getattr(dataset, "on_device", False) else args.workers
+    return torch.utils.data.DataLoader(dataset, batch_size=args.batch_size, shuffle=False, num_workers=workers,
+                                       pin_memory=workers > 0)
+
+
+def _n_clips(args):
+    return int(args.sample_style.split("-")[-1]) if args.arch == "tanet" else args.num_clips
+
+
+def _dist():
+    d = torch.distributed
+    if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
+# ------------------------------------------------------------------------------------------------
+# source statistics
+# ------------------------------------------------------------------------------------------------
+def load_source_statistics(args, chosen_layers):
+    """np.load both object arrays and align them with `chosen_layers` by position
+    (corpus/basics.py:480-509): TANet lists hold BN2d/3d entries only -> None at BatchNorm1d slots."""
+    mean_list = list(np.load(args.spatiotemp_mean_clean_file, allow_pickle=True))
+    var_list = list(np.load(args.spatiotemp_var_clean_file, allow_pickle=True))
+    if args.arch == "tanet":
+        means, vars_, k = [], [], 0
+        for _, layer in chosen_layers:
+            if isinstance(layer, nn.BatchNorm1d):
+                means.append(None)
+                vars_.append(None)
+            else:
+                means.append(mean_list[k])
+                vars_.append(var_list[k])
+                k += 1
+    else:
+        means, vars_ = mean_list, var_list
+    assert len(means) == len(chosen_layers), (len(means), len(chosen_layers))
+    return means, vars_
+
+
+def candidate_layers_for(args, model):
+    """All norm layers eligible for hooks, in named_modules() order (corpus/basics.py:486-505)."""
+    if args.arch == "tanet":
+        return choose_layers(model, [nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d])
+    return choose_layers(model, [nn.LayerNorm])[1:]  # the first LN sees (B, L, C): excluded
+
+
+def select_hooked(args, chosen_layers):
+    """[(position, name, layer)] of the layers whose name contains a chosen block (basics.py:571-573)."""
+    return [(i, nm, layer) for i, (nm, layer) in enumerate(chosen_layers)
+            if any(block in nm for block in args.chosen_blocks)]
+
+
+# ------------------------------------------------------------------------------------------------
+# data-parallel gradient exchange
+# ------------------------------------------------------------------------------------------------
+class GradBucket:
+    """All gradients live in ONE flat buffer (p.grad are views into it): a single SUM all-reduce per
+    step, no flatten/unflatten copies.  SUM, not mean: loss_consis is a sum over videos and loss_reg
+    is one global scalar whose per-rank partial derivatives add."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self):
+        torch.distributed.all_reduce(self.flat, op=torch.distributed.ReduceOp.SUM)
+
+
+class DeferredLog:
+    """Per-video metrics are written to a device row and fetched with a lag so the host never blocks
+    on the stream inside the loop; the lines come out in order, formatted like corpus/basics.py:730-738."""
+
+    FIELDS = 5  # loss_reg, loss_consis, loss_ce, prec1, prec5
+
+    def __init__(self, device, logger, total, verbose, lag=8):
+        self.logger, self.total, self.verbose, self.lag = logger, total, verbose, lag
+        self.device = device
+        self.pending = []
+        self.meters = dict(batch_time=AverageMeter(), loss_reg=AverageMeter(), loss_consis=AverageMeter(),
+                           loss_ce=AverageMeter(), top1=AverageMeter(), top5=AverageMeter())
+
+    def push(self, batch_id, row, bz, elapsed):
+        host = torch.empty(self.FIELDS, dtype=torch.float32, pin_memory=row.is_cuda)
+        host.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event() if row.is_cuda else None
+        if ev is not None:
+            ev.record()
+        self.pending.append((batch_id, host, ev, bz, elapsed))
+        while len(self.pending) > self.lag:
+            self._emit(self.pending.pop(0), wait=True)
+        while self.pending and (self.pending[0][2] is None or self.pending[0][2].query()):
+            self._emit(self.pending.pop(0), wait=False)
+
+    def flush(self):
+        while self.pending:
+            self._emit(self.pending.pop(0), wait=True)
+
+    def _emit(self, item, wait):
+        batch_id, host, ev, bz, elapsed = item
+        if ev is not None and wait:
+            ev.synchronize()
+        reg, consis, ce, p1, p5 = host.tolist()
+        m = self.meters
+        m["batch_time"].update(elapsed)
+        m["loss_reg"].update(reg, bz)
+        m["loss_consis"].update(consis, bz)
+        m["loss_ce"].update(ce, bz)
+        m["top1"].update(p1, bz)
+        m["top5"].update(p5, bz)
+        if self.verbose and self.logger is not None:
+            self.logger.debug(("TTA Epoch{epoch}: [{0}/{1}]\t"
+                               "Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t"
+                               "Loss reg {loss_reg.val:.4f} ({loss_reg.avg:.4f})\t"
+                               "Loss consis {loss_consis.val:.4f} ({loss_consis.avg:.4f})\t"
+                               "Prec@1 {top1.val:.3f} ({top1.avg:.3f})\t"
+                               "Prec@5 {top5.val:.3f} ({top5.avg:.3f})").format(
+                batch_id, self.total, epoch=1, batch_time=m["batch_time"], loss_reg=m["loss_reg"],
+                loss_consis=m["loss_consis"], top1=m["top1"], top5=m["top5"]))
+
+
+# ------------------------------------------------------------------------------------------------
+# adapter: model + optimizer + hooks of one adaptation run
+# ------------------------------------------------------------------------------------------------
+class ViTTAAdapter:
+    """Everything `tta_standard` sets up before the first video (corpus/basics.py:525-601), plus the
+    adapt / evaluate steps of the loop body so bench.py and the tests can drive them directly."""
+
+    def __init__(self, model_origin, args, engine_backend=None, use_engine=None):
+        self.args = args
+        self.model = cp.deepcopy(model_origin)
+        model = self.model
+        self.device = _device_of(model)
+        self.rank, self.world = _dist()
+        self.bn_types = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+        self.chosen_layers = candidate_layers_for(args, model)
+
+        if args.update_only_bn_affine:
+            kinds = list(self.bn_types) if args.arch == "tanet" else [nn.LayerNorm]
+            freeze_except_bn(model, bn_condidiate_layers=kinds)
+            params, self.param_names = collect_bn_params(model, bn_candidate_layers=kinds)
+            self.optimizer = torch.optim.Adam(params, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0)
+        else:
+            params = list(model.parameters())
+            self.optimizer = torch.optim.SGD(params=params, lr=args.lr, momentum=args.momentum,
+                                             weight_decay=args.weight_decay)
+        self.params = [p for p in params if p.requires_grad]
+        self.bucket = GradBucket(self.params) if self.world > 1 else None
+
+        if args.stat_reg != "mean_var":
+            raise Exception(f"undefined regularization type {args.stat_reg}")
+        if isinstance(args.stat_type, str):
+            raise NotImplementedError("args.stat_type of str is deprecated, use list instead.")
+        means, vars_ = load_source_statistics(args, self.chosen_layers)
+        if use_engine is None:
+            use_engine = bool(args.moving_avg) and not args.before_norm
+        if engine_backend is None and BACKEND_FACTORY is not None:
+            engine_backend = BACKEND_FACTORY()
+        self.backend = engine_backend
+        self.engine = StatAlignEngine(args.reg_type, args.momentum_mvg, backend=engine_backend) if use_engine else None
+        self.hooked = select_hooked(args, self.chosen_layers)
+        self.stat_reg_hooks = [
+            CombineNormStatsRegHook_onereg(layer, clip_len=args.clip_length,
+                                           spatiotemp_stats_clean_tuple=(means[i], vars_[i]), reg_type=args.reg_type,
+                                           moving_avg=args.moving_avg, momentum=args.momentum_mvg,
+                                           stat_type_list=args.stat_type, reduce_dim=args.reduce_dim,
+                                           before_norm=args.before_norm,
+                                           if_sample_tta_aug_views=args.if_sample_tta_aug_views,
+                                           n_augmented_views=args.n_augmented_views, engine=self.engine,
+                                           backend=engine_backend)
+            for i, _, layer in self.hooked]
+        self.n_clips = _n_clips(args)
+        self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
+        self.n_views = args.test_crops * (args.n_augmented_views if args.if_sample_tta_aug_views else self.n_clips)
+
+    # -- modes --------------------------------------------------------------------------------
+    def set_adapt_mode(self):
+        """model.train() with every BatchNorm back in eval() when fix_BNS (basics.py:606-611): dropout
+        and drop-path stay ACTIVE during the adaptation forward."""
+        self.model.train()
+        if self.args.fix_BNS:
+            for m in self.model.modules():
+                if isinstance(m, self.bn_types):
+                    m.eval()
+
+    def close_hooks(self):
+        for h in self.stat_reg_hooks:
+            h.close()
+
+    def add_hooks_back(self):
+        for h, (_, _, layer) in zip(self.stat_reg_hooks, self.hooked):
+            h.add_hook_back(layer)
+
+    # -- steps ---------------------------------------------------------------------------------
+    def shape_tta_input(self, input):
+        a = self.args
+        if a.arch == "tanet":
+            bz = input.shape[0]
+            input = input.view(-1, 3, input.size(2), input.size(3))
+            return input.view(bz * self.n_views, a.clip_length, 3, input.size(2), input.size(3))
+        return input
+
+    def shape_eval_input(self, input):
+        a = self.args
+        if a.arch == "tanet":
+            bz = input.shape[0]
+            input = input.view(-1, 3, input.size(2), input.size(3))
+            return input.view(bz * a.test_crops * self.n_clips, a.clip_length, 3, input.size(2), input.size(3))
+        return input
+
+    def forward_losses(self, input, actual_bz):
+        """Adaptation forward: (video logits, loss_reg, loss_consis or None)."""
+        a = self.args
+        loss_consis = None
+        if a.arch == "tanet":
+            output = self.model(input).reshape(actual_bz, self.n_views, -1)
+            if self.if_pred_consistency:
+                loss_consis = compute_pred_consis(output)
+            output = output.mean(1)
+        else:
+            output, view_cls_score = self.model(input)
+            if self.if_pred_consistency:
+                loss_consis = compute_pred_consis(view_cls_score)
+        if self.engine is not None:
+            loss_reg = self.engine.finish()
+        else:
+            loss_reg = torch.zeros((), dtype=torch.float32, device=output.device)
+            for h in self.stat_reg_hooks:
+                loss_reg = loss_reg + h.r_feature.to(output.device)
+        return output, loss_reg, loss_consis
+
+    def adapt_step(self, input, has_video=True):
+        """One gradient step on one (already device-resident, already reshaped) TTA input.
+        `has_video=False`: ragged tail of a data-parallel run -- this rank only takes part in the two
+        exchanges so that EMA state and weights stay identical everywhere."""
+        a = self.args
+        if self.bucket is not None:
+            self.bucket.zero()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        output = loss_reg = loss_consis = None
+        if has_video:
+            actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
+            output, loss_reg, loss_consis = self.forward_losses(input, actual_bz)
+            if self.if_pred_consistency:
+                loss = a.lambda_feature_reg * loss_reg + a.lambda_pred_consis * loss_consis
+            else:
+                loss = loss_reg
+            loss.backward()
+        else:
+            if self.engine is None:
+                raise RuntimeError("ragged data-parallel steps need the batched engine")
+            loss_reg = self.engine.finish_empty()
+        if self.bucket is not None:
+            self.bucket.all_reduce()
+        self.optimizer.step()
+        return output, loss_reg, loss_consis
+
+    @torch.no_grad()
+    def evaluate(self, input):
+        self.model.eval()
+        a = self.args
+        if a.arch == "tanet":
+            bz = input.shape[0] // (a.test_crops * self.n_clips)
+            return self.model(input).reshape(bz, a.test_crops * self.n_clips, -1).mean(1)
+        output, _ = self.model(input)
+        return output
+
+
+# ------------------------------------------------------------------------------------------------
+# the online TTA loop
+# ------------------------------------------------------------------------------------------------
+def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
+    """'tta_online': one gradient step per video, evaluate that video right after, keep the model.
+    'tta_standard': re-initialise model/optimizer/hooks for every video (momentum_mvg must be 1)."""
+    if args.if_tta_standard == "tta_standard":
+        assert args.momentum_mvg == 1.0
+        assert args.n_epoch_adapat == 1
+    elif args.if_tta_standard == "tta_online":
+        assert args.momentum_mvg != 1.0
+        assert args.n_gradient_steps == 1
+        assert args.n_epoch_adapat == 1
+    if not hasattr(args, "moving_avg"):
+        args.moving_avg = False
+    if not hasattr(args, "momentum_mvg"):
+        args.momentum_mvg = 0.1
+
+    device = _device_of(model_origin)
+    rank, world = _dist()
+    if args.arch == "tanet":
+        tta_set = get_dataset_tanet(args, split="val", dataset_type="tta")
+        eval_set = get_dataset_tanet(args, split="val", dataset_type="eval")
+    elif args.arch == "videoswintransformer":
+        tta_set = get_dataset_videoswin(args, split="val", dataset_type="tta")
+        eval_set = get_dataset_videoswin(args, split="val", dataset_type="eval")
+    else:
+        raise NotImplementedError(f"Incorrect model type {args.arch}")
+    n_total = len(tta_set)
+    if world > 1:
+        # rank r adapts videos R*k + r; batch_size videos per rank and step
+        mine = list(range(rank, n_total, world))
+        tta_set = torch.utils.data.Subset(tta_set, mine)
+        eval_set = torch.utils.data.Subset(eval_set, mine)
+        per_rank = -(-n_total // world)  # ceil
+        n_steps = -(-per_rank // args.batch_size)
+    tta_loader, eval_loader = _loader(tta_set, args), _loader(eval_set, args)
+    if world == 1:
+        n_steps = len(tta_loader)
+    tta_iter, eval_iter = iter(tta_loader), iter(eval_loader)
+
+    log = DeferredLog(device, logger, n_steps, args.verbose)
+    adapter = None
+    end = time.time()
+    for batch_id in range(n_steps):
+        try:
+            input, target = next(tta_iter)
+            has_video = True
+        except StopIteration:
+            input = target = None
+            has_video = False
+        if adapter is None or args.if_tta_standard == "tta_standard":
+            print(f"Batch {batch_id}, initialize the model, update chosen layers, initialize hooks, intialize average meter")
+            adapter = ViTTAAdapter(model_origin, args)
+        adapter.set_adapt_mode()
+        row = torch.zeros(DeferredLog.FIELDS, dtype=torch.float32, device=device)
+        actual_bz = 0
+        if has_video:
+            actual_bz = input.shape[0]
+            input = adapter.shape_tta_input(input.to(device, non_blocking=True))
+            target = target.to(device, non_blocking=True)
+        for _ in range(args.n_gradient_steps):
+            output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
+        if has_video:
+            row[0] = loss_reg.detach()
+            if loss_consis is not None:
+                row[1] = loss_consis.detach()
+            row[2] = criterion(output.detach(), target)  # logging only, never part of the loss (basics.py:657)
+        adapter.close_hooks()
+        if has_video:
+            ev_input, ev_target = next(eval_iter)
+            ev_input = adapter.shape_eval_input(ev_input.to(device, non_blocking=True))
+            ev_target = ev_target.to(device, non_blocking=True)
+            output = adapter.evaluate(ev_input)
+            prec1, prec5 = accuracy(output.data, ev_target, topk=(1, 5))
+            row[3], row[4] = prec1, prec5
+        if args.if_tta_standard == "tta_online":
+            adapter.add_hooks_back()
+        now = time.time()
+        if has_video:
+            log.push(batch_id, row, actual_bz, now - end)
+        end = now
+    log.flush()
+    top1 = log.meters["top1"]
+    if world > 1:
+        t = torch.tensor([top1.sum, top1.count], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t)
+        return [float(t[0] / t[1])]
+    return [top1.avg]
+
+
+# ------------------------------------------------------------------------------------------------
+# source-only validation (BASELINE config 0: runs on the host CPU as well)
+# ------------------------------------------------------------------------------------------------
+def validate(val_loader, model, criterion, iter, epoch=None, args=None, logger=None, writer=None, optimizer=None):
+    batch_time, losses, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    n_clips = _n_clips(args)
+    device = _device_of(model)
+    if getattr(args, "evaluate_baselines", False) and getattr(args, "baseline", None) == "source":
+        logger.debug(f"Starting ---- {getattr(args, 'corruptions', None)} ---- evaluation for Source...")
+    with torch.no_grad():
+        end = time.time()
+        for i, (input, target) in enumerate(val_loader):
+            model.eval()
+            actual_bz = input.shape[0]
+            input, target = input.to(device), target.to(device)
+            if args.arch == "tanet":
+                input = input.view(-1, 3, input.size(2), input.size(3))
+                input = input.view(actual_bz * args.test_crops * n_clips, args.clip_length, 3, input.size(2), input.size(3))
+                output = model(input).reshape(actual_bz, args.test_crops * n_clips, -1).mean(1)
+            elif args.arch == "videoswintransformer":
+                output, _ = model(input)
+            else:
+                raise NotImplementedError(f"Incorrect model type {args.arch}")
+            loss = criterion(output, target)
+            prec1, prec5 = accuracy(output.data, target, topk=(1, 5))
+            losses.update(loss.item(), actual_bz)
+            top1.update(prec1.item(), actual_bz)
+            top5.update(prec5.item(), actual_bz)
+            batch_time.update(time.time() - end)
+            end = time.time()
+            if args.verbose and i % args.print_freq == 0:
+                logger.debug(("Test: [{0}/{1}]\t"
+                              "Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t"
+                              "Loss {loss.val:.4f} ({loss.avg:.4f})\t"
+                              "Prec@1 {top1.val:.3f} ({top1.avg:.3f})\t"
+                              "Prec@5 {top5.val:.3f} ({top5.avg:.3f})").format(
+                    i, len(val_loader), batch_time=batch_time, loss=losses, top1=top1, top5=top5))
+    logger.debug("Testing Results: Prec@1 {top1.avg:.3f} Prec@5 {top5.avg:.3f} Loss {loss.avg:.5f}".format(
+        top1=top1, top5=top5, loss=losses))
+    logger.debug(f"Validation acc {top1.avg} ")
+    return top1.avg
+
+
+# ------------------------------------------------------------------------------------------------
+# source-statistics producer
+# ------------------------------------------------------------------------------------------------
+def compute_statistics(model=None, args=None, logger=None, log_time=None):
+    """Batch-size-weighted average of per-batch means and per-batch biased variances over the clean
+    training videos, one entry per BN2d/3d (TANet) or LayerNorm[1:] (Swin); written as two object
+    arrays list_<stat_type>_{mean,var}_<log_time>.npy (corpus/basics.py:220-307)."""
+    if args.stat_type != "spatiotemp":
+        raise NotImplementedError("only stat_type 'spatiotemp' is on the ViTTA path")
+    if args.arch == "tanet":
+        chosen_layers = choose_layers(model, [nn.BatchNorm2d, nn.BatchNorm3d])
+        dataset = get_dataset_tanet(args, split="val", dataset_type="eval")
+    elif args.arch == "videoswintransformer":
+        chosen_layers = choose_layers(model, [nn.LayerNorm])[1:]
+        dataset = get_dataset_videoswin(args, split="val", dataset_type="eval")
+    else:
+        raise NotImplementedError(f"Incorrect model type {args.arch}")
+    backend = BACKEND_FACTORY() if BACKEND_FACTORY is not None else None
+    hooks = [ComputeNormStatsHook(layer, clip_len=args.clip_length, stat_type=args.stat_type,
+                                  before_norm=args.before_norm, batch_size=args.batch_size, backend=backend)
+             for _, layer in chosen_layers]
+    device = _device_of(model)
+    n_clips = _n_clips(args)
+    loader = _loader(dataset, args)
+    sum_mean = [None] * len(hooks)
+    sum_var = [None] * len(hooks)
+    count = 0
+    model.eval()
+    with torch.no_grad():
+        for batch_id, (input, _) in enumerate(loader):
+            actual_bz = input.shape[0]
+            input = input.to(device)
+            if args.arch == "tanet":
+                input = input.view(-1, 3, input.size(2), input.size(3))
+                input = input.view(actual_bz * args.test_crops * n_clips, args.clip_length, 3, input.size(2), input.size(3))
+            model(input)
+            if batch_id % 1000 == 0:
+                print(f"{batch_id}/{len(loader)} batches completed ...")
+            for k, h in enumerate(hooks):
+                sum_mean[k] = h.batch_mean * actual_bz if sum_mean[k] is None else sum_mean[k] + h.batch_mean * actual_bz
+                sum_var[k] = h.batch_var * actual_bz if sum_var[k] is None else sum_var[k] + h.batch_var * actual_bz
+            count += actual_bz
+    for h in hooks:
+        h.close()
+    means = np.empty(len(hooks), dtype=object)
+    vars_ = np.empty(len(hooks), dtype=object)
+    for k in range(len(hooks)):
+        means[k] = (sum_mean[k] / count).cpu().numpy()
+        vars_[k] = (sum_var[k] / count).cpu().numpy()
+    np.save(osp.join(args.result_dir, f"list_{args.stat_type}_mean_{log_time}.npy"), means, allow_pickle=True)
+    np.save(osp.join(args.result_dir, f"list_{args.stat_type}_var_{log_time}.npy"), vars_, allow_pickle=True)
+    return means, vars_
