@@ -1,0 +1,253 @@
+"""bench.py -- videos/sec of the ViTTA online TTA step on MI355X (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): TANet-R50 (random init of the real architecture, BN statistics
+calibrated), UCF101 head (101 classes), one video per GPU and step = 2 temporally augmented views x 8
+frames x 3 x 224 x 224 fp32 synthetic N(0,1) clips resident in HBM, statistics alignment (l1_loss,
+momentum 0.1) on the 29 BatchNorm2d outputs of layer3/layer4 + prediction consistency, Adam on the BN
+affine parameters (--update_only_bn_affine).  A "step" is the reference's per-video iteration
+(corpus/basics.py:516-738): adaptation forward + losses + backward + optimizer step, then the
+evaluation forward of the same video (centre view).  `value` = videos of all ranks / max-over-ranks
+wall time of the K timed steps (barrier + synchronize on both sides).
+
+Extra objects on the JSON line:
+  roofline      the north-star kernel, moments_nchw_partial_kernel (one launch over all 29 hooked
+                layers): algorithmic bytes = 4 B x 44 556 288 hooked elements per video,
+                time = HIP events recorded on the launch stream around that kernel inside the timed
+                steps.  The hooked tensors were just written by the BN kernels and fit the 256 MiB
+                Infinity Cache, so `achieved` is an on-die rate; `streaming` repeats the launch on
+                1.07 GB of features (6 videos' worth per layer) that cannot be cache resident.
+  cpu_baseline  the CPU restatement of the reference path (oracle/: stock PyTorch CPU ops in the
+                reference's op order), same workload, a few steps on the host cores of this box.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOOKED_ELEMENTS_PER_VIDEO = 44556288  # 29 BN2d outputs of layer3/4 at 2x8x224^2
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--optimizer", default="adam_affine", choices=["adam_affine", "sgd_all"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=4)
+    p.add_argument("--no-streaming", action="store_true")
+    p.add_argument("--size", type=int, default=224)
+    p.add_argument("--clip-length", type=int, default=8)
+    return p.parse_args()
+
+
+def make_args(tmp, size, clip_length, optimizer, device, n_videos):
+    from vitta_amd.opts import get_opts
+    a = get_opts([])
+    a.arch, a.dataset, a.datatype, a.num_classes = "tanet", "ucf101", "synthetic", 101
+    a.clip_length, a.input_size, a.batch_size, a.workers = clip_length, size, 1, 0
+    a.n_augmented_views, a.verbose, a.result_dir, a.gpus = 2, False, tmp, [0]
+    a.update_only_bn_affine = optimizer == "adam_affine"
+    a.lr = 5e-5
+    a.synthetic_n_videos, a.synthetic_device = n_videos, device
+    return a
+
+
+def build_model_and_stats(tmp, size, T, device):
+    """Seeded TANet-R50 with BN calibrated on a 224^2 batch, source statistics = moments of a second
+    calibration pass (seed 1000) on the 53 BatchNorm2d outputs (what compute_statistics would write)."""
+    from vitta_amd import synthetic as S
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    from vitta_amd.tanet import TSN
+    torch.manual_seed(0)
+    model = TSN(101, T, "RGB", base_model="resnet50", consensus_type="avg", tam=True, partial_bn=False)
+    with torch.no_grad():
+        model.new_fc.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(1))
+    S.perturb_affine(model, 2)
+    model = model.to(device)
+    S.calibrate_bn(model, S.seeded_randn((4, T, 3, size, size), 3, device))
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                m.running_var.clamp_(min=0.05)
+    model.eval()
+    bn2d = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    hooks = [ComputeNormStatsHook(m, clip_len=T, stat_type="spatiotemp", before_norm=False, batch_size=2) for m in bn2d]
+    with torch.no_grad():
+        model(S.seeded_randn((2, T, 3, size, size), 1000, device))
+    means = [h.batch_mean.cpu().numpy() for h in hooks]
+    vars_ = [h.batch_var.cpu().numpy() for h in hooks]
+    for h in hooks:
+        h.close()
+    mp, vp = S.write_stat_files(tmp, means, vars_, tag="bench")
+    return model, mp, vp
+
+
+def run_gpu(opt, rank, world, device):
+    from vitta_amd import data, tta
+    tmp = tempfile.mkdtemp(prefix="vitta_bench_")
+    n_videos = max(16, min(64, opt.steps + opt.warmup))
+    model, mp, vp = build_model_and_stats(tmp, opt.size, opt.clip_length, device)
+    args = make_args(tmp, opt.size, opt.clip_length, opt.optimizer, device, n_videos)
+    args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+    args.synthetic_seed = 10000 * rank  # every rank adapts to its own videos (weak scaling)
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+    tta_set = data.build_tanet_dataset(args, "val", "tta")
+    eval_set = data.build_tanet_dataset(args, "val", "eval")
+    torch.cuda.synchronize()
+
+    # live timing of the moments kernel: one (start, stop) event pair per step, on the launch stream
+    pairs = []
+
+    def new_events():
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        pairs.append(pair)
+        return pair
+
+    def one_step(i):
+        x, _ = tta_set[i % n_videos]
+        adapter.set_adapt_mode()
+        adapter.adapt_step(adapter.shape_tta_input(x.unsqueeze(0)))
+        adapter.close_hooks()
+        ev, _ = eval_set[i % n_videos]
+        out = adapter.evaluate(adapter.shape_eval_input(ev.unsqueeze(0)))
+        adapter.add_hooks_back()
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(opt.warmup):
+        one_step(i)
+    adapter.engine.timing_events = new_events
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(opt.steps):
+        one_step(opt.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    adapter.engine.timing_events = None
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # adapt-only timing (no evaluation forward), same videos, for the report
+    barrier()
+    t1 = time.perf_counter()
+    for i in range(max(4, opt.steps // 3)):
+        x, _ = tta_set[i % n_videos]
+        adapter.set_adapt_mode()
+        adapter.adapt_step(adapter.shape_tta_input(x.unsqueeze(0)))
+    barrier()
+    adapt_only = (time.perf_counter() - t1) / max(4, opt.steps // 3)
+
+    streaming = None
+    if rank == 0 and not opt.no_streaming:
+        streaming = streaming_moments(adapter, device)
+    return elapsed, kern_ms, adapt_only, streaming, adapter
+
+
+def streaming_moments(adapter, device, copies=6, reps=20):
+    """The same batched launch on features that cannot be cache resident: every hooked layer with
+    `copies` videos' worth of frames (6 x 178 MB = 1.07 GB > 256 MiB Infinity Cache)."""
+    from vitta_amd import ops
+    base = adapter.engine.plan.shapes
+    shapes = [(outer * copies, c, inner, layout) for outer, c, inner, layout in base]
+    plan = ops.StatPlan(shapes, device)
+    feats = [torch.randn(outer * c * inner, device=device) for outer, c, inner, _ in shapes]
+    nbytes = 4 * sum(f.numel() for f in feats)
+    shift = torch.zeros(plan.total_channels, device=device)
+    times = []
+    for r in range(reps + 3):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        plan.moments(feats, shift, events=ev)
+        torch.cuda.synchronize()
+        if r >= 3:
+            times.append(ev[0].elapsed_time(ev[1]))
+    ms = float(np.mean(times))
+    return dict(bytes=nbytes, ms=ms, achieved=nbytes / ms / 1e6, frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
+                workgroups=plan.num_blocks)
+
+
+def run_cpu_baseline(opt):
+    """The reference path restated on the CPU (oracle/), same workload, bounded sample."""
+    from oracle import cpu_path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sec, steps = cpu_path.time_tta_steps(size=opt.size, clip_length=opt.clip_length, optimizer=opt.optimizer,
+                                         warmup=1, steps=opt.cpu_steps)
+    return dict(value=steps / sec, unit="videos/s", cores=cores, kind="port",
+                sample=f"{steps} full per-video iterations (adapt step + eval forward) after 1 warm-up, TANet-R50 "
+                       f"2x{opt.clip_length}x{opt.size}^2 fp32, torch CPU ops in the reference's op order, "
+                       f"{cores} threads")
+
+
+def main():
+    opt = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    torch.backends.cudnn.benchmark = True  # corpus/main_eval.py:77 (MIOpen find mode on ROCm)
+
+    elapsed, kern_ms, adapt_only, streaming, adapter = run_gpu(opt, rank, world, device)
+    videos = opt.steps * world
+    value = videos / elapsed
+    algo_bytes = 4 * HOOKED_ELEMENTS_PER_VIDEO * (opt.size / 224.0) ** 2 * (opt.clip_length / 8.0)
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
+
+    line = {
+        "metric": "videos/sec TTA step (TANet-R50, 2x8x224^2), whole job", "value": value, "unit": "videos/s",
+        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "TANet-R50 UCF101 ViTTA online TTA, per-video iteration = adapt step (2 views x "
+                               f"{opt.clip_length} frames x {opt.size}^2, 29 hooked BN2d layers, l1 stat alignment + "
+                               "prediction consistency, backward, optimizer) + eval forward (1 view)",
+                   "optimizer": "Adam on BN affine (update_only_bn_affine)" if opt.optimizer == "adam_affine" else "SGD all parameters",
+                   "videos_per_gpu_per_step": 1, "parallelism": f"dp{world}",
+                   "exchanges": "moments all-reduce (43k floats) + gradient all-reduce" if world > 1 else "none"},
+        "adapt_only_ms": 1e3 * adapt_only,
+        "roofline": {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch)", "bound": "hbm",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "algorithmic_bytes": algo_bytes, "avg_ms": kern_ms,
+                     "note": "in-step operands are Infinity-Cache resident (178 MB just written by BN)",
+                     "streaming": streaming},
+    }
+    if rank == 0 and world == 1 and not opt.no_cpu_baseline:
+        del adapter
+        torch.cuda.empty_cache()
+        line["cpu_baseline"] = run_cpu_baseline(opt)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

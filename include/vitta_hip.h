@@ -94,6 +94,14 @@ int vitta_moments_batched_f32(const vitta_plan* plan, const void* const* h_x, co
                               float* d_cnt, float* d_s1, float* d_s2, void* d_workspace,
                               size_t workspace_bytes, void* stream);
 
+/* The two stages of vitta_moments_batched_f32 as separate calls (same arguments): the streaming
+ * pass over the features (per-workgroup partial triples into the workspace) and the tiny fp64
+ * combine.  bench.py brackets the first with events to time the HBM-bound kernel alone. */
+int vitta_moments_partials_f32(const vitta_plan* plan, const void* const* h_x, void* d_workspace,
+                               size_t workspace_bytes, void* stream);
+int vitta_moments_finalize_f32(const vitta_plan* plan, const float* d_shift, float* d_cnt, float* d_s1,
+                               float* d_s2, const void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Convert additive sums to (mean, biased var): mean = k + s1/n, var = s2/n - (s1/n)^2. */
 int vitta_moments_to_meanvar_f32(const vitta_plan* plan, const float* d_shift, const float* d_cnt,
                                  const float* d_s1, const float* d_s2, float* d_mean, float* d_var,

@@ -1,0 +1,92 @@
+"""CPU ORACLE of the whole per-video iteration -- test infrastructure / bench.py's cpu_baseline leg.
+
+The reference path restated with stock PyTorch CPU ops in the reference's op order:
+  * one stand-alone statistics hook per layer (permute -> contiguous -> mean -> permute -> contiguous
+    -> var, zero-init EMA, L1), i.e. utils/norm_stats_utils.py:153-253 via oracle.vitta_oracle;
+  * TAM with the two permute+contiguous copies, broadcast multiply and grouped conv
+    (models/tanet_models/temporal_module.py:43-65);
+  * autograd backward, Adam on the BN affine parameters or SGD on all parameters
+    (corpus/basics.py:547-560), then the evaluation forward (corpus/basics.py:691-716).
+The network definition is the product's TSN (same state_dict); its numerics were checked against the
+reference import in tests/test_host_cpu.py.  Never used by the product path.
+"""
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import vitta_oracle as O
+from .oracle_backend import OracleBackend
+
+
+def _reference_order_tam_forward(self, x):
+    nt, c, h, w = x.size()
+    t = self.n_segment
+    n = nt // t
+    pooled = O.tam_pool(x, t)
+    kern = self.G(pooled.view(-1, t))
+    gate = self.L(pooled.view(n, c, t))
+    return O.tam_aggregate(x, gate, kern, t)
+
+
+def install_reference_order(model):
+    from vitta_amd.tanet import TAM
+    for m in model.modules():
+        if isinstance(m, TAM):
+            m.forward = types.MethodType(_reference_order_tam_forward, m)
+    return model
+
+
+def build_adapter(size=224, clip_length=8, optimizer="adam_affine"):
+    from vitta_amd import synthetic as S
+    from vitta_amd import tta
+    from vitta_amd.opts import get_opts
+    from vitta_amd.tanet import TSN
+    torch.manual_seed(0)
+    model = TSN(101, clip_length, "RGB", base_model="resnet50", consensus_type="avg", tam=True, partial_bn=False)
+    with torch.no_grad():
+        model.new_fc.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(1))
+    S.perturb_affine(model, 2)
+    S.calibrate_bn(model, S.seeded_randn((2, clip_length, 3, 64, 64), 3))
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                m.running_var.clamp_(min=0.05)
+    model.eval()
+    bn2d = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    tmp = tempfile.mkdtemp(prefix="vitta_cpu_")
+    mp, vp = S.write_stat_files(tmp, [np.zeros(b.num_features, np.float32) for b in bn2d],
+                                [np.ones(b.num_features, np.float32) for b in bn2d], tag="cpu")
+    a = get_opts([])
+    a.arch, a.dataset, a.datatype, a.num_classes = "tanet", "ucf101", "synthetic", 101
+    a.clip_length, a.input_size, a.batch_size, a.workers, a.verbose = clip_length, size, 1, 0, False
+    a.result_dir, a.gpus, a.lr = tmp, [0], 5e-5
+    a.update_only_bn_affine = optimizer == "adam_affine"
+    a.spatiotemp_mean_clean_file, a.spatiotemp_var_clean_file = mp, vp
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), a, engine_backend=OracleBackend(), use_engine=False)
+    install_reference_order(adapter.model)
+    return adapter, a
+
+
+def time_tta_steps(size=224, clip_length=8, optimizer="adam_affine", warmup=1, steps=4):
+    from vitta_amd import data
+    adapter, a = build_adapter(size, clip_length, optimizer)
+    tta_set = data.SyntheticVideoDataset(warmup + steps, 2, clip_length, size, 101, "tanet", seed0=0)
+    eval_set = data.SyntheticVideoDataset(warmup + steps, 1, clip_length, size, 101, "tanet", seed0=0)
+
+    def one(i):
+        adapter.set_adapt_mode()
+        adapter.adapt_step(adapter.shape_tta_input(tta_set[i][0].unsqueeze(0)))
+        adapter.close_hooks()
+        adapter.evaluate(adapter.shape_eval_input(eval_set[i][0].unsqueeze(0)))
+        adapter.add_hooks_back()
+
+    for i in range(warmup):
+        one(i)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(warmup + i)
+    return time.perf_counter() - t0, steps

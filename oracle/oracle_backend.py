@@ -2,11 +2,11 @@
 
 Lets the CPU test-suite drive the product's host logic (hook protocol, engine bookkeeping, the
 tta_standard loop, the data-parallel exchanges over gloo) without a GPU, by computing what the HIP
-launches would compute with the CPU oracle.  Never imported by vitta_amd/.
+launches would compute with the CPU oracle.  Never imported by vitta_amd/ (only tests/, smoke() and bench.py's cpu_baseline leg).
 """
 import torch
 
-from oracle import vitta_oracle as O
+from . import vitta_oracle as O
 from vitta_amd._lib import LAYOUT_NCHW, LAYOUT_NHWC
 
 

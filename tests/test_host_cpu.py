@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 import helpers as H
-from oracle_backend import OracleBackend
+from oracle.oracle_backend import OracleBackend
 from vitta_amd import data, tta
 from vitta_amd.bns_utils import choose_layers, collect_bn_params, freeze_except_bn
 

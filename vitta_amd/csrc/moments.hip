@@ -443,6 +443,25 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
   return VITTA_OK;
 }
 
+int vitta_moments_partials_f32(const vitta_plan* p, const void* const* h_x, void* d_ws, size_t ws_bytes,
+                               void* stream) {
+  if (!p || !h_x) return VITTA_ERR_INVALID_ARG;
+  if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
+  return launch_partials(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream));
+}
+
+int vitta_moments_finalize_f32(const vitta_plan* p, const float* d_shift, float* d_cnt, float* d_s1,
+                               float* d_s2, const void* d_ws, size_t ws_bytes, void* stream) {
+  if (!p || !d_cnt || !d_s1 || !d_s2) return VITTA_ERR_INVALID_ARG;
+  if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
+  const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream),
+                     p->d_info, p->d_chan2layer, p->total_channels, static_cast<const float*>(d_ws), d_shift, 0,
+                     d_cnt, d_s1, d_s2);
+  VITTA_CHECK_LAUNCH();
+  return VITTA_OK;
+}
+
 int vitta_moments_batched_f32(const vitta_plan* p, const void* const* h_x, const float* d_shift,
                               float* d_cnt, float* d_s1, float* d_s2, void* d_ws, size_t ws_bytes,
                               void* stream) {

@@ -168,6 +168,7 @@ class StatAlignEngine:
         self.plan = None
         self.gscale = None
         self._gscale_set = False
+        self.timing_events = None  # bench.py: callable returning (start, stop) events per step
 
     # -- registration -------------------------------------------------------------------------
     def register(self, hook, src_mean, src_var):
@@ -218,7 +219,7 @@ class StatAlignEngine:
         if plan is None:
             plan = self._plans[shapes] = self.backend.make_plan(shapes, self.device)
         self.plan = plan
-        plan.moments(feats, self.src_mean)
+        plan.moments(feats, self.src_mean, **({"events": self.timing_events()} if self.timing_events else {}))
         if self.distributed:
             torch.distributed.all_reduce(plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
         total, layer = plan.align(self.src_mean, self.ema_mean, self.ema_var, self.src_mean, self.src_var,

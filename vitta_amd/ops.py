@@ -179,8 +179,10 @@ class StatPlan:
         o = self.offsets[layer]
         return slice(o, o + self.shapes[layer][1])
 
-    def moments(self, feats, shift=None):
-        """feats: list of contiguous CUDA fp32 tensors (one per layer) -> fills cnt/s1/s2."""
+    def moments(self, feats, shift=None, events=None):
+        """feats: list of contiguous CUDA fp32 tensors (one per layer) -> fills cnt/s1/s2.
+        `events=(start, stop)`: torch.cuda.Events recorded on the launch stream around the streaming
+        (partials) kernel only -- bench.py's live kernel timing."""
         if len(feats) != self.n_layers:
             raise ValueError("one feature per planned layer expected")
         for i, t in enumerate(feats):
@@ -191,9 +193,18 @@ class StatPlan:
             if t.numel() != outer * c * inner:
                 raise _lib.VittaHipError(f"feature {i} has {t.numel()} elements, plan expects {outer * c * inner}")
             self._ptr_arr[i] = t.data_ptr()
-        check(lib().vitta_moments_batched_f32(self._h, self._ptr_arr, _p(shift), _p(self.cnt), _p(self.s1),
-                                              _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
-              "vitta_moments_batched_f32")
+        if events is None:
+            check(lib().vitta_moments_batched_f32(self._h, self._ptr_arr, _p(shift), _p(self.cnt), _p(self.s1),
+                                                  _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
+                  "vitta_moments_batched_f32")
+        else:
+            events[0].record()
+            check(lib().vitta_moments_partials_f32(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream()),
+                  "vitta_moments_partials_f32")
+            events[1].record()
+            check(lib().vitta_moments_finalize_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2),
+                                                   _p(self.ws), self.ws_bytes, _stream()),
+                  "vitta_moments_finalize_f32")
         return self.cnt, self.s1, self.s2
 
     def mean_var(self, shift=None):
