@@ -41,6 +41,14 @@ HOOKED_ELEMENTS_PER_VIDEO = 44556288  # 29 BN2d outputs of lay
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -105,6 +113,7 @@ def run_gpu(opt, rank, world, device):
     args = make_args(tmp, opt.size, opt.clip_length, opt.optimizer, device, n_videos)
     args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
     args.synthetic_seed = 10000 * rank  # every rank adapts to its own videos (weak scaling)
+    log("model + source statistics ready")
     adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
     tta_set = data.build_tanet_dataset(args, "val", "tta")
     eval_set = data.build_tanet_dataset(args, "val", "eval")
@@ -135,6 +144,11 @@ def run_gpu(opt, rank, world, device):
 
     for i in range(opt.warmup):
         one_step(i)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first warm-up step done")
+    torch.cuda.synchronize()
+    log("warm-up done")
     adapter.engine.timing_events = new_events
     barrier()
     t0 = time.perf_counter()
@@ -142,6 +156,7 @@ def run_gpu(opt, rank, world, device):
         one_step(opt.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps")
     adapter.engine.timing_events = None
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")
 
@@ -163,6 +178,7 @@ def run_gpu(opt, rank, world, device):
     streaming = None
     if rank == 0 and not opt.no_streaming:
         streaming = streaming_moments(adapter, device)
+        log("streaming-size moments done")
     return elapsed, kern_ms, adapt_only, streaming, adapter
 
 
@@ -213,7 +229,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=device)
-    torch.backends.cudnn.benchmark = True  # corpus/main_eval.py:77 (MIOpen find mode on ROCm)
+    # corpus/main_eval.py:77 sets cudnn.benchmark (an exhaustive MIOpen find on ROCm: minutes of search
+    # per conv shape); the bench keeps MIOpen's default immediate mode
 
     elapsed, kern_ms, adapt_only, streaming, adapter = run_gpu(opt, rank, world, device)
     videos = opt.steps * world
@@ -242,7 +259,9 @@ def main():
     if rank == 0 and world == 1 and not opt.no_cpu_baseline:
         del adapter
         torch.cuda.empty_cache()
+        log("cpu baseline ...")
         line["cpu_baseline"] = run_cpu_baseline(opt)
+        log("cpu baseline done")
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

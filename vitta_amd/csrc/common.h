@@ -107,7 +107,16 @@ struct vitta_plan {
   int32_t* d_chan2layer = nullptr;
 };
 
-#define VITTA_CHECK_LAUNCH()                                  \
-  do {                                                        \
-    if (hipGetLastError() != hipSuccess) return VITTA_ERR_LAUNCH; \
+// hipGetLastError() is sticky per host thread: an unrelated earlier runtime call (e.g. a probing call
+// of the framework that owns the context) may have left an error behind.  VITTA_LAUNCH clears it,
+// launches, and returns VITTA_ERR_LAUNCH from the enclosing ABI function if THIS launch failed.
+#define VITTA_LAUNCH(...)                                          \
+  do {                                                             \
+    (void)hipGetLastError();                                       \
+    hipLaunchKernelGGL(__VA_ARGS__);                               \
+    if (hipGetLastError() != hipSuccess) return VITTA_ERR_LAUNCH;  \
+  } while (0)
+
+#define VITTA_CHECK_LAUNCH() \
+  do {                       \
   } while (0)

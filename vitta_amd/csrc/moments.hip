@@ -431,12 +431,12 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     pack.x[l] = x;
   }
   if (p->n_blocks_nchw) {
-    hipLaunchKernelGGL(moments_nchw_partial_kernel, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
+    VITTA_LAUNCH(moments_nchw_partial_kernel, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
                        p->d_info, p->d_tab_nchw, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
   if (p->n_blocks_nhwc) {
-    hipLaunchKernelGGL(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
+    VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
                        p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
@@ -455,7 +455,7 @@ int vitta_moments_finalize_f32(const vitta_plan* p, const float* d_shift, float*
   if (!p || !d_cnt || !d_s1 || !d_s2) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
-  hipLaunchKernelGGL(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream),
+  VITTA_LAUNCH(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream),
                      p->d_info, p->d_chan2layer, p->total_channels, static_cast<const float*>(d_ws), d_shift, 0,
                      d_cnt, d_s1, d_s2);
   VITTA_CHECK_LAUNCH();
@@ -472,7 +472,7 @@ int vitta_moments_batched_f32(const vitta_plan* p, const void* const* h_x, const
   const int rc = launch_partials(p, h_x, ws, st);
   if (rc != VITTA_OK) return rc;
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
-  hipLaunchKernelGGL(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info,
+  VITTA_LAUNCH(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info,
                      p->d_chan2layer, p->total_channels, ws, d_shift, 0, d_cnt, d_s1, d_s2);
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
@@ -483,7 +483,7 @@ int vitta_moments_to_meanvar_f32(const vitta_plan* p, const float* d_shift, cons
                                  void* stream) {
   if (!p || !d_cnt || !d_s1 || !d_s2 || !d_mean || !d_var) return VITTA_ERR_INVALID_ARG;
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
-  hipLaunchKernelGGL(moments_to_meanvar_kernel, dim3(grid), dim3(VITTA_BLOCK), 0,
+  VITTA_LAUNCH(moments_to_meanvar_kernel, dim3(grid), dim3(VITTA_BLOCK), 0,
                      static_cast<hipStream_t>(stream), p->d_info, p->d_chan2layer, p->total_channels,
                      d_shift, d_cnt, d_s1, d_s2, d_mean, d_var);
   VITTA_CHECK_LAUNCH();
@@ -551,20 +551,20 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
   int32_t* d_c2l = reinterpret_cast<int32_t*>(base + sp.bytes_info + sp.bytes_tab);
   float* d_part = reinterpret_cast<float*>(base + sp.bytes_info + sp.bytes_tab + sp.bytes_c2l);
   // tables + the layer record are written by a small kernel (stream ordered, no host staging)
-  hipLaunchKernelGGL(single_tables_kernel, dim3((std::max(sp.n_blocks, (int)C) + 255) / 256), dim3(256),
+  VITTA_LAUNCH(single_tables_kernel, dim3((std::max(sp.n_blocks, (int)C) + 255) / 256), dim3(256),
                      0, s, d_tab, d_c2l, d_info, sp.info, sp.info.nchunks, sp.n_blocks, (int)C);
   VITTA_CHECK_LAUNCH();
   PtrPack pack;
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   pack.x[0] = d_x;
   if (layout == VITTA_LAYOUT_NCHW)
-    hipLaunchKernelGGL(moments_nchw_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+    VITTA_LAUNCH(moments_nchw_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
   else
-    hipLaunchKernelGGL(moments_nhwc_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+    VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
   VITTA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(moments_finalize_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK),
+  VITTA_LAUNCH(moments_finalize_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK),
                      0, s, d_info, d_c2l, (int64_t)C, d_part, (const float*)nullptr, 1, (float*)nullptr,
                      d_mean, d_var);
   VITTA_CHECK_LAUNCH();

@@ -270,14 +270,14 @@ int vitta_stat_align_fwd_f32(const vitta_plan* p, const float* d_shift, const fl
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* term = static_cast<float*>(d_ws) + 3 * (size_t)p->ws_triples;
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
-  hipLaunchKernelGGL(stat_align_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info, p->d_chan2layer,
+  VITTA_LAUNCH(stat_align_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info, p->d_chan2layer,
                      p->total_channels, d_shift, d_cnt, d_s1, d_s2, d_ema_mean, d_ema_var, d_src_mean,
                      d_src_var, momentum, reg_type, term, d_mu, d_coef_a, d_coef_b);
   VITTA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(layer_loss_kernel, dim3(p->n_layers), dim3(VITTA_BLOCK), 0, st, p->d_info, term,
+  VITTA_LAUNCH(layer_loss_kernel, dim3(p->n_layers), dim3(VITTA_BLOCK), 0, st, p->d_info, term,
                      d_layer_loss);
   VITTA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, d_layer_loss, p->n_layers,
+  VITTA_LAUNCH(total_loss_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, d_layer_loss, p->n_layers,
                      d_total_loss);
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
@@ -299,7 +299,7 @@ int vitta_stat_align_bwd_f32(const float* d_x, const float* d_gout, float* d_gin
     if (nsplit > outer / 4) nsplit = outer / 4;       // keep >= 4 frames per lane
     if (nsplit < 1) nsplit = 1;
     if (nsplit > 65535) nsplit = 65535;
-    hipLaunchKernelGGL(align_bwd_nchw_kernel, dim3((unsigned)nchunks, (unsigned)nsplit), dim3(VITTA_BLOCK), 0,
+    VITTA_LAUNCH(align_bwd_nchw_kernel, dim3((unsigned)nchunks, (unsigned)nsplit), dim3(VITTA_BLOCK), 0,
                        st, d_x, d_gout, d_gin, outer, plane, inner, (int)nsplit, d_mu, d_coef_a, d_coef_b,
                        d_gscale, vec);
   } else if (layout == VITTA_LAYOUT_NHWC) {
@@ -310,7 +310,7 @@ int vitta_stat_align_bwd_f32(const float* d_x, const float* d_gout, float* d_gin
     const int64_t work = (outer * C) / vec;
     int64_t grid = (work + VITTA_BLOCK - 1) / VITTA_BLOCK;
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(align_bwd_nhwc_kernel, dim3((unsigned)grid), dim3(VITTA_BLOCK), 0, st, d_x, d_gout,
+    VITTA_LAUNCH(align_bwd_nhwc_kernel, dim3((unsigned)grid), dim3(VITTA_BLOCK), 0, st, d_x, d_gout,
                        d_gin, outer, (int)C, d_mu, d_coef_a, d_coef_b, d_gscale, vec);
   } else {
     return VITTA_ERR_INVALID_ARG;
@@ -327,10 +327,10 @@ int vitta_pred_consis_f32(const float* d_logits, int32_t B, int32_t V, int32_t K
   hipStream_t st = static_cast<hipStream_t>(stream);
   // d_loss has room for 1 + B floats: [0] = total, [1..B] = per-video partial sums (see header)
   float* part = d_loss + 1;
-  hipLaunchKernelGGL(pred_consis_kernel, dim3(B), dim3(VITTA_BLOCK), lds, st, d_logits, (int)V, (int)K, part,
+  VITTA_LAUNCH(pred_consis_kernel, dim3(B), dim3(VITTA_BLOCK), lds, st, d_logits, (int)V, (int)K, part,
                      d_grad);
   VITTA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(pred_consis_total_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, part, (int)B, d_loss);
+  VITTA_LAUNCH(pred_consis_total_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, part, (int)B, d_loss);
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }

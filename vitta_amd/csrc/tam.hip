@@ -223,9 +223,9 @@ inline unsigned row_grid(int64_t rows, int lpr) {
 #define TAM_DISPATCH(KERNEL, rows, HW, st, ...)                                                          \
   do {                                                                                                   \
     if ((HW) > 256)                                                                                      \
-      hipLaunchKernelGGL(KERNEL<64>, dim3(row_grid(rows, 64)), dim3(VITTA_BLOCK), 0, st, __VA_ARGS__);   \
+      VITTA_LAUNCH(KERNEL<64>, dim3(row_grid(rows, 64)), dim3(VITTA_BLOCK), 0, st, __VA_ARGS__);   \
     else                                                                                                 \
-      hipLaunchKernelGGL(KERNEL<16>, dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, __VA_ARGS__);   \
+      VITTA_LAUNCH(KERNEL<16>, dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, __VA_ARGS__);   \
   } while (0)
 
 extern "C" {
@@ -270,7 +270,7 @@ int vitta_tam_agg_bwd_f32(const float* d_x, const float* d_gate, const float* d_
                d_gx, dots);
   VITTA_CHECK_LAUNCH();
   const int64_t NC = (int64_t)N * C;
-  hipLaunchKernelGGL(tam_finish_bwd_kernel, dim3((unsigned)((NC + VITTA_BLOCK - 1) / VITTA_BLOCK)),
+  VITTA_LAUNCH(tam_finish_bwd_kernel, dim3((unsigned)((NC + VITTA_BLOCK - 1) / VITTA_BLOCK)),
                      dim3(VITTA_BLOCK), 0, st, d_gate, d_kern, dots, NC, (int)T, d_ggate, d_gkern);
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
