@@ -207,10 +207,16 @@ def streaming_moments(adapter, device, copies=6, reps=20):
 def run_cpu_baseline(opt):
     """The reference path restated on the CPU (oracle/), same workload, bounded sample."""
     from oracle import cpu_path
-    cores = os.cpu_count() or 1
+    # threads = the CPUs this process may actually run on (cgroup / affinity), not every core of the host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
     sec, steps = cpu_path.time_tta_steps(size=opt.size, clip_length=opt.clip_length, optimizer=opt.optimizer,
-                                         warmup=1, steps=opt.cpu_steps)
+                                         warmup=1, steps=opt.cpu_steps, budget_s=25.0, log=log)
     return dict(value=steps / sec, unit="videos/s", cores=cores, kind="port",
                 sample=f"{steps} full per-video iterations (adapt step + eval forward) after 1 warm-up, TANet-R50 "
                        f"2x{opt.clip_length}x{opt.size}^2 fp32, torch CPU ops in the reference's op order, "

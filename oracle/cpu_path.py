@@ -71,7 +71,8 @@ def build_adapter(size=224, clip_length=8, optimizer="adam_affine"):
     return adapter, a
 
 
-def time_tta_steps(size=224, clip_length=8, optimizer="adam_affine", warmup=1, steps=4):
+def time_tta_steps(size=224, clip_length=8, optimizer="adam_affine", warmup=1, steps=4, budget_s=30.0, log=None):
+    """Time up to `steps` iterations; stops early once `budget_s` seconds of timed work are spent."""
     from vitta_amd import data
     adapter, a = build_adapter(size, clip_length, optimizer)
     tta_set = data.SyntheticVideoDataset(warmup + steps, 2, clip_length, size, 101, "tanet", seed0=0)
@@ -85,8 +86,17 @@ def time_tta_steps(size=224, clip_length=8, optimizer="adam_affine", warmup=1, s
         adapter.add_hooks_back()
 
     for i in range(warmup):
+        tw = time.perf_counter()
         one(i)
+        if log:
+            log(f"cpu warm-up step {i}: {time.perf_counter() - tw:.2f}s")
     t0 = time.perf_counter()
+    done = 0
     for i in range(steps):
         one(warmup + i)
-    return time.perf_counter() - t0, steps
+        done += 1
+        if log:
+            log(f"cpu step {i}: cumulative {time.perf_counter() - t0:.2f}s")
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return time.perf_counter() - t0, done

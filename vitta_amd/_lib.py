@@ -68,6 +68,12 @@ def lib():
         raise VittaHipError(
             f"{LIB_PATH} not found: build it with `python -m vitta_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    # Load order matters: PyTorch-ROCm ships its own libamdhip64; importing torch (and creating its HIP
+    # context) first makes libvitta_hip.so bind to the SAME runtime instance that owns the tensors and
+    # streams it is handed.  Loaded the other way round, launches on torch's streams fail.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
