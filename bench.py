@@ -212,6 +212,12 @@ def run_cpu_baseline(opt):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:  # cgroup v2 CPU quota ("<quota> <period>"), e.g. 16 CPUs on a 256-thread host
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
