@@ -69,3 +69,52 @@ def test_hip_path_refuses_cpu_tensors():
     from vitta_amd import _lib, ops
     with pytest.raises(_lib.VittaHipError):
         ops.moments(torch.randn(4, 3, 2, 2), "bn2d")
+
+
+def test_graph_replay_equals_eager_on_gpu(tmp_path):
+    """hipGraph replay of the adapt step / eval forward == eager launches (dropout disabled so both
+    arms see the same arithmetic): same losses, same adapted logits, same EMA state after 4 videos."""
+    import json
+    import numpy as np
+    from vitta_amd import data, tta
+    g = H.golden("tta3.npz")
+    cfg = json.loads(str(g["config"]))
+    T, size = cfg["T"], cfg["size"]
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    means = [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))]
+    vars_ = [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))]
+    mp, vp = H.write_stat_files(str(tmp_path), means, vars_)
+    args = H.tanet_args(tmp_path, clip_length=T, input_size=size, spatiotemp_mean_clean_file=mp,
+                        spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=1e-4)
+    tta_set = data.SyntheticVideoDataset(5, 2, T, size, 101, "tanet", seed0=700)
+    eval_set = data.SyntheticVideoDataset(5, 1, T, size, 101, "tanet", seed0=700)
+
+    def run(capture_at):
+        model = H.build_tanet(101, T, 0)
+        model.base_model.fc = nn.Identity()  # no dropout: eager and graph arms must agree exactly
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(_dev()), args)
+        out = []
+        for i in range(5):
+            x = adapter.shape_tta_input(tta_set[i][0].unsqueeze(0).to(_dev()))
+            ev = adapter.shape_eval_input(eval_set[i][0].unsqueeze(0).to(_dev()))
+            if capture_at is not None and i == capture_at:
+                adapter.capture_graphs(x, ev)
+            if adapter._graph is None:
+                adapter.set_adapt_mode()
+            _, lr_, lc_ = adapter.adapt_step(x)
+            lr_, lc_ = lr_.detach().clone(), lc_.detach().clone()
+            if adapter._graph is None:
+                adapter.close_hooks()
+            logits = adapter.evaluate(ev).clone()
+            if adapter._graph is None:
+                adapter.add_hooks_back()
+            out.append((lr_.item(), lc_.item(), logits.cpu()))
+        return out, adapter.engine.ema_mean.cpu().clone()
+
+    eager, ema_e = run(None)
+    graphed, ema_g = run(2)
+    for (a, b, c), (d, e, f) in zip(eager, graphed):
+        assert a == pytest.approx(d, rel=1e-5) and b == pytest.approx(e, rel=1e-4)
+        assert_logits_close(f, c, 2e-3)
+    torch.testing.assert_close(ema_g, ema_e, rtol=1e-4, atol=1e-6)

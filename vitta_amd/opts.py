@@ -4,7 +4,8 @@
 * flags the reference declares with `type=bool` (any non-empty string parsed as True,
   opts.py:52,67,72-75,84-86,93,97) parse "false"/"0"/"no" as False here; defaults unchanged;
 * `get_opts(argv=None)` accepts an explicit argv (the reference always reads sys.argv);
-* `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py.
+* `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py;
+* `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 """
 import argparse
 
@@ -92,6 +93,7 @@ _FLAGS = [
     (("--reg_type",), dict(type=str, default="l1_loss")),
     (("--chosen_blocks",), dict(default=["layer3", "layer4"])),
     (("--moving_avg",), dict(type=_bool, default=True)),
+    (("--hip_graph",), dict(type=_bool, default=True, help="(extension) replay the per-video step from captured hipGraphs")),
     (("--n_gradient_steps",), dict(type=int, default=1, help="number of gradient steps per sample")),
     # input / optimiser
     (("--full_res",), dict(action="store_true")),

@@ -33,6 +33,9 @@ from .utils_ import AverageMeter, accuracy
 # the product default (None) is the HIP backend, which raises on CPU tensors.
 BACKEND_FACTORY = None
 
+# tta_standard runs this many videos eagerly, then captures the step into hipGraphs (None: never)
+GRAPH_AFTER_STEPS = 3
+
 NUM_CLASSES = {"ucf101": 101, "hmdb51": 51, "kinetics": 400, "somethingv2": 174, "kth": 6, "u2h": 12, "h2u": 12}
 
 
@@ -229,7 +232,9 @@ class ViTTAAdapter:
             kinds = list(self.bn_types) if args.arch == "tanet" else [nn.LayerNorm]
             freeze_except_bn(model, bn_condidiate_layers=kinds)
             params, self.param_names = collect_bn_params(model, bn_candidate_layers=kinds)
-            self.optimizer = torch.optim.Adam(params, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0)
+            # capturable: the step counter lives on the device, so the whole step can sit in a hipGraph
+            self.optimizer = torch.optim.Adam(params, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0,
+                                              capturable=self.device.type == "cuda")
         else:
             params = list(model.parameters())
             self.optimizer = torch.optim.SGD(params=params, lr=args.lr, momentum=args.momentum,
@@ -259,6 +264,7 @@ class ViTTAAdapter:
                                            n_augmented_views=args.n_augmented_views, engine=self.engine,
                                            backend=engine_backend)
             for i, _, layer in self.hooked]
+        self._graph = None  # (adapt graph, eval graph, static buffers) once capture_graphs() ran
         self.n_clips = _n_clips(args)
         self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
         self.n_views = args.test_crops * (args.n_augmented_views if args.if_sample_tta_aug_views else self.n_clips)
@@ -322,7 +328,16 @@ class ViTTAAdapter:
     def adapt_step(self, input, has_video=True):
         """One gradient step on one (already device-resident, already reshaped) TTA input.
         `has_video=False`: ragged tail of a data-parallel run -- this rank only takes part in the two
-        exchanges so that EMA state and weights stay identical everywhere."""
+        exchanges so that EMA state and weights stay identical everywhere.
+        With captured graphs (capture_graphs) a step is: copy the clip into the static buffer, replay."""
+        g = self._graph
+        if g is not None and has_video and input.shape == g["tta_in"].shape:
+            g["tta_in"].copy_(input)
+            g["adapt"].replay()
+            return g["adapt_out"]
+        return self._adapt_step_eager(input, has_video)
+
+    def _adapt_step_eager(self, input, has_video=True):
         a = self.args
         if self.bucket is not None:
             self.bucket.zero()
@@ -346,8 +361,42 @@ class ViTTAAdapter:
         self.optimizer.step()
         return output, loss_reg, loss_consis
 
-    @torch.no_grad()
     def evaluate(self, input):
+        g = self._graph
+        if g is not None and input.shape == g["eval_in"].shape:
+            g["eval_in"].copy_(input)
+            g["eval"].replay()
+            return g["eval_out"]
+        return self._evaluate_eager(input)
+
+    def capture_graphs(self, tta_input, eval_input):
+        """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
+        evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
+        the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
+        step).  Requirements: a few eager steps ran before (launch plans, optimizer state and MIOpen
+        solutions exist), fixed input shapes, single process (no collective inside the capture).
+        Capturing records launches without executing them: model, EMA and optimizer state are untouched."""
+        if self.device.type != "cuda" or self.world > 1:
+            raise RuntimeError("graph capture needs a single-process CUDA(HIP) run")
+        if self.engine is not None and self.engine.plan is None:
+            raise RuntimeError("run at least one eager step before capturing")
+        g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
+        torch.cuda.synchronize()
+        self.set_adapt_mode()
+        self.optimizer.zero_grad(set_to_none=True)
+        g["adapt"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["adapt"]):
+            g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True)
+        self.close_hooks()
+        g["eval"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["eval"]):
+            g["eval_out"] = self._evaluate_eager(g["eval_in"])
+        self.add_hooks_back()
+        torch.cuda.synchronize()
+        self._graph = g
+
+    @torch.no_grad()
+    def _evaluate_eager(self, input):
         self.model.eval()
         a = self.args
         if a.arch == "tanet":
@@ -411,6 +460,11 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
         if adapter is None or args.if_tta_standard == "tta_standard":
             print(f"Batch {batch_id}, initialize the model, update chosen layers, initialize hooks, intialize average meter")
             adapter = ViTTAAdapter(model_origin, args)
+        if (adapter._graph is None and GRAPH_AFTER_STEPS is not None and batch_id == GRAPH_AFTER_STEPS and has_video
+                and getattr(args, "hip_graph", True) and device.type == "cuda" and world == 1
+                and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1):
+            ev0 = eval_set[0][0].unsqueeze(0).expand(input.shape[0], *eval_set[0][0].shape)
+            adapter.capture_graphs(adapter.shape_tta_input(input.to(device)), adapter.shape_eval_input(ev0.to(device)))
         adapter.set_adapt_mode()
         row = torch.zeros(DeferredLog.FIELDS, dtype=torch.float32, device=device)
         actual_bz = 0
