@@ -68,6 +68,12 @@ typedef struct vitta_plan vitta_plan;
 
 int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
                       vitta_plan** out_plan);
+/* The plan itself is a host object.  Its device tables live in a CALLER-OWNED device buffer of
+ * vitta_plan_table_bytes() bytes (256-byte aligned) that must outlive the plan's launches;
+ * vitta_plan_upload copies them there (stream-ordered) and must precede the first launch.  The
+ * library never allocates or frees device memory. */
+size_t vitta_plan_table_bytes(const vitta_plan* plan);
+int vitta_plan_upload(vitta_plan* plan, void* d_tables, size_t bytes, void* stream);
 void vitta_plan_destroy(vitta_plan* plan);
 int64_t vitta_plan_total_channels(const vitta_plan* plan);
 int64_t vitta_plan_channel_offset(const vitta_plan* plan, int layer);

@@ -110,7 +110,9 @@ def test_graph_replay_equals_eager_on_gpu(tmp_path):
             if adapter._graph is None:
                 adapter.add_hooks_back()
             out.append((lr_.item(), lc_.item(), logits.cpu()))
-        return out, adapter.engine.ema_mean.cpu().clone()
+        ema = adapter.engine.ema_mean.cpu().clone()
+        torch.cuda.synchronize()
+        return out, ema
 
     eager, ema_e = run(None)
     graphed, ema_g = run(2)

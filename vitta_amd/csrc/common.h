@@ -100,7 +100,10 @@ struct vitta_plan {
   int64_t ws_triples = 0;
   int n_blocks_nchw = 0, n_blocks_nhwc = 0;
   vitta::LayerInfo h_info[VITTA_MAX_LAYERS];
-  // device tables
+  // host image of the device tables: [LayerInfo x L | BlockEnt nchw | BlockEnt nhwc | chan2layer]
+  void* h_tables = nullptr;
+  size_t table_bytes = 0, off_nchw = 0, off_nhwc = 0, off_c2l = 0;
+  // device tables: views into the CALLER-OWNED buffer handed to vitta_plan_upload (never freed here)
   vitta::LayerInfo* d_info = nullptr;
   vitta::BlockEnt* d_tab_nchw = nullptr;
   vitta::BlockEnt* d_tab_nhwc = nullptr;

@@ -23,6 +23,8 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <new>
 #include <vector>
 
@@ -385,28 +387,41 @@ int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int targe
   for (int l = 0; l < n_layers; ++l)
     for (int c = 0; c < p->h_info[l].C; ++c) c2l[(size_t)p->h_info[l].chan_off + c] = l;
 
-  bool ok = hipMalloc(&p->d_info, sizeof(LayerInfo) * n_layers) == hipSuccess;
-  ok = ok && hipMalloc(&p->d_chan2layer, sizeof(int32_t) * (size_t)coff) == hipSuccess;
-  if (ok && !tab_nchw.empty()) ok = hipMalloc(&p->d_tab_nchw, sizeof(BlockEnt) * tab_nchw.size()) == hipSuccess;
-  if (ok && !tab_nhwc.empty()) ok = hipMalloc(&p->d_tab_nhwc, sizeof(BlockEnt) * tab_nhwc.size()) == hipSuccess;
-  if (!ok) { vitta_plan_destroy(p); return VITTA_ERR_ALLOC; }
-  ok = hipMemcpy(p->d_info, p->h_info, sizeof(LayerInfo) * n_layers, hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && hipMemcpy(p->d_chan2layer, c2l.data(), sizeof(int32_t) * (size_t)coff, hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && !tab_nchw.empty())
-    ok = hipMemcpy(p->d_tab_nchw, tab_nchw.data(), sizeof(BlockEnt) * tab_nchw.size(), hipMemcpyHostToDevice) == hipSuccess;
-  if (ok && !tab_nhwc.empty())
-    ok = hipMemcpy(p->d_tab_nhwc, tab_nhwc.data(), sizeof(BlockEnt) * tab_nhwc.size(), hipMemcpyHostToDevice) == hipSuccess;
-  if (!ok) { vitta_plan_destroy(p); return VITTA_ERR_ALLOC; }
+  auto pad = [](size_t v) { return (v + 255) / 256 * 256; };
+  p->off_nchw = pad(sizeof(LayerInfo) * n_layers);
+  p->off_nhwc = p->off_nchw + pad(sizeof(BlockEnt) * tab_nchw.size());
+  p->off_c2l = p->off_nhwc + pad(sizeof(BlockEnt) * tab_nhwc.size());
+  p->table_bytes = p->off_c2l + pad(sizeof(int32_t) * (size_t)coff);
+  p->h_tables = calloc(1, p->table_bytes);
+  if (!p->h_tables) { delete p; return VITTA_ERR_ALLOC; }
+  char* h = static_cast<char*>(p->h_tables);
+  memcpy(h, p->h_info, sizeof(LayerInfo) * n_layers);
+  if (!tab_nchw.empty()) memcpy(h + p->off_nchw, tab_nchw.data(), sizeof(BlockEnt) * tab_nchw.size());
+  if (!tab_nhwc.empty()) memcpy(h + p->off_nhwc, tab_nhwc.data(), sizeof(BlockEnt) * tab_nhwc.size());
+  memcpy(h + p->off_c2l, c2l.data(), sizeof(int32_t) * (size_t)coff);
   *out_plan = p;
+  return VITTA_OK;
+}
+
+size_t vitta_plan_table_bytes(const vitta_plan* p) { return p ? p->table_bytes : 0; }
+
+int vitta_plan_upload(vitta_plan* p, void* d_tables, size_t bytes, void* stream) {
+  if (!p || !d_tables || bytes < p->table_bytes) return VITTA_ERR_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(d_tables) & 255u) return VITTA_ERR_INVALID_ARG;
+  if (hipMemcpyAsync(d_tables, p->h_tables, p->table_bytes, hipMemcpyHostToDevice,
+                     static_cast<hipStream_t>(stream)) != hipSuccess)
+    return VITTA_ERR_LAUNCH;
+  char* d = static_cast<char*>(d_tables);
+  p->d_info = reinterpret_cast<LayerInfo*>(d);
+  p->d_tab_nchw = reinterpret_cast<BlockEnt*>(d + p->off_nchw);
+  p->d_tab_nhwc = reinterpret_cast<BlockEnt*>(d + p->off_nhwc);
+  p->d_chan2layer = reinterpret_cast<int32_t*>(d + p->off_c2l);
   return VITTA_OK;
 }
 
 void vitta_plan_destroy(vitta_plan* p) {
   if (!p) return;
-  if (p->d_info) (void)hipFree(p->d_info);
-  if (p->d_tab_nchw) (void)hipFree(p->d_tab_nchw);
-  if (p->d_tab_nhwc) (void)hipFree(p->d_tab_nhwc);
-  if (p->d_chan2layer) (void)hipFree(p->d_chan2layer);
+  free(p->h_tables);  // device tables belong to the caller
   delete p;
 }
 
@@ -422,6 +437,7 @@ size_t vitta_plan_workspace_bytes(const vitta_plan* p) {
 int64_t vitta_plan_num_blocks(const vitta_plan* p) { return p ? p->n_blocks_nchw + p->n_blocks_nhwc : -1; }
 
 static int launch_partials(const vitta_plan* p, const void* const* h_x, float* ws, hipStream_t st) {
+  if (!p->d_info) return VITTA_ERR_INVALID_ARG;  // vitta_plan_upload not called
   PtrPack pack;
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   for (int l = 0; l < p->n_layers; ++l) {

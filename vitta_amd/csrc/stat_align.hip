@@ -265,7 +265,7 @@ int vitta_stat_align_fwd_f32(const vitta_plan* p, const float* d_shift, const fl
   if (!p || !d_cnt || !d_s1 || !d_s2 || !d_ema_mean || !d_ema_var || !d_src_mean || !d_src_var ||
       !d_layer_loss || !d_total_loss || !d_mu || !d_coef_a || !d_coef_b)
     return VITTA_ERR_INVALID_ARG;
-  if (reg_type < VITTA_REG_L1 || reg_type > VITTA_REG_KLD) return VITTA_ERR_INVALID_ARG;
+  if (reg_type < VITTA_REG_L1 || reg_type > VITTA_REG_KLD || !p->d_info) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* term = static_cast<float*>(d_ws) + 3 * (size_t)p->ws_triples;

@@ -147,6 +147,10 @@ class StatPlan:
             check(lib().vitta_plan_create(arr, n, target_blocks, C.byref(handle)), "vitta_plan_create")
         self._h = handle
         L = lib()
+        # device tables of the plan: a torch-owned buffer (the library never allocates device memory)
+        self.tables = torch.empty(int(L.vitta_plan_table_bytes(self._h)), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(L.vitta_plan_upload(self._h, _p(self.tables), self.tables.numel(), _stream()), "vitta_plan_upload")
         self.n_layers = n
         self.total_channels = int(L.vitta_plan_total_channels(self._h))
         self.offsets = [int(L.vitta_plan_channel_offset(self._h, i)) for i in range(n)]

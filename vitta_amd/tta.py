@@ -378,7 +378,10 @@ class ViTTAAdapter:
         Capturing records launches without executing them: model, EMA and optimizer state are untouched."""
         if self.device.type != "cuda" or self.world > 1:
             raise RuntimeError("graph capture needs a single-process CUDA(HIP) run")
-        if self.engine is not None and self.engine.plan is None:
+        if self.engine is None:
+            raise RuntimeError("graph capture needs the batched engine (the stand-alone hooks keep host-side "
+                               "EMA scalars that cannot be captured)")
+        if self.engine.plan is None:
             raise RuntimeError("run at least one eager step before capturing")
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
@@ -461,7 +464,7 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
             print(f"Batch {batch_id}, initialize the model, update chosen layers, initialize hooks, intialize average meter")
             adapter = ViTTAAdapter(model_origin, args)
         if (adapter._graph is None and GRAPH_AFTER_STEPS is not None and batch_id == GRAPH_AFTER_STEPS and has_video
-                and getattr(args, "hip_graph", True) and device.type == "cuda" and world == 1
+                and getattr(args, "hip_graph", True) and device.type == "cuda" and world == 1 and adapter.engine is not None
                 and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1):
             ev0 = eval_set[0][0].unsqueeze(0).expand(input.shape[0], *eval_set[0][0].shape)
             adapter.capture_graphs(adapter.shape_tta_input(input.to(device)), adapter.shape_eval_input(ev0.to(device)))
