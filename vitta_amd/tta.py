@@ -359,7 +359,10 @@ class ViTTAAdapter:
         if self.bucket is not None:
             self.bucket.all_reduce()
         self.optimizer.step()
-        return output, loss_reg, loss_consis
+        # detached: nothing the caller holds may keep this step's autograd graph (and its AccumulateGrad
+        # nodes, which remember the stream they were created on) alive into a later graph capture
+        det = lambda t: None if t is None else t.detach()
+        return det(output), det(loss_reg), det(loss_consis)
 
     def evaluate(self, input):
         g = self._graph
