@@ -1,0 +1,125 @@
+"""Data-parallel path on the CPU: 2 ranks over gloo reproduce the reference run with batch_size=2
+(SURVEY section 8e).  Exchanges under test: ONE all-reduce of the packed moments [cnt|s1|s2] before the
+EMA update, ONE SUM all-reduce of the flat gradient buffer before the optimizer step, the ragged tail."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import helpers as H
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_main(rank, world, port, tmp, mode):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import test_host_cpu as T
+    from oracle.oracle_backend import OracleBackend
+    from vitta_amd import data, tta
+    g = H.golden("tta3_bz2.npz")
+    cfg = json.loads(str(g["config"]))
+    Tn, size = cfg["T"], cfg["size"]
+    model = H.build_tanet(101, Tn, 0)
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    rdir = os.path.join(tmp, f"r{rank}")
+    os.makedirs(rdir, exist_ok=True)
+    mp_, vp_ = H.write_stat_files(rdir, [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                  [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(rdir, clip_length=Tn, input_size=size, batch_size=1, spatiotemp_mean_clean_file=mp_,
+                        spatiotemp_var_clean_file=vp_, lr=cfg["lr_sgd"])
+    # rank r sees rows [16 r, 16 r + 16) of the reference's batch-of-two dropout masks
+    masks = []
+    for i in range(3):
+        m = H.unpack_mask(g[f"sgd_step{i}_dropmask"], g[f"sgd_step{i}_dropmask_shape"])
+        masks.append(m[rank * 2 * Tn:(rank + 1) * 2 * Tn])
+    tta.BACKEND_FACTORY = OracleBackend
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+    tta.BACKEND_FACTORY = None
+    assert adapter.world == 2 and adapter.bucket is not None and adapter.engine.distributed
+    adapter.model.module.base_model.fc = H.ReplayDropout(0.8, masks)
+    tta_set = data.SyntheticVideoDataset(cfg["n_videos"], 2, Tn, size, 101, "tanet", seed0=cfg["seed0"])
+    eval_set = data.SyntheticVideoDataset(cfg["n_videos"], 1, Tn, size, 101, "tanet", seed0=cfg["seed0"])
+    out = {}
+    steps = 3 if mode == "full" else 2
+    for step in range(steps):
+        vid = 2 * step + rank
+        has_video = not (mode == "ragged" and step == 1 and rank == 1)  # rank 1 runs dry on the last step
+        adapter.set_adapt_mode()
+        x = adapter.shape_tta_input(tta_set[vid][0].unsqueeze(0)) if has_video else None
+        _, loss_reg, loss_consis = adapter.adapt_step(x, has_video)
+        named = dict(adapter.model.named_parameters())
+        adapter.close_hooks()
+        logits = adapter.evaluate(adapter.shape_eval_input(eval_set[vid][0].unsqueeze(0)))
+        adapter.add_hooks_back()
+        out[f"step{step}_loss_reg"] = float(loss_reg)
+        out[f"step{step}_loss_consis"] = float(loss_consis) if loss_consis is not None else float("nan")
+        out[f"step{step}_logits"] = logits.numpy()
+        out[f"step{step}_ema_sum"] = float(adapter.engine.ema_mean.double().sum())
+        out[f"step{step}_param_sum"] = float(sum(float(p.double().sum()) for p in named.values()))
+        for name in map(str, g["sampled_params"]):
+            out[f"step{step}_param::{name}"] = named[name].detach().numpy()[:int(g["sample_rows"])].copy()
+            out[f"step{step}_grad::{name}"] = named[name].grad.detach().numpy()[:int(g["sample_rows"])].copy()
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **out)
+    torch.distributed.destroy_process_group()
+
+
+def _run(tmp_path, mode):
+    port = _free_port()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
+
+
+def test_two_ranks_equal_reference_batch_of_two(tmp_path):
+    g = H.golden("tta3_bz2.npz")
+    r0, r1 = _run(tmp_path, "full")
+    rows = int(g["sample_rows"])
+    for i in range(3):
+        k = f"sgd_step{i}_"
+        ref_reg, ref_con = float(g[k + "loss_reg"]), float(g[k + "loss_consis"])
+        floor_reg = 4 * float(g[k + "noise_loss_reg"])
+        # identical on both ranks (same all-reduced moments), equal to the reference's pooled statistics
+        assert r0[f"step{i}_loss_reg"] == pytest.approx(float(r1[f"step{i}_loss_reg"]), rel=1e-6)
+        assert abs(float(r0[f"step{i}_loss_reg"]) - ref_reg) <= max(1e-5 * ref_reg, floor_reg) + 1e-7
+        # the consistency loss is a SUM over videos: per-rank parts add up to the reference's batch value
+        total_con = float(r0[f"step{i}_loss_consis"]) + float(r1[f"step{i}_loss_consis"])
+        assert abs(total_con - ref_con) <= max(1e-5 * ref_con, 4 * float(g[k + "noise_loss_consis"])) + 1e-7
+        # replicas stay identical: same EMA, same weights
+        assert float(r0[f"step{i}_ema_sum"]) == pytest.approx(float(r1[f"step{i}_ema_sum"]), rel=1e-9)
+        assert float(r0[f"step{i}_param_sum"]) == pytest.approx(float(r1[f"step{i}_param_sum"]), rel=1e-12)
+        ref_logits = g[k + "eval_logits"]
+        got = np.concatenate([r0[f"step{i}_logits"], r1[f"step{i}_logits"]])
+        bound = max(2e-3 * np.abs(ref_logits).max(), 4 * float(g[k + "noise_eval_logits"]))
+        assert np.abs(got - ref_logits).max() <= bound
+        for name in map(str, g["sampled_params"]):
+            ref_g = g[k + f"grad::{name}"]
+            bound = max(5e-3 * np.abs(ref_g).max(), 4 * float(g[k + f"noise_grad::{name}"])) + 1e-10
+            assert np.abs(r0[f"step{i}_grad::{name}"] - ref_g).max() <= bound, (i, name)  # all-reduced SUM gradient
+            np.testing.assert_array_equal(r0[f"step{i}_grad::{name}"], r1[f"step{i}_grad::{name}"])
+            np.testing.assert_array_equal(r0[f"step{i}_param::{name}"], r1[f"step{i}_param::{name}"])
+
+
+def test_ragged_tail_keeps_replicas_in_sync(tmp_path):
+    """3 videos on 2 ranks: in the last step rank 1 has no video, contributes n = 0 to the moments and
+    zeros to the gradient all-reduce, and still ends with the same EMA state and weights as rank 0."""
+    r0, r1 = _run(tmp_path, "ragged")
+    assert float(r0["step1_ema_sum"]) == pytest.approx(float(r1["step1_ema_sum"]), rel=1e-9)
+    assert float(r0["step1_param_sum"]) == pytest.approx(float(r1["step1_param_sum"]), rel=1e-12)
+    assert float(r0["step1_loss_reg"]) == pytest.approx(float(r1["step1_loss_reg"]), rel=1e-6)
