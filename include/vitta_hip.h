@@ -75,6 +75,9 @@ int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int targe
 size_t vitta_plan_table_bytes(const vitta_plan* plan);
 int vitta_plan_upload(vitta_plan* plan, void* d_tables, size_t bytes, void* stream);
 void vitta_plan_destroy(vitta_plan* plan);
+/* tuning knobs of a plan */
+#define VITTA_OPT_NT_LOADS 1 /* non-temporal loads in the NCHW moments kernel (value 0/1) */
+int vitta_plan_set_option(vitta_plan* plan, int option, int value);
 int64_t vitta_plan_total_channels(const vitta_plan* plan);
 int64_t vitta_plan_channel_offset(const vitta_plan* plan, int layer);
 size_t vitta_plan_workspace_bytes(const vitta_plan* plan);

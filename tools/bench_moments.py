@@ -1,0 +1,35 @@
+"""Micro-benchmark of the batched moments launch (GPU box): workgroup count, NT loads, in-cache vs streaming."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vitta_amd import ops
+
+C2 = [(16, 256, 784, 0), (16, 256, 196, 0), (16, 1024, 196, 0), (16, 1024, 196, 0)] + \
+     [(16, 256, 196, 0), (16, 256, 196, 0), (16, 1024, 196, 0)] * 5 + \
+     [(16, 512, 196, 0), (16, 512, 49, 0), (16, 2048, 49, 0), (16, 2048, 49, 0)] + [(16, 512, 49, 0), (16, 512, 49, 0), (16, 2048, 49, 0)] * 2
+assert len(C2) == 29 and sum(o * c * i for o, c, i, _ in C2) == 44556288, (len(C2), sum(o * c * i for o, c, i, _ in C2))
+dev = torch.device("cuda:0")
+
+
+def run(copies, target, nt, reps=30):
+    shapes = [(o * copies, c, i, l) for o, c, i, l in C2]
+    plan = ops.StatPlan(shapes, dev, target_blocks=target, nt_loads=nt)
+    feats = [torch.randn(o * c * i, device=dev) for o, c, i, _ in shapes]
+    nbytes = 4 * sum(f.numel() for f in feats)
+    shift = torch.zeros(plan.total_channels, device=dev)
+    ts = []
+    for r in range(reps + 5):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        plan.moments(feats, shift, events=ev)
+        torch.cuda.synchronize()
+        if r >= 5:
+            ts.append(ev[0].elapsed_time(ev[1]))
+    ms = float(np.median(ts))
+    return dict(copies=copies, target=target, nt=nt, blocks=plan.num_blocks, MB=nbytes / 1e6, us=1e3 * ms, TBs=nbytes / ms / 1e9)
+
+
+for copies in (1, 6, 16):
+    for target in (1024, 2048, 4096, 8192, 16384):
+        for nt in (False, True):
+            print(json.dumps(run(copies, target, nt)), flush=True)

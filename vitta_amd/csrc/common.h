@@ -99,6 +99,7 @@ struct vitta_plan {
   int64_t total_channels = 0;
   int64_t ws_triples = 0;
   int n_blocks_nchw = 0, n_blocks_nhwc = 0;
+  bool nt_loads = false;
   vitta::LayerInfo h_info[VITTA_MAX_LAYERS];
   // host image of the device tables: [LayerInfo x L | BlockEnt nchw | BlockEnt nhwc | chan2layer]
   void* h_tables = nullptr;

@@ -37,6 +37,22 @@ constexpr int kUnroll = 8;
 // ----------------------------------------------------------------------------
 // NCHW partial kernel
 // ----------------------------------------------------------------------------
+// streaming load: NT = non-temporal hint (the features are read exactly once by this kernel)
+template <bool NT>
+__device__ __forceinline__ float4 ld4(const float4* p) {
+  if constexpr (NT) {
+    float4 v;
+    v.x = __builtin_nontemporal_load(&p->x);
+    v.y = __builtin_nontemporal_load(&p->y);
+    v.z = __builtin_nontemporal_load(&p->z);
+    v.w = __builtin_nontemporal_load(&p->w);
+    return v;
+  } else {
+    return *p;
+  }
+}
+
+template <bool NT>
 __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
     const LayerInfo* __restrict__ linfo, const BlockEnt* __restrict__ tab, PtrPack ptrs,
     float* __restrict__ ws) {
@@ -61,14 +77,14 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
     if (j < plane && n1 > n0) {
       const float4* p = reinterpret_cast<const float4*>(x + n0 * plane + j);
       const int64_t stride4 = plane >> 2;
-      const float4 f = *p;
+      const float4 f = ld4<NT>(p);
       x0[0] = f.x; x0[1] = f.y; x0[2] = f.z; x0[3] = f.w;
       const int64_t nn = n1 - n0;
       int64_t n = 0;
       for (; n + kUnroll <= nn; n += kUnroll) {
         float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = p[(n + u) * stride4];
+        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NT>(p + (n + u) * stride4);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const float d0 = v[u].x - x0[0], d1 = v[u].y - x0[1], d2 = v[u].z - x0[2], d3 = v[u].w - x0[3];
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
         }
       }
       for (; n < nn; ++n) {
-        const float4 v = p[n * stride4];
+        const float4 v = ld4<NT>(p + n * stride4);
         const float d0 = v.x - x0[0], d1 = v.y - x0[1], d2 = v.z - x0[2], d3 = v.w - x0[3];
         s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
         q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]);
@@ -403,6 +419,12 @@ int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int targe
   return VITTA_OK;
 }
 
+int vitta_plan_set_option(vitta_plan* p, int option, int value) {
+  if (!p) return VITTA_ERR_INVALID_ARG;
+  if (option == VITTA_OPT_NT_LOADS) { p->nt_loads = value != 0; return VITTA_OK; }
+  return VITTA_ERR_UNSUPPORTED;
+}
+
 size_t vitta_plan_table_bytes(const vitta_plan* p) { return p ? p->table_bytes : 0; }
 
 int vitta_plan_upload(vitta_plan* p, void* d_tables, size_t bytes, void* stream) {
@@ -447,8 +469,12 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     pack.x[l] = x;
   }
   if (p->n_blocks_nchw) {
-    VITTA_LAUNCH(moments_nchw_partial_kernel, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
-                       p->d_info, p->d_tab_nchw, pack, ws);
+    if (p->nt_loads)
+      VITTA_LAUNCH(moments_nchw_partial_kernel<true>, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
+                   p->d_info, p->d_tab_nchw, pack, ws);
+    else
+      VITTA_LAUNCH(moments_nchw_partial_kernel<false>, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
+                   p->d_info, p->d_tab_nchw, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
   if (p->n_blocks_nhwc) {
@@ -574,8 +600,8 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   pack.x[0] = d_x;
   if (layout == VITTA_LAYOUT_NCHW)
-    VITTA_LAUNCH(moments_nchw_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
-                       d_tab, pack, d_part);
+    VITTA_LAUNCH(moments_nchw_partial_kernel<false>, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+                 d_tab, pack, d_part);
   else
     VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
