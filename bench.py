@@ -18,7 +18,7 @@ Extra objects on the JSON line:
                 time = HIP events recorded on the launch stream around that kernel inside the timed
                 steps.  The hooked tensors were just written by the BN kernels and fit the 256 MiB
                 Infinity Cache, so `achieved` is an on-die rate; `streaming` repeats the launch on
-                1.07 GB of features (6 videos' worth per layer) that cannot be cache resident.
+                2.85 GB of features (16 videos' worth per layer) that cannot be cache resident.
   cpu_baseline  the CPU restatement of the reference path (oracle/: stock PyTorch CPU ops in the
                 reference's op order), same workload, a few steps on the host cores of this box.
 """
@@ -211,9 +211,9 @@ def run_gpu(opt, rank, world, device):
     return elapsed, kern_ms, adapt_only, streaming, adapter
 
 
-def streaming_moments(adapter, device, copies=6, reps=20):
+def streaming_moments(adapter, device, copies=16, reps=20):
     """The same batched launch on features that cannot be cache resident: every hooked layer with
-    `copies` videos' worth of frames (6 x 178 MB = 1.07 GB > 256 MiB Infinity Cache)."""
+    `copies` videos' worth of frames (16 x 178 MB = 2.85 GB >> 256 MiB Infinity Cache)."""
     from vitta_amd import ops
     base = adapter.engine.plan.shapes
     shapes = [(outer * copies, c, inner, layout) for outer, c, inner, layout in base]

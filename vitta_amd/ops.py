@@ -134,7 +134,7 @@ def pred_consis(preds):
 class StatPlan:
     """Owns a vitta_plan plus the packed per-channel device buffers of the batched path."""
 
-    def __init__(self, shapes, device, target_blocks=0, nt_loads=False):
+    def __init__(self, shapes, device, target_blocks=0, nt_loads=None):
         # shapes: list of (outer, C, inner, layout)
         self.device = torch.device(device)
         self.shapes = [tuple(int(v) for v in s) for s in shapes]
@@ -147,8 +147,8 @@ class StatPlan:
             check(lib().vitta_plan_create(arr, n, target_blocks, C.byref(handle)), "vitta_plan_create")
         self._h = handle
         L = lib()
-        if nt_loads:
-            check(L.vitta_plan_set_option(self._h, 1, 1), "vitta_plan_set_option")
+        if nt_loads is not None:  # default: the library decides (non-temporal beyond the Infinity Cache size)
+            check(L.vitta_plan_set_option(self._h, 1, int(bool(nt_loads))), "vitta_plan_set_option")
         # device tables of the plan: a torch-owned buffer (the library never allocates device memory)
         self.tables = torch.empty(int(L.vitta_plan_table_bytes(self._h)), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
