@@ -41,7 +41,7 @@ def feature_module(kind, c):
     return {"bn2d": nn.BatchNorm2d, "bn3d": nn.BatchNorm3d, "bn1d": nn.BatchNorm1d}[kind](c).eval()
 
 
-from vitta_amd.synthetic import build_tanet, calibrate_bn, perturb_affine, write_stat_files  # noqa: E402,F401
+from vitta_amd.synthetic import build_swin, build_tanet, calibrate_bn, perturb_affine, write_stat_files  # noqa: E402,F401
 
 
 class ReplayDropout(nn.Module):
@@ -57,6 +57,32 @@ class ReplayDropout(nn.Module):
         m = self.masks[self.calls].to(x.device, x.dtype).view_as(x)
         self.calls += 1
         return x * m / (1.0 - self.p)
+
+
+class MaskTape:
+    """Recorded per-sample keep flags of every stochastic-depth call of a run, in call order."""
+
+    def __init__(self, masks):
+        self.masks, self.pos = masks, 0
+
+    def next(self):
+        m = self.masks[self.pos]
+        self.pos += 1
+        return m
+
+
+class ReplayDropPath(nn.Module):
+    """DropPath replaying recorded keep flags (timm semantics: kept samples are scaled by 1/keep_prob)."""
+
+    def __init__(self, drop_prob, tape):
+        super().__init__()
+        self.drop_prob, self.tape = drop_prob, tape
+
+    def forward(self, x):
+        if not self.training or self.drop_prob == 0.0:
+            return x
+        keep = torch.as_tensor(self.tape.next(), dtype=x.dtype, device=x.device)
+        return x * (keep / (1.0 - self.drop_prob)).view((-1,) + (1,) * (x.dim() - 1))
 
 
 def pack_mask(mask):

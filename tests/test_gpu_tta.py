@@ -122,3 +122,30 @@ def test_graph_replay_equals_eager_on_gpu(tmp_path):
         assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
         assert_logits_close(f, c, 2e-2)
     torch.testing.assert_close(ema_g, ema_e, rtol=1e-3, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Video Swin-B: LayerNorm hooks -> NHWC moments / injection kernels
+# ---------------------------------------------------------------------------------------------------
+def test_swin_forward_matches_reference_on_gpu():
+    from vitta_amd.bns_utils import choose_layers
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    g = H.golden("swin_fwd.npz")
+    model = H.build_swin(11, 0).to(_dev())
+    lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
+    hooks = [ComputeNormStatsHook(m, clip_len=16, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+    with torch.no_grad():
+        vid, view = model(H.seeded_randn((1, 2, 3, 16, 112, 112), 31).to(_dev()))
+    for h in hooks:
+        h.close()
+    assert_logits_close(view.cpu(), torch.from_numpy(g["view"]), 2e-3)
+    torch.testing.assert_close(torch.cat([h.batch_mean for h in hooks]).cpu(), torch.from_numpy(g["means"]), rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(torch.cat([h.batch_var for h in hooks]).cpu(), torch.from_numpy(g["vars"]), rtol=5e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode,use_engine", [("sgd", True), ("adam", True), ("sgd", False)])
+def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine):
+    from test_swin_cpu import run_product_tta_swin
+    g = H.golden("tta3_swin.npz")
+    recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
+    check_tta_records(g, mode, recs, BASE_GPU)

@@ -1,0 +1,107 @@
+"""Video Swin-B restatement + LayerNorm statistics hooks against goldens from the reference (CPU)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import helpers as H
+from oracle.oracle_backend import OracleBackend
+from test_host_cpu import BASE, assert_logits_close, check_tta_records
+from vitta_amd import data, scripts, tta
+from vitta_amd.bns_utils import choose_layers, collect_bn_params, freeze_except_bn
+
+SWIN_BLOCKS = ["module.backbone.layers.2", "module.backbone.layers.3", "module.backbone.norm"]
+
+
+@pytest.fixture(scope="module")
+def swin11():
+    return H.build_swin(11, 0)
+
+
+def test_swin_layer_selection_matches_reference(swin11):
+    g = H.golden("layers_swin.npz")
+    chosen = choose_layers(tta.SingleDeviceParallel(swin11), [nn.LayerNorm])
+    assert [n for n, _ in chosen] == [str(s) for s in g["names"]] and len(chosen) == 53
+    args = scripts.swin_ucf101_args([])
+    cands = tta.candidate_layers_for(args, tta.SingleDeviceParallel(swin11))
+    assert len(cands) == 52
+    hooked = [i for i, _, _ in tta.select_hooked(args, cands)]
+    assert hooked == g["hooked"].tolist() and len(hooked) == 42
+    assert sum(m.normalized_shape[0] for _, _, m in tta.select_hooked(args, cands)) == 25600
+    kinds = [nn.LayerNorm]
+    import copy
+    model = copy.deepcopy(swin11)
+    freeze_except_bn(model, kinds)
+    params, _ = collect_bn_params(model, kinds)
+    assert sum(p.numel() for p in params) == 57600
+
+
+def test_swin_forward_matches_reference(swin11):
+    g = H.golden("swin_fwd.npz")
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    lns = [m for _, m in choose_layers(swin11, [nn.LayerNorm])][1:]
+    hooks = [ComputeNormStatsHook(m, clip_len=16, stat_type="spatiotemp", before_norm=False, batch_size=1,
+                                  backend=OracleBackend()) for m in lns]
+    with torch.no_grad():
+        vid, view = swin11(H.seeded_randn((1, 2, 3, 16, 112, 112), 31))
+    for h in hooks:
+        h.close()
+    assert_logits_close(view, torch.from_numpy(g["view"]), 1e-4)
+    assert_logits_close(vid, torch.from_numpy(g["vid"]), 1e-4)
+    torch.testing.assert_close(torch.cat([h.batch_mean for h in hooks]), torch.from_numpy(g["means"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.cat([h.batch_var for h in hooks]), torch.from_numpy(g["vars"]), rtol=1e-4, atol=1e-6)
+
+
+def run_product_tta_swin(g, mode, tmp_path, device, backend_factory, use_engine=None):
+    cfg = json.loads(str(g["config"]))
+    T, size = cfg["T"], cfg["size"]
+    model = H.build_swin(101, 0)
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = scripts.swin_ucf101_args([])
+    args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "synthetic", size, size, 0, False
+    args.result_dir, args.num_classes, args.batch_size = str(tmp_path), 101, 1
+    args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+    args.update_only_bn_affine = mode == "adam"
+    args.lr = cfg["lr_sgd"] if mode == "sgd" else cfg["lr_adam"]
+    tta.BACKEND_FACTORY = backend_factory
+    try:
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(device), args, use_engine=use_engine)
+    finally:
+        tta.BACKEND_FACTORY = None
+    masks = [H.unpack_mask(g[f"{mode}_step{i}_dropmask"], g[f"{mode}_step{i}_dropmask_shape"]) for i in range(3)]
+    adapter.model.module.cls_head.dropout = H.ReplayDropout(0.5, masks)
+    tape = H.MaskTape([m for i in range(3) for m in g[f"{mode}_step{i}_droppath"]])
+    from vitta_amd.swin import DropPath, SwinTransformerBlock3D
+    for blk in adapter.model.modules():
+        if isinstance(blk, SwinTransformerBlock3D) and isinstance(blk.drop_path, DropPath):
+            blk.drop_path = H.ReplayDropPath(blk.drop_path.drop_prob, tape)
+    tta_set = data.SyntheticVideoDataset(cfg["n_videos"], 2, T, size, 101, "swin", seed0=cfg["seed0"])
+    eval_set = data.SyntheticVideoDataset(cfg["n_videos"], 1, T, size, 101, "swin", seed0=cfg["seed0"])
+    records = []
+    for step in range(3):
+        x = tta_set[step][0].unsqueeze(0).to(device)
+        adapter.set_adapt_mode()
+        _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+        named = dict(adapter.model.named_parameters())
+        adapter.close_hooks()
+        logits = adapter.evaluate(adapter.shape_eval_input(eval_set[step][0].unsqueeze(0).to(device)))
+        adapter.add_hooks_back()
+        names = [str(s) for s in g["sampled_params"]]
+        records.append(dict(loss_reg=float(loss_reg), loss_consis=float(loss_consis), eval_logits=logits.cpu(),
+                            params={k: named[k].detach().cpu().clone() for k in names},
+                            grads={k: (named[k].grad.detach().cpu().clone() if named[k].grad is not None else None)
+                                   for k in names}))
+    assert tape.pos == len(tape.masks)
+    return records
+
+
+@pytest.mark.parametrize("mode,use_engine", [("sgd", True), ("adam", True), ("sgd", False)])
+def test_three_swin_tta_steps_match_reference(tmp_path, mode, use_engine):
+    g = H.golden("tta3_swin.npz")
+    recs = run_product_tta_swin(g, mode, tmp_path, torch.device("cpu"), OracleBackend, use_engine=use_engine)
+    check_tta_records(g, mode, recs, BASE)

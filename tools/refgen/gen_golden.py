@@ -429,8 +429,200 @@ def gen_opts():
     print("wrote opts_defaults.json", len(d))
 
 
+# --------------------------------------------------------------------------------------------
+def ref_swin(num_class, seed, **kw):
+    from models.videoswintransformer_models.recognizer3d import Recognizer3D
+    mine = H.build_swin(num_class, seed, **kw)
+    ref = Recognizer3D(num_classes=num_class, patch_size=(2, 4, 4), window_size=(8, 7, 7), drop_path_rate=0.2)
+    ref.load_state_dict(mine.state_dict(), strict=True)
+    ref.eval()
+    return ref, mine
+
+
+SWIN_BLOCKS = ["module.backbone.layers.2", "module.backbone.layers.3", "module.backbone.norm"]
+SWIN_SAMPLED = ["module.backbone.layers.2.blocks.0.norm1.weight", "module.backbone.layers.3.blocks.1.norm2.bias",
+                "module.backbone.norm.weight", "module.backbone.layers.2.blocks.5.attn.qkv.weight",
+                "module.backbone.layers.2.blocks.3.attn.relative_position_bias_table",
+                "module.backbone.layers.0.blocks.1.mlp.fc1.weight", "module.cls_head.fc_cls.weight",
+                "module.backbone.layers.2.downsample.norm.weight"]
+
+
+def gen_swin():
+    """A0/A10 for Video Swin-B: layer selection (53 -> 52 -> 42), full forward + per-layer moments."""
+    from utils.BNS_utils import choose_layers
+    from utils.norm_stats_utils import ComputeNormStatsHook
+    ref, _ = ref_swin(11, 0)
+    chosen = choose_layers(Wrap(ref), [nn.LayerNorm])
+    names = [n for n, _ in chosen]
+    kept = names[1:]
+    hooked = [i for i, n in enumerate(kept) if any(b in n for b in SWIN_BLOCKS)]
+    save("layers_swin.npz", names=np.array(names), hooked=np.array(hooked),
+         channels=np.array([m.normalized_shape[0] for _, m in chosen]))
+    x = H.seeded_randn((1, 2, 3, 16, 112, 112), 31)
+    lns = [m for _, m in choose_layers(ref, [nn.LayerNorm])][1:]
+    hooks = [ComputeNormStatsHook(m, clip_len=16, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+    with torch.no_grad():
+        vid, view = ref(x)
+    save("swin_fwd.npz", vid=t2n(vid), view=t2n(view), means=np.concatenate([t2n(h.batch_mean) for h in hooks]),
+         vars=np.concatenate([t2n(h.batch_var) for h in hooks]), channels=np.array([m.normalized_shape[0] for m in lns]))
+    for h in hooks:
+        h.close()
+
+
+def run_reference_tta_swin(args, model_origin, n_videos, capture, perturb=0.0, perturb_seed=90000):
+    import corpus.basics as B
+    import copy as _copy
+    from timm.models.layers import DropPath
+
+    real_deepcopy = _copy.deepcopy
+    capture.droppath = []
+
+    def spy_deepcopy(obj, *a, **k):
+        c = real_deepcopy(obj, *a, **k)
+        if isinstance(obj, nn.Module) and capture.model is None:
+            capture.model = c
+            for m in c.modules():
+                if isinstance(m, nn.Dropout) and m.p > 0:
+                    m.register_forward_hook(lambda mod, i, o: capture.drop_masks.append(t2n(o != 0)) if mod.training else None)
+                if isinstance(m, DropPath) and m.drop_prob > 0:
+                    m.register_forward_hook(
+                        lambda mod, i, o: capture.droppath.append(t2n(o.flatten(1).abs().sum(1) > 0)) if mod.training else None)
+            c.register_forward_hook(lambda mod, i, o: capture.eval_logits.append(t2n(o[0])) if not mod.training else None)
+        return c
+
+    B.cp.deepcopy = spy_deepcopy
+    real_consis = B.compute_pred_consis
+
+    def spy_consis(p):
+        v = real_consis(p)
+        capture.consis.append(t2n(v))
+        return v
+
+    B.compute_pred_consis = spy_consis
+    saved_steps = {}
+    for cls in (torch.optim.SGD, torch.optim.Adam):
+        real = cls.step
+
+        def step(self, *a, _real=real, **k):
+            hooks = []
+            for m in capture.model.modules():
+                for h in m._forward_hooks.values():
+                    owner = getattr(h, "__self__", None)
+                    if owner is not None and hasattr(owner, "r_feature") and owner not in hooks:
+                        hooks.append(owner)
+            rec = dict(loss_reg=float(sum(float(h.r_feature.detach()) for h in hooks)))
+            named = dict(capture.model.named_parameters())
+            for key in SWIN_SAMPLED:
+                rec[f"grad::{key}"] = t2n(named[key].grad[:SAMPLE_ROWS]) if named[key].grad is not None else None
+            r = _real(self, *a, **k)
+            for key in SWIN_SAMPLED:
+                rec[f"param::{key}"] = t2n(named[key][:SAMPLE_ROWS])
+            capture.steps.append(rec)
+            return r
+
+        saved_steps[cls] = real
+        cls.step = step
+
+    from vitta_amd.data import SyntheticVideoDataset
+
+    def fake_dataset(args, split="val", dataset_type=None):
+        views = args.n_augmented_views if dataset_type == "tta" else 1
+        ds = SyntheticVideoDataset(n_videos, views, args.clip_length, args.input_size, args.num_classes, "swin", seed0=800)
+        return _Perturbed(ds, perturb, perturb_seed) if perturb else ds
+
+    B.get_dataset_videoswin = fake_dataset
+    logger = logging.getLogger("refgen")
+    logger.addHandler(logging.NullHandler())
+    try:
+        res = B.tta_standard(Wrap(model_origin), nn.CrossEntropyLoss(), args=args, logger=logger, writer=None)
+    finally:
+        B.cp.deepcopy = real_deepcopy
+        B.compute_pred_consis = real_consis
+        for cls, real in saved_steps.items():
+            cls.step = real
+    return res
+
+
+def gen_tta_swin():
+    """A11/A7 for Video Swin-B: three online steps through the reference's tta_standard, both optimizers."""
+    from utils.opts import get_opts
+    from utils.norm_stats_utils import ComputeNormStatsHook
+    from utils.BNS_utils import choose_layers
+    T, size, n_videos = 16, 64, 3
+    out = {}
+    for mode in ("sgd", "adam"):
+        ref, _ = ref_swin(101, 0)
+        lns = [m for _, m in choose_layers(ref, [nn.LayerNorm])][1:]
+        hooks = [ComputeNormStatsHook(m, clip_len=T, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+        with torch.no_grad():
+            ref(H.seeded_randn((1, 2, 3, T, size, size), 1000))
+        g = torch.Generator().manual_seed(77)
+        means = [t2n(h.batch_mean + 0.05 * torch.randn(h.batch_mean.shape, generator=g)) for h in hooks]
+        vars_ = [t2n(h.batch_var * (1 + 0.2 * torch.rand(h.batch_var.shape, generator=g))) for h in hooks]
+        for h in hooks:
+            h.close()
+        with tempfile.TemporaryDirectory() as tmp:
+            mp, vp = H.write_stat_files(tmp, means, vars_)
+            args = get_opts()
+            args.arch, args.dataset, args.clip_length, args.workers = "videoswintransformer", "ucf101", T, 0
+            args.input_size, args.scale_size, args.verbose, args.batch_size = size, size, False, 1
+            args.num_clips, args.test_crops, args.frame_uniform, args.frame_interval = 1, 1, True, 2
+            args.patch_size, args.window_size = (2, 4, 4), (8, 7, 7)
+            args.lambda_pred_consis, args.momentum_mvg, args.chosen_blocks = 0.05, 0.05, SWIN_BLOCKS
+            args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+            args.num_classes, args.gpus, args.result_dir = 101, [0], tmp
+            args.update_only_bn_affine = mode == "adam"
+            args.lr = 1e-5 if mode == "sgd" else 1e-3
+            cap = _Capture()
+            torch.manual_seed(4321)
+            res = run_reference_tta_swin(args, ref, n_videos, cap)
+            caps = []
+            for trial in range(3):
+                c2 = _Capture()
+                torch.manual_seed(4321)
+                run_reference_tta_swin(args, ref, n_videos, c2, perturb=1e-7, perturb_seed=90000 + 1000 * trial)
+                caps.append(c2)
+        assert len(cap.steps) == 3 and len(cap.drop_masks) == 3, (len(cap.steps), len(cap.drop_masks))
+        per = len(cap.droppath) // 3
+        for i in range(3):
+            a = cap.steps[i]
+            noise = {}
+
+            def bump(key, val):
+                noise[key] = max(noise.get(key, 0.0), float(val))
+
+            for c2 in caps:
+                assert all((x == y).all() for x, y in zip(cap.droppath, c2.droppath))
+                b = c2.steps[i]
+                bump("loss_reg", abs(a["loss_reg"] - b["loss_reg"]))
+                bump("loss_consis", np.abs(cap.consis[i] - c2.consis[i]))
+                bump("eval_logits", np.abs(cap.eval_logits[i] - c2.eval_logits[i]).max())
+                for key in SWIN_SAMPLED:
+                    if a.get(f"grad::{key}") is not None:
+                        bump(f"grad::{key}", np.abs(a[f"grad::{key}"] - b[f"grad::{key}"]).max())
+                    bump(f"param::{key}", np.abs(a[f"param::{key}"] - b[f"param::{key}"]).max())
+            for key, val in noise.items():
+                out[f"{mode}_step{i}_noise_{key}"] = np.array(val)
+            for k, v in a.items():
+                if v is not None:
+                    out[f"{mode}_step{i}_{k}"] = np.asarray(v)
+            out[f"{mode}_step{i}_loss_consis"] = cap.consis[i]
+            out[f"{mode}_step{i}_eval_logits"] = cap.eval_logits[i]
+            bits, shape = H.pack_mask(cap.drop_masks[i])
+            out[f"{mode}_step{i}_dropmask"], out[f"{mode}_step{i}_dropmask_shape"] = bits, shape
+            out[f"{mode}_step{i}_droppath"] = np.stack(cap.droppath[i * per:(i + 1) * per])
+        if mode == "sgd":
+            out["src_means"], out["src_vars"] = np.concatenate(means), np.concatenate(vars_)
+            out["src_channels"] = np.array([len(m) for m in means])
+    out["sampled_params"] = np.array(SWIN_SAMPLED)
+    out["sample_rows"] = np.array(SAMPLE_ROWS)
+    out["config"] = np.array(json.dumps(dict(T=T, size=size, n_videos=n_videos, batch_size=1, seed0=800, lr_sgd=1e-5,
+                                             lr_adam=1e-3, momentum_mvg=0.05, lambda_pred_consis=0.05)))
+    save("tta3_swin.npz", **out)
+
+
 SECTIONS = dict(l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
-                opts=gen_opts, dp=gen_dp)
+                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin)
 
 if __name__ == "__main__":
     for n in (ARGV or list(SECTIONS)):

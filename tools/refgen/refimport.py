@@ -145,7 +145,12 @@ def install():
 
     # reference modules parse sys.argv at import time (baselines/setup_baseline.py:9, baselines/shot.py:38)
     sys.argv = [sys.argv[0]]
-    # reference first, so `utils`, `corpus`, `models` resolve to the reference packages
+    # `utils`, `corpus`, `models` must resolve to the REFERENCE packages.  The reference's are namespace
+    # packages (no __init__.py) while this repo's root-level drop-in shims are regular packages, and a
+    # regular package anywhere on sys.path wins over a namespace portion: take the repo root OFF sys.path
+    # (vitta_amd is already imported; its sub-modules resolve through vitta_amd.__path__).
+    import vitta_amd  # noqa: F401
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != REPO]
     sys.path.insert(0, REFERENCE)
     for name in list(sys.modules):
         if name.split(".")[0] in ("utils", "corpus", "models", "baselines", "datasets_"):

@@ -1,0 +1,348 @@
+"""Video Swin Transformer (Swin-B) + I3D head + Recognizer3D, MI355X-native restatement.
+
+Interface / state_dict / named_modules mirror of
+    models/videoswintransformer_models/swin_transformer.py:18-663
+    models/videoswintransformer_models/recognizer3d.py:46-115
+    models/videoswintransformer_models/i3d_head.py:11-77
+so mmaction-style checkpoints (`backbone.layers.2.blocks.0.attn.relative_position_bias_table`,
+`cls_head.fc_cls.weight`, ...) load unchanged and choose_layers(LayerNorm)[1:] yields the same 52
+layers in the same order (42 of them under layers.2 / layers.3 / backbone.norm).
+
+MI355X-first differences:
+* activations stay channels-last (B, D, H, W, C) through the whole backbone; the reference converts
+  to (B, C, D, H, W) and back around every stage (`rearrange` + `.contiguous()`, swin_transformer.py:
+  402,412,654-661), two full copies per stage that buy nothing;
+* the attention core (scale, QK^T, relative-position bias gather, shift mask, softmax, AV) is one
+  call (`window_attention`): a fused HIP kernel on the GPU, plain torch on CPU tensors;
+* LayerNorm outputs are never modified in place, so the statistics hooks can read them in backward.
+"""
+from functools import lru_cache
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm 0.6.7 semantics: bernoulli(keep) / keep)."""
+
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+def get_window_size(x_size, window_size, shift_size=None):
+    """Clamp the window to the feature size; a clamped axis is not shifted (swin_transformer.py:71-84)."""
+    ws = [min(x, w) for x, w in zip(x_size, window_size)]
+    if shift_size is None:
+        return tuple(ws)
+    ss = [0 if x <= w else s for x, w, s in zip(x_size, window_size, shift_size)]
+    return tuple(ws), tuple(ss)
+
+
+def window_partition(x, ws):
+    """(B, D, H, W, C) -> (B * nW, wd*wh*ww, C), windows ordered (d, h, w) like the reference."""
+    B, D, H, W, C = x.shape
+    x = x.view(B, D // ws[0], ws[0], H // ws[1], ws[1], W // ws[2], ws[2], C)
+    return x.permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(-1, ws[0] * ws[1] * ws[2], C)
+
+
+def window_reverse(windows, ws, B, D, H, W):
+    x = windows.view(B, D // ws[0], H // ws[1], W // ws[2], ws[0], ws[1], ws[2], -1)
+    return x.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, D, H, W, -1)
+
+
+def _axis_region(size, w, s):
+    """Region id along one axis of the shifted-window mask: [0, size-w) -> 0, [size-w, size-s) -> 1,
+    [size-s, size) -> 2; with s == 0 the whole axis is one region (swin_transformer.py:316-323)."""
+    r = torch.full((size,), 2, dtype=torch.long)
+    if s > 0:
+        r[:size - w] = 0
+        r[size - w:size - s] = 1
+    return r
+
+
+@lru_cache()
+def compute_mask(D, H, W, window_size, shift_size, device):
+    """(nW, N, N): 0 where both tokens of a window come from the same pre-shift region, -100 elsewhere."""
+    rd = _axis_region(D, window_size[0], shift_size[0])
+    rh = _axis_region(H, window_size[1], shift_size[1])
+    rw = _axis_region(W, window_size[2], shift_size[2])
+    region = (rd[:, None, None] * 3 + rh[None, :, None]) * 3 + rw[None, None, :]
+    win = window_partition(region.view(1, D, H, W, 1).float(), window_size).squeeze(-1)  # nW, N
+    diff = win.unsqueeze(1) - win.unsqueeze(2)
+    return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).to(device)
+
+
+def relative_position_index(window_size):
+    """(N, N) index into the (2wd-1)(2wh-1)(2ww-1) bias table (swin_transformer.py:113-124)."""
+    wd, wh, ww = window_size
+    coords = torch.stack(torch.meshgrid(torch.arange(wd), torch.arange(wh), torch.arange(ww), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + torch.tensor([wd - 1, wh - 1, ww - 1])
+    return (rel[..., 0] * (2 * wh - 1) + rel[..., 1]) * (2 * ww - 1) + rel[..., 2]
+
+
+def window_attention(qkv, bias, mask, scale, num_heads):
+    """softmax(scale * Q K^T + bias (+ mask)) V per (window, head).
+
+    qkv (B_, N, 3*C) straight from the qkv Linear; bias (nH, N, N); mask (nW, N, N) or None
+    (window b uses mask[b % nW]); returns (B_, N, C) with heads concatenated (swin_transformer.py:144-168)."""
+    if qkv.is_cuda:
+        from . import ops
+        if hasattr(ops, "WindowAttention"):
+            return ops.WindowAttention.apply(qkv, bias, mask, scale, num_heads)
+    B_, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.view(B_, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, num_heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, num_heads, N, N)
+    attn = attn.softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B_, N, C)
+
+
+class WindowAttention3D(nn.Module):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if attn_drop != 0.0:
+            raise NotImplementedError("attention dropout is 0 on the ViTTA path (recognizer3d.py:61)")
+        self.dim, self.window_size, self.num_heads = dim, window_size, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        table = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) * (2 * window_size[2] - 1)
+        self.relative_position_bias_table = nn.Parameter(torch.zeros(table, num_heads))
+        self.register_buffer("relative_position_index", relative_position_index(window_size))
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        self.softmax = nn.Softmax(dim=-1)
+
+    def forward(self, x, mask=None):
+        B_, N, C = x.shape
+        idx = self.relative_position_index[:N, :N].reshape(-1)
+        bias = self.relative_position_bias_table[idx].view(N, N, self.num_heads).permute(2, 0, 1).contiguous()
+        out = window_attention(self.qkv(x), bias, mask, self.scale, self.num_heads)
+        return self.proj_drop(self.proj(out))
+
+
+class SwinTransformerBlock3D(nn.Module):
+    def __init__(self, dim, num_heads, window_size=(2, 7, 7), shift_size=(0, 0, 0), mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop=0.0, attn_drop=0.0, drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm,
+                 use_checkpoint=False):
+        super().__init__()
+        assert all(0 <= s < w for s, w in zip(shift_size, window_size)), "shift_size must in 0-window_size"
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, num_heads, window_size, shift_size
+        self.mlp_ratio, self.use_checkpoint = mlp_ratio, use_checkpoint
+        self.norm1 = norm_layer(dim)
+        self.attn = WindowAttention3D(dim, window_size=window_size, num_heads=num_heads, qkv_bias=qkv_bias,
+                                      qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def attention_branch(self, x, mask_matrix):
+        B, D, H, W, C = x.shape
+        ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
+        x = self.norm1(x)
+        pad = [(w - n % w) % w for n, w in zip((D, H, W), ws)]
+        if any(pad):
+            x = F.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
+        Dp, Hp, Wp = D + pad[0], H + pad[1], W + pad[2]
+        shifted = any(s > 0 for s in ss)
+        if shifted:
+            x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
+        windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None)
+        x = window_reverse(windows, ws, B, Dp, Hp, Wp)
+        if shifted:
+            x = torch.roll(x, shifts=ss, dims=(1, 2, 3))
+        if any(pad):
+            x = x[:, :D, :H, :W, :].contiguous()
+        return x
+
+    def forward(self, x, mask_matrix):
+        x = x + self.drop_path(self.attention_branch(x, mask_matrix))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PatchMerging(nn.Module):
+    def __init__(self, dim, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = norm_layer(4 * dim)
+
+    def forward(self, x):
+        B, D, H, W, C = x.shape
+        if H % 2 or W % 2:
+            x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+        x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+        return self.reduction(self.norm(x))
+
+
+class BasicLayer(nn.Module):
+    """One stage; input and output are channels-last (B, D, H, W, C)."""
+
+    def __init__(self, dim, depth, num_heads, window_size=(1, 7, 7), mlp_ratio=4.0, qkv_bias=False, qk_scale=None,
+                 drop=0.0, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, downsample=None, use_checkpoint=False):
+        super().__init__()
+        self.window_size = window_size
+        self.shift_size = tuple(i // 2 for i in window_size)
+        self.depth, self.use_checkpoint = depth, use_checkpoint
+        self.blocks = nn.ModuleList([
+            SwinTransformerBlock3D(dim=dim, num_heads=num_heads, window_size=window_size,
+                                   shift_size=(0, 0, 0) if i % 2 == 0 else self.shift_size, mlp_ratio=mlp_ratio,
+                                   qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop, attn_drop=attn_drop,
+                                   drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                                   norm_layer=norm_layer, use_checkpoint=use_checkpoint)
+            for i in range(depth)])
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        B, D, H, W, C = x.shape
+        ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
+        Dp, Hp, Wp = (int(np.ceil(n / w)) * w for n, w in zip((D, H, W), ws))
+        attn_mask = compute_mask(Dp, Hp, Wp, ws, ss, x.device)
+        for blk in self.blocks:
+            x = blk(x, attn_mask)
+        return self.downsample(x) if self.downsample is not None else x
+
+
+class PatchEmbed3D(nn.Module):
+    def __init__(self, patch_size=(2, 4, 4), in_chans=3, embed_dim=96, norm_layer=None):
+        super().__init__()
+        self.patch_size, self.in_chans, self.embed_dim = patch_size, in_chans, embed_dim
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.norm = norm_layer(embed_dim) if norm_layer is not None else None
+
+    def forward(self, x):
+        """(B, 3, T, H, W) -> channels-last tokens (B, D, H', W', C)."""
+        _, _, D, H, W = x.size()
+        p = self.patch_size
+        if W % p[2] or H % p[1] or D % p[0]:
+            x = F.pad(x, (0, (-W) % p[2], 0, (-H) % p[1], 0, (-D) % p[0]))
+        x = self.proj(x)
+        B, C, D, Hh, Ww = x.shape
+        x = x.flatten(2).transpose(1, 2)  # (B, L, C): the first LayerNorm sees a 3-D tensor, as in the reference
+        if self.norm is not None:
+            x = self.norm(x)
+        return x.reshape(B, D, Hh, Ww, C)
+
+
+class SwinTransformer3D(nn.Module):
+    """forward returns channels-last (B, D, H, W, C) features (the reference returns (B, C, D, H, W))."""
+
+    def __init__(self, pretrained=None, pretrained2d=True, patch_size=(4, 4, 4), in_chans=3, embed_dim=96,
+                 depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=(2, 7, 7), mlp_ratio=4.0, qkv_bias=True,
+                 qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.2, norm_layer=nn.LayerNorm,
+                 patch_norm=False, frozen_stages=-1, use_checkpoint=False):
+        super().__init__()
+        self.num_layers, self.embed_dim, self.patch_norm = len(depths), embed_dim, patch_norm
+        self.frozen_stages, self.window_size, self.patch_size = frozen_stages, window_size, patch_size
+        self.patch_embed = PatchEmbed3D(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                        norm_layer=norm_layer if patch_norm else None)
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(
+                dim=int(embed_dim * 2 ** i), depth=depths[i], num_heads=num_heads[i], window_size=window_size,
+                mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate,
+                drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])], norm_layer=norm_layer,
+                downsample=PatchMerging if i < self.num_layers - 1 else None, use_checkpoint=use_checkpoint))
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.norm = norm_layer(self.num_features)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x):
+        x = self.pos_drop(self.patch_embed(x))
+        for layer in self.layers:
+            x = layer(x)
+        return self.norm(x)
+
+
+class I3DHead(nn.Module):
+    """avg-pool over (D, H, W) -> dropout -> fc (i3d_head.py:57-77) on channels-last features."""
+
+    def __init__(self, num_classes, in_channels, spatial_type="avg", dropout_ratio=0.5, init_std=0.01):
+        super().__init__()
+        self.num_classes, self.in_channels, self.spatial_type = num_classes, in_channels, spatial_type
+        self.dropout_ratio, self.init_std = dropout_ratio, init_std
+        self.dropout = nn.Dropout(p=dropout_ratio) if dropout_ratio != 0 else None
+        self.fc_cls = nn.Linear(in_channels, num_classes)
+        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1)) if spatial_type == "avg" else None
+        nn.init.normal_(self.fc_cls.weight, 0, init_std)
+        nn.init.constant_(self.fc_cls.bias, 0)
+
+    def forward(self, x):
+        if self.avg_pool is not None:
+            x = x.mean(dim=(1, 2, 3))  # channels-last: pool the three middle axes
+        else:
+            x = x.reshape(x.shape[0], -1)
+        if self.dropout is not None:
+            x = self.dropout(x)
+        return self.fc_cls(x)
+
+
+class Recognizer3D(nn.Module):
+    """Swin-B recognizer: forward(x[B, V, 3, T, H, W]) -> (video scores [B, K], per-view scores [B, V, K])."""
+
+    def __init__(self, num_classes=None, patch_size=None, window_size=None, drop_path_rate=None,
+                 embed_dim=128, depths=(2, 2, 18, 2), num_heads=(4, 8, 16, 32)):
+        super().__init__()
+        self.patch_size, self.window_size, self.drop_path_rate = patch_size, window_size, drop_path_rate
+        self.embed_dim, self.depths, self.num_heads = embed_dim, list(depths), list(num_heads)
+        self.num_classes, self.in_channels = num_classes, int(embed_dim * 2 ** (len(depths) - 1))
+        self.score_type = "score"
+        self.backbone = SwinTransformer3D(patch_size=patch_size, in_chans=3, embed_dim=embed_dim, depths=self.depths,
+                                          num_heads=self.num_heads, window_size=window_size, mlp_ratio=4.0,
+                                          qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
+                                          drop_path_rate=drop_path_rate, patch_norm=True)
+        self.cls_head = I3DHead(num_classes=num_classes, in_channels=self.in_channels, spatial_type="avg",
+                                dropout_ratio=0.5)
+
+    def forward(self, x):
+        n_views = x.shape[1]
+        feat = self.backbone(x.reshape((-1,) + x.shape[2:]))
+        return self.average_clips(self.cls_head(feat), num_segs=n_views)
+
+    def average_clips(self, cls_score, num_segs=1):
+        cls_score = cls_score.view(cls_score.shape[0] // num_segs, num_segs, -1)
+        if self.score_type == "prob":
+            return F.softmax(cls_score, dim=2).mean(dim=2)
+        return cls_score.mean(dim=1), cls_score

@@ -78,3 +78,20 @@ def write_stat_files(dirname, means, vars_, tag="golden"):
     return mp, vp
 
 
+
+
+def build_swin(num_class, seed, patch_size=(2, 4, 4), window_size=(8, 7, 7), drop_path_rate=0.2, **kw):
+    """Seeded Video Swin-B recognizer (this repo's Recognizer3D) with non-trivial LN affine / biases."""
+    from vitta_amd.swin import Recognizer3D
+    torch.manual_seed(seed)
+    model = Recognizer3D(num_classes=num_class, patch_size=patch_size, window_size=window_size,
+                         drop_path_rate=drop_path_rate, **kw)
+    perturb_affine(model, seed + 2)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.add_(torch.randn(m.bias.shape, generator=g) * 0.02)
+        model.cls_head.fc_cls.weight.normal_(0, 0.05, generator=g)
+    model.eval()
+    return model
