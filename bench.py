@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--no-streaming", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
     p.add_argument("--size", type=int, default=224)
     p.add_argument("--clip-length", type=int, default=8)
     return p.parse_args()
@@ -270,6 +271,8 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=device)
+    if opt.miopen_find:
+        torch.backends.cudnn.benchmark = True
     # corpus/main_eval.py:77 sets cudnn.benchmark (an exhaustive MIOpen find on ROCm: minutes of search
     # per conv shape); the bench keeps MIOpen's default immediate mode
 
