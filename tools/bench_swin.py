@@ -1,0 +1,74 @@
+"""Video Swin-B TTA iteration timing on MI355X (BASELINE config 2 shape: 2 views x 16 frames x 224^2,
+LN-affine Adam).  Not the driver's bench line (that is bench.py / TANet); used to size the W-MSA work."""
+import argparse, json, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vitta_amd import data, scripts, tta
+from vitta_amd import synthetic as S
+from vitta_amd.bns_utils import choose_layers
+from vitta_amd.norm_stats import ComputeNormStatsHook
+
+p = argparse.ArgumentParser()
+p.add_argument("--steps", type=int, default=10)
+p.add_argument("--warmup", type=int, default=3)
+p.add_argument("--size", type=int, default=224)
+p.add_argument("--frames", type=int, default=16)
+p.add_argument("--no-graph", action="store_true")
+p.add_argument("--sgd", action="store_true")
+opt = p.parse_args()
+dev = torch.device("cuda:0")
+tmp = tempfile.mkdtemp()
+model = S.build_swin(101, 0).to(dev)
+lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
+hooks = [ComputeNormStatsHook(m, clip_len=opt.frames, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+with torch.no_grad():
+    model(S.seeded_randn((1, 2, 3, opt.frames, opt.size, opt.size), 1000, dev))
+means = [h.batch_mean.cpu().numpy() for h in hooks]
+vars_ = [h.batch_var.cpu().numpy() for h in hooks]
+for h in hooks:
+    h.close()
+mp, vp = S.write_stat_files(tmp, means, vars_, tag="swin")
+args = scripts.swin_ucf101_args([])
+args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "synthetic", opt.size, opt.size, 0, False
+args.clip_length, args.result_dir, args.num_classes = opt.frames, tmp, 101
+args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+args.update_only_bn_affine = not opt.sgd
+args.synthetic_n_videos, args.synthetic_device = 8, dev
+adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+tta_set = data.build_videoswin_dataset(args, "val", "tta")
+eval_set = data.build_videoswin_dataset(args, "val", "eval")
+
+
+def one(i):
+    x, _ = tta_set[i % 8]
+    ev, _ = eval_set[i % 8]
+    if adapter._graph is not None:
+        adapter.adapt_step(x.unsqueeze(0))
+        return adapter.evaluate(ev.unsqueeze(0))
+    adapter.set_adapt_mode()
+    adapter.adapt_step(x.unsqueeze(0))
+    adapter.close_hooks()
+    out = adapter.evaluate(ev.unsqueeze(0))
+    adapter.add_hooks_back()
+    return out
+
+
+for i in range(opt.warmup):
+    one(i)
+torch.cuda.synchronize()
+if not opt.no_graph:
+    adapter.capture_graphs(tta_set[0][0].unsqueeze(0), eval_set[0][0].unsqueeze(0))
+    one(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(opt.steps):
+    one(i)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / opt.steps
+print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph,
+                      frames=opt.frames, size=opt.size, optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
+                      max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))
