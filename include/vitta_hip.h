@@ -189,6 +189,30 @@ int vitta_tam_agg_bwd_f32(const float* d_x, const float* d_gate, const float* d_
 int vitta_tam_pool_bwd_f32(const float* d_gpool, int32_t N, int32_t T, int32_t C, int32_t HW,
                            float* d_gx_accum, void* stream);
 
+/* --------------------------------------------------------------------------
+ * A10 -- fused 3-D (shifted-)window multi-head self-attention of Video Swin.
+ * Replaces WindowAttention3D.forward between the qkv and proj Linears
+ * (models/videoswintransformer_models/swin_transformer.py:144-168): q*scale, q@k^T, + relative
+ * position bias, + shift mask, softmax, @v and the head reshapes/permutes, per window and head,
+ * without materialising the [N x N] attention matrix.
+ *   d_qkv  [B_, N, 3, nH, head_dim]  output of the qkv Linear, untouched
+ *   d_bias [nH, N, N]                relative_position_bias_table[relative_position_index]
+ *   d_mask [nW, N, N] or NULL        window b uses mask[b % nW] (B_ % nW == 0)
+ *   d_out  [B_, N, nH*head_dim]      input layout of the proj Linear
+ *   d_lse  [B_, nH, N]               row max + log(row sum), consumed by the backward
+ * Backward: d_dqkv [B_, N, 3, nH, head_dim] (fully written), d_dbias [nH, N, N] or NULL
+ * (accumulated with atomics: zero it first), d_delta [B_, nH, N] scratch.
+ * Supported: head_dim == 32, N <= 400 (vitta_wmsa_supported); otherwise VITTA_ERR_UNSUPPORTED.
+ * -------------------------------------------------------------------------- */
+int vitta_wmsa_supported(int32_t N, int32_t head_dim);
+int vitta_wmsa_fwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_,
+                       int32_t N, int32_t nH, int32_t head_dim, float scale, float* d_out, float* d_lse,
+                       void* stream);
+int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_,
+                       int32_t N, int32_t nH, int32_t head_dim, float scale, const float* d_out,
+                       const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv, float* d_dbias,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

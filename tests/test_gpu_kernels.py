@@ -216,3 +216,50 @@ def test_tam_kernels(dims):
     torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(kd.grad.cpu(), kr.grad, rtol=1e-4, atol=1e-3)
+
+
+def _wmsa_reference(qkv, bias, mask, scale, nh):
+    """swin_transformer.py:144-168 in fp64 on the CPU (composed ops)."""
+    B_, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.view(B_, N, 3, nh, C // nh).permute(2, 0, 3, 1, 4)
+    attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, nh, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, nh, N, N)
+    attn = attn.softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B_, N, C)
+
+
+@pytest.mark.parametrize("B_,N,nh,nW", [(4, 392, 4, 2), (2, 392, 2, None), (6, 98, 3, 3), (2, 8, 1, None),
+                                        (3, 100, 2, None), (2, 400, 1, 2), (64, 392, 4, 64)])
+def test_wmsa_fused_forward_backward(B_, N, nh, nW):
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(17)
+    C = nh * 32
+    qkv = torch.randn(B_, N, 3 * C, generator=g)
+    bias = torch.randn(nh, N, N, generator=g) * 0.5
+    mask = None
+    if nW is not None:
+        region = torch.randint(0, 3, (nW, N), generator=g).float()
+        mask = torch.where(region.unsqueeze(1) != region.unsqueeze(2), torch.tensor(-100.0), torch.tensor(0.0))
+    gout = torch.randn(B_, N, C, generator=g)
+    scale = 32 ** -0.5
+    qr, br = qkv.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = _wmsa_reference(qr, br, mask.double() if mask is not None else None, scale, nh)
+    ref.backward(gout.double())
+    d = _dev()
+    qd, bd = qkv.to(d).requires_grad_(True), bias.to(d).requires_grad_(True)
+    out = ops.WindowAttention.apply(qd, bd, mask.to(d) if mask is not None else None, scale, nh)
+    out.backward(gout.to(d))
+    assert ops.wmsa_supported(N, 32)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=2e-5)
+    sc = qr.grad.abs().max().item()
+    assert (qd.grad.cpu().double() - qr.grad).abs().max().item() <= 2e-4 * sc
+    sb = br.grad.abs().max().item()
+    assert (bd.grad.cpu().double() - br.grad).abs().max().item() <= 2e-4 * sb + 1e-6
+
+
+def test_wmsa_unsupported_shapes_are_reported():
+    from vitta_amd import ops
+    assert not ops.wmsa_supported(784, 32) and not ops.wmsa_supported(392, 64)

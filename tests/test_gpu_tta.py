@@ -149,3 +149,22 @@ def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine)
     g = H.golden("tta3_swin.npz")
     recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
     check_tta_records(g, mode, recs, BASE_GPU)
+
+
+def test_swin_fused_attention_equals_composed_ops_on_gpu():
+    """Whole Swin-B forward + backward: fused W-MSA kernel vs the composed matmul/softmax ops."""
+    from vitta_amd import swin
+    model = H.build_swin(11, 0).to(_dev())
+    x = H.seeded_randn((1, 2, 3, 16, 112, 112), 31).to(_dev())
+    outs = []
+    for fused in (True, False):
+        swin.FUSED_ATTENTION = fused
+        model.zero_grad()
+        vid, view = model(x)
+        view.square().sum().backward()
+        outs.append((view.detach().cpu(), model.backbone.layers[2].blocks[3].attn.qkv.weight.grad.cpu().clone(),
+                     model.backbone.layers[0].blocks[1].attn.relative_position_bias_table.grad.cpu().clone()))
+    swin.FUSED_ATTENTION = True
+    assert_logits_close(outs[0][0], outs[1][0], 1e-4)
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-9

@@ -1,0 +1,424 @@
+// Fused 3-D shifted-window multi-head self-attention (W-MSA / SW-MSA) for Video Swin.
+//
+// Reference (models/videoswintransformer_models/swin_transformer.py:138-169), per window b and head h:
+//   q = q * scale ; attn = q @ k^T                       [N x N] materialised (315 MB per block at stage 1)
+//   attn += relative_position_bias[h] (+ mask[b % nW])    2 more passes
+//   attn = softmax(attn) ; x = attn @ v                   2 more passes, + the head permutes
+// Here: one kernel keeps the [16 x N] score rows of a wave in registers (N <= 400: 25 MFMA tiles of
+// 4 accumulators), nothing of size N x N ever reaches HBM.  fp32 in / fp32 accumulate on
+// v_mfma_f32_16x16x4_f32 (exact f32, the reference is fp32 end to end).
+//
+// Layouts: qkv [B_, N, 3, nH, 32] exactly as the qkv Linear writes it; out [B_, N, nH*32] as the proj
+// Linear reads it (the reference's reshape/permute/transpose copies disappear); bias [nH, N, N];
+// mask [nW, N, N] or null (window b uses mask[b % nW]); lse [B_, nH, N] = row max + log row sum.
+//
+// MFMA operand trick: the score tile is computed TRANSPOSED, S^T[key][query] = K Q^T.  Its C/D layout
+// (col = lane&15 = query, row = 4*(lane>>4)+r = key) is exactly the A-operand layout the second GEMM
+// needs (A[i = lane&15][k = lane>>4] with key = 16t + 4*(lane>>4) + r at k-step r), so P feeds P.V
+// straight from the accumulators: no LDS round trip, no shuffles.
+#include "common.h"
+
+using namespace vitta;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HD = 32;          // head dim of every Swin variant on the path (C / nH)
+constexpr int KPAD = 36;        // LDS row stride in floats: 36 j mod 64 are distinct multiples of 4 -> conflict-free b128
+constexpr int NT_MAX = 25;      // 16-token tiles per window: N <= 400 (8*7*7 = 392)
+constexpr int WMSA_THREADS = 512;
+constexpr int WMSA_WAVES = WMSA_THREADS / 64;
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// stage rows [0, N) of one of q/k/v (sel) of (b, h) into LDS with row stride KPAD; rows [N, 16*nt) zeroed
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ qkv, int64_t b, int h,
+                                           int sel, int N, int nH, int nt) {
+  const int64_t rs = 3 * (int64_t)nH * HD;  // floats per token
+  const float* src = qkv + b * N * rs + (int64_t)sel * nH * HD + (int64_t)h * HD;
+  for (int i = threadIdx.x; i < 16 * nt * (HD / 4); i += WMSA_THREADS) {
+    const int row = i / (HD / 4), c4 = i % (HD / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N) v = *reinterpret_cast<const float4*>(src + row * rs + 4 * c4);
+    *reinterpret_cast<float4*>(dst + row * KPAD + 4 * c4) = v;
+  }
+}
+
+__device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const float* __restrict__ src_base,
+                                                 int64_t row_stride, int N, int nt) {
+  for (int i = threadIdx.x; i < 16 * nt * (HD / 4); i += WMSA_THREADS) {
+    const int row = i / (HD / 4), c4 = i % (HD / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < N) v = *reinterpret_cast<const float4*>(src_base + row * row_stride + 4 * c4);
+    *reinterpret_cast<float4*>(dst + row * KPAD + 4 * c4) = v;
+  }
+}
+
+// 8 contiguous floats of a row (d = 8*kk .. 8*kk+7)
+__device__ __forceinline__ void load8(float (&r)[8], const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+}
+
+// S^T tile t for the wave's 16 queries: acc[r] = S[query = lane&15][key = 16t + 4*(lane>>4) + r] (scaled, + bias + mask)
+__device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, const float (&qf)[8], int t, int lane,
+                                            const float* __restrict__ bias_row, const float* __restrict__ mask_row,
+                                            int N) {
+  const int j = lane & 15, kk = lane >> 4;
+  float kf[8];
+  load8(kf, k_lds + (16 * t + j) * KPAD + 8 * kk);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = mfma(kf[s], qf[s], acc);
+  const int key0 = 16 * t + 4 * kk;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int key = key0 + r;
+    if (key < N) {
+      float add = bias_row[key];
+      if (mask_row) add += mask_row[key];
+      acc[r] += add;
+    } else {
+      acc[r] = -INFINITY;
+    }
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ bias,
+                                                                const float* __restrict__ mask, int nW, int N, int nH,
+                                                                float scale, int qsplit, float* __restrict__ out,
+                                                                float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nt = (N + 15) / 16;
+  float* k_lds = smem;                      // [16*nt][KPAD]
+  float* v_lds = smem + 16 * nt * KPAD;     // [16*nt][KPAD]
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
+  stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
+  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
+  const int C = nH * HD;
+
+  // row tiles of this workgroup: [rt0, rt1) of the nt tiles, split over `qsplit` workgroups
+  const int per = (nt + qsplit - 1) / qsplit;
+  const int rt0 = blockIdx.x * per, rt1 = min(nt, rt0 + per);
+  for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
+    const int q = min(16 * rt + i, N - 1);  // clamped: rows >= N are computed but never stored
+    float qf[8];
+    load8(qf, q_base + q * rs + 8 * kk);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] *= scale;
+    const float* bias_row = bias + ((int64_t)h * N + q) * N;
+    const float* mask_row = mask_b ? mask_b + (int64_t)q * N : nullptr;
+
+    f32x4 acc[NT_MAX];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t) {
+      if (t < nt) {
+        acc[t] = score_tile(k_lds, qf, t, lane, bias_row, mask_row, N);
+        m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(acc[t][r] - m);
+          acc[t][r] = p;
+          l += p;
+        }
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.f / l;
+
+    // O = P V: two 16-wide halves of the head dim
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT_MAX; ++t) {
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* vrow = v_lds + (16 * t + 4 * kk + r) * KPAD;
+          o0 = mfma(acc[t][r], vrow[i], o0);
+          o1 = mfma(acc[t][r], vrow[16 + i], o1);
+        }
+      }
+    }
+    // C layout: row = query 4*kk + r, col = d = i; the row's 1/l lives in lane (4*kk + r)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * kk + r;
+      const float il = __shfl(inv_l, 4 * kk + r, 64);
+      if (qrow < N) {
+        float* o = out + (b * N + qrow) * C + h * HD;
+        o[i] = o0[r] * il;
+        o[16 + i] = o1[r] * il;
+      }
+    }
+    if (kk == 0 && 16 * rt + i < N) lse[(b * nH + h) * N + 16 * rt + i] = m + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 1: dQ (query-tile major, K and V staged) + optional dbias via atomics
+//   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask, int nW, int N,
+    int nH, float scale, int qsplit, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nt = (N + 15) / 16;
+  float* k_lds = smem;
+  float* v_lds = smem + 16 * nt * KPAD;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
+  stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
+  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
+  const int per = (nt + qsplit - 1) / qsplit;
+  const int rt0 = blockIdx.x * per, rt1 = min(nt, rt0 + per);
+  for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
+    const bool qvalid = 16 * rt + i < N;
+    const int q = min(16 * rt + i, N - 1);
+    float qf[8], gf[8], of[8];
+    load8(qf, q_base + q * rs + 8 * kk);
+    load8(gf, dout + (b * N + q) * C + h * HD + 8 * kk);
+    load8(of, out + (b * N + q) * C + h * HD + 8 * kk);
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qf[s] *= scale;
+      dl = fmaf(gf[s], of[s], dl);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);  // delta[q] = sum_d dO[q][d] O[q][d]
+    const float L = lse[(b * nH + h) * N + q];
+    if (kk == 0 && qvalid) delta[(b * nH + h) * N + q] = dl;
+    const float* bias_row = bias + ((int64_t)h * N + q) * N;
+    const float* mask_row = mask_b ? mask_b + (int64_t)q * N : nullptr;
+    float* dbias_row = dbias ? dbias + ((int64_t)h * N + q) * N : nullptr;
+
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      f32x4 s = score_tile(k_lds, qf, t, lane, bias_row, mask_row, N);
+      // dP^T tile = V dO^T (same C layout as S^T)
+      float vf[8];
+      load8(vf, v_lds + (16 * t + i) * KPAD + 8 * kk);
+      f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dp = mfma(vf[u], gf[u], dp);
+      f32x4 ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[r] - L);  // exp(-inf) = 0 for padded keys
+        ds[r] = p * (dp[r] - dl);
+      }
+      if (dbias_row && qvalid) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * kk + r;
+          if (key < N) atomicAdd(dbias_row + key, ds[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* krow = k_lds + (16 * t + 4 * kk + r) * KPAD;
+        dq0 = mfma(ds[r], krow[i], dq0);
+        dq1 = mfma(ds[r], krow[16 + i], dq1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * kk + r;
+      if (qrow < N) {
+        float* o = dqkv + (b * N + qrow) * rs + (int64_t)h * HD;  // sel 0 = q
+        o[i] = dq0[r] * scale;
+        o[16 + i] = dq1[r] * scale;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2: dK, dV (key-tile major, Q and dO staged)
+//   dV = P^T dO ; dK = scale * dS^T Q
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask, int nW, int N,
+    int nH, float scale, int qsplit, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta, float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nt = (N + 15) / 16;
+  float* q_lds = smem;                       // raw (unscaled) Q
+  float* g_lds = smem + 16 * nt * KPAD;      // dO
+  float* l_lds = g_lds + 16 * nt * KPAD;     // lse  [16*nt]
+  float* d_lds = l_lds + 16 * nt;            // delta [16*nt]
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int C = nH * HD;
+  stage_rows(q_lds, qkv, b, h, 0, N, nH, nt);
+  stage_rows_dense(g_lds, dout + b * N * C + h * HD, C, N, nt);
+  for (int r = threadIdx.x; r < 16 * nt; r += WMSA_THREADS) {
+    l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
+    d_lds[r] = r < N ? delta[(b * nH + h) * N + r] : 0.f;
+  }
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const float* k_base = qkv + b * N * rs + (int64_t)(nH + h) * HD;
+  const float* v_base = qkv + b * N * rs + (int64_t)(2 * nH + h) * HD;
+  const float* bias_h = bias + (int64_t)h * N * N;
+  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
+  const int per = (nt + qsplit - 1) / qsplit;
+  const int kt0 = blockIdx.x * per, kt1 = min(nt, kt0 + per);
+  for (int kt = kt0 + wave; kt < kt1; kt += WMSA_WAVES) {
+    const int key = min(16 * kt + i, N - 1);
+    const bool kvalid = 16 * kt + i < N;
+    float kf[8], vf[8];
+    load8(kf, k_base + key * rs + 8 * kk);
+    load8(vf, v_base + key * rs + 8 * kk);
+    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < nt; ++qt) {
+      // S tile [query][key]: A = Q tile (LDS), B = K^T (registers); C layout: col = key i, row = query 4kk + r
+      float qf[8], gf[8];
+      load8(qf, q_lds + (16 * qt + i) * KPAD + 8 * kk);
+      load8(gf, g_lds + (16 * qt + i) * KPAD + 8 * kk);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s = mfma(qf[u], kf[u], s);
+        dp = mfma(gf[u], vf[u], dp);
+      }
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = 16 * qt + 4 * kk + r;
+        float sv = -INFINITY;
+        if (q < N && kvalid) {
+          sv = s[r] * scale + bias_h[(int64_t)q * N + key];
+          if (mask_b) sv += mask_b[(int64_t)q * N + key];
+        }
+        p[r] = __expf(sv - l_lds[q]);
+        ds[r] = p[r] * (dp[r] - d_lds[q]);
+      }
+      // dV[key][d] += P^T dO ; dK[key][d] += dS^T Q   (A = C-layout values, B rows = queries 16qt + 4kk + r)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* grow = g_lds + (16 * qt + 4 * kk + r) * KPAD;
+        const float* qrow = q_lds + (16 * qt + 4 * kk + r) * KPAD;
+        dv0 = mfma(p[r], grow[i], dv0);
+        dv1 = mfma(p[r], grow[16 + i], dv1);
+        dk0 = mfma(ds[r], qrow[i], dk0);
+        dk1 = mfma(ds[r], qrow[16 + i], dk1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = 16 * kt + 4 * kk + r;
+      if (krow < N) {
+        float* ok = dqkv + (b * N + krow) * rs + (int64_t)(nH + h) * HD;
+        float* ov = dqkv + (b * N + krow) * rs + (int64_t)(2 * nH + h) * HD;
+        ok[i] = dk0[r] * scale;
+        ok[16 + i] = dk1[r] * scale;
+        ov[i] = dv0[r];
+        ov[16 + i] = dv1[r];
+      }
+    }
+  }
+}
+
+inline int pick_qsplit(int64_t pairs, int nt) {
+  // aim at >= ~512 workgroups (2 per CU) while keeping >= 2 row tiles per wave-slot busy
+  int qs = 1;
+  while (pairs * qs < 512 && qs * 2 <= nt && qs < 8) qs *= 2;
+  return qs;
+}
+
+inline size_t lds_bytes(int N, bool bwd2) {
+  const int nt = (N + 15) / 16;
+  return sizeof(float) * ((size_t)2 * 16 * nt * KPAD + (bwd2 ? 2 * 16 * nt : 0));
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitta_wmsa_supported(int32_t N, int32_t head_dim) { return (head_dim == HD && N >= 1 && N <= 16 * NT_MAX) ? 1 : 0; }
+
+int vitta_wmsa_fwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_, int32_t N,
+                       int32_t nH, int32_t head_dim, float scale, float* d_out, float* d_lse, void* stream) {
+  if (!d_qkv || !d_bias || !d_out || !d_lse || B_ <= 0 || nH <= 0) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(d_out)) & 15u) return VITTA_ERR_INVALID_ARG;
+  const int nt = (N + 15) / 16;
+  const int qs = pick_qsplit(B_ * nH, nt);
+  const size_t lds = lds_bytes(N, false);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return VITTA_ERR_LAUNCH;
+  VITTA_LAUNCH(wmsa_fwd_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds, static_cast<hipStream_t>(stream),
+               d_qkv, d_bias, d_mask, (int)(d_mask ? nW : 1), (int)N, (int)nH, scale, qs, d_out, d_lse);
+  return VITTA_OK;
+}
+
+int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_, int32_t N,
+                       int32_t nH, int32_t head_dim, float scale, const float* d_out, const float* d_dout,
+                       const float* d_lse, float* d_delta, float* d_dqkv, float* d_dbias, void* stream) {
+  if (!d_qkv || !d_bias || !d_out || !d_dout || !d_lse || !d_delta || !d_dqkv || B_ <= 0 || nH <= 0)
+    return VITTA_ERR_INVALID_ARG;
+  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if ((reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_dout) |
+       reinterpret_cast<uintptr_t>(d_dqkv)) & 15u)
+    return VITTA_ERR_INVALID_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = (N + 15) / 16;
+  const int qs = pick_qsplit(B_ * nH, nt);
+  const size_t lds1 = lds_bytes(N, false), lds2 = lds_bytes(N, true);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds1) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds2) != hipSuccess)
+    return VITTA_ERR_LAUNCH;
+  const int nWk = d_mask ? nW : 1;
+  VITTA_LAUNCH(wmsa_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds1, st, d_qkv, d_bias, d_mask, nWk,
+               (int)N, (int)nH, scale, qs, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dbias);
+  VITTA_LAUNCH(wmsa_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds2, st, d_qkv, d_bias, d_mask, nWk,
+               (int)N, (int)nH, scale, qs, d_dout, d_lse, d_delta, d_dqkv);
+  return VITTA_OK;
+}
+
+}  // extern "C"

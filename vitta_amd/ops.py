@@ -285,3 +285,45 @@ class TamAggregate(torch.autograd.Function):
                                           _p(gkern), _stream()), "vitta_tam_agg_bwd_f32")
         ggate = ggate_buf[: n * c * t].view_as(gate)
         return gx, ggate, gkern, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fused window attention (Video Swin)
+# ------------------------------------------------------------------------------------------------
+def wmsa_supported(n_tokens, head_dim):
+    return bool(lib().vitta_wmsa_supported(int(n_tokens), int(head_dim)))
+
+
+class WindowAttention(torch.autograd.Function):
+    """softmax(scale q k^T + bias (+ mask)) v per (window, head) in one launch; the N x N matrix never
+    reaches HBM (swin_transformer.py:144-168).  qkv (B_, N, 3C) -> (B_, N, C)."""
+
+    @staticmethod
+    def forward(ctx, qkv, bias, mask, scale, num_heads):
+        _require_cuda_f32(qkv, "qkv")
+        qkv, bias = qkv.contiguous(), bias.contiguous()
+        mask = mask.contiguous() if mask is not None else None
+        b_, n, c3 = qkv.shape
+        c = c3 // 3
+        hd = c // num_heads
+        out = torch.empty(b_, n, c, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
+        nw = mask.shape[0] if mask is not None else 1
+        check(lib().vitta_wmsa_fwd_f32(_p(qkv), _p(bias), _p(mask), nw, b_, n, num_heads, hd, float(scale), _p(out),
+                                       _p(lse), _stream()), "vitta_wmsa_fwd_f32")
+        ctx.save_for_backward(qkv, bias, mask, out, lse)
+        ctx.meta = (float(scale), num_heads, hd, nw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, bias, mask, out, lse = ctx.saved_tensors
+        scale, nh, hd, nw = ctx.meta
+        b_, n, _ = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        dbias = torch.zeros_like(bias) if ctx.needs_input_grad[1] else None
+        check(lib().vitta_wmsa_bwd_f32(_p(qkv), _p(bias), _p(mask), nw, b_, n, nh, hd, scale, _p(out), _p(dout), _p(lse),
+                                       _p(delta), _p(dqkv), _p(dbias), _stream()), "vitta_wmsa_bwd_f32")
+        return dqkv, dbias, None, None, None
