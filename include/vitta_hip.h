@@ -213,6 +213,20 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
                        const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv, float* d_dbias,
                        void* stream);
 
+/* Same attention with the additive terms kept ON CHIP: the relative-position bias is
+ * table[code[q] - code[k] + code_off][h] (the index of swin_transformer.py:113-124 is linear in the
+ * token coordinates; code[t] = (t_d*(2wh-1) + t_h)*(2ww-1) + t_w) and the shift mask is -100 where
+ * region[b % nW][q] != region[b % nW][k] (swin_transformer.py:316-329).  No [N x N] operand exists.
+ *   d_table [T, nH] (the module's parameter as stored), T <= 4096; d_code int32 [N];
+ *   d_region int32 [nW, N] or NULL; d_dtable [T, nH] or NULL (accumulated: zero it first). */
+int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code,
+                           int32_t code_off, const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH,
+                           int32_t head_dim, float scale, float* d_out, float* d_lse, void* stream);
+int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code,
+                           int32_t code_off, const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH,
+                           int32_t head_dim, float scale, const float* d_out, const float* d_dout,
+                           const float* d_lse, float* d_delta, float* d_dqkv, float* d_dtable, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,37 @@ def test_wmsa_fused_forward_backward(B_, N, nh, nW):
 def test_wmsa_unsupported_shapes_are_reported():
     from vitta_amd import ops
     assert not ops.wmsa_supported(784, 32) and not ops.wmsa_supported(392, 64)
+
+
+@pytest.mark.parametrize("ws,clamp,B,nh,shift", [((8, 7, 7), (8, 7, 7), 2, 4, True), ((8, 7, 7), (4, 7, 7), 3, 2, False),
+                                               ((8, 7, 7), (8, 4, 4), 2, 2, True), ((2, 3, 3), (2, 3, 3), 5, 1, True)])
+def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
+    """On-chip bias/mask variant == dense variant semantics: table[index[:N,:N]] and compute_mask."""
+    from vitta_amd import ops, swin
+    g = torch.Generator().manual_seed(23)
+    N = clamp[0] * clamp[1] * clamp[2]
+    C = nh * 32
+    T = (2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    table = torch.randn(T, nh, generator=g) * 0.5
+    index = swin.relative_position_index(ws)[:N, :N]
+    code, off = swin.relative_position_code(ws)
+    nW = 4
+    region = torch.randint(0, 4, (nW, N), generator=g, dtype=torch.int32) if shift else None
+    mask = None
+    if shift:
+        mask = torch.where(region.unsqueeze(1) != region.unsqueeze(2), torch.tensor(-100.0), torch.tensor(0.0))
+    B_ = B * nW
+    qkv = torch.randn(B_, N, 3 * C, generator=g)
+    gout = torch.randn(B_, N, C, generator=g)
+    scale = 32 ** -0.5
+    qr, tr = qkv.double().requires_grad_(True), table.double().requires_grad_(True)
+    bias = tr[index.reshape(-1)].view(N, N, nh).permute(2, 0, 1)
+    ref = _wmsa_reference(qr, bias, mask.double() if mask is not None else None, scale, nh)
+    ref.backward(gout.double())
+    d = _dev()
+    qd, td = qkv.to(d).requires_grad_(True), table.to(d).requires_grad_(True)
+    out = ops.WindowAttentionRel.apply(qd, td, code[:N].to(d), off, region.to(d) if shift else None, scale, nh)
+    out.backward(gout.to(d))
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=2e-5)
+    assert (qd.grad.cpu().double() - qr.grad).abs().max().item() <= 2e-4 * qr.grad.abs().max().item()
+    assert (td.grad.cpu().double() - tr.grad).abs().max().item() <= 5e-4 * tr.grad.abs().max().item() + 1e-6

@@ -55,6 +55,9 @@ SIGNATURES = {
     "vitta_tam_pool_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_wmsa_supported": (C.c_int, [_i32, _i32]),
     "vitta_wmsa_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p]),
+    "vitta_wmsa_rel_fwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p]),
+    "vitta_wmsa_rel_bwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p,
+                                         _p, _p, _p]),
     "vitta_wmsa_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -64,10 +64,40 @@ __device__ __forceinline__ void load8(float (&r)[8], const float* p) {
   r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
 }
 
-// S^T tile t for the wave's 16 queries: acc[r] = S[query = lane&15][key = 16t + 4*(lane>>4) + r] (scaled, + bias + mask)
+// Where the additive terms of a score come from.
+//  DENSE: bias [nH,N,N] and mask [nW,N,N] in global memory (generic form, what the reference builds).
+//  REL  : the relative-position bias is table[code[q] - code[k] + off][h] (the index is linear in the
+//         token coordinates, swin_transformer.py:113-124) and the shift mask is -100 where the tokens'
+//         pre-shift region ids differ (swin_transformer.py:316-329): table column, codes and region ids
+//         sit in LDS, so the N x N terms cost no memory traffic at all.
+struct AddTerms {
+  // DENSE
+  const float* bias_h;   // bias + h*N*N
+  const float* mask_b;   // mask + (b % nW)*N*N or null
+  // REL
+  const float* tab;      // LDS: table[:, h]            [T]
+  const int* code;       // LDS: code[N]
+  const int* region;     // LDS: region ids of window b  [N] or null
+  int off;
+};
+
+template <bool REL>
+__device__ __forceinline__ float add_term(const AddTerms& a, int q, int key, int N) {
+  if constexpr (REL) {
+    float v = a.tab[a.code[q] - a.code[key] + a.off];
+    if (a.region && a.region[q] != a.region[key]) v -= 100.f;
+    return v;
+  } else {
+    float v = a.bias_h[(int64_t)q * N + key];
+    if (a.mask_b) v += a.mask_b[(int64_t)q * N + key];
+    return v;
+  }
+}
+
+// S^T tile t for the wave's 16 queries: acc[r] = S[query q][key = 16t + 4*(lane>>4) + r] (scaled, + bias + mask)
+template <bool REL>
 __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, const float (&qf)[8], int t, int lane,
-                                            const float* __restrict__ bias_row, const float* __restrict__ mask_row,
-                                            int N) {
+                                            const AddTerms& a, int q, int N) {
   const int j = lane & 15, kk = lane >> 4;
   float kf[8];
   load8(kf, k_lds + (16 * t + j) * KPAD + 8 * kk);
@@ -75,43 +105,103 @@ __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, con
 #pragma unroll
   for (int s = 0; s < 8; ++s) acc = mfma(kf[s], qf[s], acc);
   const int key0 = 16 * t + 4 * kk;
+  if constexpr (REL) {
+    const int cq = a.code[q] + a.off;
+    const int rq = a.region ? a.region[q] : 0;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int key = key0 + r;
-    if (key < N) {
-      float add = bias_row[key];
-      if (mask_row) add += mask_row[key];
-      acc[r] += add;
+    for (int r = 0; r < 4; ++r) {
+      const int key = key0 + r;
+      if (key < N) {
+        float v = a.tab[cq - a.code[key]];
+        if (a.region && a.region[key] != rq) v -= 100.f;
+        acc[r] += v;
+      } else {
+        acc[r] = -INFINITY;
+      }
+    }
+  } else {
+    if (key0 + 3 < N && (N & 3) == 0) {  // 4 consecutive keys of one row: one 16-byte load each
+      const float4 bv = *reinterpret_cast<const float4*>(a.bias_h + (int64_t)q * N + key0);
+      acc[0] += bv.x; acc[1] += bv.y; acc[2] += bv.z; acc[3] += bv.w;
+      if (a.mask_b) {
+        const float4 mv = *reinterpret_cast<const float4*>(a.mask_b + (int64_t)q * N + key0);
+        acc[0] += mv.x; acc[1] += mv.y; acc[2] += mv.z; acc[3] += mv.w;
+      }
     } else {
-      acc[r] = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + r;
+        if (key < N) acc[r] += add_term<false>(a, q, key, N);
+        else acc[r] = -INFINITY;
+      }
     }
   }
   return acc;
 }
 
+// LDS carve shared by the three kernels: [buf0 | buf1 | extra floats | tab | code | region]
+struct Carve {
+  float* buf0; float* buf1; float* extra; float* tab; int* code; int* region;
+};
+__device__ __forceinline__ Carve carve(float* smem, int nt, int extra_floats, int T) {
+  Carve c;
+  c.buf0 = smem;
+  c.buf1 = c.buf0 + 16 * nt * KPAD;
+  c.extra = c.buf1 + 16 * nt * KPAD;
+  c.tab = c.extra + extra_floats;
+  c.code = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
+  c.region = c.code + 16 * nt;
+  return c;
+}
+
+// fill the REL terms of (b, h) into LDS and return the provider
+template <bool REL>
+__device__ __forceinline__ AddTerms setup_terms(const Carve& c, const float* bias_or_table, const float* mask,
+                                                const int* code_g, const int* region_g, int T, int off, int nW, int N,
+                                                int nH, int h, int64_t b, int nt) {
+  AddTerms a;
+  a.bias_h = nullptr; a.mask_b = nullptr; a.tab = nullptr; a.code = nullptr; a.region = nullptr; a.off = off;
+  if constexpr (REL) {
+    for (int i = threadIdx.x; i < T; i += WMSA_THREADS) c.tab[i] = bias_or_table[(int64_t)i * nH + h];
+    for (int i = threadIdx.x; i < 16 * nt; i += WMSA_THREADS) {
+      c.code[i] = code_g[i < N ? i : N - 1];
+      if (region_g) c.region[i] = region_g[(b % nW) * (int64_t)N + (i < N ? i : N - 1)];
+    }
+    a.tab = c.tab; a.code = c.code; a.region = region_g ? c.region : nullptr;
+  } else {
+    a.bias_h = bias_or_table + (int64_t)h * N * N;
+    a.mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
+  }
+  return a;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+template <bool REL>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __restrict__ qkv,
                                                                 const float* __restrict__ bias,
-                                                                const float* __restrict__ mask, int nW, int N, int nH,
-                                                                float scale, int qsplit, float* __restrict__ out,
-                                                                float* __restrict__ lse) {
+                                                                const float* __restrict__ mask,
+                                                                const int* __restrict__ code_g,
+                                                                const int* __restrict__ region_g, int T, int off,
+                                                                int nW, int N, int nH, float scale, int qsplit,
+                                                                float* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
-  float* k_lds = smem;                      // [16*nt][KPAD]
-  float* v_lds = smem + 16 * nt * KPAD;     // [16*nt][KPAD]
+  const Carve cv = carve(smem, nt, 0, T);
+  float* k_lds = cv.buf0;                   // [16*nt][KPAD]
+  float* v_lds = cv.buf1;                   // [16*nt][KPAD]
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
   stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 15, kk = lane >> 4;
   const int64_t rs = 3 * (int64_t)nH * HD;
   const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
-  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
   const int C = nH * HD;
 
   // row tiles of this workgroup: [rt0, rt1) of the nt tiles, split over `qsplit` workgroups
@@ -123,15 +213,13 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
     load8(qf, q_base + q * rs + 8 * kk);
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] *= scale;
-    const float* bias_row = bias + ((int64_t)h * N + q) * N;
-    const float* mask_row = mask_b ? mask_b + (int64_t)q * N : nullptr;
 
     f32x4 acc[NT_MAX];
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT_MAX; ++t) {
       if (t < nt) {
-        acc[t] = score_tile(k_lds, qf, t, lane, bias_row, mask_row, N);
+        acc[t] = score_tile<REL>(k_lds, qf, t, lane, terms, q, N);
         m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
       }
     }
@@ -185,18 +273,27 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
 // backward 1: dQ (query-tile major, K and V staged) + optional dbias via atomics
 //   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
 // ------------------------------------------------------------------------------------------------
+template <bool REL>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask, int nW, int N,
-    int nH, float scale, int qsplit, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
+    const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
+    float scale, int qsplit, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
-  float* k_lds = smem;
-  float* v_lds = smem + 16 * nt * KPAD;
+  // REL + dbias: the table gradient of this workgroup accumulates in LDS (ds_add_f32), one global
+  // atomic per table entry at the end
+  const Carve cv = carve(smem, nt, (REL && dbias) ? ((T + 3) & ~3) : 0, T);
+  float* k_lds = cv.buf0;
+  float* v_lds = cv.buf1;
+  float* dtab = cv.extra;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
   stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
+  if (REL && dbias)
+    for (int i = threadIdx.x; i < T; i += WMSA_THREADS) dtab[i] = 0.f;
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -204,7 +301,6 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   const int64_t rs = 3 * (int64_t)nH * HD;
   const int C = nH * HD;
   const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
-  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
   const int per = (nt + qsplit - 1) / qsplit;
   const int rt0 = blockIdx.x * per, rt1 = min(nt, rt0 + per);
   for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
@@ -224,13 +320,11 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
     dl += __shfl_xor(dl, 32, 64);  // delta[q] = sum_d dO[q][d] O[q][d]
     const float L = lse[(b * nH + h) * N + q];
     if (kk == 0 && qvalid) delta[(b * nH + h) * N + q] = dl;
-    const float* bias_row = bias + ((int64_t)h * N + q) * N;
-    const float* mask_row = mask_b ? mask_b + (int64_t)q * N : nullptr;
-    float* dbias_row = dbias ? dbias + ((int64_t)h * N + q) * N : nullptr;
+    float* dbias_row = (!REL && dbias) ? dbias + ((int64_t)h * N + q) * N : nullptr;
 
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nt; ++t) {
-      f32x4 s = score_tile(k_lds, qf, t, lane, bias_row, mask_row, N);
+      f32x4 s = score_tile<REL>(k_lds, qf, t, lane, terms, q, N);
       // dP^T tile = V dO^T (same C layout as S^T)
       float vf[8];
       load8(vf, v_lds + (16 * t + i) * KPAD + 8 * kk);
@@ -243,11 +337,14 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
         const float p = __expf(s[r] - L);  // exp(-inf) = 0 for padded keys
         ds[r] = p * (dp[r] - dl);
       }
-      if (dbias_row && qvalid) {
+      if (dbias && qvalid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * t + 4 * kk + r;
-          if (key < N) atomicAdd(dbias_row + key, ds[r]);
+          if (key < N) {
+            if constexpr (REL) atomicAdd(dtab + (terms.code[q] - terms.code[key] + terms.off), ds[r]);
+            else atomicAdd(dbias_row + key, ds[r]);
+          }
         }
       }
 #pragma unroll
@@ -267,27 +364,38 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
       }
     }
   }
+  if (REL && dbias) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += WMSA_THREADS) {
+      const float v = dtab[t];
+      if (v != 0.f) atomicAdd(dbias + (int64_t)t * nH + h, v);  // REL: dbias is the table gradient [T, nH]
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward 2: dK, dV (key-tile major, Q and dO staged)
 //   dV = P^T dO ; dK = scale * dS^T Q
 // ------------------------------------------------------------------------------------------------
+template <bool REL>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask, int nW, int N,
-    int nH, float scale, int qsplit, const float* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
+    const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
+    float scale, int qsplit, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
-  float* q_lds = smem;                       // raw (unscaled) Q
-  float* g_lds = smem + 16 * nt * KPAD;      // dO
-  float* l_lds = g_lds + 16 * nt * KPAD;     // lse  [16*nt]
+  const Carve cv = carve(smem, nt, 2 * 16 * nt, T);
+  float* q_lds = cv.buf0;                    // raw (unscaled) Q
+  float* g_lds = cv.buf1;                    // dO
+  float* l_lds = cv.extra;                   // lse  [16*nt]
   float* d_lds = l_lds + 16 * nt;            // delta [16*nt]
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int C = nH * HD;
   stage_rows(q_lds, qkv, b, h, 0, N, nH, nt);
   stage_rows_dense(g_lds, dout + b * N * C + h * HD, C, N, nt);
+  const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   for (int r = threadIdx.x; r < 16 * nt; r += WMSA_THREADS) {
     l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
     d_lds[r] = r < N ? delta[(b * nH + h) * N + r] : 0.f;
@@ -299,8 +407,6 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
   const int64_t rs = 3 * (int64_t)nH * HD;
   const float* k_base = qkv + b * N * rs + (int64_t)(nH + h) * HD;
   const float* v_base = qkv + b * N * rs + (int64_t)(2 * nH + h) * HD;
-  const float* bias_h = bias + (int64_t)h * N * N;
-  const float* mask_b = mask ? mask + (b % nW) * (int64_t)N * N : nullptr;
   const int per = (nt + qsplit - 1) / qsplit;
   const int kt0 = blockIdx.x * per, kt1 = min(nt, kt0 + per);
   for (int kt = kt0 + wave; kt < kt1; kt += WMSA_WAVES) {
@@ -326,10 +432,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
       for (int r = 0; r < 4; ++r) {
         const int q = 16 * qt + 4 * kk + r;
         float sv = -INFINITY;
-        if (q < N && kvalid) {
-          sv = s[r] * scale + bias_h[(int64_t)q * N + key];
-          if (mask_b) sv += mask_b[(int64_t)q * N + key];
-        }
+        if (q < N && kvalid) sv = s[r] * scale + add_term<REL>(terms, q, key, N);
         p[r] = __expf(sv - l_lds[q]);
         ds[r] = p[r] * (dp[r] - d_lds[q]);
       }
@@ -366,9 +469,53 @@ inline int pick_qsplit(int64_t pairs, int nt) {
   return qs;
 }
 
-inline size_t lds_bytes(int N, bool bwd2) {
+constexpr int T_MAX = 4096;  // (2wd-1)(2wh-1)(2ww-1): 2535 for the (8,7,7) window
+
+inline size_t lds_bytes(int N, int extra_floats, int T) {
   const int nt = (N + 15) / 16;
-  return sizeof(float) * ((size_t)2 * 16 * nt * KPAD + (bwd2 ? 2 * 16 * nt : 0));
+  return sizeof(float) * ((size_t)2 * 16 * nt * KPAD + extra_floats + ((T + 3) & ~3) + 2 * 16 * nt);
+}
+
+struct WmsaArgs {
+  const float* qkv; const float* bias; const float* mask; const int* code; const int* region;
+  int T, off, nW; int64_t B_; int N, nH; float scale;
+};
+
+template <bool REL>
+int launch_fwd(const WmsaArgs& a, float* out, float* lse, hipStream_t st) {
+  const int nt = (a.N + 15) / 16;
+  const int qs = pick_qsplit(a.B_ * a.nH, nt);
+  const size_t lds = lds_bytes(a.N, 0, REL ? a.T : 0);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_fwd_kernel<REL>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return VITTA_ERR_LAUNCH;
+  VITTA_LAUNCH(wmsa_fwd_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds, st, a.qkv, a.bias, a.mask,
+               a.code, a.region, REL ? a.T : 0, a.off, a.nW, a.N, a.nH, a.scale, qs, out, lse);
+  return VITTA_OK;
+}
+
+template <bool REL>
+int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+               float* dbias, hipStream_t st) {
+  const int nt = (a.N + 15) / 16;
+  const int qs = pick_qsplit(a.B_ * a.nH, nt);
+  const int T = REL ? a.T : 0;
+  const size_t lds1 = lds_bytes(a.N, (REL && dbias) ? ((T + 3) & ~3) : 0, T), lds2 = lds_bytes(a.N, 2 * 16 * nt, T);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel<REL>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dkv_kernel<REL>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+    return VITTA_ERR_LAUNCH;
+  VITTA_LAUNCH(wmsa_bwd_dq_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, a.mask,
+               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, out, dout, lse, delta, dqkv, dbias);
+  VITTA_LAUNCH(wmsa_bwd_dkv_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, a.mask,
+               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, dout, lse, delta, dqkv);
+  return VITTA_OK;
+}
+
+inline bool misaligned(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) & 15u) != 0;
 }
 
 }  // namespace
@@ -382,16 +529,9 @@ int vitta_wmsa_fwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
   if (!d_qkv || !d_bias || !d_out || !d_lse || B_ <= 0 || nH <= 0) return VITTA_ERR_INVALID_ARG;
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(d_out)) & 15u) return VITTA_ERR_INVALID_ARG;
-  const int nt = (N + 15) / 16;
-  const int qs = pick_qsplit(B_ * nH, nt);
-  const size_t lds = lds_bytes(N, false);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return VITTA_ERR_LAUNCH;
-  VITTA_LAUNCH(wmsa_fwd_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds, static_cast<hipStream_t>(stream),
-               d_qkv, d_bias, d_mask, (int)(d_mask ? nW : 1), (int)N, (int)nH, scale, qs, d_out, d_lse);
-  return VITTA_OK;
+  if (misaligned(d_qkv, d_out, d_bias, d_mask)) return VITTA_ERR_INVALID_ARG;
+  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale};
+  return launch_fwd<false>(a, d_out, d_lse, static_cast<hipStream_t>(stream));
 }
 
 int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_, int32_t N,
@@ -401,24 +541,35 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
-  if ((reinterpret_cast<uintptr_t>(d_qkv) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_dout) |
-       reinterpret_cast<uintptr_t>(d_dqkv)) & 15u)
+  if (misaligned(d_qkv, d_out, d_dout, d_dqkv) || misaligned(d_bias, d_mask)) return VITTA_ERR_INVALID_ARG;
+  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale};
+  return launch_bwd<false>(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dbias, static_cast<hipStream_t>(stream));
+}
+
+int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                           const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                           float scale, float* d_out, float* d_lse, void* stream) {
+  if (!d_qkv || !d_table || !d_code || !d_out || !d_lse || B_ <= 0 || nH <= 0 || T <= 0 || T > T_MAX)
     return VITTA_ERR_INVALID_ARG;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int nt = (N + 15) / 16;
-  const int qs = pick_qsplit(B_ * nH, nt);
-  const size_t lds1 = lds_bytes(N, false), lds2 = lds_bytes(N, true);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds1) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds2) != hipSuccess)
-    return VITTA_ERR_LAUNCH;
-  const int nWk = d_mask ? nW : 1;
-  VITTA_LAUNCH(wmsa_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds1, st, d_qkv, d_bias, d_mask, nWk,
-               (int)N, (int)nH, scale, qs, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dbias);
-  VITTA_LAUNCH(wmsa_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(WMSA_THREADS), lds2, st, d_qkv, d_bias, d_mask, nWk,
-               (int)N, (int)nH, scale, qs, d_dout, d_lse, d_delta, d_dqkv);
-  return VITTA_OK;
+  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
+  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale};
+  return launch_fwd<true>(a, d_out, d_lse, static_cast<hipStream_t>(stream));
+}
+
+int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                           const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                           float scale, const float* d_out, const float* d_dout, const float* d_lse, float* d_delta,
+                           float* d_dqkv, float* d_dtable, void* stream) {
+  if (!d_qkv || !d_table || !d_code || !d_out || !d_dout || !d_lse || !d_delta || !d_dqkv || B_ <= 0 || nH <= 0 ||
+      T <= 0 || T > T_MAX)
+    return VITTA_ERR_INVALID_ARG;
+  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
+  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale};
+  return launch_bwd<true>(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dtable, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -327,3 +327,39 @@ class WindowAttention(torch.autograd.Function):
         check(lib().vitta_wmsa_bwd_f32(_p(qkv), _p(bias), _p(mask), nw, b_, n, nh, hd, scale, _p(out), _p(dout), _p(lse),
                                        _p(delta), _p(dqkv), _p(dbias), _stream()), "vitta_wmsa_bwd_f32")
         return dqkv, dbias, None, None, None
+
+
+class WindowAttentionRel(torch.autograd.Function):
+    """WindowAttention with the relative-position bias looked up from the [T, nH] table and the shift
+    mask derived from region ids inside the kernel (nothing of size N x N in memory)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, code, code_off, region, scale, num_heads):
+        _require_cuda_f32(qkv, "qkv")
+        qkv, table = qkv.contiguous(), table.contiguous()
+        b_, n, c3 = qkv.shape
+        c = c3 // 3
+        hd = c // num_heads
+        out = torch.empty(b_, n, c, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
+        nw = region.shape[0] if region is not None else 1
+        check(lib().vitta_wmsa_rel_fwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
+                                           b_, n, num_heads, hd, float(scale), _p(out), _p(lse), _stream()),
+              "vitta_wmsa_rel_fwd_f32")
+        ctx.save_for_backward(qkv, table, code, region, out, lse)
+        ctx.meta = (int(code_off), float(scale), num_heads, hd, nw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, table, code, region, out, lse = ctx.saved_tensors
+        off, scale, nh, hd, nw = ctx.meta
+        b_, n, _ = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        dtable = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        check(lib().vitta_wmsa_rel_bwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
+                                           hd, scale, _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dtable),
+                                           _stream()), "vitta_wmsa_rel_bwd_f32")
+        return dqkv, dtable, None, None, None, None, None

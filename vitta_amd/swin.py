@@ -98,6 +98,28 @@ def compute_mask(D, H, W, window_size, shift_size, device):
     return torch.where(diff != 0, torch.tensor(-100.0), torch.tensor(0.0)).to(device)
 
 
+@lru_cache()
+def compute_region(D, H, W, window_size, shift_size, device):
+    """(nW, N) int32 pre-shift region id of every token of every window: compute_mask == -100 exactly
+    where two tokens of a window differ in it.  The fused kernel derives the mask from these."""
+    rd = _axis_region(D, window_size[0], shift_size[0])
+    rh = _axis_region(H, window_size[1], shift_size[1])
+    rw = _axis_region(W, window_size[2], shift_size[2])
+    region = (rd[:, None, None] * 3 + rh[None, :, None]) * 3 + rw[None, None, :]
+    return window_partition(region.view(1, D, H, W, 1), window_size).squeeze(-1).to(torch.int32).contiguous().to(device)
+
+
+def relative_position_code(window_size):
+    """code[t] with relative_position_index[q, k] == code[q] - code[k] + offset (the index is linear in
+    the token coordinates): lets a kernel index the bias table without any (N, N) operand."""
+    wd, wh, ww = window_size
+    t = torch.arange(wd * wh * ww)
+    td, th, tw = t // (wh * ww), (t // ww) % wh, t % ww
+    code = (td * (2 * wh - 1) + th) * (2 * ww - 1) + tw
+    offset = ((wd - 1) * (2 * wh - 1) + (wh - 1)) * (2 * ww - 1) + (ww - 1)
+    return code.to(torch.int32), int(offset)
+
+
 def relative_position_index(window_size):
     """(N, N) index into the (2wd-1)(2wh-1)(2ww-1) bias table (swin_transformer.py:113-124)."""
     wd, wh, ww = window_size
@@ -141,6 +163,9 @@ class WindowAttention3D(nn.Module):
         table = (2 * window_size[0] - 1) * (2 * window_size[1] - 1) * (2 * window_size[2] - 1)
         self.relative_position_bias_table = nn.Parameter(torch.zeros(table, num_heads))
         self.register_buffer("relative_position_index", relative_position_index(window_size))
+        code, self.code_offset = relative_position_code(window_size)
+        assert torch.equal(code[:, None].long() - code[None, :].long() + self.code_offset, self.relative_position_index)
+        self.register_buffer("relative_position_code", code, persistent=False)  # not part of checkpoints
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
@@ -148,8 +173,15 @@ class WindowAttention3D(nn.Module):
         nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
         self.softmax = nn.Softmax(dim=-1)
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, region=None):
         B_, N, C = x.shape
+        if x.is_cuda and FUSED_ATTENTION and (mask is None or region is not None):
+            from . import ops
+            if ops.wmsa_supported(N, C // self.num_heads) and self.relative_position_bias_table.shape[0] <= 4096:
+                out = ops.WindowAttentionRel.apply(self.qkv(x), self.relative_position_bias_table,
+                                                   self.relative_position_code[:N], self.code_offset, region, self.scale,
+                                                   self.num_heads)
+                return self.proj_drop(self.proj(out))
         idx = self.relative_position_index[:N, :N].reshape(-1)
         bias = self.relative_position_bias_table[idx].view(N, N, self.num_heads).permute(2, 0, 1).contiguous()
         out = window_attention(self.qkv(x), bias, mask, self.scale, self.num_heads)
@@ -171,7 +203,7 @@ class SwinTransformerBlock3D(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
-    def attention_branch(self, x, mask_matrix):
+    def attention_branch(self, x, mask_matrix, region=None):
         B, D, H, W, C = x.shape
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
         x = self.norm1(x)
@@ -182,7 +214,8 @@ class SwinTransformerBlock3D(nn.Module):
         shifted = any(s > 0 for s in ss)
         if shifted:
             x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-        windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None)
+        windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None,
+                            region=region if shifted else None)
         x = window_reverse(windows, ws, B, Dp, Hp, Wp)
         if shifted:
             x = torch.roll(x, shifts=ss, dims=(1, 2, 3))
@@ -190,8 +223,8 @@ class SwinTransformerBlock3D(nn.Module):
             x = x[:, :D, :H, :W, :].contiguous()
         return x
 
-    def forward(self, x, mask_matrix):
-        x = x + self.drop_path(self.attention_branch(x, mask_matrix))
+    def forward(self, x, mask_matrix, region=None):
+        x = x + self.drop_path(self.attention_branch(x, mask_matrix, region))
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
 
@@ -233,8 +266,9 @@ class BasicLayer(nn.Module):
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
         Dp, Hp, Wp = (int(np.ceil(n / w)) * w for n, w in zip((D, H, W), ws))
         attn_mask = compute_mask(Dp, Hp, Wp, ws, ss, x.device)
+        region = compute_region(Dp, Hp, Wp, ws, ss, x.device) if x.is_cuda else None
         for blk in self.blocks:
-            x = blk(x, attn_mask)
+            x = blk(x, attn_mask, region)
         return self.downsample(x) if self.downsample is not None else x
 
 
