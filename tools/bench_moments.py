@@ -9,7 +9,7 @@ C2 = [(16, 256, 784, 0), (16, 256, 196, 0), (16, 1024, 196, 0), (16, 1024, 196, 
      [(16, 256, 196, 0), (16, 256, 196, 0), (16, 1024, 196, 0)] * 5 + \
      [(16, 512, 196, 0), (16, 512, 49, 0), (16, 2048, 49, 0), (16, 2048, 49, 0)] + [(16, 512, 49, 0), (16, 512, 49, 0), (16, 2048, 49, 0)] * 2
 assert len(C2) == 29 and sum(o * c * i for o, c, i, _ in C2) == 44556288, (len(C2), sum(o * c * i for o, c, i, _ in C2))
-dev = torch.device("cuda:0")
+dev = torch.device("cuda:0") if torch.cuda.is_available() else None
 
 
 def run(copies, target, nt, reps=30):
@@ -29,7 +29,8 @@ def run(copies, target, nt, reps=30):
     return dict(copies=copies, target=target, nt=nt, blocks=plan.num_blocks, MB=nbytes / 1e6, us=1e3 * ms, TBs=nbytes / ms / 1e9)
 
 
-for copies in (1, 6, 16):
-    for target in (1024, 2048, 4096, 8192, 16384):
-        for nt in (False, True):
-            print(json.dumps(run(copies, target, nt)), flush=True)
+if __name__ == "__main__":
+    for copies in (1, 6, 16):
+        for target in (1024, 2048, 4096, 8192, 16384):
+            for nt in (False, True):
+                print(json.dumps(run(copies, target, nt)), flush=True)
