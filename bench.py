@@ -282,6 +282,14 @@ def main():
     algo_bytes = 4 * HOOKED_ELEMENTS_PER_VIDEO * (opt.size / 224.0) ** 2 * (opt.clip_length / 8.0)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
 
+    # HBM traffic of the moments launch from the PMC passes committed under profiles/ (bench.py itself
+    # cannot run rocprofv3 --pmc): corrected read bytes + write bytes of the in-step (1 video) launch
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r1_moments_pmc.json")
+    if os.path.exists(pmc_file) and opt.size == 224 and opt.clip_length == 8:
+        pmc = json.load(open(pmc_file))["in_step_1_video"]
+        traffic = pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]
+
     line = {
         "metric": "videos/sec TTA step (TANet-R50, 2x8x224^2), whole job", "value": value, "unit": "videos/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
@@ -295,7 +303,8 @@ def main():
         "adapt_only_ms": 1e3 * adapt_only, "launch_mode": run_gpu.mode, "eager_ms_per_step": run_gpu.eager_ms,
         "roofline": {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "traffic_source": "profiles/r1_moments_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per the gfx950 note)",
                      "algorithmic_bytes": algo_bytes, "avg_ms": kern_ms,
                      "note": "in-step operands are Infinity-Cache resident (178 MB just written by BN)",
                      "streaming": streaming},
