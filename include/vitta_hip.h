@@ -213,6 +213,31 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
                        const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv, float* d_dbias,
                        void* stream);
 
+/* --------------------------------------------------------------------------
+ * A8 glue -- eval-mode BatchNorm2d fused with its neighbours and with the ViTTA statistics.
+ * During adaptation every BatchNorm is in eval() (corpus/basics.py:606-611).  One pass replaces
+ * net.bnK(x) [+ identity] [-> relu] of TemporalBottleneck.forward (temporal_module.py:88-104) and, for a
+ * hooked layer, the moments pass of A1 (the BN output y is consumed from registers, never stored);
+ * the backward pass replaces ReLU-backward + the A6 injection + BatchNorm-backward.
+ *   x [outer, C, HW] conv output; res [outer, C, HW] or NULL; z = act(bn(x) + res)
+ *   d_triples: NULL, or the layer's (n, mean, M2) partial area of a plan workspace
+ *              (float* workspace + 3*ws_off, geometry from vitta_plan_layer_geometry; nsplit must match)
+ *   backward: d_gres NULL iff no residual; d_mu/d_coef_a/d_coef_b/d_gscale NULL iff not hooked;
+ *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch.
+ * Requires C*HW % 4 == 0 (VITTA_ERR_UNSUPPORTED otherwise: use the unfused ops).
+ * -------------------------------------------------------------------------- */
+size_t vitta_bn_act_partial_floats(int64_t outer, int32_t C, int64_t HW, int32_t nsplit);
+int vitta_bn_act_fwd_f32(const float* d_x, const float* d_res, float* d_z, const float* d_weight, const float* d_bias,
+                         const float* d_rmean, const float* d_rvar, float eps, int64_t outer, int32_t C, int64_t HW,
+                         int32_t nsplit, int32_t relu, float* d_triples, void* stream);
+int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, float* d_gx, float* d_gres,
+                         const float* d_weight, const float* d_bias, const float* d_rmean, const float* d_rvar,
+                         float eps, const float* d_mu, const float* d_coef_a, const float* d_coef_b,
+                         const float* d_gscale, int64_t outer, int32_t C, int64_t HW, int32_t nsplit, int32_t relu,
+                         float* d_partial, float* d_dgamma, float* d_dbeta, void* stream);
+/* out5 = {nsplit, nchunks, slots, ws_off (in triples), vec} of one layer of a plan */
+int vitta_plan_layer_geometry(const vitta_plan* plan, int layer, int64_t* out5);
+
 /* Same attention with the additive terms kept ON CHIP: the relative-position bias is
  * table[code[q] - code[k] + code_off][h] (the index of swin_transformer.py:113-124 is linear in the
  * token coordinates; code[t] = (t_d*(2wh-1) + t_h)*(2ww-1) + t_w) and the shift mask is -100 where

@@ -297,3 +297,91 @@ def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
     torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=2e-5)
     assert (qd.grad.cpu().double() - qr.grad).abs().max().item() <= 2e-4 * qr.grad.abs().max().item()
     assert (td.grad.cpu().double() - tr.grad).abs().max().item() <= 5e-4 * tr.grad.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("shape", [(16, 64, 14, 14), (16, 512, 7, 7), (8, 24, 5, 4)])
+def test_fused_bn_act_matches_torch(shape, relu, res):
+    """FusedBNAct (no statistics site) == relu(batch_norm_eval(x) + residual), forward and all gradients."""
+    import torch.nn.functional as F
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(31)
+    c = shape[1]
+    x = torch.randn(shape, generator=g)
+    r = torch.randn(shape, generator=g) if res else None
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.3
+    gout = torch.randn(shape, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (x, w, b)] + ([r.double().requires_grad_(True)] if res else [])
+    y = F.batch_norm(leaves[0], rm.double(), rv.double(), leaves[1], leaves[2], False, 0.0, 1e-5)
+    if res:
+        y = y + leaves[3]
+    if relu:
+        y = torch.relu(y)
+    y.backward(gout.double())
+    d = _dev()
+    dl = [t.to(d).requires_grad_(True) for t in (x, w, b)] + ([r.to(d).requires_grad_(True)] if res else [])
+    z = ops.FusedBNAct.apply(dl[0], dl[1], dl[2], rm.to(d), rv.to(d), 1e-5, dl[3] if res else None, relu, None)
+    z.backward(gout.to(d))
+    torch.testing.assert_close(z.detach().cpu().double(), y.detach(), rtol=1e-5, atol=1e-5)
+    for a, bref in zip(dl, leaves):
+        ref = bref.grad
+        assert (a.grad.cpu().double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6
+
+
+def test_fused_bn_statistics_site_equals_recorded_hooks():
+    """Hooked BN layers: fused pass (moments in the BN kernel, injection in the BN backward) == recorded
+    features + batched moments kernel + separate injection, over three engine steps."""
+    import torch.nn as nn
+    from vitta_amd import fused_bn
+    from vitta_amd.fused_bn import bn_act
+    from vitta_amd.norm_stats import CombineNormStatsRegHook_onereg, StatAlignEngine
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = nn.Conv2d(3, 16, 3, padding=1, bias=False), nn.BatchNorm2d(16)
+            self.c2, self.b2 = nn.Conv2d(16, 16, 1, bias=False), nn.BatchNorm2d(16)
+            self.c3, self.b3 = nn.Conv2d(16, 8, 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(8)
+
+        def forward(self, x):
+            a = bn_act(self.b1, self.c1(x), relu=True)
+            b = bn_act(self.b2, self.c2(a), residual=a, relu=True)
+            return bn_act(self.b3, self.c3(b), relu=False).mean((2, 3))
+
+    def run(enabled):
+        fused_bn.ENABLED = enabled
+        torch.manual_seed(0)
+        net = Tiny().to(_dev())
+        with torch.no_grad():
+            for m in net.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.3)
+                    m.running_var.uniform_(0.5, 1.5)
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.2)
+        net.eval()
+        engine = StatAlignEngine("l1_loss", 0.1)
+        hooks = [CombineNormStatsRegHook_onereg(m, clip_len=8, spatiotemp_stats_clean_tuple=(torch.zeros(c), torch.ones(c)),
+                                                reg_type="l1_loss", moving_avg=True, momentum=0.1,
+                                                stat_type_list=["spatiotemp"], before_norm=False,
+                                                if_sample_tta_aug_views=True, n_augmented_views=2, engine=engine)
+                 for m, c in ((net.b1, 16), (net.b2, 16), (net.b3, 8))]
+        out = []
+        for step in range(3):
+            x = H.seeded_randn((16, 3, 12, 12), 50 + step).to(_dev())
+            net.zero_grad()
+            y = net(x)
+            loss_reg = engine.finish()
+            (loss_reg + 0.1 * y.square().sum()).backward()
+            out.append((loss_reg.item(), [p.grad.detach().cpu().clone() for p in net.parameters()],
+                        engine.ema_var.cpu().clone()))
+        fused_bn.ENABLED = True
+        return out
+
+    fused, plain = run(True), run(False)
+    for (la, ga, ea), (lb, gb, eb) in zip(fused, plain):
+        assert la == pytest.approx(lb, rel=1e-5)
+        torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-7)
+        for a, b in zip(ga, gb):
+            assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-7

@@ -113,6 +113,31 @@ class HipBackend:
         return ops.stat_align_bwd(x, gout, kind, mu, a, b, gscale)
 
 
+class FusedSite:
+    """Handle a fused BN pass (ops.FusedBNAct) uses to talk to the engine for one hooked layer: where to put
+    the partial moments of this step, and -- at backward time -- which coefficient slices to inject."""
+
+    def __init__(self, engine, index):
+        self.engine, self.index = engine, index
+
+    def begin(self, x):
+        e = self.engine
+        plan = e.plan
+        outer, c, inner, _ = plan.shapes[self.index]
+        if (x.shape[0], x.shape[1], x.shape[2] * x.shape[3]) != (outer, c, inner):
+            raise RuntimeError("fused statistics pass: feature shape differs from the planned one")
+        e._fused_seen.add(self.index)
+        return plan.layer_geometry(self.index)[0], plan.triples_ptr(self.index)
+
+    def coefficients(self):
+        e = self.engine
+        if not e._gscale_set:
+            # loss_reg did not take part in this backward: inject nothing (gscale is 0 on the device)
+            pass
+        sl = e.plan.channel_slice(self.index)
+        return e.plan.mu[sl], e.plan.coef_a[sl], e.plan.coef_b[sl], e.gscale
+
+
 class _Inject(torch.autograd.Function):
     """Identity in the forward; adds the stat-loss gradient of its layer in the backward."""
 
@@ -168,6 +193,7 @@ class StatAlignEngine:
         self.plan = None
         self.gscale = None
         self._gscale_set = False
+        self._fused_seen = set()
         self.timing_events = None  # bench.py: callable returning (start, stop) events per step
 
     # -- registration -------------------------------------------------------------------------
@@ -190,6 +216,16 @@ class StatAlignEngine:
         self._built = True
 
     # -- per-step protocol --------------------------------------------------------------------
+    def fused_site(self, index, x):
+        """A FusedSite if this step can take the fused BN path for hooked layer `index` (a plan for exactly
+        these shapes exists, i.e. not the very first step and not a ragged batch); else None."""
+        if not self._built or self.plan is None or not torch.is_grad_enabled() or not hasattr(self.plan, "triples_ptr"):
+            return None
+        outer, c, inner, _ = self.plan.shapes[index]
+        if (x.shape[0], x.shape[1], x.shape[2] * x.shape[3]) != (outer, c, inner) or self._feats:
+            return None
+        return FusedSite(self, index)
+
     def collect(self, index, feature, kind):
         """Called by hook `index` during the forward; returns the tensor that replaces the output."""
         if not self._built:
@@ -206,6 +242,15 @@ class StatAlignEngine:
     def finish(self):
         """Batched moments -> (all-reduce) -> EMA + loss + coefficients.  Returns loss_reg."""
         n = len(self.hooks)
+        if self._fused_seen:
+            # every hooked layer went through a fused BN pass: the partial triples are already in the plan's
+            # workspace, only the tiny combine + align remain
+            if len(self._fused_seen) != n or self._feats:
+                raise RuntimeError("a step must be either all-fused or all-recorded")
+            plan = self.plan
+            self._fused_seen = set()
+            plan.finalize(self.src_mean)
+            return self._align_and_wrap(plan)
         if len(self._feats) != n:
             missing = [i for i in range(n) if i not in self._feats]
             raise RuntimeError(f"hooks {missing} did not fire in this forward")
@@ -220,6 +265,10 @@ class StatAlignEngine:
             plan = self._plans[shapes] = self.backend.make_plan(shapes, self.device)
         self.plan = plan
         plan.moments(feats, self.src_mean, **({"events": self.timing_events()} if self.timing_events else {}))
+        self._feats, self._kinds = {}, {}
+        return self._align_and_wrap(plan)
+
+    def _align_and_wrap(self, plan):
         if self.distributed:
             torch.distributed.all_reduce(plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
         total, layer = plan.align(self.src_mean, self.ema_mean, self.ema_var, self.src_mean, self.src_var,

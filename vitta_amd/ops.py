@@ -213,6 +213,21 @@ class StatPlan:
                   "vitta_moments_finalize_f32")
         return self.cnt, self.s1, self.s2
 
+    def layer_geometry(self, layer):
+        """(nsplit, nchunks, slots, ws_off) of a layer: where a fused BN pass deposits its partial triples."""
+        out = (C.c_int64 * 5)()
+        check(lib().vitta_plan_layer_geometry(self._h, layer, out), "vitta_plan_layer_geometry")
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+    def triples_ptr(self, layer):
+        return self.ws.data_ptr() + 12 * self.layer_geometry(layer)[3]
+
+    def finalize(self, shift=None):
+        """Second stage only: the partial triples were written by fused BN passes (vitta_bn_act_fwd_f32)."""
+        check(lib().vitta_moments_finalize_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2), _p(self.ws),
+                                               self.ws_bytes, _stream()), "vitta_moments_finalize_f32")
+        return self.cnt, self.s1, self.s2
+
     def mean_var(self, shift=None):
         mean = torch.empty(self.total_channels, dtype=torch.float32, device=self.device)
         var = torch.empty_like(mean)
@@ -363,3 +378,63 @@ class WindowAttentionRel(torch.autograd.Function):
                                            hd, scale, _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dtable),
                                            _stream()), "vitta_wmsa_rel_bwd_f32")
         return dqkv, dtable, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fused eval-mode BatchNorm2d (+ residual) (+ ReLU) (+ ViTTA statistics)
+# ------------------------------------------------------------------------------------------------
+def bn_act_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and (x.shape[1] * x.shape[2] * x.shape[3]) % 4 == 0
+
+
+def _bn_nsplit(outer, c, hw):
+    nchunks = (c * hw + 1023) // 1024
+    return max(1, min(outer, -(-1024 // nchunks)))
+
+
+class FusedBNAct(torch.autograd.Function):
+    """z = act(batch_norm_eval(x) + residual) in one pass; with `site` (a hooked layer of the batched
+    engine) the per-channel moments of the BN output come out of the same pass and the backward adds the
+    statistics-loss gradient; backward = ReLU mask + injection + BN backward (dx, dgamma, dbeta) in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, residual, relu, site):
+        x = x.contiguous()
+        outer, c, h, w = x.shape
+        hw = h * w
+        res = residual.contiguous() if residual is not None else None
+        z = torch.empty_like(x)
+        triples = C.c_void_p(0)
+        if site is not None:
+            nsplit, triples_ptr = site.begin(x)
+            triples = C.c_void_p(triples_ptr)
+        else:
+            nsplit = _bn_nsplit(outer, c, hw)
+        check(lib().vitta_bn_act_fwd_f32(_p(x), _p(res), _p(z), _p(weight), _p(bias), _p(running_mean), _p(running_var),
+                                         float(eps), outer, c, hw, nsplit, int(bool(relu)), triples, _stream()),
+              "vitta_bn_act_fwd_f32")
+        ctx.save_for_backward(x, z if (relu and res is not None) else None, weight, bias, running_mean, running_var)
+        ctx.meta = (float(eps), bool(relu), res is not None, site, nsplit)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, z, weight, bias, running_mean, running_var = ctx.saved_tensors
+        eps, relu, has_res, site, nsplit = ctx.meta
+        outer, c, h, w = x.shape
+        hw = h * w
+        gz = gz.contiguous()
+        gx = torch.empty_like(x)
+        gres = torch.empty_like(x) if has_res else None
+        nfl = lib().vitta_bn_act_partial_floats(outer, c, hw, nsplit)
+        partial = torch.empty(nfl, dtype=torch.float32, device=x.device)
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(bias)
+        mu = ca = cb = gs = None
+        if site is not None:
+            mu, ca, cb, gs = site.coefficients()
+        check(lib().vitta_bn_act_bwd_f32(_p(x), _p(z), _p(gz), _p(gx), _p(gres), _p(weight), _p(bias), _p(running_mean),
+                                         _p(running_var), eps, _p(mu), _p(ca), _p(cb), _p(gs), outer, c, hw, nsplit,
+                                         int(relu), _p(partial), _p(dgamma), _p(dbeta), _stream()),
+              "vitta_bn_act_bwd_f32")
+        return gx, dgamma, dbeta, None, None, None, gres, None, None

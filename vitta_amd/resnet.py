@@ -14,6 +14,16 @@ them), so nothing downstream may overwrite them.
 import torch
 import torch.nn as nn
 
+from .fused_bn import bn_act
+
+
+def downsample_forward(downsample, x):
+    """`downsample(x)` for the standard Sequential(conv1x1, BatchNorm2d) with the BN on the fused path."""
+    if isinstance(downsample, nn.Sequential) and len(downsample) == 2 and isinstance(downsample[1], nn.BatchNorm2d) \
+            and not downsample._forward_hooks:
+        return bn_act(downsample[1], downsample[0](x), relu=False)
+    return downsample(x)
+
 
 class Bottleneck(nn.Module):
     expansion = 4
@@ -31,11 +41,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        return self.relu(out + identity)
+        identity = x if self.downsample is None else downsample_forward(self.downsample, x)
+        out = bn_act(self.bn1, self.conv1(x), relu=True, act=self.relu)
+        out = bn_act(self.bn2, self.conv2(out), relu=True, act=self.relu)
+        return bn_act(self.bn3, self.conv3(out), residual=identity, relu=True, act=self.relu)
 
 
 class ResNet(nn.Module):
@@ -71,7 +80,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*stage)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True, act=self.relu))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)

@@ -19,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import resnet as _resnet
+from .fused_bn import bn_act
 
 
 def _tam_aggregate_torch(x, gate, kern, t):
@@ -80,12 +81,11 @@ class TemporalBottleneck(nn.Module):
 
     def forward(self, x):
         net = self.net
-        identity = x if net.downsample is None else net.downsample(x)
-        out = net.relu(net.bn1(net.conv1(x)))
+        identity = x if net.downsample is None else _resnet.downsample_forward(net.downsample, x)
+        out = bn_act(net.bn1, net.conv1(x), relu=True, act=net.relu)
         out = self.tam(out)
-        out = net.relu(net.bn2(net.conv2(out)))
-        out = net.bn3(net.conv3(out))
-        return net.relu(out + identity)
+        out = bn_act(net.bn2, net.conv2(out), relu=True, act=net.relu)
+        return bn_act(net.bn3, net.conv3(out), residual=identity, relu=True, act=net.relu)
 
 
 def make_temporal_modeling(net, n_segment=8, t_kernel_size=3, t_stride=1, t_padding=1):
