@@ -2,6 +2,7 @@
 import pytest
 import torch
 
+import helpers as H
 from oracle import vitta_oracle as O
 
 pytestmark = pytest.mark.gpu
