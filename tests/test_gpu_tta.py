@@ -115,13 +115,17 @@ def test_graph_replay_equals_eager_on_gpu(tmp_path):
         return out, ema
 
     eager, ema_e = run(None)
+    eager2, ema_e2 = run(None)
     graphed, ema_g = run(2)
+    # two GPU runs are not bit-reproducible (atomics in the library backward kernels) and Adam's sign-like
+    # first updates amplify the round-off: the yardstick is the spread of two EAGER runs
+    floor_ema = (ema_e - ema_e2).abs().max().item()
+    floor_logit = max((c - c2).abs().max().item() for (_, _, c), (_, _, c2) in zip(eager, eager2))
+    print("eager-vs-eager spread: ema %.3e logits %.3e" % (floor_ema, floor_logit))
     for (a, b, c), (d, e, f) in zip(eager, graphed):
-        # two GPU runs are not bit-reproducible (atomics in the library backward kernels) and Adam's
-        # sign-like first updates amplify the round-off: bounds are those of two eager runs
         assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
-        assert_logits_close(f, c, 2e-2)
-    torch.testing.assert_close(ema_g, ema_e, rtol=1e-3, atol=1e-5)
+        assert (f - c).abs().max().item() <= max(4 * floor_logit, 2e-3 * c.abs().max().item())
+    assert (ema_g - ema_e).abs().max().item() <= max(4 * floor_ema, 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------
