@@ -1,7 +1,7 @@
 """Summarise a rocprofv3 rocpd database (the default --kernel-trace --stats output of ROCm 7.2) into
 a CSV like rocprofv3's kernel_stats: name, calls, total_us, avg_us, pct.  Kernel names are shortened.
 
-    python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db profiles/r1_kernel_stats.csv
+    python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db profiles/r1_kernel_stats.csv [last_ms]
 """
 import csv
 import re
@@ -20,9 +20,18 @@ def short(name, n=110):
     return name[:n]
 
 
-def main(db_path, out_path):
+def main(db_path, out_path, last_ms=None):
     db = sqlite3.connect(db_path)
-    rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    if last_ms is None:
+        rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    else:
+        # steady state only: kernels that started in the last `last_ms` milliseconds of the trace (drops model
+        # construction, calibration and MIOpen's first-call solver warm-up, which runs naive reference convs)
+        t1 = db.execute("select max(end) from kernels").fetchone()[0]
+        raw = list(db.execute("select name, count(*), sum(duration)/1000.0 from kernels where start >= ? group by name",
+                              (t1 - int(last_ms * 1e6),)))
+        tot = sum(r[2] for r in raw) or 1.0
+        rows = [(n, c, d, d / c, 100.0 * d / tot) for n, c, d in raw]
     agg = {}
     for name, calls, total, avg, pct in rows:
         k = short(name)
@@ -39,4 +48,4 @@ def main(db_path, out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else None)
