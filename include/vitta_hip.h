@@ -213,6 +213,25 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
                        const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv, float* d_dbias,
                        void* stream);
 
+/* TAM branches fused: pooled [N,C,T] -> kern [N*C,3] (G: Linear-BN1d-ReLU-Linear-Softmax) and gate [N,C,T]
+ * (L: Conv1d k3-BN1d-ReLU-Conv1d k1-Sigmoid), temporal_module.py:27-41,53-55, every BatchNorm1d in eval().
+ * One launch forward, one backward (the module chain is ~14 + ~25 launches of KB-sized tensors).
+ *   h_bn_g / h_bn_l: HOST arrays of 4 device pointers {weight, bias, running_mean, running_var};
+ *   d_hpre [N, C/4, T]: conv1 output saved for the backward;
+ *   backward: h_dbn = {dG.weight, dG.bias, dL.weight, dL.bias} and h_dw = {dG.0.w, dG.3.w, dL.0.w, dL.3.w}
+ *   (entries or the whole array may be NULL when the weights are frozen) are ACCUMULATED: zero them first.
+ * Supported: T <= 16, C % 4 == 0 (vitta_tam_branch_supported). */
+int vitta_tam_branch_supported(int32_t C, int32_t T);
+int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                             const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                             const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
+                             float* d_hpre, void* stream);
+int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                             const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                             const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
+                             const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
+                             float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* stream);
+
 /* --------------------------------------------------------------------------
  * A8 glue -- eval-mode BatchNorm2d fused with its neighbours and with the ViTTA statistics.
  * During adaptation every BatchNorm is in eval() (corpus/basics.py:606-611).  One pass replaces

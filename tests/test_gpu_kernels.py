@@ -386,3 +386,49 @@ def test_fused_bn_statistics_site_equals_recorded_hooks():
         torch.testing.assert_close(ea, eb, rtol=1e-4, atol=1e-7)
         for a, b in zip(ga, gb):
             assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("name", ["c64_t8", "c16_t16"])
+def test_tam_module_on_gpu_matches_reference_golden(name):
+    """Whole TAM on the GPU (pool + fused G/L branches + aggregation kernels) vs the reference's TAM."""
+    from test_oracle_golden import _golden_tam
+    g, tam, (c, t, n, hw) = _golden_tam(name)
+    tam = tam.to(_dev())
+    x = H.seeded_randn((n * t, c, hw, hw), 9).to(_dev()).requires_grad_(True)
+    gout = H.seeded_randn((n * t, c, hw, hw), 10).to(_dev())
+    y = tam(x)
+    grads = torch.autograd.grad(y, [x] + list(tam.parameters()), gout)
+    torch.testing.assert_close(y.detach().cpu(), torch.from_numpy(g[f"{name}_y"]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(grads[0].cpu(), torch.from_numpy(g[f"{name}_gx"]), rtol=1e-3, atol=1e-5)
+    for (pn, _), gp in zip(tam.named_parameters(), grads[1:]):
+        ref = torch.from_numpy(g[f"{name}_g_{pn}"])
+        assert (gp.cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-6, pn
+
+
+@pytest.mark.parametrize("c,t,n,hw", [(64, 8, 2, 14), (512, 8, 2, 7), (256, 16, 1, 7), (128, 8, 3, 5)])
+def test_tam_fused_branches_equal_torch_modules(c, t, n, hw):
+    import torch.nn as nn
+    from vitta_amd import tanet
+    torch.manual_seed(5)
+    tam = tanet.TAM(c, t).to(_dev())
+    with torch.no_grad():
+        for m in tam.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    tam.eval()
+    x0 = H.seeded_randn((n * t, c, hw, hw), 3).to(_dev())
+    gout = H.seeded_randn((n * t, c, hw, hw), 4).to(_dev())
+    res = []
+    for fused in (True, False):
+        tanet.FUSED_TAM_BRANCHES = fused
+        x = x0.clone().requires_grad_(True)
+        y = tam(x)
+        res.append((y.detach(), torch.autograd.grad(y, [x] + list(tam.parameters()), gout)))
+    tanet.FUSED_TAM_BRANCHES = True
+    torch.testing.assert_close(res[0][0], res[1][0], rtol=1e-4, atol=1e-5)
+    names = ["x"] + [k for k, _ in tam.named_parameters()]
+    for nm, a, b in zip(names, res[0][1], res[1][1]):
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-6, nm

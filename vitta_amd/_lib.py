@@ -53,6 +53,11 @@ SIGNATURES = {
     "vitta_tam_agg_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_bwd_f32": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "vitta_tam_pool_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitta_tam_branch_supported": (C.c_int, [_i32, _i32]),
+    "vitta_tam_branch_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
+                                           _p, _p, _p, _p]),
+    "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
+                                           _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_bn_act_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i64, _i32, _i32, _p, _p]),
     "vitta_bn_act_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _i32, _i64, _i32,

@@ -325,7 +325,9 @@ class CombineNormStatsRegHook_onereg:
         self.source_mean_spatiotemp, self.source_var_spatiotemp = spatiotemp_stats_clean_tuple
         self.kind = feature_kind(module)
         self.engine, self.index = None, None
-        self.r_feature = None
+        # BatchNorm1d carries no spatio-temporal statistics: the term is identically 0 whether or not the hook
+        # fires (a fused TAM-branch kernel bypasses the module call)
+        self.r_feature = torch.zeros(()) if self.kind == "bn1d" else None
         if self.kind != "bn1d" and self.source_mean_spatiotemp is not None:
             self.source_mean_spatiotemp = torch.as_tensor(self.source_mean_spatiotemp, dtype=torch.float32)
             self.source_var_spatiotemp = torch.as_tensor(self.source_var_spatiotemp, dtype=torch.float32)

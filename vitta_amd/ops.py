@@ -438,3 +438,61 @@ class FusedBNAct(torch.autograd.Function):
                                          int(relu), _p(partial), _p(dgamma), _p(dbeta), _stream()),
               "vitta_bn_act_bwd_f32")
         return gx, dgamma, dbeta, None, None, None, gres, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# TAM branches (G and L) fused
+# ------------------------------------------------------------------------------------------------
+def tam_branch_supported(c, t):
+    return bool(lib().vitta_tam_branch_supported(int(c), int(t)))
+
+
+def _ptr4(*tensors):
+    arr = (C.c_void_p * 4)()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+class TamBranches(torch.autograd.Function):
+    """(kern [N*C,3], gate [N,C,T]) = TAM.G / TAM.L applied to pooled [N,C,T], eval-mode BatchNorm1d, in one
+    launch; analytic backward in one launch (temporal_module.py:27-41, 53-55)."""
+
+    @staticmethod
+    def forward(ctx, pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, eps_g, bnl_rm, bnl_rv, eps_l):
+        _require_cuda_f32(pooled, "pooled")
+        pooled = pooled.contiguous()
+        n, c, t = pooled.shape
+        kern = torch.empty(n * c, 3, dtype=torch.float32, device=pooled.device)
+        gate = torch.empty(n, c, t, dtype=torch.float32, device=pooled.device)
+        hpre = torch.empty(n, c // 4, t, dtype=torch.float32, device=pooled.device)
+        w0c, w3c = w0.contiguous(), w3.contiguous()
+        check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
+                                             _p(wg3), _p(w0c), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3c),
+                                             n, c, t, _p(kern), _p(gate), _p(hpre), _stream()), "vitta_tam_branch_fwd_f32")
+        ctx.save_for_backward(pooled, wg1, bng_w, bng_b, wg3, w0c, bnl_w, bnl_b, w3c, bng_rm, bng_rv, bnl_rm, bnl_rv, kern,
+                              gate, hpre)
+        ctx.eps = (float(eps_g), float(eps_l))
+        ctx.w_shapes = (w0.shape, w3.shape)
+        return kern, gate
+
+    @staticmethod
+    def backward(ctx, gkern, ggate):
+        (pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern, gate,
+         hpre) = ctx.saved_tensors
+        n, c, t = pooled.shape
+        gpooled = torch.empty_like(pooled)
+        dgw, dgb, dlw, dlb = (torch.zeros_like(v) for v in (bng_w, bng_b, bnl_w, bnl_b))
+        need = ctx.needs_input_grad
+        dwg1 = torch.zeros_like(wg1) if need[1] else None
+        dwg3 = torch.zeros_like(wg3) if need[4] else None
+        dw0 = torch.zeros_like(w0) if need[5] else None
+        dw3 = torch.zeros_like(w3) if need[8] else None
+        check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), ctx.eps[0], _p(wg3),
+                                             _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), ctx.eps[1], _p(w3), n, c, t,
+                                             _p(kern), _p(gate), _p(hpre), _p(gkern.contiguous()), _p(ggate.contiguous()),
+                                             _p(gpooled), _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), _stream()),
+              "vitta_tam_branch_bwd_f32")
+        s0, s3 = ctx.w_shapes
+        return (gpooled, dwg1, dgw, dgb, dwg3, dw0.view(s0) if dw0 is not None else None, dlw, dlb,
+                dw3.view(s3) if dw3 is not None else None, None, None, None, None, None, None)

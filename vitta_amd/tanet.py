@@ -22,6 +22,19 @@ from . import resnet as _resnet
 from .fused_bn import bn_act
 
 
+FUSED_TAM_BRANCHES = True  # tests flip this to compare the fused G/L kernels with the torch modules
+
+
+def _noop_hooks_only(module):
+    """True if every forward hook on a BatchNorm1d of a TAM is a ViTTA statistics hook, which contributes
+    exactly 0 there (norm_stats_utils.py:158-162) -- the only hooks the fused branch kernel may skip."""
+    for fn in module._forward_hooks.values():
+        owner = getattr(fn, "__self__", None)
+        if owner is None or getattr(owner, "kind", None) != "bn1d":
+            return False
+    return not module._forward_pre_hooks
+
+
 def _tam_aggregate_torch(x, gate, kern, t):
     """out[n,t] = K0 g[t-1] x[t-1] + K1 g[t] x[t] + K2 g[t+1] x[t+1] with zero padding in T."""
     nt, c, h, w = x.shape
@@ -60,6 +73,13 @@ class TAM(nn.Module):
             pooled = ops.TamPool.apply(x, t)  # (n, c, t)
         else:
             pooled = x.view(n, t, c, h * w).mean(-1).permute(0, 2, 1).contiguous()
+        bg, bl = self.G[1], self.L[1]
+        if (x.is_cuda and FUSED_TAM_BRANCHES and not bg.training and not bl.training and _noop_hooks_only(bg)
+                and _noop_hooks_only(bl) and ops.tam_branch_supported(c, t)):
+            kern, gate = ops.TamBranches.apply(pooled, self.G[0].weight, bg.weight, bg.bias, self.G[3].weight,
+                                               self.L[0].weight, bl.weight, bl.bias, self.L[3].weight, bg.running_mean,
+                                               bg.running_var, bg.eps, bl.running_mean, bl.running_var, bl.eps)
+            return ops.TamAggregate.apply(x, gate, kern, t)
         kern = self.G(pooled.reshape(n * c, t))  # (n*c, 3)
         gate = self.L(pooled)  # (n, c, t)
         if x.is_cuda:
