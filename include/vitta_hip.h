@@ -217,7 +217,8 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
  * (L: Conv1d k3-BN1d-ReLU-Conv1d k1-Sigmoid), temporal_module.py:27-41,53-55, every BatchNorm1d in eval().
  * One launch forward, one backward (the module chain is ~14 + ~25 launches of KB-sized tensors).
  *   h_bn_g / h_bn_l: HOST arrays of 4 device pointers {weight, bias, running_mean, running_var};
- *   d_hpre [N, C/4, T]: conv1 output saved for the backward;
+ *   d_hpre [2, N, C/4, T]: conv1 output before BN and after BN+ReLU, saved for the backward;
+ *   d_gpooled: N*C*T floats of result followed by N*(C/4)*T floats of scratch;
  *   backward: h_dbn = {dG.weight, dG.bias, dL.weight, dL.bias} and h_dw = {dG.0.w, dG.3.w, dL.0.w, dL.3.w}
  *   (entries or the whole array may be NULL when the weights are frozen) are ACCUMULATED: zero them first.
  * Supported: T <= 16, C % 4 == 0 (vitta_tam_branch_supported). */

@@ -465,7 +465,7 @@ class TamBranches(torch.autograd.Function):
         n, c, t = pooled.shape
         kern = torch.empty(n * c, 3, dtype=torch.float32, device=pooled.device)
         gate = torch.empty(n, c, t, dtype=torch.float32, device=pooled.device)
-        hpre = torch.empty(n, c // 4, t, dtype=torch.float32, device=pooled.device)
+        hpre = torch.empty(2, n, c // 4, t, dtype=torch.float32, device=pooled.device)  # conv1 out: pre-BN | post-ReLU
         w0c, w3c = w0.contiguous(), w3.contiguous()
         check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
                                              _p(wg3), _p(w0c), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3c),
@@ -481,7 +481,8 @@ class TamBranches(torch.autograd.Function):
         (pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern, gate,
          hpre) = ctx.saved_tensors
         n, c, t = pooled.shape
-        gpooled = torch.empty_like(pooled)
+        gbuf = torch.empty(n * c * t + n * (c // 4) * t, dtype=torch.float32, device=pooled.device)
+        gpooled = gbuf[: n * c * t].view(n, c, t)  # the tail is the kernel's scratch for d(conv1 output)
         dgw, dgb, dlw, dlb = (torch.zeros_like(v) for v in (bng_w, bng_b, bnl_w, bnl_b))
         need = ctx.needs_input_grad
         dwg1 = torch.zeros_like(wg1) if need[1] else None
@@ -491,7 +492,7 @@ class TamBranches(torch.autograd.Function):
         check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), ctx.eps[0], _p(wg3),
                                              _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), ctx.eps[1], _p(w3), n, c, t,
                                              _p(kern), _p(gate), _p(hpre), _p(gkern.contiguous()), _p(ggate.contiguous()),
-                                             _p(gpooled), _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), _stream()),
+                                             _p(gbuf), _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), _stream()),
               "vitta_tam_branch_bwd_f32")
         s0, s3 = ctx.w_shapes
         return (gpooled, dwg1, dgw, dgb, dwg3, dw0.view(s0) if dw0 is not None else None, dlw, dlb,
