@@ -59,6 +59,8 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--no-streaming", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--segmented-graph", action="store_true",
+                   help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
     p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
     p.add_argument("--size", type=int, default=224)
     p.add_argument("--clip-length", type=int, default=8)
@@ -153,11 +155,12 @@ def run_gpu(opt, rank, world, device):
             torch.cuda.synchronize()
             log("first warm-up step done")
     torch.cuda.synchronize()
-    use_graph = not opt.no_graph and world == 1 and opt.warmup >= 2
+    use_graph = not opt.no_graph and opt.warmup >= 2
     if use_graph:
         x, _ = tta_set[0]
         ev, _ = eval_set[0]
-        adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)))
+        adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
+                               segmented=opt.segmented_graph)
         one_step(opt.warmup)  # first replay outside the timed region
         torch.cuda.synchronize()
         log("hipGraphs captured")
@@ -213,7 +216,8 @@ def run_gpu(opt, rank, world, device):
     if rank == 0 and not opt.no_streaming:
         streaming = streaming_moments(adapter, device)
         log("streaming-size moments done")
-    run_gpu.mode = "hipGraph replay" if use_graph else "eager launches"
+    run_gpu.mode = ("hipGraph replay" + (" (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph) else "")) \
+        if use_graph else "eager launches"
     run_gpu.eager_ms = (1e3 * eager_elapsed / opt.steps) if use_graph else None
     return elapsed, kern_ms, adapt_only, streaming, adapter
 

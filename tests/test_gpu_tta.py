@@ -172,3 +172,52 @@ def test_swin_fused_attention_equals_composed_ops_on_gpu():
     assert_logits_close(outs[0][0], outs[1][0], 1e-4)
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-9
+
+
+def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
+    """The data-parallel capture (forward | backward | optimizer segments, exchanges outside any graph) must
+    replay the same step as the single-graph capture; exercised here on one GPU (exchanges are no-ops)."""
+    import json
+    import numpy as np
+    from vitta_amd import data, tta
+    g = H.golden("tta3.npz")
+    cfg = json.loads(str(g["config"]))
+    T, size = cfg["T"], cfg["size"]
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(tmp_path, clip_length=T, input_size=size, spatiotemp_mean_clean_file=mp,
+                        spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=1e-4)
+    tta_set = data.SyntheticVideoDataset(5, 2, T, size, 101, "tanet", seed0=700)
+    eval_set = data.SyntheticVideoDataset(5, 1, T, size, 101, "tanet", seed0=700)
+
+    def run(segmented):
+        model = H.build_tanet(101, T, 0)
+        model.base_model.fc = nn.Identity()
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(_dev()), args)
+        out = []
+        for i in range(5):
+            x = adapter.shape_tta_input(tta_set[i][0].unsqueeze(0).to(_dev()))
+            ev = adapter.shape_eval_input(eval_set[i][0].unsqueeze(0).to(_dev()))
+            if i == 2:
+                adapter.capture_graphs(x, ev, segmented=segmented)
+            if adapter._graph is None:
+                adapter.set_adapt_mode()
+            _, lr_, lc_ = adapter.adapt_step(x)
+            lr_, lc_ = lr_.clone(), lc_.clone()
+            if adapter._graph is None:
+                adapter.close_hooks()
+            logits = adapter.evaluate(ev).clone()
+            if adapter._graph is None:
+                adapter.add_hooks_back()
+            out.append((lr_.item(), lc_.item(), logits.cpu()))
+        assert ("seg_fwd" in adapter._graph) == segmented
+        torch.cuda.synchronize()
+        return out
+
+    single, single2, seg = run(False), run(False), run(True)
+    floor = max((c - c2).abs().max().item() for (_, _, c), (_, _, c2) in zip(single, single2))
+    for (a, b, c), (d, e, f) in zip(single, seg):
+        assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
+        assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())

@@ -241,16 +241,30 @@ class StatAlignEngine:
 
     def finish(self):
         """Batched moments -> (all-reduce) -> EMA + loss + coefficients.  Returns loss_reg."""
+        self.reduce_local()
+        self.exchange()
+        return self.finish_global()
+
+    def exchange(self):
+        """The moments all-reduce (data-parallel only): one SUM over the packed [cnt | s1 | s2] buffer."""
+        if self.distributed:
+            torch.distributed.all_reduce(self.plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+
+    def finish_global(self):
+        """EMA update + loss + backward coefficients from the (reduced) statistics."""
+        return self._align_and_wrap(self.plan)
+
+    def reduce_local(self):
+        """This rank's additive statistics of the step into plan.stats (no communication)."""
         n = len(self.hooks)
         if self._fused_seen:
             # every hooked layer went through a fused BN pass: the partial triples are already in the plan's
             # workspace, only the tiny combine + align remain
             if len(self._fused_seen) != n or self._feats:
                 raise RuntimeError("a step must be either all-fused or all-recorded")
-            plan = self.plan
             self._fused_seen = set()
-            plan.finalize(self.src_mean)
-            return self._align_and_wrap(plan)
+            self.plan.finalize(self.src_mean)
+            return
         if len(self._feats) != n:
             missing = [i for i in range(n) if i not in self._feats]
             raise RuntimeError(f"hooks {missing} did not fire in this forward")
@@ -266,11 +280,8 @@ class StatAlignEngine:
         self.plan = plan
         plan.moments(feats, self.src_mean, **({"events": self.timing_events()} if self.timing_events else {}))
         self._feats, self._kinds = {}, {}
-        return self._align_and_wrap(plan)
 
     def _align_and_wrap(self, plan):
-        if self.distributed:
-            torch.distributed.all_reduce(plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
         total, layer = plan.align(self.src_mean, self.ema_mean, self.ema_var, self.src_mean, self.src_var,
                                   self.momentum, self.reg_type)
         for i, h in enumerate(self.hooks):

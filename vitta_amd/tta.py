@@ -306,6 +306,19 @@ class ViTTAAdapter:
 
     def forward_losses(self, input, actual_bz):
         """Adaptation forward: (video logits, loss_reg, loss_consis or None)."""
+        output, loss_consis = self.forward_local(input, actual_bz)
+        if self.engine is not None:
+            self.engine.exchange()
+            loss_reg = self.engine.finish_global()
+        else:
+            loss_reg = torch.zeros((), dtype=torch.float32, device=output.device)
+            for h in self.stat_reg_hooks:
+                loss_reg = loss_reg + h.r_feature.to(output.device)
+        return output, loss_reg, loss_consis
+
+    def forward_local(self, input, actual_bz):
+        """Everything of the adaptation forward that needs no communication: model forward, view
+        consistency, this rank's additive moments."""
         a = self.args
         loss_consis = None
         if a.arch == "tanet":
@@ -318,12 +331,14 @@ class ViTTAAdapter:
             if self.if_pred_consistency:
                 loss_consis = compute_pred_consis(view_cls_score)
         if self.engine is not None:
-            loss_reg = self.engine.finish()
-        else:
-            loss_reg = torch.zeros((), dtype=torch.float32, device=output.device)
-            for h in self.stat_reg_hooks:
-                loss_reg = loss_reg + h.r_feature.to(output.device)
-        return output, loss_reg, loss_consis
+            self.engine.reduce_local()
+        return output, loss_consis
+
+    def total_loss(self, loss_reg, loss_consis):
+        a = self.args
+        if self.if_pred_consistency:
+            return a.lambda_feature_reg * loss_reg + a.lambda_pred_consis * loss_consis
+        return loss_reg
 
     def adapt_step(self, input, has_video=True):
         """One gradient step on one (already device-resident, already reshaped) TTA input.
@@ -333,7 +348,15 @@ class ViTTAAdapter:
         g = self._graph
         if g is not None and has_video and input.shape == g["tta_in"].shape:
             g["tta_in"].copy_(input)
-            g["adapt"].replay()
+            if "adapt" in g:
+                g["adapt"].replay()
+            else:  # data-parallel: three graph segments with the two exchanges launched eagerly in between
+                g["seg_fwd"].replay()
+                self.engine.exchange()
+                g["seg_bwd"].replay()
+                if self.bucket is not None:
+                    self.bucket.all_reduce()
+                g["seg_opt"].replay()
             return g["adapt_out"]
         return self._adapt_step_eager(input, has_video)
 
@@ -347,11 +370,7 @@ class ViTTAAdapter:
         if has_video:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
             output, loss_reg, loss_consis = self.forward_losses(input, actual_bz)
-            if self.if_pred_consistency:
-                loss = a.lambda_feature_reg * loss_reg + a.lambda_pred_consis * loss_consis
-            else:
-                loss = loss_reg
-            loss.backward()
+            self.total_loss(loss_reg, loss_consis).backward()
         else:
             if self.engine is None:
                 raise RuntimeError("ragged data-parallel steps need the batched engine")
@@ -372,15 +391,39 @@ class ViTTAAdapter:
             return g["eval_out"]
         return self._evaluate_eager(input)
 
-    def capture_graphs(self, tta_input, eval_input):
+    def _capture_segments(self, g):
+        """Data-parallel capture: no collective inside a graph.  The step is cut at its two exchanges into
+        forward | backward | optimizer segments sharing one memory pool (the backward segment walks the
+        autograd graph recorded while the forward segment was captured, like make_graphed_callables)."""
+        a = self.args
+        x = g["tta_in"]
+        actual_bz = x.shape[0] // self.n_views if a.arch == "tanet" else x.shape[0]
+        pool = torch.cuda.graph_pool_handle()
+        if self.bucket is None:
+            self.optimizer.zero_grad(set_to_none=True)
+        g["seg_fwd"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["seg_fwd"], pool=pool):
+            if self.bucket is not None:
+                self.bucket.zero()
+            output, loss_consis = self.forward_local(x, actual_bz)
+        g["seg_bwd"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["seg_bwd"], pool=pool):
+            loss_reg = self.engine.finish_global()
+            self.total_loss(loss_reg, loss_consis).backward()
+        g["seg_opt"] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g["seg_opt"], pool=pool):
+            self.optimizer.step()
+        g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
+
+    def capture_graphs(self, tta_input, eval_input, segmented=False):
         """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
         evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
         the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
         step).  Requirements: a few eager steps ran before (launch plans, optimizer state and MIOpen
         solutions exist), fixed input shapes, single process (no collective inside the capture).
         Capturing records launches without executing them: model, EMA and optimizer state are untouched."""
-        if self.device.type != "cuda" or self.world > 1:
-            raise RuntimeError("graph capture needs a single-process CUDA(HIP) run")
+        if self.device.type != "cuda":
+            raise RuntimeError("graph capture needs a CUDA(HIP) device")
         if self.engine is None:
             raise RuntimeError("graph capture needs the batched engine (the stand-alone hooks keep host-side "
                                "EMA scalars that cannot be captured)")
@@ -389,10 +432,13 @@ class ViTTAAdapter:
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
         self.set_adapt_mode()
-        self.optimizer.zero_grad(set_to_none=True)
-        g["adapt"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["adapt"]):
-            g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True)
+        if self.world > 1 or segmented:
+            self._capture_segments(g)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            g["adapt"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["adapt"]):
+                g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True)
         self.close_hooks()
         g["eval"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["eval"]):
@@ -467,7 +513,7 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
             print(f"Batch {batch_id}, initialize the model, update chosen layers, initialize hooks, intialize average meter")
             adapter = ViTTAAdapter(model_origin, args)
         if (adapter._graph is None and GRAPH_AFTER_STEPS is not None and batch_id == GRAPH_AFTER_STEPS and has_video
-                and getattr(args, "hip_graph", True) and device.type == "cuda" and world == 1 and adapter.engine is not None
+                and getattr(args, "hip_graph", True) and device.type == "cuda" and adapter.engine is not None
                 and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1):
             ev0 = eval_set[0][0].unsqueeze(0).expand(input.shape[0], *eval_set[0][0].shape)
             adapter.capture_graphs(adapter.shape_tta_input(input.to(device)), adapter.shape_eval_input(ev0.to(device)))
