@@ -34,27 +34,35 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// stage rows [0, N) of one of q/k/v (sel) of (b, h) into LDS with row stride KPAD; rows [N, 16*nt) zeroed
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ qkv, int64_t b, int h,
-                                           int sel, int N, int nH, int nt) {
-  const int64_t rs = 3 * (int64_t)nH * HD;  // floats per token
-  const float* src = qkv + b * N * rs + (int64_t)sel * nH * HD + (int64_t)h * HD;
-  for (int i = threadIdx.x; i < 16 * nt * (HD / 4); i += WMSA_THREADS) {
-    const int row = i / (HD / 4), c4 = i % (HD / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < N) v = *reinterpret_cast<const float4*>(src + row * rs + 4 * c4);
-    *reinterpret_cast<float4*>(dst + row * KPAD + 4 * c4) = v;
+// Stage rows [0, N) of a [rows, row_stride] fp32 matrix slice (32 floats per row) into LDS with row stride KPAD;
+// rows [N, 16*nt) are zeroed.  The loads of a lane are issued four at a time BEFORE their LDS stores so that
+// 4 x 16 B per lane are in flight (a load->store loop serialises on every HBM/L2 round trip; the staging of the
+// two 50 KB operands was longer than the MFMA work of a workgroup at the late stages).
+__device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const float* __restrict__ src_base,
+                                                 int64_t row_stride, int N, int nt) {
+  const int total = 16 * nt * (HD / 4);
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * WMSA_THREADS) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * WMSA_THREADS;
+      const int row = i / (HD / 4), c4 = i % (HD / 4);
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src_base + row * row_stride + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * WMSA_THREADS;
+      if (i < total) *reinterpret_cast<float4*>(dst + (i / (HD / 4)) * KPAD + 4 * (i % (HD / 4))) = v[u];
+    }
   }
 }
 
-__device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const float* __restrict__ src_base,
-                                                 int64_t row_stride, int N, int nt) {
-  for (int i = threadIdx.x; i < 16 * nt * (HD / 4); i += WMSA_THREADS) {
-    const int row = i / (HD / 4), c4 = i % (HD / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < N) v = *reinterpret_cast<const float4*>(src_base + row * row_stride + 4 * c4);
-    *reinterpret_cast<float4*>(dst + row * KPAD + 4 * c4) = v;
-  }
+// rows of one of q/k/v (sel) of (b, h): qkv is [B_, N, 3, nH, 32]
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ qkv, int64_t b, int h,
+                                           int sel, int N, int nH, int nt) {
+  const int64_t rs = 3 * (int64_t)nH * HD;  // floats per token
+  stage_rows_dense(dst, qkv + b * N * rs + (int64_t)sel * nH * HD + (int64_t)h * HD, rs, N, nt);
 }
 
 // 8 contiguous floats of a row (d = 8*kk .. 8*kk+7)
@@ -463,9 +471,11 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
 }
 
 inline int pick_qsplit(int64_t pairs, int nt) {
-  // aim at >= ~512 workgroups (2 per CU) while keeping >= 2 row tiles per wave-slot busy
+  // One workgroup per CU at a time (the staged operands take ~115 KB of LDS) and every workgroup re-stages
+  // K and V: split the query tiles of a (window, head) pair only until every CU has one workgroup (256),
+  // and never below one row tile per wave.
   int qs = 1;
-  while (pairs * qs < 512 && qs * 2 <= nt && qs < 8) qs *= 2;
+  while (pairs * qs < 256 && (nt + qs * 2 - 1) / (qs * 2) >= WMSA_WAVES / 2 && qs < 8) qs *= 2;
   return qs;
 }
 
