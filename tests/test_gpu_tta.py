@@ -221,3 +221,46 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
     for (a, b, c), (d, e, f) in zip(single, seg):
         assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
         assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
+
+
+def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
+    """BASELINE config 5 shape in small: Video Swin-B, window (16,7,7), 4 views x 32 frames.  N = 784 tokens per
+    window at the first stages exceeds the fused W-MSA kernel's 400 -> composed GPU ops there, fused kernel at
+    the clamped later stages; LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU
+    with the oracle backend."""
+    import numpy as np
+    from oracle.oracle_backend import OracleBackend
+    from vitta_amd import data, scripts, tta
+    from vitta_amd.bns_utils import choose_layers
+    T, size, views = 32, 112, 4
+
+    def build():
+        m = H.build_swin(174, 0, window_size=(16, 7, 7), drop_path_rate=0.0)
+        m.cls_head.dropout = None
+        return m
+
+    model = build()
+    lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
+    g = torch.Generator().manual_seed(3)
+    mp, vp = H.write_stat_files(str(tmp_path), [torch.randn(m.normalized_shape[0], generator=g).numpy() * 0.1 for m in lns],
+                                [torch.rand(m.normalized_shape[0], generator=g).numpy() + 0.5 for m in lns])
+    args = scripts.swin_ucf101_args([])
+    args.dataset, args.num_classes, args.datatype = "somethingv2", 174, "synthetic"
+    args.clip_length, args.n_augmented_views, args.window_size = T, views, (16, 7, 7)
+    args.input_size, args.scale_size, args.workers, args.verbose, args.result_dir = size, size, 0, False, str(tmp_path)
+    args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+    args.update_only_bn_affine, args.lr = True, 1e-4
+    x = data.SyntheticVideoDataset(1, views, T, size, 174, "swin", seed0=40)[0][0].unsqueeze(0)
+    res = {}
+    for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(dev), args, engine_backend=backend)
+        adapter.set_adapt_mode()
+        _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(dev)))
+        named = dict(adapter.model.named_parameters())
+        res[dev.type] = (float(loss_reg), float(loss_consis),
+                         named["module.backbone.layers.2.blocks.4.norm1.weight"].grad.cpu().clone(),
+                         named["module.backbone.norm.bias"].grad.cpu().clone())
+    c, gdev = res["cpu"], res["cuda"]
+    assert gdev[0] == pytest.approx(c[0], rel=2e-5) and gdev[1] == pytest.approx(c[1], rel=1e-3, abs=1e-6)
+    for a, b in zip(gdev[2:], c[2:]):
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-9
