@@ -17,6 +17,8 @@ def _kind_of(feature, layout):
 
 
 def _layout(feature, kind):
+    if kind in ("rows", "nct"):
+        return _bns_kind_layout(feature, kind)
     if kind == "bn2d":
         nt, c, h, w = feature.shape
         return nt, c, h * w, LAYOUT_NCHW
@@ -30,6 +32,13 @@ def _layout(feature, kind):
 def _moments(feature, kind):
     clip = feature.shape[0] if kind == "bn2d" else None
     return O.moments(feature, kind, clip)
+
+
+def _bns_kind_layout(feature, kind):
+    if kind == "rows":
+        return feature.shape[0], feature.shape[1], 1, LAYOUT_NHWC
+    n, c, t = feature.shape
+    return n, c, t, LAYOUT_NCHW
 
 
 class OraclePlan:

@@ -43,6 +43,12 @@ def moments_ncthw(output):
 
 
 def moments(feature, kind, clip_len=None):
+    if kind == "rows":  # utils/BNS_utils.py:43-45, BatchNorm1d input (N*C, T)
+        nch = feature.shape[1]
+        return feature.mean([0]), feature.permute(1, 0).contiguous().view([nch, -1]).var(1, unbiased=False)
+    if kind == "nct":  # utils/BNS_utils.py:46-48, BatchNorm1d input (N, C, T)
+        nch = feature.shape[1]
+        return feature.mean([0, 2]), feature.permute(1, 0, 2).contiguous().view([nch, -1]).var(1, unbiased=False)
     return moments_ncthw(to_ncthw(feature, kind, clip_len))
 
 

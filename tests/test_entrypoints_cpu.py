@@ -92,3 +92,60 @@ def test_eval_compute_statistics_on_cpu(tmp_path, monkeypatch):
     chosen = tta.candidate_layers_for(args2, tta.SingleDeviceParallel(model))
     m2, v2 = tta.load_source_statistics(args2, chosen)
     assert len(m2) == 85 and sum(x is None for x in m2) == 32
+
+
+def test_episodic_mode_matches_reference(tmp_path, monkeypatch):
+    """if_tta_standard='tta_standard' -- model, optimizer, hooks and EMA re-initialised for
+    every video, momentum_mvg = 1, two gradient steps per video; the product's tta_standard driven end to end
+    against the reference's own run (dropout masks replayed)."""
+    g = H.golden("episodic.npz")
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(tmp_path, clip_length=8, input_size=64, spatiotemp_mean_clean_file=mp,
+                        spatiotemp_var_clean_file=vp, lr=5e-5, if_tta_standard="tta_standard", momentum_mvg=1.0,
+                        n_gradient_steps=2, synthetic_n_videos=2, synthetic_seed=500, device="cpu")
+    masks = [H.unpack_mask(g[f"step{i}_dropmask"], g[f"step{i}_dropmask_shape"]) for i in range(4)]
+    model = tta.SingleDeviceParallel(H.build_tanet(101, 8, 0))
+    monkeypatch.setattr(tta, "BACKEND_FACTORY", OracleBackend)
+    seen = {"losses": [], "adapters": []}
+    real_init = tta.ViTTAAdapter.__init__
+
+    def init(self, *a, **k):
+        real_init(self, *a, **k)
+        vid = len(seen["adapters"])
+        self.model.module.base_model.fc = H.ReplayDropout(0.8, masks[2 * vid:2 * vid + 2])
+        seen["adapters"].append(self)
+
+    real_step = tta.ViTTAAdapter.adapt_step
+
+    def step(self, *a, **k):
+        out = real_step(self, *a, **k)
+        seen["losses"].append((float(out[1]), float(out[2])))
+        return out
+
+    real_eval = tta.ViTTAAdapter.evaluate
+    logits = []
+
+    def evaluate(self, x):
+        o = real_eval(self, x)
+        logits.append(o.clone())
+        return o
+
+    monkeypatch.setattr(tta.ViTTAAdapter, "__init__", init)
+    monkeypatch.setattr(tta.ViTTAAdapter, "adapt_step", step)
+    monkeypatch.setattr(tta.ViTTAAdapter, "evaluate", evaluate)
+    import logging
+    res = tta.tta_standard(model, torch.nn.CrossEntropyLoss(), args=args, logger=logging.getLogger("t"), writer=None)
+    assert len(seen["adapters"]) == 2 and len(seen["losses"]) == 4  # re-initialised per video, 2 steps each
+    for i, (lr_, lc_) in enumerate(seen["losses"]):
+        first = i % 2 == 0  # first step of a video starts from the pristine model: tight; second: after one update
+        assert lr_ == pytest.approx(float(g[f"step{i}_loss_reg"]), rel=1e-5 if first else 1e-3)
+        assert lc_ == pytest.approx(float(g[f"step{i}_loss_consis"]), rel=1e-5 if first else 5e-3)
+    for v in range(2):
+        ref = torch.from_numpy(g[f"video{v}_eval_logits"])
+        # momentum_mvg = 1 and two steps make this regime chaotic: the reference re-run with inputs perturbed
+        # by 1e-7 relative moves its own adapted logits by `noise_eval_logits` (0.66 on a scale of 7.7)
+        assert (logits[v] - ref).abs().max().item() <= max(2e-3 * ref.abs().max().item(), float(g["noise_eval_logits"]))
+    assert res == pytest.approx(g["top1"].tolist())

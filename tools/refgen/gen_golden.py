@@ -225,7 +225,8 @@ def run_reference_tta(args, model_origin, n_videos, batch_size, capture, perturb
 
     def spy_deepcopy(obj, *a, **k):
         c = real_deepcopy(obj, *a, **k)
-        if isinstance(obj, nn.Module) and capture.model is None:
+        if isinstance(obj, nn.Module) and (capture.model is None or getattr(capture, "episodic", False)) \
+                and isinstance(obj, Wrap):
             capture.model = c
             for m in c.modules():
                 if isinstance(m, nn.Dropout):
@@ -383,6 +384,48 @@ def gen_tta(batch_size=1, tag="tta3"):
     out["config"] = np.array(json.dumps(dict(T=T, size=size, n_videos=n_videos, batch_size=batch_size, seed0=500,
                                              lr_sgd=5e-5, lr_adam=1e-3)))
     save(f"{tag}.npz", **out)
+
+
+def gen_episodic():
+    """N4: if_tta_standard='tta_standard' (episodic): model re-initialised per video, momentum_mvg = 1, two
+    gradient steps per video; two videos through the reference's own tta_standard."""
+    from utils.opts import get_opts
+    T, size, n_videos = 8, 64, 2
+    ref, _ = ref_tanet(101, T, 0)
+    means, vars_ = source_stats_for(ref, T, size)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        mp, vp = H.write_stat_files(tmp, means, vars_)
+        args = get_opts()
+        args.arch, args.dataset, args.clip_length, args.workers = "tanet", "ucf101", T, 0
+        args.input_size, args.verbose, args.batch_size = size, False, 1
+        args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+        args.num_classes, args.gpus, args.result_dir, args.lr = 101, [0], tmp, 5e-5
+        args.if_tta_standard, args.momentum_mvg, args.n_gradient_steps = "tta_standard", 1.0, 2
+        cap = _Capture()
+        cap.episodic = True
+        torch.manual_seed(99)
+        res = run_reference_tta(args, ref, n_videos, 1, cap)
+        floor = 0.0
+        for trial in range(3):  # the reference against itself, inputs perturbed by 1e-7 relative
+            c2 = _Capture()
+            c2.episodic = True
+            torch.manual_seed(99)
+            run_reference_tta(args, ref, n_videos, 1, c2, perturb=1e-7, perturb_seed=90000 + 1000 * trial)
+            floor = max(floor, max(float(np.abs(a - b).max()) for a, b in zip(cap.eval_logits, c2.eval_logits)))
+        out["noise_eval_logits"] = np.array(floor)
+    assert len(cap.steps) == 4 and len(cap.eval_logits) == 2, (len(cap.steps), len(cap.eval_logits))
+    for i, rec in enumerate(cap.steps):
+        out[f"step{i}_loss_reg"] = np.array(rec["loss_reg"])
+        out[f"step{i}_loss_consis"] = cap.consis[i]
+        bits, shape = H.pack_mask(cap.drop_masks[i])
+        out[f"step{i}_dropmask"], out[f"step{i}_dropmask_shape"] = bits, shape
+    for v in range(2):
+        out[f"video{v}_eval_logits"] = cap.eval_logits[v]
+    out["src_means"], out["src_vars"] = np.concatenate(means), np.concatenate(vars_)
+    out["src_channels"] = np.array([len(m) for m in means])
+    out["top1"] = np.array(res)
+    save("episodic.npz", **out)
 
 
 def gen_dp():
@@ -621,8 +664,33 @@ def gen_tta_swin():
     save("tta3_swin.npz", **out)
 
 
+def gen_bns():
+    """N3: BNFeatureHook (stat_reg='BNS'): BN-input statistics vs the layer's running statistics, 3 steps."""
+    from utils.BNS_utils import BNFeatureHook
+    out = {}
+    cases = {"bn2d": (nn.BatchNorm2d, 8, (16, 8, 7, 7)), "bn1d_rows": (nn.BatchNorm1d, 16, (64, 16)),
+             "bn1d_nct": (nn.BatchNorm1d, 16, (2, 16, 8))}
+    for name, (cls, c, shape) in cases.items():
+        for reg in ("l1_loss", "mse_loss", "kld"):
+            mod = cls(c).eval()
+            g = torch.Generator().manual_seed(9)
+            with torch.no_grad():
+                mod.running_mean.copy_(torch.randn(c, generator=g) * 0.3)
+                mod.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+            hook = BNFeatureHook(mod, reg_type=reg, running_manner=True, use_src_stat_in_reg=True, momentum=0.1)
+            for step in range(3):
+                x = H.channel_feature(shape, 300 + step, 1, offset_scale=0.5).requires_grad_(True)
+                mod(x)
+                (gx,) = torch.autograd.grad(hook.r_feature, x)
+                key = f"{name}_{reg}_{step}"
+                out[key + "_r"], out[key + "_mean"], out[key + "_var"], out[key + "_gx"] = (
+                    t2n(hook.r_feature), t2n(hook.mean), t2n(hook.var), t2n(gx))
+            hook.close()
+    save("bns.npz", **out)
+
+
 SECTIONS = dict(l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
-                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin)
+                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic)
 
 if __name__ == "__main__":
     for n in (ARGV or list(SECTIONS)):

@@ -43,6 +43,12 @@ def feature_layout(feature, kind):
     if kind == "ln":
         c = feature.shape[-1]
         return feature.numel() // c, c, 1, LAYOUT_NHWC
+    if kind == "rows":  # (R, C): BatchNorm1d input of TAM.G, statistics over the rows (BNS_utils.py:43-45)
+        r, c = feature.shape
+        return r, c, 1, LAYOUT_NHWC
+    if kind == "nct":  # (N, C, T): BatchNorm1d input of TAM.L, statistics over (N, T) (BNS_utils.py:46-48)
+        n, c, t = feature.shape
+        return n, c, t, LAYOUT_NCHW
     raise ValueError(f"unknown feature kind {kind}")
 
 

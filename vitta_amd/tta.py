@@ -242,6 +242,21 @@ class ViTTAAdapter:
         self.params = [p for p in params if p.requires_grad]
         self.bucket = GradBucket(self.params) if self.world > 1 else None
 
+        self.n_clips = _n_clips(args)
+        self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
+        self.n_views = args.test_crops * (args.n_augmented_views if args.if_sample_tta_aug_views else self.n_clips)
+        self._graph = None
+        self.engine = None
+        if args.stat_reg == "BNS":
+            # regularise the BN INPUT statistics towards the layer's own running statistics (basics.py:588-599)
+            from .bns_utils import BNFeatureHook
+            self.chosen_layers = choose_layers(model, list(self.bn_types))
+            self.hooked = select_hooked(args, self.chosen_layers)
+            backend = BACKEND_FACTORY() if (engine_backend is None and BACKEND_FACTORY is not None) else engine_backend
+            self.stat_reg_hooks = [BNFeatureHook(layer, reg_type=args.reg_type, running_manner=args.running_manner,
+                                                 use_src_stat_in_reg=args.use_src_stat_in_reg, momentum=args.momentum_bns,
+                                                 backend=backend) for _, _, layer in self.hooked]
+            return
         if args.stat_reg != "mean_var":
             raise Exception(f"undefined regularization type {args.stat_reg}")
         if isinstance(args.stat_type, str):
