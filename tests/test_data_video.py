@@ -1,0 +1,79 @@
+"""Input pipelines against goldens produced by the reference's own transform classes /
+samplers (tools/refgen/gen_golden.py data).  decord itself is not installed here: decode is not exercised."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from vitta_amd import data_video as DV
+
+
+def _frames(n, w, h, seed):
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n):
+        base = rng.randint(0, 256, size=(h // 8 + 1, w // 8 + 1, 3)).astype(np.uint8)
+        out.append(Image.fromarray(base).resize((w, h), Image.BICUBIC))
+    return out
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_tanet_tta_transform_matches_reference(case):
+    g = H.golden("data_pipeline.npz")
+    w, h, views, T, size = (int(v) for v in g[f"tanet_{case}_cfg"])
+    frames = _frames(views * T, w, h, 11)
+    random.seed(5)  # same draws as the reference: (crop pair, offset) per view
+    imgs = DV.subgroup_multiscale_crop(frames, views, T, size)
+    ten = DV.stack_to_tensor(imgs, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+    assert list(ten.shape) == g[f"tanet_{case}_shape"].tolist()
+    torch.testing.assert_close(ten[:, ::16, ::16], torch.from_numpy(g[f"tanet_{case}_sub"]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ten.double().sum((1, 2)), torch.from_numpy(g[f"tanet_{case}_chsum"]), rtol=1e-9, atol=1e-3)
+
+
+def test_crop_candidates_and_eval_transform():
+    offs = DV.fixed_crop_offsets(340, 256, 224, 224)
+    assert len(offs) == 13 and offs[0] == (0, 0) and offs[4] == (2 * 29, 2 * 8) and offs[3] == (116, 32)
+    random.seed(0)
+    w, h, ow, oh = DV.sample_multiscale_crop((340, 256), (224, 224))
+    assert w in (256, 224, 192, 168) and h in (256, 224, 192, 168) and 0 <= ow <= 340 - w and 0 <= oh <= 256 - h
+    img = _frames(1, 340, 256, 3)[0]
+    s = DV.scale_short_edge(img, 256)
+    assert s.size == (340, 256)
+    s2 = DV.scale_short_edge(_frames(1, 320, 240, 3)[0], 256)
+    assert s2.size == (int(256 * 320 / 240), 256)
+    c = DV.center_crop(s2, 224)
+    assert c.size == (224, 224)
+
+
+def test_swin_samplers_match_reference():
+    g = H.golden("data_pipeline.npz")
+    for key in g.files:
+        parts = key.split("_")
+        if key.startswith("swin_uniform"):
+            T, n = int(parts[2][1:]), int(parts[3][1:])
+            np.testing.assert_array_equal(DV.swin_uniform_indices(n, T), g[key], err_msg=key)
+        elif key.startswith("swin_dense"):
+            T, n, c = int(parts[2][1:]), int(parts[3][1:]), int(parts[4][1:])
+            np.testing.assert_array_equal(DV.swin_dense_test_indices(n, T, 2, c), g[key], err_msg=key)
+
+
+def test_random_resized_crop_box_is_inside_the_frame():
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        l, t, r, b = DV.random_resized_crop_box(224, 298, rng=rng)
+        assert 0 <= l < r <= 298 and 0 <= t < b <= 224
+
+
+def test_real_video_datasets_need_decord(tmp_path):
+    lst = tmp_path / "list.txt"
+    lst.write_text("a.mp4 100 3\nb.mp4 2 1\n")
+    try:
+        import decord  # noqa: F401
+        pytest.skip("decord present")
+    except ImportError:
+        pass
+    with pytest.raises(ImportError):
+        DV.VideoTANetDataset(str(lst), 8, str(tmp_path))

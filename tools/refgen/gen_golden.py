@@ -428,6 +428,49 @@ def gen_episodic():
     save("episodic.npz", **out)
 
 
+def synthetic_frames(n, w, h, seed):
+    """Seeded smooth-ish RGB frames as PIL images."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        base = rng.randint(0, 256, size=(h // 8 + 1, w // 8 + 1, 3)).astype(np.uint8)
+        img = Image.fromarray(base).resize((w, h), Image.BICUBIC)
+        out.append(img)
+    return out
+
+
+def gen_data():
+    """N1: the reference's own TANet transform classes on seeded frames + the Swin index samplers."""
+    import random as pyrandom
+    from models.tanet_models.transforms import (SubgroupWise_MultiScaleCrop_TANet, Stack_TANet, ToTorchFormatTensor_TANet,
+                                                GroupNormalize_TANet)
+    from models.videoswintransformer_models.transforms_backup import SampleFrames
+    out = {}
+    for case, (w, h, views, T, size) in {"a": (340, 256, 2, 8, 224), "b": (320, 240, 4, 4, 112)}.items():
+        frames = synthetic_frames(views * T, w, h, 11)
+        pyrandom.seed(5)
+        crop = SubgroupWise_MultiScaleCrop_TANet(input_size=size, n_temp_clips=views, clip_len=T)
+        imgs, _ = crop((frames, 0))
+        arr, _ = Stack_TANet(roll=False)((imgs, 0))
+        ten, _ = ToTorchFormatTensor_TANet(div=True)((arr, 0))
+        ten, _ = GroupNormalize_TANet([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])((ten, 0))
+        out[f"tanet_{case}_shape"] = np.array(ten.shape)
+        out[f"tanet_{case}_sub"] = t2n(ten[:, ::16, ::16])
+        out[f"tanet_{case}_chsum"] = t2n(ten.double().sum((1, 2)))
+        out[f"tanet_{case}_cfg"] = np.array([w, h, views, T, size])
+    for T in (8, 16, 32):
+        for n in (300, 100, 37, 16, 9):
+            sf = SampleFrames(clip_len=T, frame_interval=2, num_clips=1, test_mode=True, frame_uniform=True)
+            out[f"swin_uniform_T{T}_n{n}"] = np.asarray(sf.get_seq_frames(n))
+            for clips in (1, 4):
+                sf = SampleFrames(clip_len=T, frame_interval=2, num_clips=clips, test_mode=True, frame_uniform=False)
+                offs = sf._sample_clips(n)
+                idx = np.mod(offs[:, None] + np.arange(T)[None, :] * 2, n).reshape(-1)
+                out[f"swin_dense_T{T}_n{n}_c{clips}"] = idx
+    save("data_pipeline.npz", **out)
+
+
 def gen_dp():
     """8e: the reference with batch_size=2 -- what two data-parallel ranks must reproduce."""
     gen_tta(batch_size=2, tag="tta3_bz2")
@@ -690,7 +733,7 @@ def gen_bns():
 
 
 SECTIONS = dict(l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
-                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic)
+                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic, data=gen_data)
 
 if __name__ == "__main__":
     for n in (ARGV or list(SECTIONS)):

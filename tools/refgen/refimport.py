@@ -122,6 +122,12 @@ def install():
     _mod("tensorboardX", SummaryWriter=_Anything)
     _mod("cv2")
 
+    # numpy aliases the reference's pinned numpy 1.19.5 still had (transforms_backup.py:505,527,531,689 use np.int)
+    import numpy as _np
+    for _alias, _typ in (("int", int), ("float", float), ("bool", bool)):
+        if _alias not in _np.__dict__:
+            setattr(_np, _alias, _typ)
+
     # no GPU in the build container: .cuda() / .to('cuda:0') become no-ops
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
