@@ -64,6 +64,24 @@ constexpr int OB = 8;    // conv1 output channels per workgroup
 constexpr int CB = 32;   // channels per workgroup in the per-channel stages
 constexpr int TBW = 256; // threads of the split kernels
 
+// copy `n` contiguous floats global -> LDS with every lane keeping four 4-byte loads in flight (the weights of a
+// TAM are read once per workgroup: a load -> fma loop over them is pure latency, ~60 us per launch in the r1g profile)
+__device__ __forceinline__ void stage_linear(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * TBW) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TBW;
+      v[u] = i < n ? src[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TBW;
+      if (i < n) dst[i] = v[u];
+    }
+  }
+}
+
 __device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, float* pl, int nthreads) {
   const int C = a.C, T = a.T, TP = T + 2;
   for (int i = threadIdx.x; i < C * TP; i += nthreads) {
@@ -79,7 +97,12 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2;
   float* pl = smem;                 // [C][T+2]
   float* red = pl + C * TP;         // [OB*T][CS] partial sums
+  float* wl = red + TBW;            // [OB][C*3] conv1 weights of this tile
   load_pooled_t(a, n, pl, TBW);
+  {
+    const int o0 = tile * OB, rows = min(OB, O - o0);
+    stage_linear(wl, a.w0 + (int64_t)o0 * C * 3, rows * C * 3);
+  }
   __syncthreads();
   // G branch: this workgroup's slice of channels
   const int cper = (C + ntiles - 1) / ntiles;
@@ -96,7 +119,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   float acc = 0.f;
   const int o = tile * OB + item / T, t = item % T;
   if (item < items && o < O) {
-    const float* w = a.w0 + (int64_t)o * C * 3;
+    const float* w = wl + (item / T) * C * 3;
     for (int c = cs; c < C; c += CS) {
       const float* p = pl + c * TP + t;
       acc = fmaf(w[3 * c], p[0], acc);
@@ -121,13 +144,15 @@ __global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, con
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, c0 = blockIdx.y * CB;
   const int C = a.C, T = a.T, O = C / 4;
-  float* hl = smem;  // [O][T]
-  for (int i = threadIdx.x; i < O * T; i += TBW) hl[i] = h_act[(int64_t)n * O * T + i];
+  float* hl = smem;          // [O][T]
+  float* wl = hl + O * T;    // [CB][O] conv2 weights of this tile
+  stage_linear(hl, h_act + (int64_t)n * O * T, O * T);
+  stage_linear(wl, a.w3 + (int64_t)c0 * O, min(CB, C - c0) * O);
   __syncthreads();
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
     const int c = c0 + i / T, t = i % T;
     if (c >= C) continue;
-    const float* w = a.w3 + (int64_t)c * O;
+    const float* w = wl + (i / T) * O;
     float acc = 0.f;
     for (int o = 0; o < O; ++o) acc = fmaf(w[o], hl[o * T + t], acc);
     gate[((int64_t)n * C + c) * T + t] = sigmoidf(acc);
@@ -154,9 +179,15 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   const int C = a.C, T = a.T, O = C / 4;
   float* dz = smem;            // [C][T]
   float* red = dz + C * T;     // [OB*T][CS]
+  float* wl = red + TBW;       // [C][OB] conv2 weights W3[c, o0 .. o0+OB)
   for (int i = threadIdx.x; i < C * T; i += TBW) {
     const float gt = gate[(int64_t)n * C * T + i];
     dz[i] = ggate[(int64_t)n * C * T + i] * gt * (1.f - gt);
+  }
+#pragma unroll 4
+  for (int i = threadIdx.x; i < C * OB; i += TBW) {
+    const int c = i / OB, oo = tile * OB + i % OB;
+    wl[i] = oo < O ? a.w3[(int64_t)c * O + oo] : 0.f;
   }
   __syncthreads();
   const int items = OB * T;
@@ -165,7 +196,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   const int o = tile * OB + item / T, t = item % T;
   float acc = 0.f;
   if (item < items && o < O)
-    for (int c = cs; c < C; c += CS) acc = fmaf(a.w3[(int64_t)c * O + o], dz[c * T + t], acc);
+    for (int c = cs; c < C; c += CS) acc = fmaf(wl[c * OB + item / T], dz[c * T + t], acc);
   if (threadIdx.x < items * CS) red[threadIdx.x] = acc;
   __syncthreads();
   if (cs == 0 && item < items && o < O) {
@@ -200,6 +231,15 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
   float* pl = dpre + O * TP;       // [CB][T+2] pooled of this tile, zero padded
   float* gp = pl + CB * TP;        // [CB][T] result staging
   float* gacc = gp + CB * T;       // [5M + M*T] block accumulators of the G-branch parameter gradients
+  float* wl = gacc + 5 * M + M * T;  // [O][CB*3] conv1 weights W0[o, c0 .. c0+CB, :]
+  {
+    const int cw = min(CB, C - c0) * 3;  // floats per o-row of this tile (contiguous in W0)
+#pragma unroll 4
+    for (int i = threadIdx.x; i < O * CB * 3; i += TBW) {
+      const int o = i / (CB * 3), r = i % (CB * 3);
+      wl[i] = r < cw ? a.w0[((int64_t)o * C + c0) * 3 + r] : 0.f;
+    }
+  }
   for (int i = threadIdx.x; i < O * TP; i += TBW) {
     const int o = i / TP, t = i % TP - 1;
     dpre[i] = (t >= 0 && t < T) ? dpre_g[((int64_t)n * O + o) * T + t] : 0.f;
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     float acc = 0.f;
     if (c < C) {
       for (int o = 0; o < O; ++o) {
-        const float* w = a.w0 + ((int64_t)o * C + c) * 3;
+        const float* w = wl + (o * CB + cl) * 3;
         const float* d = dpre + o * TP + t;
         acc = fmaf(w[0], d[2], acc);
         acc = fmaf(w[1], d[1], acc);
@@ -281,11 +321,12 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     for (int i = threadIdx.x; i < M * T; i += TBW) atomicAdd(g.dwg1 + i, gacc[5 * M + i]);
 }
 
-inline size_t f1_lds(int C, int T) { return sizeof(float) * ((size_t)C * (T + 2) + TBW) + 64; }
-inline size_t f2_lds(int C, int T) { return sizeof(float) * ((size_t)(C / 4) * T) + 64; }
-inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)C * T + TBW) + 64; }
+inline size_t f1_lds(int C, int T) { return sizeof(float) * ((size_t)C * (T + 2) + TBW + (size_t)OB * C * 3) + 64; }
+inline size_t f2_lds(int C, int T) { return sizeof(float) * ((size_t)(C / 4) * T + (size_t)CB * (C / 4)) + 64; }
+inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)C * T + TBW + (size_t)C * OB) + 64; }
 inline size_t b2_lds(int C, int T) {
-  return sizeof(float) * ((size_t)(C / 4) * (T + 2) + CB * (T + 2) + CB * T + 5 * 2 * T + 2 * T * T) + 64;
+  return sizeof(float) * ((size_t)(C / 4) * (T + 2) + CB * (T + 2) + CB * T + 5 * 2 * T + 2 * T * T +
+                          (size_t)(C / 4) * CB * 3) + 64;
 }
 
 template <typename K>
@@ -304,7 +345,7 @@ inline bool tb_bad(const TamBranchArgs& a) {
 extern "C" {
 
 int vitta_tam_branch_supported(int32_t C, int32_t T) {
-  return (T >= 1 && T <= T_MAX && OB * T <= TBW && C >= 4 && C % 4 == 0 && f1_lds(C, T) <= 160 * 1024 &&
+  return (T >= 1 && T <= T_MAX && OB * T <= TBW && C >= 4 && C % 4 == 0 && f1_lds(C, T) <= 160 * 1024 && f2_lds(C, T) <= 160 * 1024 &&
           b1_lds(C, T) <= 160 * 1024 && b2_lds(C, T) <= 160 * 1024) ? 1 : 0;
 }
 
