@@ -1,6 +1,6 @@
 """Data-parallel path on the CPU: 2 ranks over gloo reproduce the reference run with batch_size=2
 (SURVEY section 8e).  Exchanges under test: ONE all-reduce of the packed moments [cnt|s1|s2] before the
-EMA update, ONE SUM all-reduce of the flat gradient buffer before the optimizer step, the ragged tail."""
+EMA update, ONE SUM all-reduce of the flat gradient arena before the optimizer step, the ragged tail."""
 import json
 import os
 import socket

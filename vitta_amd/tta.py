@@ -138,26 +138,37 @@ def select_hooked(args, chosen_layers):
 # ------------------------------------------------------------------------------------------------
 # data-parallel gradient exchange
 # ------------------------------------------------------------------------------------------------
-class GradBucket:
-    """All gradients live in ONE flat buffer (p.grad are views into it): a single SUM all-reduce per
-    step, no flatten/unflatten copies.  SUM, not mean: loss_consis is a sum over videos and loss_reg
-    is one global scalar whose per-rank partial derivatives add."""
+class FlatArena:
+    """Trainable parameters AND their gradients live in two flat fp32 buffers; every `p.data` / `p.grad` is a
+    view.  The optimizer sees ONE tensor: its whole step is a handful of launches instead of a handful per
+    parameter tensor (capturable Adam over 170 affine tensors issued ~290 three-microsecond kernels per step in
+    the r1g profile), and the data-parallel gradient exchange is ONE all-reduce of `grad` with no flatten copies.
+    Element-wise optimizers (SGD with momentum / weight decay, Adam) compute exactly what they compute per tensor.
+    SUM, not mean, across ranks: loss_consis is a sum over videos and loss_reg is one global scalar whose per-rank
+    partial derivatives add."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                flat[off:off + k].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + k].view_as(p)
+                p.grad = self.grad[off:off + k].view_as(p)
+                off += k
+        self.flat_param = nn.Parameter(flat)  # shares storage with every p.data view
+        self.flat_param.grad = self.grad
 
-    def zero(self):
-        self.flat.zero_()
+    def zero_grad(self):
+        self.grad.zero_()
 
     def all_reduce(self):
-        torch.distributed.all_reduce(self.flat, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
 
 
 class DeferredLog:
@@ -232,15 +243,17 @@ class ViTTAAdapter:
             kinds = list(self.bn_types) if args.arch == "tanet" else [nn.LayerNorm]
             freeze_except_bn(model, bn_condidiate_layers=kinds)
             params, self.param_names = collect_bn_params(model, bn_candidate_layers=kinds)
+            self.arena = FlatArena(params)
             # capturable: the step counter lives on the device, so the whole step can sit in a hipGraph
-            self.optimizer = torch.optim.Adam(params, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0,
+            self.optimizer = torch.optim.Adam([self.arena.flat_param], lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0,
                                               capturable=self.device.type == "cuda")
         else:
             params = list(model.parameters())
-            self.optimizer = torch.optim.SGD(params=params, lr=args.lr, momentum=args.momentum,
+            self.arena = FlatArena(params)
+            self.optimizer = torch.optim.SGD(params=[self.arena.flat_param], lr=args.lr, momentum=args.momentum,
                                              weight_decay=args.weight_decay)
-        self.params = [p for p in params if p.requires_grad]
-        self.bucket = GradBucket(self.params) if self.world > 1 else None
+        self.params = self.arena.params
+        self.bucket = self.arena if self.world > 1 else None
 
         self.n_clips = _n_clips(args)
         self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
@@ -377,10 +390,7 @@ class ViTTAAdapter:
 
     def _adapt_step_eager(self, input, has_video=True):
         a = self.args
-        if self.bucket is not None:
-            self.bucket.zero()
-        else:
-            self.optimizer.zero_grad(set_to_none=True)
+        self.arena.zero_grad()
         output = loss_reg = loss_consis = None
         if has_video:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
@@ -414,12 +424,9 @@ class ViTTAAdapter:
         x = g["tta_in"]
         actual_bz = x.shape[0] // self.n_views if a.arch == "tanet" else x.shape[0]
         pool = torch.cuda.graph_pool_handle()
-        if self.bucket is None:
-            self.optimizer.zero_grad(set_to_none=True)
         g["seg_fwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_fwd"], pool=pool):
-            if self.bucket is not None:
-                self.bucket.zero()
+            self.arena.zero_grad()
             output, loss_consis = self.forward_local(x, actual_bz)
         g["seg_bwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_bwd"], pool=pool):
@@ -450,7 +457,6 @@ class ViTTAAdapter:
         if self.world > 1 or segmented:
             self._capture_segments(g)
         else:
-            self.optimizer.zero_grad(set_to_none=True)
             g["adapt"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["adapt"]):
                 g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True)
