@@ -58,6 +58,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=4)
     p.add_argument("--no-streaming", action="store_true")
+    p.add_argument("--timed-only", action="store_true",
+                   help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
+                        "the tail of a rocprofv3 trace is the shipped hipGraph replay and nothing else")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     p.add_argument("--segmented-graph", action="store_true",
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
@@ -174,6 +177,10 @@ def run_gpu(opt, rank, world, device):
     barrier()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps ({'hipGraph replay' if use_graph else 'eager'})")
+    eager_elapsed = float("nan")
+    if opt.timed_only:
+        run_gpu.mode, run_gpu.eager_ms = ("hipGraph replay" if use_graph else "eager launches"), None
+        return elapsed, float("nan"), float("nan"), None, adapter
     if use_graph:
         # A kernel inside a replayed graph cannot be bracketed by events; its duration does not depend
         # on how it was launched, so the K steps are repeated eagerly (same videos, same kernels) with an

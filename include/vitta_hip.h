@@ -243,7 +243,9 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  *   d_triples: NULL, or the layer's (n, mean, M2) partial area of a plan workspace
  *              (float* workspace + 3*ws_off, geometry from vitta_plan_layer_geometry; nsplit must match)
  *   backward: d_gres NULL iff no residual; d_mu/d_coef_a/d_coef_b/d_gscale NULL iff not hooked;
- *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch.
+ *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch;
+ *             accumulate != 0: d_dgamma / d_dbeta += (the caller hands the parameters' live .grad storage,
+ *             which is what autograd's AccumulateGrad would do with one more launch per tensor).
  * Requires C*HW % 4 == 0 (VITTA_ERR_UNSUPPORTED otherwise: use the unfused ops).
  * -------------------------------------------------------------------------- */
 size_t vitta_bn_act_partial_floats(int64_t outer, int32_t C, int64_t HW, int32_t nsplit);
@@ -254,7 +256,7 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
                          const float* d_weight, const float* d_bias, const float* d_rmean, const float* d_rvar,
                          float eps, const float* d_mu, const float* d_coef_a, const float* d_coef_b,
                          const float* d_gscale, int64_t outer, int32_t C, int64_t HW, int32_t nsplit, int32_t relu,
-                         float* d_partial, float* d_dgamma, float* d_dbeta, void* stream);
+                         float* d_partial, float* d_dgamma, float* d_dbeta, int32_t accumulate, void* stream);
 /* out5 = {nsplit, nchunks, slots, ws_off (in triples), vec} of one layer of a plan */
 int vitta_plan_layer_geometry(const vitta_plan* plan, int layer, int64_t* out5);
 

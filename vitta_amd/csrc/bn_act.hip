@@ -220,7 +220,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
 // sum the (split, chunk) partials of every channel -> dgamma[c], dbeta[c]
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_affine_grad_kernel(const float* __restrict__ partial, BnGeom g, int C,
                                                                      float* __restrict__ dgamma,
-                                                                     float* __restrict__ dbeta) {
+                                                                     float* __restrict__ dbeta, int accumulate) {
   const int c = blockIdx.x * VITTA_BLOCK + threadIdx.x;
   if (c >= C) return;
   const int64_t k0 = ((int64_t)c * g.HW) / VITTA_CHUNK;
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_affine_grad_kernel(const float
       a += (double)t[0];
       b += (double)t[1];
     }
-  dgamma[c] = (float)a;
-  dbeta[c] = (float)b;
+  dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
+  dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
 }
 
 inline int make_geom(int64_t outer, int32_t C, int64_t HW, int nsplit, BnGeom* g) {
@@ -298,7 +298,7 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
                          const float* d_weight, const float* d_bias, const float* d_rmean, const float* d_rvar,
                          float eps, const float* d_mu, const float* d_coef_a, const float* d_coef_b, const float* d_gscale,
                          int64_t outer, int32_t C, int64_t HW, int32_t nsplit, int32_t relu, float* d_partial,
-                         float* d_dgamma, float* d_dbeta, void* stream) {
+                         float* d_dgamma, float* d_dbeta, int32_t accumulate, void* stream) {
   BnGeom g;
   const int rc = make_geom(outer, C, HW, nsplit, &g);
   if (rc != VITTA_OK) return rc;
@@ -319,7 +319,7 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
   else if (I) BN_BWD_CASE(false, false, true);
   else BN_BWD_CASE(false, false, false);
   VITTA_LAUNCH(bn_affine_grad_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK), 0, st, d_partial, g,
-               (int)C, d_dgamma, d_dbeta);
+               (int)C, d_dgamma, d_dbeta, (int)accumulate);
   return VITTA_OK;
 }
 

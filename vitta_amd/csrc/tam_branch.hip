@@ -31,49 +31,48 @@ struct TamBranchArgs {
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// G branch for one (n, c) row: u_pre (pre-BN), kern[3]
-__device__ __forceinline__ void g_forward(const TamBranchArgs& a, const float* prow /* pl + c*(T+2) + 1 */, float* u_pre,
-                                          float* u, float* kern3) {
-  const int T = a.T, M = 2 * a.T;
-  float v[3] = {0.f, 0.f, 0.f};
-  for (int m = 0; m < M; ++m) {
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc = fmaf(a.wg1[m * T + t], prow[t], acc);
-    u_pre[m] = acc;
-    const float s = a.bng.w[m] * rsqrtf(a.bng.rv[m] + a.bng.eps);
-    const float y = fmaxf(fmaf(acc - a.bng.rm[m], s, a.bng.b[m]), 0.f);
-    u[m] = y;
-    v[0] = fmaf(a.wg3[m], y, v[0]);
-    v[1] = fmaf(a.wg3[M + m], y, v[1]);
-    v[2] = fmaf(a.wg3[2 * M + m], y, v[2]);
-  }
-  const float mx = fmaxf(v[0], fmaxf(v[1], v[2]));
-  const float e0 = __expf(v[0] - mx), e1 = __expf(v[1] - mx), e2 = __expf(v[2] - mx);
-  const float inv = 1.f / (e0 + e1 + e2);
-  kern3[0] = e0 * inv; kern3[1] = e1 * inv; kern3[2] = e2 * inv;
-}
-
 // ------------------------------------------------------------------------------------------------
 // The work of one clip is spread over several workgroups (a clip is only N = B*V = 2 workgroups otherwise):
 //   forward  F1 grid (N, O/OB): h_pre / h for OB conv1 output channels + the G branch of a slice of channels
 //            F2 grid (N, C/CB): gate for CB channels
 //   backward B1 grid (N, O/OB): d(conv1 output) for OB channels (+ dW3 slice, BN1d(L) affine grads)
 //            B2 grid (N, C/CB): d pooled for CB channels (L transposed conv + G branch) (+ dW0 slice, G grads)
+// These launches are 4..32 workgroups of a few microseconds: what they cost is LATENCY.  Every operand is
+// therefore brought into LDS with wide loads that are all in flight together (a load -> fma loop over global
+// weights measured 30-60 us per launch in the r1g profile), and nothing in the arithmetic loops touches global.
 // ------------------------------------------------------------------------------------------------
 constexpr int OB = 8;    // conv1 output channels per workgroup
 constexpr int CB = 32;   // channels per workgroup in the per-channel stages
 constexpr int TBW = 256; // threads of the split kernels
+constexpr int GL = 8;    // lanes that share one (n, c) row of the G branch
+constexpr int GM = (2 * T_MAX + GL - 1) / GL;  // hidden units of G per lane
+static_assert(CB * GL == TBW, "B2 maps one G row per 8 lanes");
 
-// copy `n` contiguous floats global -> LDS with every lane keeping four 4-byte loads in flight (the weights of a
-// TAM are read once per workgroup: a load -> fma loop over them is pure latency, ~60 us per launch in the r1g profile)
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// n contiguous floats global -> LDS; 16-byte loads, four per lane in flight, when both sides allow it
 __device__ __forceinline__ void stage_linear(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  if (aligned16(src) && aligned16(dst)) {
+    const int n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * TBW) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = s4[min(i0 + u * TBW, n4 - 1)];  // clamped: loads stay unconditional
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * TBW;
+        if (i < n4) d4[i] = v[u];
+      }
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += TBW) dst[i] = src[i];
+    return;
+  }
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * TBW) {
     float v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * TBW;
-      v[u] = i < n ? src[i] : 0.f;
-    }
+    for (int u = 0; u < 4; ++u) v[u] = src[min(i0 + u * TBW, n - 1)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * TBW;
@@ -82,12 +81,91 @@ __device__ __forceinline__ void stage_linear(float* __restrict__ dst, const floa
   }
 }
 
-__device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, float* pl, int nthreads) {
-  const int C = a.C, T = a.T, TP = T + 2;
-  for (int i = threadIdx.x; i < C * TP; i += nthreads) {
-    const int c = i / TP, t = i % TP - 1;
-    pl[i] = (t >= 0 && t < T) ? a.pooled[((int64_t)n * C + c) * T + t] : 0.f;
+// `rows` rows of `len` floats (len % 4 == 0), source rows `stride` floats apart, packed densely into LDS
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ src, int rows, int len,
+                                           int64_t stride) {
+  if (aligned16(src) && aligned16(dst) && (stride & 3) == 0 && (len & 3) == 0) {
+    const int l4 = len >> 2, n4 = rows * l4;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * TBW) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + u * TBW, n4 - 1);
+        v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(i / l4) * stride + 4 * (i % l4));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * TBW;
+        if (i < n4) d4[i] = v[u];
+      }
+    }
+    return;
   }
+  for (int i = threadIdx.x; i < rows * len; i += TBW) dst[i] = src[(int64_t)(i / len) * stride + i % len];
+}
+
+// pooled [C][T] of clip n -> LDS [C][T+2], zero padded in t
+__device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, int c0, int nc, float* pl) {
+  const int C = a.C, T = a.T, TP = T + 2;
+  for (int i = threadIdx.x; i < nc * TP; i += TBW) {
+    const int c = c0 + i / TP, t = i % TP - 1;
+    pl[i] = (c < C && t >= 0 && t < T) ? a.pooled[((int64_t)n * C + c) * T + t] : 0.f;
+  }
+}
+
+// G-branch parameters in LDS: W1 [2T][T] | W3 [3][2T] | running mean | scale = gamma*rsqrt(var+eps) | beta |
+// rsqrt(var+eps) | gamma
+struct GLds {
+  const float* wg1; const float* wg3; const float* rm; const float* s; const float* b; const float* is; const float* w;
+};
+__device__ __forceinline__ GLds stage_g(const TamBranchArgs& a, float* gl) {
+  const int T = a.T, M = 2 * T;
+  float* wg1 = gl; float* wg3 = wg1 + M * T; float* rm = wg3 + 3 * M; float* sc = rm + M; float* b = sc + M;
+  float* is = b + M; float* w = is + M;
+  for (int i = threadIdx.x; i < M * T; i += TBW) wg1[i] = a.wg1[i];
+  for (int i = threadIdx.x; i < 3 * M; i += TBW) wg3[i] = a.wg3[i];
+  for (int m = threadIdx.x; m < M; m += TBW) {
+    const float r = rsqrtf(a.bng.rv[m] + a.bng.eps), g = a.bng.w[m];
+    rm[m] = a.bng.rm[m]; sc[m] = g * r; b[m] = a.bng.b[m]; is[m] = r; w[m] = g;
+  }
+  return GLds{wg1, wg3, rm, sc, b, is, w};
+}
+
+__device__ __forceinline__ float group_sum(float v) {  // over the GL lanes of one row
+  v += __shfl_xor(v, 1, VITTA_WAVE); v += __shfl_xor(v, 2, VITTA_WAVE); v += __shfl_xor(v, 4, VITTA_WAVE);
+  return v;
+}
+__device__ __forceinline__ float rows_sum(float v) {  // over the 8 rows of a wave, same sub-lane
+  v += __shfl_xor(v, 8, VITTA_WAVE); v += __shfl_xor(v, 16, VITTA_WAVE); v += __shfl_xor(v, 32, VITTA_WAVE);
+  return v;
+}
+
+// G branch of one (n, c) row on GL lanes: lane `sub` owns hidden units m = sub, sub+GL, ...  Every lane of the
+// wave must call this (shuffles); `active` masks rows past the end.
+__device__ __forceinline__ void g_forward(const GLds& p, int T, int sub, bool active, const float* prow, float* u_pre,
+                                          float* u, float* k3) {
+  const int M = 2 * T;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < GM; ++j) {
+    const int m = sub + j * GL;
+    float acc = 0.f, y = 0.f;
+    if (active && m < M) {
+      for (int t = 0; t < T; ++t) acc = fmaf(p.wg1[m * T + t], prow[t], acc);
+      y = fmaxf(fmaf(acc - p.rm[m], p.s[m], p.b[m]), 0.f);
+      v0 = fmaf(p.wg3[m], y, v0);
+      v1 = fmaf(p.wg3[M + m], y, v1);
+      v2 = fmaf(p.wg3[2 * M + m], y, v2);
+    }
+    u_pre[j] = acc;
+    u[j] = y;
+  }
+  v0 = group_sum(v0); v1 = group_sum(v1); v2 = group_sum(v2);
+  const float mx = fmaxf(v0, fmaxf(v1, v2));
+  const float e0 = __expf(v0 - mx), e1 = __expf(v1 - mx), e2 = __expf(v2 - mx);
+  const float inv = 1.f / (e0 + e1 + e2);
+  k3[0] = e0 * inv; k3[1] = e1 * inv; k3[2] = e2 * inv;
 }
 
 __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, float* __restrict__ kern,
@@ -95,22 +173,26 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tile = blockIdx.y, ntiles = gridDim.y;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2;
-  float* pl = smem;                 // [C][T+2]
-  float* red = pl + C * TP;         // [OB*T][CS] partial sums
-  float* wl = red + TBW;            // [OB][C*3] conv1 weights of this tile
-  load_pooled_t(a, n, pl, TBW);
+  float* wl = smem;                      // [OB][C*3] conv1 weights of this tile
+  float* pl = wl + OB * C * 3;           // [C][T+2]
+  float* red = pl + C * TP;              // [OB*T][CS] partial sums
+  float* gl = red + TBW;                 // G parameters
   {
     const int o0 = tile * OB, rows = min(OB, O - o0);
     stage_linear(wl, a.w0 + (int64_t)o0 * C * 3, rows * C * 3);
   }
+  load_pooled_t(a, n, 0, C, pl);
+  const GLds gp = stage_g(a, gl);
   __syncthreads();
-  // G branch: this workgroup's slice of channels
-  const int cper = (C + ntiles - 1) / ntiles;
-  for (int c = tile * cper + threadIdx.x; c < min(C, (tile + 1) * cper); c += TBW) {
-    float u_pre[2 * T_MAX], u[2 * T_MAX], k3[3];
-    g_forward(a, pl + c * TP + 1, u_pre, u, k3);
-    float* o = kern + ((int64_t)n * C + c) * 3;
-    o[0] = k3[0]; o[1] = k3[1]; o[2] = k3[2];
+  // G branch: this workgroup's slice of channels, GL lanes per channel
+  const int cper = (C + ntiles - 1) / ntiles, cend = min(C, (tile + 1) * cper);
+  const int sub = threadIdx.x % GL;
+  for (int g0 = tile * cper; g0 < cend; g0 += TBW / GL) {
+    const int c = g0 + threadIdx.x / GL;
+    const bool active = c < cend;
+    float u_pre[GM], u[GM], k3[3];
+    g_forward(gp, T, sub, active, pl + (active ? c : 0) * TP + 1, u_pre, u, k3);
+    if (active && sub < 3) kern[((int64_t)n * C + c) * 3 + sub] = sub == 0 ? k3[0] : (sub == 1 ? k3[1] : k3[2]);
   }
   // conv1 for OB output channels: item (o_local, t), CS lanes split the C reduction
   const int items = OB * T;
@@ -144,10 +226,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, con
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, c0 = blockIdx.y * CB;
   const int C = a.C, T = a.T, O = C / 4;
-  float* hl = smem;          // [O][T]
-  float* wl = hl + O * T;    // [CB][O] conv2 weights of this tile
-  stage_linear(hl, h_act + (int64_t)n * O * T, O * T);
+  float* wl = smem;            // [CB][O] conv2 weights of this tile
+  float* hl = wl + CB * O;     // [O][T]
   stage_linear(wl, a.w3 + (int64_t)c0 * O, min(CB, C - c0) * O);
+  stage_linear(hl, h_act + (int64_t)n * O * T, O * T);
   __syncthreads();
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
     const int c = c0 + i / T, t = i % T;
@@ -161,10 +243,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, con
 
 struct TamBranchGrads {
   float* gpooled;  // [N, C, T]
-  // eval-BN affine gradients (always produced; zero-initialised by the caller, accumulated with atomics)
+  // eval-BN affine gradients: ACCUMULATED with atomics (the caller hands zeroed buffers or live .grad views)
   float* dbng_w; float* dbng_b;   // [2T]
   float* dbnl_w; float* dbnl_b;   // [C/4]
-  // weight gradients: NULL when the weights are frozen (update_only_bn_affine)
+  // weight gradients, accumulated likewise: NULL when the weights are frozen (update_only_bn_affine)
   float* dwg1; float* dwg3; float* dw0; float* dw3;
 };
 
@@ -177,17 +259,24 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tile = blockIdx.y;
   const int C = a.C, T = a.T, O = C / 4;
-  float* dz = smem;            // [C][T]
-  float* red = dz + C * T;     // [OB*T][CS]
-  float* wl = red + TBW;       // [C][OB] conv2 weights W3[c, o0 .. o0+OB)
-  for (int i = threadIdx.x; i < C * T; i += TBW) {
-    const float gt = gate[(int64_t)n * C * T + i];
-    dz[i] = ggate[(int64_t)n * C * T + i] * gt * (1.f - gt);
+  float* dz = smem;            // [C][T]   (staged as gate, then overwritten by d(pre-sigmoid))
+  float* gg = dz + C * T;      // [C][T]   upstream gradient of the gate
+  float* wl = gg + C * T;      // [C][OB] conv2 weights W3[c, o0 .. o0+OB)
+  float* red = wl + C * OB;    // [OB*T][CS]
+  stage_linear(dz, gate + (int64_t)n * C * T, C * T);
+  stage_linear(gg, ggate + (int64_t)n * C * T, C * T);
+  if (tile * OB + OB <= O) {
+    stage_rows(wl, a.w3 + tile * OB, C, OB, O);
+  } else {
+    for (int i = threadIdx.x; i < C * OB; i += TBW) {
+      const int c = i / OB, oo = tile * OB + i % OB;
+      wl[i] = oo < O ? a.w3[(int64_t)c * O + oo] : 0.f;
+    }
   }
-#pragma unroll 4
-  for (int i = threadIdx.x; i < C * OB; i += TBW) {
-    const int c = i / OB, oo = tile * OB + i % OB;
-    wl[i] = oo < O ? a.w3[(int64_t)c * O + oo] : 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * T; i += TBW) {
+    const float gt = dz[i];
+    dz[i] = gg[i] * gt * (1.f - gt);
   }
   __syncthreads();
   const int items = OB * T;
@@ -227,14 +316,16 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, c0 = blockIdx.y * CB;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2, M = 2 * T;
-  float* dpre = smem;              // [O][T+2], zero padded in t
-  float* pl = dpre + O * TP;       // [CB][T+2] pooled of this tile, zero padded
-  float* gp = pl + CB * TP;        // [CB][T] result staging
-  float* gacc = gp + CB * T;       // [5M + M*T] block accumulators of the G-branch parameter gradients
-  float* wl = gacc + 5 * M + M * T;  // [O][CB*3] conv1 weights W0[o, c0 .. c0+CB, :]
-  {
-    const int cw = min(CB, C - c0) * 3;  // floats per o-row of this tile (contiguous in W0)
-#pragma unroll 4
+  float* wl = smem;                  // [O][CB*3] conv1 weights W0[o, c0 .. c0+CB, :]
+  float* dpre = wl + O * CB * 3;     // [O][T+2], zero padded in t
+  float* pl = dpre + O * TP;         // [CB][T+2] pooled of this tile, zero padded
+  float* gp = pl + CB * TP;          // [CB][T] result staging
+  float* gacc = gp + CB * T;         // [5M + M*T] block accumulators of the G-branch parameter gradients
+  float* gl = gacc + 5 * M + M * T;  // G parameters
+  if (c0 + CB <= C) {
+    stage_rows(wl, a.w0 + (int64_t)c0 * 3, O, CB * 3, (int64_t)C * 3);
+  } else {
+    const int cw = (C - c0) * 3;  // floats per o-row of this tile (contiguous in W0)
     for (int i = threadIdx.x; i < O * CB * 3; i += TBW) {
       const int o = i / (CB * 3), r = i % (CB * 3);
       wl[i] = r < cw ? a.w0[((int64_t)o * C + c0) * 3 + r] : 0.f;
@@ -244,11 +335,9 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     const int o = i / TP, t = i % TP - 1;
     dpre[i] = (t >= 0 && t < T) ? dpre_g[((int64_t)n * O + o) * T + t] : 0.f;
   }
-  for (int i = threadIdx.x; i < CB * TP; i += TBW) {
-    const int c = c0 + i / TP, t = i % TP - 1;
-    pl[i] = (c < C && t >= 0 && t < T) ? a.pooled[((int64_t)n * C + c) * T + t] : 0.f;
-  }
+  load_pooled_t(a, n, c0, CB, pl);
   for (int i = threadIdx.x; i < 5 * M + M * T; i += TBW) gacc[i] = 0.f;
+  const GLds p = stage_g(a, gl);
   __syncthreads();
   // L: transposed conv, one lane per (c, t)
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
@@ -275,36 +364,64 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     }
   }
   __syncthreads();
-  // G: one lane per channel of the tile
-  if (threadIdx.x < CB && c0 + threadIdx.x < C) {
-    const int cl = threadIdx.x, c = c0 + cl;
+  // G: GL lanes per channel of the tile (all 256 lanes busy), hidden unit m on lane m % GL
+  {
+    const int cl = threadIdx.x / GL, sub = threadIdx.x % GL, c = c0 + cl;
+    const bool active = c < C;
     const float* prow = pl + cl * TP + 1;
-    float u_pre[2 * T_MAX], u[2 * T_MAX], k3[3];
-    g_forward(a, prow, u_pre, u, k3);
-    const float* gk = gkern + ((int64_t)n * C + c) * 3;
-    const float* ks = kern + ((int64_t)n * C + c) * 3;
-    const float dot = gk[0] * ks[0] + gk[1] * ks[1] + gk[2] * ks[2];
-    const float dv[3] = {ks[0] * (gk[0] - dot), ks[1] * (gk[1] - dot), ks[2] * (gk[2] - dot)};
+    float u_pre[GM], u[GM], k3[3];
+    g_forward(p, T, sub, active, prow, u_pre, u, k3);
+    float dv0 = 0.f, dv1 = 0.f, dv2 = 0.f;
+    if (active) {
+      const float* gk = gkern + ((int64_t)n * C + c) * 3;
+      const float dot = gk[0] * k3[0] + gk[1] * k3[1] + gk[2] * k3[2];
+      dv0 = k3[0] * (gk[0] - dot); dv1 = k3[1] * (gk[1] - dot); dv2 = k3[2] * (gk[2] - dot);
+    }
     float dp[T_MAX];
-    for (int t = 0; t < T; ++t) dp[t] = 0.f;
-    for (int m = 0; m < M; ++m) {
-      const float du = a.wg3[m] * dv[0] + a.wg3[M + m] * dv[1] + a.wg3[2 * M + m] * dv[2];
-      const float is = rsqrtf(a.bng.rv[m] + a.bng.eps);
-      const float gy = u[m] > 0.f ? du : 0.f;
-      const float dpg = gy * a.bng.w[m] * is;
-      atomicAdd(gacc + m, gy * (u_pre[m] - a.bng.rm[m]) * is);
-      atomicAdd(gacc + M + m, gy);
-      if (g.dwg3) {
-        atomicAdd(gacc + 2 * M + m, dv[0] * u[m]);
-        atomicAdd(gacc + 3 * M + m, dv[1] * u[m]);
-        atomicAdd(gacc + 4 * M + m, dv[2] * u[m]);
+#pragma unroll
+    for (int t = 0; t < T_MAX; ++t) dp[t] = 0.f;
+    const bool lead = (threadIdx.x & (VITTA_WAVE - 1)) < GL;  // the lanes of a wave that publish its row sums
+#pragma unroll
+    for (int j = 0; j < GM; ++j) {
+      const int m = sub + j * GL;   // uniform across the rows of a wave for a given sub-lane
+      const bool on = active && m < M;
+      const int ms = m < M ? m : 0;
+      const float du = p.wg3[ms] * dv0 + p.wg3[M + ms] * dv1 + p.wg3[2 * M + ms] * dv2;
+      const float gy = (on && u[j] > 0.f) ? du : 0.f;
+      const float dpg = gy * p.w[ms] * p.is[ms];
+      const float gw = rows_sum(gy * (u_pre[j] - p.rm[ms]) * p.is[ms]);
+      const float gb = rows_sum(gy);
+      if (lead && m < M) {
+        atomicAdd(gacc + m, gw);
+        atomicAdd(gacc + M + m, gb);
       }
-      for (int t = 0; t < T; ++t) {
-        dp[t] = fmaf(a.wg1[m * T + t], dpg, dp[t]);
-        if (g.dwg1) atomicAdd(gacc + 5 * M + m * T + t, dpg * prow[t]);
+      if (g.dwg3) {
+        const float uj = on ? u[j] : 0.f;
+        const float a0 = rows_sum(dv0 * uj), a1 = rows_sum(dv1 * uj), a2 = rows_sum(dv2 * uj);
+        if (lead && m < M) {
+          atomicAdd(gacc + 2 * M + m, a0);
+          atomicAdd(gacc + 3 * M + m, a1);
+          atomicAdd(gacc + 4 * M + m, a2);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T_MAX; ++t) {
+        if (t < T) {
+          dp[t] = fmaf(p.wg1[ms * T + t], dpg, dp[t]);
+          if (g.dwg1) {
+            const float w1 = rows_sum(dpg * prow[t]);
+            if (lead && m < M) atomicAdd(gacc + 5 * M + m * T + t, w1);
+          }
+        }
       }
     }
-    for (int t = 0; t < T; ++t) gp[cl * T + t] += dp[t];
+#pragma unroll
+    for (int t = 0; t < T_MAX; ++t) {
+      if (t < T) {
+        const float sdp = group_sum(dp[t]);
+        if (active && sub == (t % GL)) gp[cl * T + t] += sdp;
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
@@ -321,12 +438,15 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     for (int i = threadIdx.x; i < M * T; i += TBW) atomicAdd(g.dwg1 + i, gacc[5 * M + i]);
 }
 
-inline size_t f1_lds(int C, int T) { return sizeof(float) * ((size_t)C * (T + 2) + TBW + (size_t)OB * C * 3) + 64; }
+inline size_t g_floats(int T) { return (size_t)2 * T * T + 3 * 2 * T + 5 * 2 * T; }
+inline size_t f1_lds(int C, int T) {
+  return sizeof(float) * ((size_t)C * (T + 2) + TBW + (size_t)OB * C * 3 + g_floats(T)) + 64;
+}
 inline size_t f2_lds(int C, int T) { return sizeof(float) * ((size_t)(C / 4) * T + (size_t)CB * (C / 4)) + 64; }
-inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)C * T + TBW + (size_t)C * OB) + 64; }
+inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)2 * C * T + TBW + (size_t)C * OB) + 64; }
 inline size_t b2_lds(int C, int T) {
   return sizeof(float) * ((size_t)(C / 4) * (T + 2) + CB * (T + 2) + CB * T + 5 * 2 * T + 2 * T * T +
-                          (size_t)(C / 4) * CB * 3) + 64;
+                          (size_t)(C / 4) * CB * 3 + g_floats(T)) + 64;
 }
 
 template <typename K>
@@ -372,8 +492,8 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                              const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
-                             float* d_gpooled, float* const* h_dbn /* {dG.w, dG.b, dL.w, dL.b} zeroed */,
-                             float* const* h_dw /* {dwg1, dwg3, dw0, dw3} zeroed, or NULL entries */, void* stream) {
+                             float* d_gpooled, float* const* h_dbn /* {dG.w, dG.b, dL.w, dL.b} accumulated into */,
+                             float* const* h_dw /* {dwg1, dwg3, dw0, dw3} accumulated into, or NULL entries */, void* stream) {
   // d_gpooled doubles as scratch: it must have room for N*C*T + N*(C/4)*T floats (result, then d conv1-output)
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn)
     return VITTA_ERR_INVALID_ARG;

@@ -251,6 +251,30 @@ class StatPlan:
 
 
 # ------------------------------------------------------------------------------------------------
+# parameter-gradient sinks
+# ------------------------------------------------------------------------------------------------
+DIRECT_PARAM_GRAD = True
+
+
+def _grad_sink(param, needed, zero=True):
+    """Where a backward kernel puts a parameter gradient: (buffer, value returned to autograd).
+
+    A leaf whose `.grad` already exists (the views of tta.FlatArena, zeroed once per step) is accumulated into IN
+    PLACE and autograd gets None -- exactly what its AccumulateGrad node would do with `grad += new`, minus one
+    launch per tensor (170 five-microsecond adds per TANet step in the r1h profile).  Only under a plain
+    `.backward()`: `torch.autograd.grad` callers must switch DIRECT_PARAM_GRAD off."""
+    if not needed:
+        return None, None
+    g = param.grad
+    if (DIRECT_PARAM_GRAD and param.is_leaf and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+            and g.device == param.device and g.shape == param.shape):
+        return g, None
+    buf = torch.zeros_like(param, memory_format=torch.contiguous_format) if zero \
+        else torch.empty_like(param, memory_format=torch.contiguous_format)
+    return buf, buf
+
+
+# ------------------------------------------------------------------------------------------------
 # TAM
 # ------------------------------------------------------------------------------------------------
 class TamPool(torch.autograd.Function):
@@ -434,16 +458,24 @@ class FusedBNAct(torch.autograd.Function):
         gres = torch.empty_like(x) if has_res else None
         nfl = lib().vitta_bn_act_partial_floats(outer, c, hw, nsplit)
         partial = torch.empty(nfl, dtype=torch.float32, device=x.device)
-        dgamma = torch.empty_like(weight)
-        dbeta = torch.empty_like(bias)
+        dgamma, ret_gamma = _grad_sink(weight, ctx.needs_input_grad[1], zero=False)
+        dbeta, ret_beta = _grad_sink(bias, ctx.needs_input_grad[2], zero=False)
+        accumulate = ret_gamma is None and ret_beta is None and dgamma is not None and dbeta is not None
+        if not accumulate:  # frozen affine, or only one of the two has a live .grad: plain outputs
+            dgamma = ret_gamma = torch.empty_like(weight)
+            dbeta = ret_beta = torch.empty_like(bias)
+            if not ctx.needs_input_grad[1]:
+                ret_gamma = None
+            if not ctx.needs_input_grad[2]:
+                ret_beta = None
         mu = ca = cb = gs = None
         if site is not None:
             mu, ca, cb, gs = site.coefficients()
         check(lib().vitta_bn_act_bwd_f32(_p(x), _p(z), _p(gz), _p(gx), _p(gres), _p(weight), _p(bias), _p(running_mean),
                                          _p(running_var), eps, _p(mu), _p(ca), _p(cb), _p(gs), outer, c, hw, nsplit,
-                                         int(relu), _p(partial), _p(dgamma), _p(dbeta), _stream()),
+                                         int(relu), _p(partial), _p(dgamma), _p(dbeta), int(accumulate), _stream()),
               "vitta_bn_act_bwd_f32")
-        return gx, dgamma, dbeta, None, None, None, gres, None, None
+        return gx, ret_gamma, ret_beta, None, None, None, gres, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -472,14 +504,14 @@ class TamBranches(torch.autograd.Function):
         kern = torch.empty(n * c, 3, dtype=torch.float32, device=pooled.device)
         gate = torch.empty(n, c, t, dtype=torch.float32, device=pooled.device)
         hpre = torch.empty(2, n, c // 4, t, dtype=torch.float32, device=pooled.device)  # conv1 out: pre-BN | post-ReLU
-        w0c, w3c = w0.contiguous(), w3.contiguous()
+        if not (w0.is_contiguous() and w3.is_contiguous() and wg1.is_contiguous() and wg3.is_contiguous()):
+            raise ValueError("TAM weights must be contiguous")
         check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
-                                             _p(wg3), _p(w0c), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3c),
+                                             _p(wg3), _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3),
                                              n, c, t, _p(kern), _p(gate), _p(hpre), _stream()), "vitta_tam_branch_fwd_f32")
-        ctx.save_for_backward(pooled, wg1, bng_w, bng_b, wg3, w0c, bnl_w, bnl_b, w3c, bng_rm, bng_rv, bnl_rm, bnl_rv, kern,
+        ctx.save_for_backward(pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern,
                               gate, hpre)
         ctx.eps = (float(eps_g), float(eps_l))
-        ctx.w_shapes = (w0.shape, w3.shape)
         return kern, gate
 
     @staticmethod
@@ -489,17 +521,79 @@ class TamBranches(torch.autograd.Function):
         n, c, t = pooled.shape
         gbuf = torch.empty(n * c * t + n * (c // 4) * t, dtype=torch.float32, device=pooled.device)
         gpooled = gbuf[: n * c * t].view(n, c, t)  # the tail is the kernel's scratch for d(conv1 output)
-        dgw, dgb, dlw, dlb = (torch.zeros_like(v) for v in (bng_w, bng_b, bnl_w, bnl_b))
         need = ctx.needs_input_grad
-        dwg1 = torch.zeros_like(wg1) if need[1] else None
-        dwg3 = torch.zeros_like(wg3) if need[4] else None
-        dw0 = torch.zeros_like(w0) if need[5] else None
-        dw3 = torch.zeros_like(w3) if need[8] else None
+        (dgw, r_gw), (dgb, r_gb), (dlw, r_lw), (dlb, r_lb) = (
+            _grad_sink(v, True) for v in (bng_w, bng_b, bnl_w, bnl_b))  # the kernel always produces these four
+        r_gw, r_gb, r_lw, r_lb = (r if nd else None for r, nd in zip((r_gw, r_gb, r_lw, r_lb),
+                                                                    (need[2], need[3], need[6], need[7])))
+        (dwg1, r_wg1), (dwg3, r_wg3), (dw0, r_w0), (dw3, r_w3) = (
+            _grad_sink(v, nd) for v, nd in zip((wg1, wg3, w0, w3), (need[1], need[4], need[5], need[8])))
         check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), ctx.eps[0], _p(wg3),
                                              _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), ctx.eps[1], _p(w3), n, c, t,
                                              _p(kern), _p(gate), _p(hpre), _p(gkern.contiguous()), _p(ggate.contiguous()),
                                              _p(gbuf), _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), _stream()),
               "vitta_tam_branch_bwd_f32")
-        s0, s3 = ctx.w_shapes
-        return (gpooled, dwg1, dgw, dgb, dwg3, dw0.view(s0) if dw0 is not None else None, dlw, dlb,
-                dw3.view(s3) if dw3 is not None else None, None, None, None, None, None, None)
+        return (gpooled, r_wg1, r_gw, r_gb, r_wg3, r_w0, r_lw, r_lb, r_w3, None, None, None, None, None, None)
+
+
+class TamFused(torch.autograd.Function):
+    """The whole temporal adaptive module as ONE autograd node: pool -> G/L branches -> adaptive aggregation
+    (temporal_module.py:43-65).  Same five kernels as TamPool + TamBranches + TamAggregate; what the single node
+    saves is autograd's glue around them in the backward pass: x feeds both the pooling and the aggregation, so as
+    separate nodes their two full-size input gradients meet in a zero-fill + an add per TAM (16 of each per step,
+    on the largest tensors of the network); here vitta_tam_pool_bwd accumulates into the aggregation's dx."""
+
+    @staticmethod
+    def forward(ctx, x, n_segment, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, eps_g, bnl_rm, bnl_rv,
+                eps_l):
+        _require_cuda_f32(x, "x")
+        x = x.contiguous()
+        nt, c, h, w = x.shape
+        t = int(n_segment)
+        n, hw = nt // t, h * w
+        if not (w0.is_contiguous() and w3.is_contiguous() and wg1.is_contiguous() and wg3.is_contiguous()):
+            raise ValueError("TAM weights must be contiguous")
+        f = dict(dtype=torch.float32, device=x.device)
+        pooled = torch.empty(n, c, t, **f)
+        kern = torch.empty(n * c, 3, **f)
+        gate = torch.empty(n, c, t, **f)
+        hpre = torch.empty(2, n, c // 4, t, **f)
+        out = torch.empty_like(x)
+        st = _stream()
+        check(lib().vitta_tam_pool_f32(_p(x), n, t, c, hw, _p(pooled), st), "vitta_tam_pool_f32")
+        check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
+                                             _p(wg3), _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3),
+                                             n, c, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
+        check(lib().vitta_tam_agg_fwd_f32(_p(x), _p(gate), _p(kern), n, t, c, hw, _p(out), st), "vitta_tam_agg_fwd_f32")
+        ctx.save_for_backward(x, pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv,
+                              kern, gate, hpre)
+        ctx.meta = (n, t, c, hw, float(eps_g), float(eps_l))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x, pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern, gate,
+         hpre) = ctx.saved_tensors
+        n, t, c, hw, eps_g, eps_l = ctx.meta
+        f = dict(dtype=torch.float32, device=x.device)
+        st = _stream()
+        gout = gout.contiguous()
+        gx = torch.empty_like(x)
+        ggate = torch.empty(n * c * t * 4, **f)  # the kernel's per-row partials, reduced in place into the head
+        gkern = torch.empty_like(kern)
+        check(lib().vitta_tam_agg_bwd_f32(_p(x), _p(gate), _p(kern), _p(gout), n, t, c, hw, _p(gx), _p(ggate), _p(gkern),
+                                          st), "vitta_tam_agg_bwd_f32")
+        need = ctx.needs_input_grad
+        (dgw, r_gw), (dgb, r_gb), (dlw, r_lw), (dlb, r_lb) = (_grad_sink(v, True) for v in (bng_w, bng_b, bnl_w, bnl_b))
+        r_gw, r_gb, r_lw, r_lb = (r if nd else None for r, nd in zip((r_gw, r_gb, r_lw, r_lb),
+                                                                    (need[3], need[4], need[7], need[8])))
+        (dwg1, r_wg1), (dwg3, r_wg3), (dw0, r_w0), (dw3, r_w3) = (
+            _grad_sink(v, nd) for v, nd in zip((wg1, wg3, w0, w3), (need[2], need[5], need[6], need[9])))
+        gbuf = torch.empty(n * c * t + n * (c // 4) * t, **f)  # d pooled | scratch: d(conv1 output)
+        check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), eps_g, _p(wg3),
+                                             _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), eps_l, _p(w3), n, c, t,
+                                             _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf),
+                                             _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), st),
+              "vitta_tam_branch_bwd_f32")
+        check(lib().vitta_tam_pool_bwd_f32(_p(gbuf), n, t, c, hw, _p(gx), st), "vitta_tam_pool_bwd_f32")
+        return (gx, None, r_wg1, r_gw, r_gb, r_wg3, r_w0, r_lw, r_lb, r_w3, None, None, None, None, None, None)

@@ -68,18 +68,17 @@ class TAM(nn.Module):
         nt, c, h, w = x.shape
         t = self.n_segment
         n = nt // t
+        bg, bl = self.G[1], self.L[1]
         if x.is_cuda:
             from . import ops
+            if (FUSED_TAM_BRANCHES and not bg.training and not bl.training and _noop_hooks_only(bg)
+                    and _noop_hooks_only(bl) and ops.tam_branch_supported(c, t)):
+                return ops.TamFused.apply(x, t, self.G[0].weight, bg.weight, bg.bias, self.G[3].weight, self.L[0].weight,
+                                          bl.weight, bl.bias, self.L[3].weight, bg.running_mean, bg.running_var, bg.eps,
+                                          bl.running_mean, bl.running_var, bl.eps)
             pooled = ops.TamPool.apply(x, t)  # (n, c, t)
         else:
             pooled = x.view(n, t, c, h * w).mean(-1).permute(0, 2, 1).contiguous()
-        bg, bl = self.G[1], self.L[1]
-        if (x.is_cuda and FUSED_TAM_BRANCHES and not bg.training and not bl.training and _noop_hooks_only(bg)
-                and _noop_hooks_only(bl) and ops.tam_branch_supported(c, t)):
-            kern, gate = ops.TamBranches.apply(pooled, self.G[0].weight, bg.weight, bg.bias, self.G[3].weight,
-                                               self.L[0].weight, bl.weight, bl.bias, self.L[3].weight, bg.running_mean,
-                                               bg.running_var, bg.eps, bl.running_mean, bl.running_var, bl.eps)
-            return ops.TamAggregate.apply(x, gate, kern, t)
         kern = self.G(pooled.reshape(n * c, t))  # (n*c, 3)
         gate = self.L(pooled)  # (n, c, t)
         if x.is_cuda:

@@ -147,11 +147,15 @@ class FlatArena:
     SUM, not mean, across ranks: loss_consis is a sum over videos and loss_reg is one global scalar whose per-rank
     partial derivatives add."""
 
+    ALIGN = 64  # floats: every tensor starts on a 256-byte boundary (the HIP kernels use 16-byte loads on weights)
+
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        pad = lambda k: -(-k // self.ALIGN) * self.ALIGN
+        n = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device
-        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        # the gaps stay zero in both buffers: a zero gradient on a zero weight is a fixed point of SGD and Adam
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         with torch.no_grad():
@@ -160,7 +164,7 @@ class FlatArena:
                 flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
-                off += k
+                off += pad(k)
         self.flat_param = nn.Parameter(flat)  # shares storage with every p.data view
         self.flat_param.grad = self.grad
 
