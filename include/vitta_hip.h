@@ -244,8 +244,9 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  *              (float* workspace + 3*ws_off, geometry from vitta_plan_layer_geometry; nsplit must match)
  *   backward: d_gres NULL iff no residual; d_mu/d_coef_a/d_coef_b/d_gscale NULL iff not hooked;
  *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch;
- *             accumulate != 0: d_dgamma / d_dbeta += (the caller hands the parameters' live .grad storage,
- *             which is what autograd's AccumulateGrad would do with one more launch per tensor).
+ *             accumulate != 0: d_dgamma / d_dbeta += with fp32 atomics from the one launch (the caller hands the
+ *             parameters' live .grad storage -- what autograd's AccumulateGrad would do with one more launch per
+ *             tensor; d_partial may be NULL); accumulate == 0: partials + a deterministic fp64 finalize launch.
  * Requires C*HW % 4 == 0 (VITTA_ERR_UNSUPPORTED otherwise: use the unfused ops).
  * -------------------------------------------------------------------------- */
 size_t vitta_bn_act_partial_floats(int64_t outer, int32_t C, int64_t HW, int32_t nsplit);

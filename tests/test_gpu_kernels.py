@@ -432,3 +432,44 @@ def test_tam_fused_branches_equal_torch_modules(c, t, n, hw):
     names = ["x"] + [k for k, _ in tam.named_parameters()]
     for nm, a, b in zip(names, res[0][1], res[1][1]):
         assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-6, nm
+
+
+def test_parameter_gradients_accumulate_into_live_grad_buffers():
+    """With a live `.grad` (the views of tta.FlatArena) the backward kernels add into it and hand autograd None;
+    the result must equal what AccumulateGrad would have produced: old grad + new grad."""
+    import torch.nn as nn
+    from vitta_amd import ops, tanet
+    from vitta_amd.fused_bn import bn_act
+    torch.manual_seed(11)
+    c, t, n, hw = 64, 8, 2, 7
+    tam = tanet.TAM(c, t).to(_dev()).eval()
+    bn = nn.BatchNorm2d(c).to(_dev()).eval()
+    with torch.no_grad():
+        for m in list(tam.modules()) + [bn]:
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    params = list(tam.parameters()) + list(bn.parameters())
+    x0 = H.seeded_randn((n * t, c, hw, hw), 3).to(_dev())
+    gout = H.seeded_randn((n * t, c, hw, hw), 4).to(_dev())
+
+    def run(direct, preset):
+        ops.DIRECT_PARAM_GRAD = direct
+        for i, p in enumerate(params):
+            p.grad = torch.full_like(p, 0.25 * (i + 1)) if preset else None
+        x = x0.clone().requires_grad_(True)
+        y = bn_act(bn, tam(x), relu=True)
+        y.backward(gout)
+        ops.DIRECT_PARAM_GRAD = True
+        return [p.grad.clone() for p in params], x.grad.clone()
+
+    (plain, gx0), (direct, gx1) = run(False, False), run(True, True)
+    torch.testing.assert_close(gx0, gx1, rtol=1e-5, atol=1e-6)
+    for i, (a, b) in enumerate(zip(direct, plain)):
+        want = b + 0.25 * (i + 1)
+        assert (a - want).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-5, i
+    again, _ = run(True, False)  # no live buffer -> ordinary autograd outputs
+    for a, b in zip(again, plain):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6

@@ -18,7 +18,9 @@ namespace {
 
 // one wave per channel touched by the chunk: sum the per-slot values staged in LDS
 __device__ __forceinline__ void segmented_sum2(const float* lds_a, const float* lds_b, int64_t base, int64_t plane,
-                                               int64_t HW, float* out2 /* [slots][2] of this (split, chunk) */) {
+                                               int64_t HW, float* out2 /* [slots][2] of this (split, chunk) */,
+                                               float* acc_a /* or NULL: per-channel totals, added atomically */,
+                                               float* acc_b) {
   const int64_t end = base + VITTA_CHUNK < plane ? base + VITTA_CHUNK : plane;
   const int64_t c_lo = base / HW, c_hi = (end - 1) / HW;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -33,8 +35,13 @@ __device__ __forceinline__ void segmented_sum2(const float* lds_a, const float* 
     a = wave_sum(a);
     b = wave_sum(b);
     if (lane == 0) {
-      out2[2 * (c - c_lo)] = a;
-      out2[2 * (c - c_lo) + 1] = b;
+      if (acc_a) {
+        atomicAdd(acc_a + c, a);
+        atomicAdd(acc_b + c, b);
+      } else {
+        out2[2 * (c - c_lo)] = a;
+        out2[2 * (c - c_lo) + 1] = b;
+      }
     }
   }
 }
@@ -147,7 +154,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
     float* __restrict__ gres, const float* __restrict__ weight, const float* __restrict__ bias,
     const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, const float* __restrict__ mu,
     const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ gscale, BnGeom g,
-    float* __restrict__ partial /* [nsplit][nchunks][slots][2] */) {
+    float* __restrict__ partial /* [nsplit][nchunks][slots][2] */, float* __restrict__ acc_gamma,
+    float* __restrict__ acc_beta) {
   __shared__ float lds_a[VITTA_CHUNK];
   __shared__ float lds_b[VITTA_CHUNK];
   const int tid = threadIdx.x;
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
     lds_b[4 * tid + k] = db[k];
   }
   __syncthreads();
-  float* out2 = partial + 2 * (((int64_t)blockIdx.y * g.nchunks + blockIdx.x) * g.slots);
-  segmented_sum2(lds_a, lds_b, base, g.plane, g.HW, out2);
+  float* out2 = acc_gamma ? nullptr : partial + 2 * (((int64_t)blockIdx.y * g.nchunks + blockIdx.x) * g.slots);
+  segmented_sum2(lds_a, lds_b, base, g.plane, g.HW, out2, acc_gamma, acc_beta);
 }
 
 // sum the (split, chunk) partials of every channel -> dgamma[c], dbeta[c]
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_affine_grad_kernel(const float* __restrict__ partial, BnGeom g, int C,
                                                                      float* __restrict__ dgamma,
-                                                                     float* __restrict__ dbeta, int accumulate) {
+                                                                     float* __restrict__ dbeta) {
   const int c = blockIdx.x * VITTA_BLOCK + threadIdx.x;
   if (c >= C) return;
   const int64_t k0 = ((int64_t)c * g.HW) / VITTA_CHUNK;
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_affine_grad_kernel(const float
       a += (double)t[0];
       b += (double)t[1];
     }
-  dgamma[c] = accumulate ? dgamma[c] + (float)a : (float)a;
-  dbeta[c] = accumulate ? dbeta[c] + (float)b : (float)b;
+  dgamma[c] = (float)a;
+  dbeta[c] = (float)b;
 }
 
 inline int make_geom(int64_t outer, int32_t C, int64_t HW, int nsplit, BnGeom* g) {
@@ -262,7 +270,7 @@ inline bool unaligned(const void* a, const void* b = nullptr, const void* c = nu
                d_rmean, d_rvar, eps, g, d_triples)
 #define BN_BWD_CASE(R, S, I)                                                                                          \
   VITTA_LAUNCH((bn_act_bwd_kernel<R, S, I>), grid, dim3(VITTA_BLOCK), 0, st, d_x, d_z, d_gz, d_gx, d_gres, d_weight, \
-               d_bias, d_rmean, d_rvar, eps, d_mu, d_coef_a, d_coef_b, d_gscale, g, d_partial)
+               d_bias, d_rmean, d_rvar, eps, d_mu, d_coef_a, d_coef_b, d_gscale, g, d_partial, acc_g, acc_b)
 
 extern "C" {
 
@@ -302,8 +310,13 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
   BnGeom g;
   const int rc = make_geom(outer, C, HW, nsplit, &g);
   if (rc != VITTA_OK) return rc;
-  if (!d_x || !d_gz || !d_gx || !d_weight || !d_bias || !d_rmean || !d_rvar || !d_partial || !d_dgamma || !d_dbeta)
+  if (!d_x || !d_gz || !d_gx || !d_weight || !d_bias || !d_rmean || !d_rvar || !d_dgamma || !d_dbeta)
     return VITTA_ERR_INVALID_ARG;
+  if (!accumulate && !d_partial) return VITTA_ERR_INVALID_ARG;
+  // accumulate: every workgroup adds its per-channel sums straight into the live gradient (fp32 atomics, no partial
+  // buffer, no second launch); otherwise partials + a deterministic fp64 finalize
+  float* acc_g = accumulate ? d_dgamma : nullptr;
+  float* acc_b = accumulate ? d_dbeta : nullptr;
   const bool R = relu != 0, S = d_gres != nullptr, I = d_mu != nullptr;
   if (I && (!d_coef_a || !d_coef_b)) return VITTA_ERR_INVALID_ARG;
   if (R && S && !d_z) return VITTA_ERR_INVALID_ARG;
@@ -318,8 +331,9 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
   else if (S) BN_BWD_CASE(false, true, false);
   else if (I) BN_BWD_CASE(false, false, true);
   else BN_BWD_CASE(false, false, false);
-  VITTA_LAUNCH(bn_affine_grad_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK), 0, st, d_partial, g,
-               (int)C, d_dgamma, d_dbeta, (int)accumulate);
+  if (!accumulate)
+    VITTA_LAUNCH(bn_affine_grad_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK), 0, st, d_partial, g,
+                 (int)C, d_dgamma, d_dbeta);
   return VITTA_OK;
 }
 

@@ -33,20 +33,24 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(
 
 // ------------------------------------------------------------------------------------------------
 // The work of one clip is spread over several workgroups (a clip is only N = B*V = 2 workgroups otherwise):
-//   forward  F1 grid (N, O/OB): h_pre / h for OB conv1 output channels + the G branch of a slice of channels
+//   forward  F1 grid (N, O/OBF): h_pre / h for OBF conv1 output channels + the G branch of a slice of channels
 //            F2 grid (N, C/CB): gate for CB channels
-//   backward B1 grid (N, O/OB): d(conv1 output) for OB channels (+ dW3 slice, BN1d(L) affine grads)
-//            B2 grid (N, C/CB): d pooled for CB channels (L transposed conv + G branch) (+ dW0 slice, G grads)
+//   backward B1 grid (N, O/OBB): d(conv1 output) for OBB channels (+ dW3 slice, BN1d(L) affine grads)
+//            B2 grid (N, C/CBB): d pooled for CBB channels (L transposed conv + G branch) (+ dW0 slice, G grads)
 // These launches are 4..32 workgroups of a few microseconds: what they cost is LATENCY.  Every operand is
 // therefore brought into LDS with wide loads that are all in flight together (a load -> fma loop over global
 // weights measured 30-60 us per launch in the r1g profile), and nothing in the arithmetic loops touches global.
 // ------------------------------------------------------------------------------------------------
-constexpr int OB = 8;    // conv1 output channels per workgroup
-constexpr int CB = 32;   // channels per workgroup in the per-channel stages
 constexpr int TBW = 256; // threads of the split kernels
-constexpr int GL = 8;    // lanes that share one (n, c) row of the G branch
+constexpr int OBF = 2;   // conv1 output channels per workgroup, forward (F1): N x C/8 workgroups
+constexpr int OBB = 4;   // conv1 output channels per workgroup, backward (B1): one 16-byte load per weight row
+constexpr int CB = 32;   // channels per workgroup in F2
+constexpr int CBB = 16;  // channels per workgroup in B2
+constexpr int GL = 16;   // lanes that share one (n, c) row of the G branch
 constexpr int GM = (2 * T_MAX + GL - 1) / GL;  // hidden units of G per lane
-static_assert(CB * GL == TBW, "B2 maps one G row per 8 lanes");
+constexpr int SU = 8;    // 16-byte loads every lane keeps in flight while staging
+static_assert(CBB * GL == TBW, "B2 maps one G row per GL lanes");
+static_assert(VITTA_WAVE % GL == 0, "the rows of a wave are whole");
 
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -56,12 +60,12 @@ __device__ __forceinline__ void stage_linear(float* __restrict__ dst, const floa
     const int n4 = n >> 2;
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(dst);
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * TBW) {
-      float4 v[4];
+    for (int i0 = threadIdx.x; i0 < n4; i0 += SU * TBW) {
+      float4 v[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = s4[min(i0 + u * TBW, n4 - 1)];  // clamped: loads stay unconditional
+      for (int u = 0; u < SU; ++u) v[u] = s4[min(i0 + u * TBW, n4 - 1)];  // clamped: loads stay unconditional
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int i = i0 + u * TBW;
         if (i < n4) d4[i] = v[u];
       }
@@ -87,15 +91,15 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
   if (aligned16(src) && aligned16(dst) && (stride & 3) == 0 && (len & 3) == 0) {
     const int l4 = len >> 2, n4 = rows * l4;
     float4* d4 = reinterpret_cast<float4*>(dst);
-    for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * TBW) {
-      float4 v[4];
+    for (int i0 = threadIdx.x; i0 < n4; i0 += SU * TBW) {
+      float4 v[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int i = min(i0 + u * TBW, n4 - 1);
         v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(i / l4) * stride + 4 * (i % l4));
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const int i = i0 + u * TBW;
         if (i < n4) d4[i] = v[u];
       }
@@ -133,11 +137,13 @@ __device__ __forceinline__ GLds stage_g(const TamBranchArgs& a, float* gl) {
 }
 
 __device__ __forceinline__ float group_sum(float v) {  // over the GL lanes of one row
-  v += __shfl_xor(v, 1, VITTA_WAVE); v += __shfl_xor(v, 2, VITTA_WAVE); v += __shfl_xor(v, 4, VITTA_WAVE);
+#pragma unroll
+  for (int m = 1; m < GL; m <<= 1) v += __shfl_xor(v, m, VITTA_WAVE);
   return v;
 }
-__device__ __forceinline__ float rows_sum(float v) {  // over the 8 rows of a wave, same sub-lane
-  v += __shfl_xor(v, 8, VITTA_WAVE); v += __shfl_xor(v, 16, VITTA_WAVE); v += __shfl_xor(v, 32, VITTA_WAVE);
+__device__ __forceinline__ float rows_sum(float v) {  // over the rows of a wave, same sub-lane
+#pragma unroll
+  for (int m = GL; m < VITTA_WAVE; m <<= 1) v += __shfl_xor(v, m, VITTA_WAVE);
   return v;
 }
 
@@ -173,12 +179,12 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.x, tile = blockIdx.y, ntiles = gridDim.y;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2;
-  float* wl = smem;                      // [OB][C*3] conv1 weights of this tile
-  float* pl = wl + OB * C * 3;           // [C][T+2]
-  float* red = pl + C * TP;              // [OB*T][CS] partial sums
+  float* wl = smem;                      // [OBF][C*3] conv1 weights of this tile
+  float* pl = wl + OBF * C * 3;           // [C][T+2]
+  float* red = pl + C * TP;              // [OBF*T][CS] partial sums
   float* gl = red + TBW;                 // G parameters
   {
-    const int o0 = tile * OB, rows = min(OB, O - o0);
+    const int o0 = tile * OBF, rows = min(OBF, O - o0);
     stage_linear(wl, a.w0 + (int64_t)o0 * C * 3, rows * C * 3);
   }
   load_pooled_t(a, n, 0, C, pl);
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
     g_forward(gp, T, sub, active, pl + (active ? c : 0) * TP + 1, u_pre, u, k3);
     if (active && sub < 3) kern[((int64_t)n * C + c) * 3 + sub] = sub == 0 ? k3[0] : (sub == 1 ? k3[1] : k3[2]);
   }
-  // conv1 for OB output channels: item (o_local, t), CS lanes split the C reduction
-  const int items = OB * T;
+  // conv1 for OBF output channels: item (o_local, t), CS lanes split the C reduction
+  const int items = OBF * T;
   const int CS = TBW / items > 0 ? TBW / items : 1;
   const int item = threadIdx.x / CS, cs = threadIdx.x % CS;
   float acc = 0.f;
-  const int o = tile * OB + item / T, t = item % T;
+  const int o = tile * OBF + item / T, t = item % T;
   if (item < items && o < O) {
     const float* w = wl + (item / T) * C * 3;
     for (int c = cs; c < C; c += CS) {
@@ -250,7 +256,7 @@ struct TamBranchGrads {
   float* dwg1; float* dwg3; float* dw0; float* dw3;
 };
 
-// B1: d(conv1 output) for OB channels
+// B1: d(conv1 output) for OBB channels
 __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, const float* __restrict__ gate,
                                                             const float* __restrict__ h_pre,
                                                             const float* __restrict__ h_act,
@@ -261,15 +267,15 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   const int C = a.C, T = a.T, O = C / 4;
   float* dz = smem;            // [C][T]   (staged as gate, then overwritten by d(pre-sigmoid))
   float* gg = dz + C * T;      // [C][T]   upstream gradient of the gate
-  float* wl = gg + C * T;      // [C][OB] conv2 weights W3[c, o0 .. o0+OB)
-  float* red = wl + C * OB;    // [OB*T][CS]
+  float* wl = gg + C * T;      // [C][OBB] conv2 weights W3[c, o0 .. o0+OBB)
+  float* red = wl + C * OBB;    // [OBB*T][CS]
   stage_linear(dz, gate + (int64_t)n * C * T, C * T);
   stage_linear(gg, ggate + (int64_t)n * C * T, C * T);
-  if (tile * OB + OB <= O) {
-    stage_rows(wl, a.w3 + tile * OB, C, OB, O);
+  if (tile * OBB + OBB <= O) {
+    stage_rows(wl, a.w3 + tile * OBB, C, OBB, O);
   } else {
-    for (int i = threadIdx.x; i < C * OB; i += TBW) {
-      const int c = i / OB, oo = tile * OB + i % OB;
+    for (int i = threadIdx.x; i < C * OBB; i += TBW) {
+      const int c = i / OBB, oo = tile * OBB + i % OBB;
       wl[i] = oo < O ? a.w3[(int64_t)c * O + oo] : 0.f;
     }
   }
@@ -279,13 +285,13 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
     dz[i] = gg[i] * gt * (1.f - gt);
   }
   __syncthreads();
-  const int items = OB * T;
+  const int items = OBB * T;
   const int CS = TBW / items > 0 ? TBW / items : 1;
   const int item = threadIdx.x / CS, cs = threadIdx.x % CS;
-  const int o = tile * OB + item / T, t = item % T;
+  const int o = tile * OBB + item / T, t = item % T;
   float acc = 0.f;
   if (item < items && o < O)
-    for (int c = cs; c < C; c += CS) acc = fmaf(wl[c * OB + item / T], dz[c * T + t], acc);
+    for (int c = cs; c < C; c += CS) acc = fmaf(wl[c * OBB + item / T], dz[c * T + t], acc);
   if (threadIdx.x < items * CS) red[threadIdx.x] = acc;
   __syncthreads();
   if (cs == 0 && item < items && o < O) {
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
     atomicAdd(g.dbnl_b + o, gy);
   }
   if (g.dw3) {  // dW3[c, o] += sum_t dz[c,t] h[o,t] for this tile's o
-    for (int i = threadIdx.x; i < C * OB; i += TBW) {
-      const int c = i / OB, oo = tile * OB + i % OB;
+    for (int i = threadIdx.x; i < C * OBB; i += TBW) {
+      const int c = i / OBB, oo = tile * OBB + i % OBB;
       if (oo >= O) continue;
       float s = 0.f;
       for (int tt = 0; tt < T; ++tt) s = fmaf(dz[c * T + tt], h_act[((int64_t)n * O + oo) * T + tt], s);
@@ -309,25 +315,25 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   }
 }
 
-// B2: d pooled for CB channels (+ G branch)
+// B2: d pooled for CBB channels (+ G branch)
 __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, const float* __restrict__ kern,
                                                             const float* __restrict__ gkern,
                                                             const float* __restrict__ dpre_g, TamBranchGrads g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, c0 = blockIdx.y * CB;
+  const int n = blockIdx.x, c0 = blockIdx.y * CBB;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2, M = 2 * T;
-  float* wl = smem;                  // [O][CB*3] conv1 weights W0[o, c0 .. c0+CB, :]
-  float* dpre = wl + O * CB * 3;     // [O][T+2], zero padded in t
-  float* pl = dpre + O * TP;         // [CB][T+2] pooled of this tile, zero padded
-  float* gp = pl + CB * TP;          // [CB][T] result staging
-  float* gacc = gp + CB * T;         // [5M + M*T] block accumulators of the G-branch parameter gradients
+  float* wl = smem;                  // [O][CBB*3] conv1 weights W0[o, c0 .. c0+CBB, :]
+  float* dpre = wl + O * CBB * 3;     // [O][T+2], zero padded in t
+  float* pl = dpre + O * TP;         // [CBB][T+2] pooled of this tile, zero padded
+  float* gp = pl + CBB * TP;          // [CBB][T] result staging
+  float* gacc = gp + CBB * T;         // [5M + M*T] block accumulators of the G-branch parameter gradients
   float* gl = gacc + 5 * M + M * T;  // G parameters
-  if (c0 + CB <= C) {
-    stage_rows(wl, a.w0 + (int64_t)c0 * 3, O, CB * 3, (int64_t)C * 3);
+  if (c0 + CBB <= C) {
+    stage_rows(wl, a.w0 + (int64_t)c0 * 3, O, CBB * 3, (int64_t)C * 3);
   } else {
     const int cw = (C - c0) * 3;  // floats per o-row of this tile (contiguous in W0)
-    for (int i = threadIdx.x; i < O * CB * 3; i += TBW) {
-      const int o = i / (CB * 3), r = i % (CB * 3);
+    for (int i = threadIdx.x; i < O * CBB * 3; i += TBW) {
+      const int o = i / (CBB * 3), r = i % (CBB * 3);
       wl[i] = r < cw ? a.w0[((int64_t)o * C + c0) * 3 + r] : 0.f;
     }
   }
@@ -335,28 +341,30 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     const int o = i / TP, t = i % TP - 1;
     dpre[i] = (t >= 0 && t < T) ? dpre_g[((int64_t)n * O + o) * T + t] : 0.f;
   }
-  load_pooled_t(a, n, c0, CB, pl);
+  load_pooled_t(a, n, c0, CBB, pl);
   for (int i = threadIdx.x; i < 5 * M + M * T; i += TBW) gacc[i] = 0.f;
   const GLds p = stage_g(a, gl);
   __syncthreads();
-  // L: transposed conv, one lane per (c, t)
-  for (int i = threadIdx.x; i < CB * T; i += TBW) {
+  // L: transposed conv, item (c, t); the lanes of a pair split the o reduction (even / odd o)
+  for (int i0 = 0; i0 < CBB * T; i0 += TBW / 2) {
+    const int i = i0 + threadIdx.x / 2, half = threadIdx.x & 1;
     const int cl = i / T, c = c0 + cl, t = i % T;
     float acc = 0.f;
-    if (c < C) {
-      for (int o = 0; o < O; ++o) {
-        const float* w = wl + (o * CB + cl) * 3;
+    if (i < CBB * T && c < C) {
+      for (int o = half; o < O; o += 2) {
+        const float* w = wl + (o * CBB + cl) * 3;
         const float* d = dpre + o * TP + t;
         acc = fmaf(w[0], d[2], acc);
         acc = fmaf(w[1], d[1], acc);
         acc = fmaf(w[2], d[0], acc);
       }
     }
-    gp[i] = acc;
+    acc += __shfl_xor(acc, 1, VITTA_WAVE);
+    if (half == 0 && i < CBB * T) gp[i] = acc;
   }
   if (g.dw0) {  // dW0[o, c, j] += sum_t dpre[o,t] pooled[c, t+j-1] for this tile's c
-    for (int i = threadIdx.x; i < O * CB * 3; i += TBW) {
-      const int j = i % 3, cl = (i / 3) % CB, o = i / (3 * CB);
+    for (int i = threadIdx.x; i < O * CBB * 3; i += TBW) {
+      const int j = i % 3, cl = (i / 3) % CBB, o = i / (3 * CBB);
       if (c0 + cl >= C) continue;
       float s = 0.f;
       for (int t = 0; t < T; ++t) s = fmaf(dpre[o * TP + t + 1], pl[cl * TP + t + j], s);
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < CB * T; i += TBW) {
+  for (int i = threadIdx.x; i < CBB * T; i += TBW) {
     const int c = c0 + i / T;
     if (c < C) g.gpooled[((int64_t)n * C + c) * T + i % T] = gp[i];
   }
@@ -440,13 +448,13 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
 
 inline size_t g_floats(int T) { return (size_t)2 * T * T + 3 * 2 * T + 5 * 2 * T; }
 inline size_t f1_lds(int C, int T) {
-  return sizeof(float) * ((size_t)C * (T + 2) + TBW + (size_t)OB * C * 3 + g_floats(T)) + 64;
+  return sizeof(float) * ((size_t)C * (T + 2) + TBW + (size_t)OBF * C * 3 + g_floats(T)) + 64;
 }
 inline size_t f2_lds(int C, int T) { return sizeof(float) * ((size_t)(C / 4) * T + (size_t)CB * (C / 4)) + 64; }
-inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)2 * C * T + TBW + (size_t)C * OB) + 64; }
+inline size_t b1_lds(int C, int T) { return sizeof(float) * ((size_t)2 * C * T + TBW + (size_t)C * OBB) + 64; }
 inline size_t b2_lds(int C, int T) {
-  return sizeof(float) * ((size_t)(C / 4) * (T + 2) + CB * (T + 2) + CB * T + 5 * 2 * T + 2 * T * T +
-                          (size_t)(C / 4) * CB * 3 + g_floats(T)) + 64;
+  return sizeof(float) * ((size_t)(C / 4) * (T + 2) + CBB * (T + 2) + CBB * T + 5 * 2 * T + 2 * T * T +
+                          (size_t)(C / 4) * CBB * 3 + g_floats(T)) + 64;
 }
 
 template <typename K>
@@ -465,7 +473,7 @@ inline bool tb_bad(const TamBranchArgs& a) {
 extern "C" {
 
 int vitta_tam_branch_supported(int32_t C, int32_t T) {
-  return (T >= 1 && T <= T_MAX && OB * T <= TBW && C >= 4 && C % 4 == 0 && f1_lds(C, T) <= 160 * 1024 && f2_lds(C, T) <= 160 * 1024 &&
+  return (T >= 1 && T <= T_MAX && OBB * T <= TBW && C >= 4 && C % 4 == 0 && f1_lds(C, T) <= 160 * 1024 && f2_lds(C, T) <= 160 * 1024 &&
           b1_lds(C, T) <= 160 * 1024 && b2_lds(C, T) <= 160 * 1024) ? 1 : 0;
 }
 
@@ -483,7 +491,7 @@ int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const fl
   const int O = C / 4;
   float* d_hact = d_hpre + (int64_t)N * O * T;
   if (!set_lds(tam_branch_f1_kernel, f1_lds(C, T)) || !set_lds(tam_branch_f2_kernel, f2_lds(C, T))) return VITTA_ERR_LAUNCH;
-  VITTA_LAUNCH(tam_branch_f1_kernel, dim3(N, (O + OB - 1) / OB), dim3(TBW), f1_lds(C, T), st, a, d_kern, d_hpre, d_hact);
+  VITTA_LAUNCH(tam_branch_f1_kernel, dim3(N, (O + OBF - 1) / OBF), dim3(TBW), f1_lds(C, T), st, a, d_kern, d_hpre, d_hact);
   VITTA_LAUNCH(tam_branch_f2_kernel, dim3(N, (C + CB - 1) / CB), dim3(TBW), f2_lds(C, T), st, a, d_hact, d_gate);
   return VITTA_OK;
 }
@@ -508,9 +516,9 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
   const float* d_hact = d_hpre + (int64_t)N * O * T;
   float* d_dpre = d_gpooled + (int64_t)N * C * T;
   if (!set_lds(tam_branch_b1_kernel, b1_lds(C, T)) || !set_lds(tam_branch_b2_kernel, b2_lds(C, T))) return VITTA_ERR_LAUNCH;
-  VITTA_LAUNCH(tam_branch_b1_kernel, dim3(N, (O + OB - 1) / OB), dim3(TBW), b1_lds(C, T), st, a, d_gate, d_hpre, d_hact,
+  VITTA_LAUNCH(tam_branch_b1_kernel, dim3(N, (O + OBB - 1) / OBB), dim3(TBW), b1_lds(C, T), st, a, d_gate, d_hpre, d_hact,
                d_ggate, d_dpre, g);
-  VITTA_LAUNCH(tam_branch_b2_kernel, dim3(N, (C + CB - 1) / CB), dim3(TBW), b2_lds(C, T), st, a, d_kern, d_gkern, d_dpre, g);
+  VITTA_LAUNCH(tam_branch_b2_kernel, dim3(N, (C + CBB - 1) / CBB), dim3(TBW), b2_lds(C, T), st, a, d_kern, d_gkern, d_dpre, g);
   return VITTA_OK;
 }
 

@@ -456,8 +456,6 @@ class FusedBNAct(torch.autograd.Function):
         gz = gz.contiguous()
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
-        nfl = lib().vitta_bn_act_partial_floats(outer, c, hw, nsplit)
-        partial = torch.empty(nfl, dtype=torch.float32, device=x.device)
         dgamma, ret_gamma = _grad_sink(weight, ctx.needs_input_grad[1], zero=False)
         dbeta, ret_beta = _grad_sink(bias, ctx.needs_input_grad[2], zero=False)
         accumulate = ret_gamma is None and ret_beta is None and dgamma is not None and dbeta is not None
@@ -468,6 +466,10 @@ class FusedBNAct(torch.autograd.Function):
                 ret_gamma = None
             if not ctx.needs_input_grad[2]:
                 ret_beta = None
+        partial = None
+        if not accumulate:
+            nfl = lib().vitta_bn_act_partial_floats(outer, c, hw, nsplit)
+            partial = torch.empty(nfl, dtype=torch.float32, device=x.device)
         mu = ca = cb = gs = None
         if site is not None:
             mu, ca, cb, gs = site.coefficients()
@@ -492,53 +494,9 @@ def _ptr4(*tensors):
     return arr
 
 
-class TamBranches(torch.autograd.Function):
-    """(kern [N*C,3], gate [N,C,T]) = TAM.G / TAM.L applied to pooled [N,C,T], eval-mode BatchNorm1d, in one
-    launch; analytic backward in one launch (temporal_module.py:27-41, 53-55)."""
-
-    @staticmethod
-    def forward(ctx, pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, eps_g, bnl_rm, bnl_rv, eps_l):
-        _require_cuda_f32(pooled, "pooled")
-        pooled = pooled.contiguous()
-        n, c, t = pooled.shape
-        kern = torch.empty(n * c, 3, dtype=torch.float32, device=pooled.device)
-        gate = torch.empty(n, c, t, dtype=torch.float32, device=pooled.device)
-        hpre = torch.empty(2, n, c // 4, t, dtype=torch.float32, device=pooled.device)  # conv1 out: pre-BN | post-ReLU
-        if not (w0.is_contiguous() and w3.is_contiguous() and wg1.is_contiguous() and wg3.is_contiguous()):
-            raise ValueError("TAM weights must be contiguous")
-        check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
-                                             _p(wg3), _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3),
-                                             n, c, t, _p(kern), _p(gate), _p(hpre), _stream()), "vitta_tam_branch_fwd_f32")
-        ctx.save_for_backward(pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern,
-                              gate, hpre)
-        ctx.eps = (float(eps_g), float(eps_l))
-        return kern, gate
-
-    @staticmethod
-    def backward(ctx, gkern, ggate):
-        (pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv, kern, gate,
-         hpre) = ctx.saved_tensors
-        n, c, t = pooled.shape
-        gbuf = torch.empty(n * c * t + n * (c // 4) * t, dtype=torch.float32, device=pooled.device)
-        gpooled = gbuf[: n * c * t].view(n, c, t)  # the tail is the kernel's scratch for d(conv1 output)
-        need = ctx.needs_input_grad
-        (dgw, r_gw), (dgb, r_gb), (dlw, r_lw), (dlb, r_lb) = (
-            _grad_sink(v, True) for v in (bng_w, bng_b, bnl_w, bnl_b))  # the kernel always produces these four
-        r_gw, r_gb, r_lw, r_lb = (r if nd else None for r, nd in zip((r_gw, r_gb, r_lw, r_lb),
-                                                                    (need[2], need[3], need[6], need[7])))
-        (dwg1, r_wg1), (dwg3, r_wg3), (dw0, r_w0), (dw3, r_w3) = (
-            _grad_sink(v, nd) for v, nd in zip((wg1, wg3, w0, w3), (need[1], need[4], need[5], need[8])))
-        check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), ctx.eps[0], _p(wg3),
-                                             _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), ctx.eps[1], _p(w3), n, c, t,
-                                             _p(kern), _p(gate), _p(hpre), _p(gkern.contiguous()), _p(ggate.contiguous()),
-                                             _p(gbuf), _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), _stream()),
-              "vitta_tam_branch_bwd_f32")
-        return (gpooled, r_wg1, r_gw, r_gb, r_wg3, r_w0, r_lw, r_lb, r_w3, None, None, None, None, None, None)
-
-
 class TamFused(torch.autograd.Function):
     """The whole temporal adaptive module as ONE autograd node: pool -> G/L branches -> adaptive aggregation
-    (temporal_module.py:43-65).  Same five kernels as TamPool + TamBranches + TamAggregate; what the single node
+    (temporal_module.py:43-65).  Same kernels as TamPool, the G/L branch launches and TamAggregate; what the single node
     saves is autograd's glue around them in the backward pass: x feeds both the pooling and the aggregation, so as
     separate nodes their two full-size input gradients meet in a zero-fill + an add per TAM (16 of each per step,
     on the largest tensors of the network); here vitta_tam_pool_bwd accumulates into the aggregation's dx."""
