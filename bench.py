@@ -62,6 +62,8 @@ def parse():
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
                         "the tail of a rocprofv3 trace is the shipped hipGraph replay and nothing else")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--sequential", action="store_true",
+                   help="adapt(i); eval(i) back to back on one stream instead of eval(i-1) beside adapt(i)")
     p.add_argument("--segmented-graph", action="store_true",
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
     p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
@@ -136,6 +138,13 @@ def run_gpu(opt, rank, world, device):
 
     def one_step(i):
         x, _ = tta_set[i % n_videos]
+        if not opt.sequential:
+            # overlapped schedule (the shipped default, ViTTAAdapter.step): video i is adapted while video i-1 is
+            # evaluated on a second stream under the same weights; every step still holds one adaptation step and
+            # one evaluation forward
+            ev = eval_set[(i - 1) % n_videos][0]
+            adapter.set_adapt_mode()
+            return adapter.step(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)))
         ev, _ = eval_set[i % n_videos]
         if adapter._graph is not None:  # hipGraph replay: mode switches / hook (de)registration are baked in
             adapter.adapt_step(adapter.shape_tta_input(x.unsqueeze(0)))
@@ -163,7 +172,7 @@ def run_gpu(opt, rank, world, device):
         x, _ = tta_set[0]
         ev, _ = eval_set[0]
         adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
-                               segmented=opt.segmented_graph)
+                               segmented=opt.segmented_graph, overlap_eval=not opt.sequential)
         one_step(opt.warmup)  # first replay outside the timed region
         torch.cuda.synchronize()
         log("hipGraphs captured")
@@ -210,14 +219,16 @@ def run_gpu(opt, rank, world, device):
         elapsed = float(t.item())
 
     # adapt-only timing (no evaluation forward), same videos, for the report
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(max(4, opt.steps // 3)):
-        x, _ = tta_set[i % n_videos]
-        adapter.set_adapt_mode()
-        adapter.adapt_step(adapter.shape_tta_input(x.unsqueeze(0)))
-    barrier()
-    adapt_only = (time.perf_counter() - t1) / max(4, opt.steps // 3)
+    adapt_only = float("nan")
+    if opt.sequential:  # (the overlapped capture has no adapt-only graph to replay)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(max(4, opt.steps // 3)):
+            x, _ = tta_set[i % n_videos]
+            adapter.set_adapt_mode()
+            adapter.adapt_step(adapter.shape_tta_input(x.unsqueeze(0)))
+        barrier()
+        adapt_only = (time.perf_counter() - t1) / max(4, opt.steps // 3)
 
     streaming = None
     if rank == 0 and not opt.no_streaming:
@@ -316,8 +327,11 @@ def main():
                                "prediction consistency, backward, optimizer) + eval forward (1 view)",
                    "optimizer": "Adam on BN affine (update_only_bn_affine)" if opt.optimizer == "adam_affine" else "SGD all parameters",
                    "videos_per_gpu_per_step": 1, "parallelism": f"dp{world}",
-                   "exchanges": "moments all-reduce (43k floats) + gradient all-reduce" if world > 1 else "none"},
-        "adapt_only_ms": 1e3 * adapt_only, "launch_mode": run_gpu.mode, "eager_ms_per_step": run_gpu.eager_ms,
+                   "exchanges": "moments all-reduce (43k floats) + gradient all-reduce" if world > 1 else "none",
+                   "schedule": "sequential: adapt(i); eval(i)" if opt.sequential else
+                               "overlapped: eval(i-1) on a second stream beside adapt(i), optimizer update after both "
+                               "(same weights and results as the sequential order)"},
+        "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "launch_mode": run_gpu.mode, "eager_ms_per_step": run_gpu.eager_ms,
         "roofline": {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch)", "bound": "hbm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,

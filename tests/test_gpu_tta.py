@@ -264,3 +264,120 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
     assert gdev[0] == pytest.approx(c[0], rel=2e-5) and gdev[1] == pytest.approx(c[1], rel=1e-3, abs=1e-6)
     for a, b in zip(gdev[2:], c[2:]):
         assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capture", [None, "single", "segmented"])
+def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture):
+    """ViTTAAdapter.step (video i adapted while video i-1 is evaluated on a second stream, the optimizer
+    update waiting for both) == adapt(i-1); eval(i-1); adapt(i): same losses and the same evaluation
+    logits, eager and as one hipGraph with a forked branch and as the data-parallel segments."""
+    import json
+    import numpy as np
+    from vitta_amd import data, tta
+    g = H.golden("tta3.npz")
+    cfg = json.loads(str(g["config"]))
+    T, size = cfg["T"], cfg["size"]
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(tmp_path, clip_length=T, input_size=size, spatiotemp_mean_clean_file=mp,
+                        spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=1e-4)
+    n = 6
+    tta_set = data.SyntheticVideoDataset(n, 2, T, size, 101, "tanet", seed0=700)
+    eval_set = data.SyntheticVideoDataset(n, 1, T, size, 101, "tanet", seed0=700)
+
+    def make():
+        model = H.build_tanet(101, T, 0)
+        model.base_model.fc = nn.Identity()
+        return tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(_dev()), args)
+
+    def clips(adapter, i):
+        return (adapter.shape_tta_input(tta_set[i][0].unsqueeze(0).to(_dev())),
+                adapter.shape_eval_input(eval_set[i][0].unsqueeze(0).to(_dev())))
+
+    def sequential():
+        adapter = make()
+        out = []
+        for i in range(n):
+            x, ev = clips(adapter, i)
+            adapter.set_adapt_mode()
+            _, lr_, lc_ = adapter.adapt_step(x)
+            adapter.close_hooks()
+            logits = adapter.evaluate(ev).clone()
+            adapter.add_hooks_back()
+            out.append((lr_.item(), lc_.item(), logits.cpu()))
+        torch.cuda.synchronize()
+        return out
+
+    def overlapped():
+        adapter = make()
+        losses, logits, prev = [], [], None
+        for i in range(n):
+            x, ev = clips(adapter, i)
+            if capture is not None and i == 2:
+                adapter.capture_graphs(x, ev, segmented=capture == "segmented", overlap_eval=True)
+            adapter.set_adapt_mode()
+            (_, lr_, lc_), ev_out = adapter.step(x, prev)
+            losses.append((lr_.item(), lc_.item()))
+            if ev_out is not None:
+                logits.append(ev_out.clone().cpu())
+            prev = ev
+        if capture is not None:
+            assert "step" in adapter._graph and (adapter._graph["step"] is None) == (capture == "segmented")
+        adapter.close_hooks()
+        logits.append(adapter.evaluate(prev).clone().cpu())
+        torch.cuda.synchronize()
+        return [(a, b, c) for (a, b), c in zip(losses, logits)]
+
+    seq, seq2, ovl = sequential(), sequential(), overlapped()
+    floor = max((c - c2).abs().max().item() for (_, _, c), (_, _, c2) in zip(seq, seq2))
+    assert len(ovl) == n
+    for (a, b, c), (d, e, f) in zip(seq, ovl):
+        assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
+        assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
+
+
+def test_tta_loop_overlapped_schedule_logs_the_same_run_on_gpu(tmp_path):
+    """corpus/main_eval.py::eval -> tta_standard on the GPU, 8 synthetic videos (eager steps, then hipGraph replay):
+    the overlapped schedule (default) and the sequential schedule log the same per-video losses and the same
+    final accuracy; every video is evaluated exactly once."""
+    import glob
+    import os
+    import re
+    import numpy as np
+    from vitta_amd import scripts, tta
+    model = H.build_tanet(101, 8, 0)
+    model.base_model.fc = nn.Identity()  # no dropout: both schedules see the same arithmetic
+    bn2d = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    mp, vp = H.write_stat_files(str(tmp_path), [np.zeros(b.num_features, np.float32) for b in bn2d],
+                                [np.ones(b.num_features, np.float32) for b in bn2d])
+
+    def run(overlap):
+        a = scripts.tanet_ucf101_args([])
+        a.datatype, a.clip_length, a.input_size, a.workers = "synthetic", 8, 64, 0
+        a.synthetic_n_videos, a.verbose, a.overlap_eval = 8, True, overlap
+        a.num_classes, a.crop_size, a.scale_size = 101, 64, 64 * 256 // 224
+        a.spatiotemp_mean_clean_file, a.spatiotemp_var_clean_file = mp, vp
+        lines = []
+
+        class Log:
+            def debug(self, msg):
+                lines.append(msg)
+        res = tta.tta_standard(tta.SingleDeviceParallel(model).to(_dev()), torch.nn.CrossEntropyLoss().to(_dev()),
+                               args=a, logger=Log(), writer=None)
+        rows = {}
+        for l in lines:
+            m = re.match(r"TTA Epoch1: \[(\d+)/8\].*Loss reg ([\d.]+) .*Loss consis ([\d.]+) .*Prec@1 ([\d.]+) ", l)
+            if m:
+                rows[int(m.group(1))] = tuple(float(v) for v in m.groups()[1:])
+        return res, rows
+
+    (acc_o, rows_o), (acc_s, rows_s) = run(True), run(False)
+    assert sorted(rows_o) == sorted(rows_s) == list(range(8))
+    assert acc_o == pytest.approx(acc_s, abs=1e-6)
+    for i in range(8):
+        assert rows_o[i][0] == pytest.approx(rows_s[i][0], rel=2e-3, abs=2e-4), i
+        assert rows_o[i][1] == pytest.approx(rows_s[i][1], rel=2e-2, abs=2e-4), i
+        assert rows_o[i][2] == rows_s[i][2], i

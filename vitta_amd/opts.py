@@ -6,6 +6,7 @@
 * `get_opts(argv=None)` accepts an explicit argv (the reference always reads sys.argv);
 * `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py;
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
+* `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
 """
 import argparse
 
@@ -94,6 +95,9 @@ _FLAGS = [
     (("--chosen_blocks",), dict(default=["layer3", "layer4"])),
     (("--moving_avg",), dict(type=_bool, default=True)),
     (("--hip_graph",), dict(type=_bool, default=True, help="(extension) replay the per-video step from captured hipGraphs")),
+    (("--overlap_eval",), dict(type=_bool, default=True,
+                               help="(extension) evaluate video i on a second stream beside the adaptation forward of "
+                                    "video i+1 (same weights, same results)")),
     (("--n_gradient_steps",), dict(type=int, default=1, help="number of gradient steps per sample")),
     # input / optimiser
     (("--full_res",), dict(action="store_true")),

@@ -263,6 +263,7 @@ class ViTTAAdapter:
         self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
         self.n_views = args.test_crops * (args.n_augmented_views if args.if_sample_tta_aug_views else self.n_clips)
         self._graph = None
+        self._side_stream = None
         self.engine = None
         if args.stat_reg == "BNS":
             # regularise the BN INPUT statistics towards the layer's own running statistics (basics.py:588-599)
@@ -372,13 +373,69 @@ class ViTTAAdapter:
             return a.lambda_feature_reg * loss_reg + a.lambda_pred_consis * loss_consis
         return loss_reg
 
+    # -- overlapped schedule -----------------------------------------------------------------------
+    def step(self, tta_input, eval_input, has_video=True):
+        """Adaptation step on `tta_input` (video i) WHILE `eval_input` (video i-1) is evaluated on a second
+        stream.  Both forward passes read the weights left by step i-1 -- exactly what the sequential order
+        `adapt(i-1); eval(i-1); adapt(i)` gives them -- and the optimizer update of step i waits for the
+        evaluation to finish.  Same results, but the small-grid kernels of the two passes (layer3/4 of an
+        8-frame clip fill well under half of 256 CUs) share the GPU instead of queueing.
+        Returns ((logits, loss_reg, loss_consis) of the adaptation, logits of the evaluation or None)."""
+        if eval_input is None:
+            return self.adapt_step(tta_input, has_video), None
+        g = self._graph
+        if (g is not None and "step" in g and has_video and tta_input.shape == g["tta_in"].shape
+                and eval_input.shape == g["eval_in"].shape):
+            g["tta_in"].copy_(tta_input)
+            g["eval_in"].copy_(eval_input)
+            if g["step"] is not None:
+                g["step"].replay()
+            else:
+                g["seg_fwd"].replay()
+                self.engine.exchange()
+                g["seg_bwd"].replay()
+                if self.bucket is not None:
+                    self.bucket.all_reduce()
+                g["seg_opt"].replay()
+            return g["adapt_out"], g["eval_out_overlapped"]
+        return self._step_eager(tta_input, eval_input, has_video)
+
+    def _fork_eval(self, eval_input):
+        """Issue the evaluation forward on the side stream (hooks closed, model.eval()); the caller joins."""
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        capturing = torch.cuda.is_current_stream_capturing()
+        side.wait_stream(cur)  # the previous optimizer step and the copy of the clip
+        self.close_hooks()
+        with torch.cuda.stream(side):
+            out = self._evaluate_eager(eval_input)
+        if not capturing:
+            eval_input.record_stream(side)
+            out.record_stream(cur)
+        self.add_hooks_back()
+        self.set_adapt_mode()
+        return out, side
+
+    def _step_eager(self, tta_input, eval_input, has_video=True):
+        if self.device.type != "cuda":  # one queue: the sequential order with the evaluation first
+            self.close_hooks()
+            ev = self._evaluate_eager(eval_input)
+            self.add_hooks_back()
+            self.set_adapt_mode()
+            return self._adapt_step_eager(tta_input, has_video), ev
+        ev, side = self._fork_eval(eval_input)
+        out = self._adapt_step_eager(tta_input, has_video, join=side)
+        return out, ev
+
     def adapt_step(self, input, has_video=True):
         """One gradient step on one (already device-resident, already reshaped) TTA input.
         `has_video=False`: ragged tail of a data-parallel run -- this rank only takes part in the two
         exchanges so that EMA state and weights stay identical everywhere.
         With captured graphs (capture_graphs) a step is: copy the clip into the static buffer, replay."""
         g = self._graph
-        if g is not None and has_video and input.shape == g["tta_in"].shape:
+        if g is not None and has_video and input.shape == g["tta_in"].shape and "step" not in g:
             g["tta_in"].copy_(input)
             if "adapt" in g:
                 g["adapt"].replay()
@@ -392,7 +449,7 @@ class ViTTAAdapter:
             return g["adapt_out"]
         return self._adapt_step_eager(input, has_video)
 
-    def _adapt_step_eager(self, input, has_video=True):
+    def _adapt_step_eager(self, input, has_video=True, join=None):
         a = self.args
         self.arena.zero_grad()
         output = loss_reg = loss_consis = None
@@ -406,6 +463,8 @@ class ViTTAAdapter:
             loss_reg = self.engine.finish_empty()
         if self.bucket is not None:
             self.bucket.all_reduce()
+        if join is not None:  # an evaluation on a side stream still reads the weights this update overwrites
+            torch.cuda.current_stream().wait_stream(join)
         self.optimizer.step()
         # detached: nothing the caller holds may keep this step's autograd graph (and its AccumulateGrad
         # nodes, which remember the stream they were created on) alive into a later graph capture
@@ -420,7 +479,7 @@ class ViTTAAdapter:
             return g["eval_out"]
         return self._evaluate_eager(input)
 
-    def _capture_segments(self, g):
+    def _capture_segments(self, g, overlap_eval=False):
         """Data-parallel capture: no collective inside a graph.  The step is cut at its two exchanges into
         forward | backward | optimizer segments sharing one memory pool (the backward segment walks the
         autograd graph recorded while the forward segment was captured, like make_graphed_callables)."""
@@ -430,8 +489,12 @@ class ViTTAAdapter:
         pool = torch.cuda.graph_pool_handle()
         g["seg_fwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_fwd"], pool=pool):
+            if overlap_eval:  # the evaluation of the previous video rides beside the adaptation forward
+                g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
             self.arena.zero_grad()
             output, loss_consis = self.forward_local(x, actual_bz)
+            if overlap_eval:
+                torch.cuda.current_stream().wait_stream(side)
         g["seg_bwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_bwd"], pool=pool):
             loss_reg = self.engine.finish_global()
@@ -441,7 +504,7 @@ class ViTTAAdapter:
             self.optimizer.step()
         g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
 
-    def capture_graphs(self, tta_input, eval_input, segmented=False):
+    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False):
         """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
         evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
         the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
@@ -459,7 +522,14 @@ class ViTTAAdapter:
         torch.cuda.synchronize()
         self.set_adapt_mode()
         if self.world > 1 or segmented:
-            self._capture_segments(g)
+            self._capture_segments(g, overlap_eval)
+            if overlap_eval:
+                g["step"] = None  # step() replays the three segments
+        elif overlap_eval:
+            g["step"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["step"]):
+                g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
+                g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
         else:
             g["adapt"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["adapt"]):
@@ -526,7 +596,19 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
 
     log = DeferredLog(device, logger, n_steps, args.verbose)
     adapter = None
+    # overlapped schedule (extension, --overlap_eval): the evaluation of video i runs beside the adaptation forward
+    # of video i+1 on a second stream -- same weights, same numbers, one iteration later (ViTTAAdapter.step)
+    overlap = (bool(getattr(args, "overlap_eval", True)) and device.type == "cuda"
+               and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1)
+    waiting = None  # (batch_id, row, actual_bz, ev_input, ev_target): adapted, not evaluated yet
     end = time.time()
+
+    def finish(item, ev_output, now):
+        batch_id_, row_, bz_, _, ev_target_ = item
+        prec1, prec5 = accuracy(ev_output.data, ev_target_, topk=(1, 5))
+        row_[3], row_[4] = prec1, prec5
+        log.push(batch_id_, row_, bz_, now - end)
+
     for batch_id in range(n_steps):
         try:
             input, target = next(tta_iter)
@@ -541,7 +623,8 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
                 and getattr(args, "hip_graph", True) and device.type == "cuda" and adapter.engine is not None
                 and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1):
             ev0 = eval_set[0][0].unsqueeze(0).expand(input.shape[0], *eval_set[0][0].shape)
-            adapter.capture_graphs(adapter.shape_tta_input(input.to(device)), adapter.shape_eval_input(ev0.to(device)))
+            adapter.capture_graphs(adapter.shape_tta_input(input.to(device)), adapter.shape_eval_input(ev0.to(device)),
+                                   overlap_eval=overlap)
         adapter.set_adapt_mode()
         row = torch.zeros(DeferredLog.FIELDS, dtype=torch.float32, device=device)
         actual_bz = 0
@@ -549,13 +632,28 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
             actual_bz = input.shape[0]
             input = adapter.shape_tta_input(input.to(device, non_blocking=True))
             target = target.to(device, non_blocking=True)
-        for _ in range(args.n_gradient_steps):
-            output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
+        ev_output = None
+        if overlap:
+            (output, loss_reg, loss_consis), ev_output = adapter.step(input, waiting[3] if waiting else None, has_video)
+        else:
+            for _ in range(args.n_gradient_steps):
+                output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
         if has_video:
             row[0] = loss_reg.detach()
             if loss_consis is not None:
                 row[1] = loss_consis.detach()
             row[2] = criterion(output.detach(), target)  # logging only, never part of the loss (basics.py:657)
+        now = time.time()
+        if overlap:
+            if waiting is not None:
+                finish(waiting, ev_output, now)
+                waiting = None
+            if has_video:
+                ev_input, ev_target = next(eval_iter)
+                waiting = (batch_id, row, actual_bz, adapter.shape_eval_input(ev_input.to(device, non_blocking=True)),
+                           ev_target.to(device, non_blocking=True))
+            end = now
+            continue
         adapter.close_hooks()
         if has_video:
             ev_input, ev_target = next(eval_iter)
@@ -570,6 +668,10 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
         if has_video:
             log.push(batch_id, row, actual_bz, now - end)
         end = now
+    if waiting is not None:  # drain: the last video's evaluation has nothing to overlap with
+        adapter.close_hooks()
+        finish(waiting, adapter.evaluate(waiting[3]), time.time())
+        adapter.add_hooks_back()
     log.flush()
     top1 = log.meters["top1"]
     if world > 1:
