@@ -275,6 +275,22 @@ int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, 
                            int32_t head_dim, float scale, const float* d_out, const float* d_dout,
                            const float* d_lse, float* d_delta, float* d_dqkv, float* d_dtable, void* stream);
 
+/* --------------------------------------------------------------------------
+ * A7 -- optimizer update on the flat parameter arena, one launch.
+ * Replaces optimizer.step() of corpus/basics.py:671 for the optimizers built at corpus/basics.py:547-560 (torch.optim.Adam over the affine tensors /
+ * torch.optim.SGD over every parameter), same element-wise arithmetic as torch's single-tensor formulation.
+ *   vitta_adam_step_f32: t = *d_step + 1 (device scalar, incremented by the call, so a captured graph advances it);
+ *                        g' = g + wd p; m = lerp(m, g', 1-b1); v = b2 v + (1-b2) g'^2;
+ *                        p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  m, v, *d_step start at 0.
+ *   vitta_sgd_step_f32:  d = g + wd p; buf = momentum buf + d (buf starts at 0); p -= lr buf.
+ *                        momentum == 0: d_momentum_buf may be NULL.
+ * All arrays n floats, 16-byte aligned.
+ * -------------------------------------------------------------------------- */
+int vitta_adam_step_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_step,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t n, void* stream);
+int vitta_sgd_step_f32(float* d_param, const float* d_grad, float* d_momentum_buf, float lr, float momentum,
+                       float weight_decay, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

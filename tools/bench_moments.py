@@ -1,4 +1,6 @@
-"""Micro-benchmark of the batched moments launch (GPU box): workgroup count, NT loads, in-cache vs streaming."""
+"""Micro-benchmark of the batched moments launch (GPU box): workgroup count, NT loads, in-cache vs streaming.
+Two timings per configuration: one event pair per launch (what bench.py reports; includes the event/dispatch
+overhead of a lone launch) and a back-to-back train of launches between one event pair (kernel time + launch gap)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +14,7 @@ assert len(C2) == 29 and sum(o * c * i for o, c, i, _ in C2) == 44556288, (len(C
 dev = torch.device("cuda:0") if torch.cuda.is_available() else None
 
 
-def run(copies, target, nt, reps=30):
+def run(copies, target, nt, reps=30, train=40):
     shapes = [(o * copies, c, i, l) for o, c, i, l in C2]
     plan = ops.StatPlan(shapes, dev, target_blocks=target, nt_loads=nt)
     feats = [torch.randn(o * c * i, device=dev) for o, c, i, _ in shapes]
@@ -26,11 +28,21 @@ def run(copies, target, nt, reps=30):
         if r >= 5:
             ts.append(ev[0].elapsed_time(ev[1]))
     ms = float(np.median(ts))
-    return dict(copies=copies, target=target, nt=nt, blocks=plan.num_blocks, MB=nbytes / 1e6, us=1e3 * ms, TBs=nbytes / ms / 1e9)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(train):
+        plan.partials(feats)
+    b.record()
+    torch.cuda.synchronize()
+    tr = a.elapsed_time(b) / train
+    return dict(copies=copies, target=target, nt=nt, blocks=plan.num_blocks, MB=round(nbytes / 1e6, 1), us=round(1e3 * ms, 1),
+                TBs=round(nbytes / ms / 1e9, 2), train_us=round(1e3 * tr, 1), train_TBs=round(nbytes / tr / 1e9, 2))
 
 
 if __name__ == "__main__":
-    for copies in (1, 6, 16):
-        for target in (1024, 2048, 4096, 8192, 16384):
+    copies_list = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 6, 16]
+    targets = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1024, 2048, 4096, 8192, 16384]
+    for copies in copies_list:
+        for target in targets:
             for nt in (False, True):
                 print(json.dumps(run(copies, target, nt)), flush=True)

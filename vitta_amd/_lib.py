@@ -69,6 +69,8 @@ SIGNATURES = {
     "vitta_wmsa_rel_bwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p,
                                          _p, _p, _p]),
     "vitta_wmsa_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    "vitta_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
+    "vitta_sgd_step_f32": (C.c_int, [_p, _p, _p, _f32, _f32, _f32, _i64, _p]),
 }
 
 _LIB = None

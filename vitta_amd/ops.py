@@ -219,6 +219,13 @@ class StatPlan:
                   "vitta_moments_finalize_f32")
         return self.cnt, self.s1, self.s2
 
+    def partials(self, feats):
+        """First stage only (the streaming kernel), for micro-benchmarks."""
+        for i, t in enumerate(feats):
+            self._ptr_arr[i] = t.data_ptr()
+        check(lib().vitta_moments_partials_f32(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream()),
+              "vitta_moments_partials_f32")
+
     def layer_geometry(self, layer):
         """(nsplit, nchunks, slots, ws_off) of a layer: where a fused BN pass deposits its partial triples."""
         out = (C.c_int64 * 5)()

@@ -248,14 +248,20 @@ class ViTTAAdapter:
             freeze_except_bn(model, bn_condidiate_layers=kinds)
             params, self.param_names = collect_bn_params(model, bn_candidate_layers=kinds)
             self.arena = FlatArena(params)
-            # capturable: the step counter lives on the device, so the whole step can sit in a hipGraph
-            self.optimizer = torch.optim.Adam([self.arena.flat_param], lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0,
-                                              capturable=self.device.type == "cuda")
+            if self.device.type == "cuda":  # one launch; the step counter is a device scalar (graph capturable)
+                from .optim import FlatAdam
+                self.optimizer = FlatAdam(self.arena, lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0)
+            else:  # host-side tests (oracle backend)
+                self.optimizer = torch.optim.Adam([self.arena.flat_param], lr=args.lr, betas=(0.9, 0.999), weight_decay=0.0)
         else:
             params = list(model.parameters())
             self.arena = FlatArena(params)
-            self.optimizer = torch.optim.SGD(params=[self.arena.flat_param], lr=args.lr, momentum=args.momentum,
-                                             weight_decay=args.weight_decay)
+            if self.device.type == "cuda":
+                from .optim import FlatSGD
+                self.optimizer = FlatSGD(self.arena, lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+            else:
+                self.optimizer = torch.optim.SGD(params=[self.arena.flat_param], lr=args.lr, momentum=args.momentum,
+                                                 weight_decay=args.weight_decay)
         self.params = self.arena.params
         self.bucket = self.arena if self.world > 1 else None
 
