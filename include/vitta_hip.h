@@ -243,6 +243,8 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  *   d_triples: NULL, or the layer's (n, mean, M2) partial area of a plan workspace
  *              (float* workspace + 3*ws_off, geometry from vitta_plan_layer_geometry; nsplit must match)
  *   backward: d_gres NULL iff no residual; d_mu/d_coef_a/d_coef_b/d_gscale NULL iff not hooked;
+ *             d_gz2: NULL, or a second gradient of z (z feeds the next block's conv AND its identity path; summing
+ *             the two here saves autograd's add pass over the largest tensors of the network);
  *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch;
  *             accumulate != 0: d_dgamma / d_dbeta += with fp32 atomics from the one launch (the caller hands the
  *             parameters' live .grad storage -- what autograd's AccumulateGrad would do with one more launch per
@@ -253,7 +255,7 @@ size_t vitta_bn_act_partial_floats(int64_t outer, int32_t C, int64_t HW, int32_t
 int vitta_bn_act_fwd_f32(const float* d_x, const float* d_res, float* d_z, const float* d_weight, const float* d_bias,
                          const float* d_rmean, const float* d_rvar, float eps, int64_t outer, int32_t C, int64_t HW,
                          int32_t nsplit, int32_t relu, float* d_triples, void* stream);
-int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, float* d_gx, float* d_gres,
+int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, const float* d_gz2, float* d_gx, float* d_gres,
                          const float* d_weight, const float* d_bias, const float* d_rmean, const float* d_rvar,
                          float eps, const float* d_mu, const float* d_coef_a, const float* d_coef_b,
                          const float* d_gscale, int64_t outer, int32_t C, int64_t HW, int32_t nsplit, int32_t relu,

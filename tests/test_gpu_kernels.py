@@ -509,3 +509,36 @@ def test_flat_optimizers_match_torch_optim(kind):
     assert float(arena.flat_param.detach()[~used].abs().max()) == 0.0
     if kind == "adam":
         assert float(opt.state["step"]) == 5.0
+
+
+def test_fused_bn_act_forked_output_sums_both_gradients():
+    """bn_act(..., fork=True): the twin handle shares the storage of z, and the two upstream gradients (conv path,
+    identity path of the next block) are summed inside the backward kernel; one of them may be absent."""
+    import torch.nn.functional as F
+    from vitta_amd import fused_bn
+    from vitta_amd.fused_bn import bn_act, identity_source
+    torch.manual_seed(8)
+    shape = (8, 32, 7, 7)
+    bn = torch.nn.BatchNorm2d(32).to(_dev()).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    x0, r0 = torch.randn(shape, device=_dev()), torch.randn(shape, device=_dev())
+    g1, g2 = torch.randn(shape, device=_dev()), torch.randn(shape, device=_dev())
+    for use_twin in (True, False):
+        res = []
+        for fused in (True, False):
+            fused_bn.ENABLED = fused
+            x, r = x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+            bn.zero_grad()
+            z = bn_act(bn, x, residual=r, relu=True, fork=True)
+            t = identity_source(z)
+            assert (t is not z) == fused and t.data_ptr() == z.data_ptr()
+            loss = (z * g1).sum() + ((t * g2).sum() if use_twin else 0.0)
+            loss.backward()
+            res.append((z.detach().clone(), x.grad.clone(), r.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+        fused_bn.ENABLED = True
+        for a, b in zip(*res):
+            assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6

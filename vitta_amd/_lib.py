@@ -60,7 +60,7 @@ SIGNATURES = {
                                            _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_bn_act_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i64, _i32, _i32, _p, _p]),
-    "vitta_bn_act_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _i32, _i64, _i32,
+    "vitta_bn_act_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _i32, _i64, _i32,
                                        _i32, _p, _p, _p, _i32, _p]),
     "vitta_plan_layer_geometry": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "vitta_wmsa_supported": (C.c_int, [_i32, _i32]),

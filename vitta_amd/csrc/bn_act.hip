@@ -150,7 +150,9 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_fwd_kernel(const float* __
 // ------------------------------------------------------------------------------------------------
 template <bool RELU, bool RES, bool INJ>
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ gz, float* __restrict__ gx,
+    const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ gz,
+    const float* __restrict__ gz2 /* or NULL: a second upstream gradient of z, summed on the fly */,
+    float* __restrict__ gx,
     float* __restrict__ gres, const float* __restrict__ weight, const float* __restrict__ bias,
     const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, const float* __restrict__ mu,
     const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ gscale, BnGeom g,
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
     const float4* px = reinterpret_cast<const float4*>(x + j);
     const float4* pz = (RELU && RES) ? reinterpret_cast<const float4*>(z + j) : nullptr;
     const float4* pg = reinterpret_cast<const float4*>(gz + j);
+    const float4* pg2 = gz2 ? reinterpret_cast<const float4*>(gz2 + j) : nullptr;
     float4* pgx = reinterpret_cast<float4*>(gx + j);
     float4* pgr = RES ? reinterpret_cast<float4*>(gres + j) : nullptr;
 #pragma unroll 4
@@ -192,6 +195,10 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
       const float4 g4 = pg[n * stride4];
       const float v[4] = {v4.x, v4.y, v4.z, v4.w};
       float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+      if (pg2) {
+        const float4 h4 = pg2[n * stride4];
+        gg[0] += h4.x; gg[1] += h4.y; gg[2] += h4.z; gg[3] += h4.w;
+      }
       float zz[4] = {1.f, 1.f, 1.f, 1.f};
       if (RELU && RES) {
         const float4 z4 = pz[n * stride4];
@@ -269,7 +276,7 @@ inline bool unaligned(const void* a, const void* b = nullptr, const void* c = nu
   VITTA_LAUNCH((bn_act_fwd_kernel<R, S, T>), grid, dim3(VITTA_BLOCK), 0, st, d_x, d_res, d_z, d_weight, d_bias,    \
                d_rmean, d_rvar, eps, g, d_triples)
 #define BN_BWD_CASE(R, S, I)                                                                                          \
-  VITTA_LAUNCH((bn_act_bwd_kernel<R, S, I>), grid, dim3(VITTA_BLOCK), 0, st, d_x, d_z, d_gz, d_gx, d_gres, d_weight, \
+  VITTA_LAUNCH((bn_act_bwd_kernel<R, S, I>), grid, dim3(VITTA_BLOCK), 0, st, d_x, d_z, d_gz, d_gz2, d_gx, d_gres, d_weight, \
                d_bias, d_rmean, d_rvar, eps, d_mu, d_coef_a, d_coef_b, d_gscale, g, d_partial, acc_g, acc_b)
 
 extern "C" {
@@ -302,7 +309,7 @@ int vitta_bn_act_fwd_f32(const float* d_x, const float* d_res, float* d_z, const
   return VITTA_OK;
 }
 
-int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, float* d_gx, float* d_gres,
+int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, const float* d_gz2, float* d_gx, float* d_gres,
                          const float* d_weight, const float* d_bias, const float* d_rmean, const float* d_rvar,
                          float eps, const float* d_mu, const float* d_coef_a, const float* d_coef_b, const float* d_gscale,
                          int64_t outer, int32_t C, int64_t HW, int32_t nsplit, int32_t relu, float* d_partial,
@@ -320,7 +327,7 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
   const bool R = relu != 0, S = d_gres != nullptr, I = d_mu != nullptr;
   if (I && (!d_coef_a || !d_coef_b)) return VITTA_ERR_INVALID_ARG;
   if (R && S && !d_z) return VITTA_ERR_INVALID_ARG;
-  if (unaligned(d_x, d_z, d_gz, d_gx, d_gres)) return VITTA_ERR_INVALID_ARG;
+  if (unaligned(d_x, d_z, d_gz, d_gx, d_gres) || unaligned(d_gz2)) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const dim3 grid(g.nchunks, g.nsplit);
   if (R && S && I) BN_BWD_CASE(true, true, true);

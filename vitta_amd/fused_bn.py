@@ -28,7 +28,19 @@ def _engine_hook(bn):
     return True, hook
 
 
-def bn_act(bn, x, residual=None, relu=True, act=None):
+TWIN = "_vitta_twin"
+
+
+def identity_source(x):
+    """The handle of a block input the identity / downsample path should read: the twin left by `bn_act(...,
+    fork=True)` of the producing block (same storage, separate gradient), or x itself."""
+    return getattr(x, TWIN, x)
+
+
+def bn_act(bn, x, residual=None, relu=True, act=None, fork=False):
+    """`fork=True`: the result feeds two consumers (the next block's conv1 and its identity / downsample path).
+    On the fused path it then carries a twin handle (see identity_source) so that the two gradients reach the
+    backward kernel separately instead of through an autograd add."""
     if ENABLED and isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.affine and not bn._forward_pre_hooks:
         from . import ops
         if ops.bn_act_supported(x):
@@ -38,6 +50,11 @@ def bn_act(bn, x, residual=None, relu=True, act=None):
                 if hook is not None and hook.kind == "bn2d" and not hook.before_norm:
                     site = hook.engine.fused_site(hook.index, x)
                 if hook is None or site is not None:
+                    if fork and torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+                        z, twin = ops.FusedBNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                                       residual, relu, site, True)
+                        setattr(z, TWIN, twin)
+                        return z
                     return ops.FusedBNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                                                 residual, relu, site)
     out = bn(x)

@@ -435,7 +435,8 @@ class FusedBNAct(torch.autograd.Function):
     statistics-loss gradient; backward = ReLU mask + injection + BN backward (dx, dgamma, dbeta) in one pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, residual, relu, site):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, residual, relu, site, fork=False):
+        ctx.set_materialize_grads(False)
         x = x.contiguous()
         outer, c, h, w = x.shape
         hw = h * w
@@ -452,15 +453,26 @@ class FusedBNAct(torch.autograd.Function):
               "vitta_bn_act_fwd_f32")
         ctx.save_for_backward(x, z if (relu and res is not None) else None, weight, bias, running_mean, running_var)
         ctx.meta = (float(eps), bool(relu), res is not None, site, nsplit)
+        if fork:
+            # a second handle on the same storage: the consumer of the identity path takes this one, so the two
+            # gradients of z arrive separately and the backward kernel sums them while it reads them
+            twin = torch.empty(0, dtype=z.dtype, device=z.device).set_(z.untyped_storage(), z.storage_offset(), z.shape,
+                                                                       z.stride())
+            return z, twin
         return z
 
     @staticmethod
-    def backward(ctx, gz):
+    def backward(ctx, gz, gz2=None):
         x, z, weight, bias, running_mean, running_var = ctx.saved_tensors
         eps, relu, has_res, site, nsplit = ctx.meta
         outer, c, h, w = x.shape
         hw = h * w
+        if gz is None:
+            gz, gz2 = gz2, None
+        if gz is None:
+            gz = torch.zeros_like(x)
         gz = gz.contiguous()
+        gz2 = gz2.contiguous() if gz2 is not None else None
         gx = torch.empty_like(x)
         gres = torch.empty_like(x) if has_res else None
         dgamma, ret_gamma = _grad_sink(weight, ctx.needs_input_grad[1], zero=False)
@@ -480,11 +492,11 @@ class FusedBNAct(torch.autograd.Function):
         mu = ca = cb = gs = None
         if site is not None:
             mu, ca, cb, gs = site.coefficients()
-        check(lib().vitta_bn_act_bwd_f32(_p(x), _p(z), _p(gz), _p(gx), _p(gres), _p(weight), _p(bias), _p(running_mean),
+        check(lib().vitta_bn_act_bwd_f32(_p(x), _p(z), _p(gz), _p(gz2), _p(gx), _p(gres), _p(weight), _p(bias), _p(running_mean),
                                          _p(running_var), eps, _p(mu), _p(ca), _p(cb), _p(gs), outer, c, hw, nsplit,
                                          int(relu), _p(partial), _p(dgamma), _p(dbeta), int(accumulate), _stream()),
               "vitta_bn_act_bwd_f32")
-        return gx, ret_gamma, ret_beta, None, None, None, gres, None, None
+        return gx, ret_gamma, ret_beta, None, None, None, gres, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -14,7 +14,7 @@ them), so nothing downstream may overwrite them.
 import torch
 import torch.nn as nn
 
-from .fused_bn import bn_act
+from .fused_bn import bn_act, identity_source
 
 
 def downsample_forward(downsample, x):
@@ -41,10 +41,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        identity = x if self.downsample is None else downsample_forward(self.downsample, x)
+        src = identity_source(x)
+        identity = src if self.downsample is None else downsample_forward(self.downsample, src)
         out = bn_act(self.bn1, self.conv1(x), relu=True, act=self.relu)
         out = bn_act(self.bn2, self.conv2(out), relu=True, act=self.relu)
-        return bn_act(self.bn3, self.conv3(out), residual=identity, relu=True, act=self.relu)
+        return bn_act(self.bn3, self.conv3(out), residual=identity, relu=True, act=self.relu, fork=True)
 
 
 class ResNet(nn.Module):

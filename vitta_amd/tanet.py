@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import resnet as _resnet
-from .fused_bn import bn_act
+from .fused_bn import bn_act, identity_source
 
 
 FUSED_TAM_BRANCHES = True  # tests flip this to compare the fused G/L kernels with the torch modules
@@ -100,11 +100,12 @@ class TemporalBottleneck(nn.Module):
 
     def forward(self, x):
         net = self.net
-        identity = x if net.downsample is None else _resnet.downsample_forward(net.downsample, x)
+        src = identity_source(x)
+        identity = src if net.downsample is None else _resnet.downsample_forward(net.downsample, src)
         out = bn_act(net.bn1, net.conv1(x), relu=True, act=net.relu)
         out = self.tam(out)
         out = bn_act(net.bn2, net.conv2(out), relu=True, act=net.relu)
-        return bn_act(net.bn3, net.conv3(out), residual=identity, relu=True, act=net.relu)
+        return bn_act(net.bn3, net.conv3(out), residual=identity, relu=True, act=net.relu, fork=True)
 
 
 def make_temporal_modeling(net, n_segment=8, t_kernel_size=3, t_stride=1, t_padding=1):
