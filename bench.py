@@ -15,8 +15,9 @@ wall time of the K timed steps (barrier + synchronize on both sides).
 Extra objects on the JSON line:
   roofline      the north-star kernel, moments_nchw_partial_kernel (one launch over all 29 hooked
                 layers): algorithmic bytes = 4 B x 44 556 288 hooked elements per video,
-                time = HIP events recorded on the launch stream around that kernel inside the timed
-                steps.  The hooked tensors were just written by the BN kernels and fit the 256 MiB
+                time = a hipEvent pair attached to that kernel's dispatch (hipExtLaunchKernelGGL via
+                vitta_moments_partials_timed_f32) in every timed step: the kernel's own duration, the
+                figure rocprofv3 --kernel-trace reports for the same launches.  The hooked tensors were just written by the BN kernels and fit the 256 MiB
                 Infinity Cache, so `achieved` is an on-die rate; `streaming` repeats the launch on
                 2.85 GB of features (16 videos' worth per layer) that cannot be cache resident.
   cpu_baseline  the CPU restatement of the reference path (oracle/: stock PyTorch CPU ops in the
@@ -56,7 +57,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=8)
     p.add_argument("--optimizer", default="adam_affine", choices=["adam_affine", "sgd_all"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=4)
+    p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--no-streaming", action="store_true")
     p.add_argument("--timed-only", action="store_true",
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
@@ -131,8 +132,10 @@ def run_gpu(opt, rank, world, device):
     # live timing of the moments kernel: one (start, stop) event pair per step, on the launch stream
     pairs = []
 
+    from vitta_amd import ops
+
     def new_events():
-        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        pair = ops.KernelEventPair()
         pairs.append(pair)
         return pair
 
@@ -211,7 +214,8 @@ def run_gpu(opt, rank, world, device):
         fused_bn.ENABLED = True
         log(f"eager repeat of the timed steps (kernel events): {eager_elapsed:.3f}s")
     adapter.engine.timing_events = None
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else float("nan")
+    torch.cuda.synchronize()
+    kern_ms = float(np.mean([p.elapsed_ms() for p in pairs])) if pairs else float("nan")
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -252,11 +256,11 @@ def streaming_moments(adapter, device, copies=16, reps=20):
     shift = torch.zeros(plan.total_channels, device=device)
     times = []
     for r in range(reps + 3):
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev = ops.KernelEventPair()
         plan.moments(feats, shift, events=ev)
         torch.cuda.synchronize()
         if r >= 3:
-            times.append(ev[0].elapsed_time(ev[1]))
+            times.append(ev.elapsed_ms())
     ms = float(np.mean(times))
     return dict(bytes=nbytes, ms=ms, achieved=nbytes / ms / 1e6, frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
                 workgroups=plan.num_blocks)

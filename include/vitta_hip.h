@@ -108,6 +108,15 @@ int vitta_moments_batched_f32(const vitta_plan* plan, const void* const* h_x, co
  * combine.  bench.py brackets the first with events to time the HBM-bound kernel alone. */
 int vitta_moments_partials_f32(const vitta_plan* plan, const void* const* h_x, void* d_workspace,
                                size_t workspace_bytes, void* stream);
+/* Measurement aid (bench.py's live roofline figure): the same first-stage launch with two hipEvents attached to the
+ * kernel's DISPATCH (hipExtLaunchKernelGGL), so that elapsed(start, stop) is the kernel's own duration -- what
+ * rocprofv3 --kernel-trace reports -- without the barrier packets and launch latency an event pair recorded
+ * around a lone launch also brackets.  Events come from vitta_event_create (plain hipEvent_t handles). */
+int vitta_moments_partials_timed_f32(const vitta_plan* plan, const void* const* h_x, void* d_ws, size_t ws_bytes,
+                                     void* stream, void* ev_start, void* ev_stop);
+int vitta_event_create(void** out_event);
+void vitta_event_destroy(void* event);
+int vitta_event_elapsed_ms(void* ev_start, void* ev_stop, float* out_ms); /* waits for ev_stop */
 int vitta_moments_finalize_f32(const vitta_plan* plan, const float* d_shift, float* d_cnt, float* d_s1,
                                float* d_s2, const void* d_workspace, size_t workspace_bytes, void* stream);
 

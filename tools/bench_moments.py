@@ -1,6 +1,5 @@
 """Micro-benchmark of the batched moments launch (GPU box): workgroup count, NT loads, in-cache vs streaming.
-Two timings per configuration: one event pair per launch (what bench.py reports; includes the event/dispatch
-overhead of a lone launch) and a back-to-back train of launches between one event pair (kernel time + launch gap)."""
+Two timings per configuration: one dispatch-attached event pair per launch (what bench.py reports) and a back-to-back train of launches between one event pair (kernel time + launch gap)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,11 +21,11 @@ def run(copies, target, nt, reps=30, train=40):
     shift = torch.zeros(plan.total_channels, device=dev)
     ts = []
     for r in range(reps + 5):
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev = ops.KernelEventPair()
         plan.moments(feats, shift, events=ev)
         torch.cuda.synchronize()
         if r >= 5:
-            ts.append(ev[0].elapsed_time(ev[1]))
+            ts.append(ev.elapsed_ms())
     ms = float(np.median(ts))
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()

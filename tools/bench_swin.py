@@ -19,6 +19,7 @@ p.add_argument("--size", type=int, default=224)
 p.add_argument("--frames", type=int, default=16)
 p.add_argument("--no-graph", action="store_true")
 p.add_argument("--sgd", action="store_true")
+p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
 dev = torch.device("cuda:0")
 tmp = tempfile.mkdtemp()
@@ -45,6 +46,9 @@ eval_set = data.build_videoswin_dataset(args, "val", "eval")
 
 def one(i):
     x, _ = tta_set[i % 8]
+    if not opt.sequential:
+        adapter.set_adapt_mode()
+        return adapter.step(x.unsqueeze(0), eval_set[(i - 1) % 8][0].unsqueeze(0))
     ev, _ = eval_set[i % 8]
     if adapter._graph is not None:
         adapter.adapt_step(x.unsqueeze(0))
@@ -61,7 +65,7 @@ for i in range(opt.warmup):
     one(i)
 torch.cuda.synchronize()
 if not opt.no_graph:
-    adapter.capture_graphs(tta_set[0][0].unsqueeze(0), eval_set[0][0].unsqueeze(0))
+    adapter.capture_graphs(tta_set[0][0].unsqueeze(0), eval_set[0][0].unsqueeze(0), overlap_eval=not opt.sequential)
     one(0)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -70,5 +74,5 @@ for i in range(opt.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
 print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph,
-                      frames=opt.frames, size=opt.size, optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
+                      frames=opt.frames, size=opt.size, schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

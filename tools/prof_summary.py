@@ -2,12 +2,15 @@
 a CSV like rocprofv3's kernel_stats: name, calls, total_us, avg_us, pct.  Kernel names are shortened.
 
     python tools/prof_summary.py gpurun_out/prof_r1/r1_results.db profiles/r1_kernel_stats.csv [last_ms]
+
+The moments kernels are listed per launch geometry ("name [grid=N workgroups]"): the same kernel serves the 29-layer
+batched launch of the step (2722 workgroups), the 16x streaming launch and 53 single-layer calibration launches, and
+one averaged line would describe none of them.  `--split-all` does that for every kernel.
 """
 import csv
 import re
 import sqlite3
 import sys
-
 
 def short(name, n=110):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
@@ -20,32 +23,46 @@ def short(name, n=110):
     return name[:n]
 
 
-def main(db_path, out_path, last_ms=None):
+def grid_expr(db):
+    cols = [r[1] for r in db.execute("PRAGMA table_info(kernels)")]
+    if "grid_x" in cols and "workgroup_x" in cols:
+        if "grid_y" in cols and "workgroup_y" in cols and "grid_z" in cols and "workgroup_z" in cols:
+            return "((grid_x / workgroup_x) * (grid_y / workgroup_y) * (grid_z / workgroup_z))", cols
+        return "(grid_x / workgroup_x)", cols
+    if "grid_size_x" in cols and "workgroup_size_x" in cols:
+        return "(grid_size_x / workgroup_size_x)", cols
+    if "grid_size" in cols and "workgroup_size" in cols:
+        return "(grid_size / workgroup_size)", cols
+    return None, cols
+
+
+def main(db_path, out_path, last_ms=None, split_all=False):
     db = sqlite3.connect(db_path)
-    if last_ms is None:
-        rows = list(db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-    else:
-        # steady state only: kernels that started in the last `last_ms` milliseconds of the trace (drops model
-        # construction, calibration and MIOpen's first-call solver warm-up, which runs naive reference convs)
-        t1 = db.execute("select max(end) from kernels").fetchone()[0]
-        raw = list(db.execute("select name, count(*), sum(duration)/1000.0 from kernels where start >= ? group by name",
-                              (t1 - int(last_ms * 1e6),)))
-        tot = sum(r[2] for r in raw) or 1.0
-        rows = [(n, c, d, d / c, 100.0 * d / tot) for n, c, d in raw]
+    gexpr, cols = grid_expr(db)
+    print("kernels view columns:", cols)
+    t1 = db.execute("select max(end) from kernels").fetchone()[0]
+    t0 = db.execute("select min(start) from kernels").fetchone()[0] if last_ms is None else t1 - int(last_ms * 1e6)
+    # last_ms: steady state only -- kernels that started in the last `last_ms` milliseconds of the trace (drops
+    # model construction, calibration and MIOpen's first-call solver warm-up, which runs naive reference convs)
+    raw = list(db.execute(f"select name, {gexpr or '0'}, count(*), sum(duration)/1000.0 from kernels where start >= ? "
+                          f"group by name, {gexpr or '0'}", (t0,)))
+    tot = sum(r[3] for r in raw) or 1.0
     agg = {}
-    for name, calls, total, avg, pct in rows:
+    for name, grid, calls, total in raw:
         k = short(name)
-        a = agg.setdefault(k, [0, 0.0, 0.0])
+        if gexpr and (split_all or "moments_" in name):
+            k = f"{k} [grid={int(grid)} workgroups]"
+        a = agg.setdefault(k, [0, 0.0])
         a[0] += calls
         a[1] += total
-        a[2] += pct
     with open(out_path, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "pct"])
-        for k, (calls, total, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            w.writerow([k, calls, f"{total:.1f}", f"{total / calls:.2f}", f"{pct:.2f}"])
-    print(f"wrote {out_path}: {len(agg)} kernels, {sum(a[1] for a in agg.values()) / 1e3:.1f} ms of GPU time")
+        for k, (calls, total) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, calls, f"{total:.1f}", f"{total / calls:.2f}", f"{100.0 * total / tot:.2f}"])
+    print(f"wrote {out_path}: {len(agg)} kernels, {tot / 1e3:.1f} ms of GPU time")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else None)
+    args = [a for a in sys.argv[1:] if a != "--split-all"]
+    main(args[0], args[1], float(args[2]) if len(args) > 2 else None, split_all="--split-all" in sys.argv)

@@ -69,6 +69,10 @@ SIGNATURES = {
     "vitta_wmsa_rel_bwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p,
                                          _p, _p, _p]),
     "vitta_wmsa_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    "vitta_moments_partials_timed_f32": (C.c_int, [_p, C.POINTER(_p), _p, _sz, _p, _p, _p]),
+    "vitta_event_create": (C.c_int, [C.POINTER(_p)]),
+    "vitta_event_destroy": (None, [_p]),
+    "vitta_event_elapsed_ms": (C.c_int, [_p, _p, C.POINTER(_f32)]),
     "vitta_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
     "vitta_sgd_step_f32": (C.c_int, [_p, _p, _p, _f32, _f32, _f32, _i64, _p]),
 }

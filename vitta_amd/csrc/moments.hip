@@ -20,6 +20,8 @@
 // walks over rows; ty-rows of the workgroup are merged through LDS.
 //
 // A tiny finalize kernel merges the per-workgroup triples in fp64.
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 #include <algorithm>
@@ -468,7 +470,11 @@ size_t vitta_plan_workspace_bytes(const vitta_plan* p) {
 }
 int64_t vitta_plan_num_blocks(const vitta_plan* p) { return p ? p->n_blocks_nchw + p->n_blocks_nhwc : -1; }
 
-static int launch_partials(const vitta_plan* p, const void* const* h_x, float* ws, hipStream_t st) {
+// ev_start / ev_stop (optional): hipEvents attached to the DISPATCH of the streaming kernel (hipExtLaunchKernelGGL):
+// they take the kernel's own begin / end timestamps, like a profiler, instead of bracketing it with barrier packets
+// (an event pair around a lone launch measured 50 us for a kernel rocprofv3 times at 40 us, r1j).
+static int launch_partials(const vitta_plan* p, const void* const* h_x, float* ws, hipStream_t st,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   if (!p->d_info) return VITTA_ERR_INVALID_ARG;  // vitta_plan_upload not called
   PtrPack pack;
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
@@ -478,7 +484,17 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     if (p->h_info[l].vec == 4 && (reinterpret_cast<uintptr_t>(x) & 15u)) return VITTA_ERR_INVALID_ARG;
     pack.x[l] = x;
   }
-  if (p->n_blocks_nchw) {
+  if (p->n_blocks_nchw && ev_start) {
+    (void)hipGetLastError();
+    if (p->nt_loads)
+      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<true>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
+                            ev_stop, 0, p->d_info, p->d_tab_nchw, pack, ws);
+    else
+      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<false>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
+                            ev_stop, 0, p->d_info, p->d_tab_nchw, pack, ws);
+    VITTA_CHECK_LAUNCH();
+    ev_start = ev_stop = nullptr;
+  } else if (p->n_blocks_nchw) {
     if (p->nt_loads)
       VITTA_LAUNCH(moments_nchw_partial_kernel<true>, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nchw, pack, ws);
@@ -487,7 +503,12 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
                    p->d_info, p->d_tab_nchw, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
-  if (p->n_blocks_nhwc) {
+  if (p->n_blocks_nhwc && ev_start) {  // channels-last plan (Swin): the events go to its kernel
+    (void)hipGetLastError();
+    hipExtLaunchKernelGGL(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start, ev_stop, 0,
+                          p->d_info, p->d_tab_nhwc, pack, ws);
+    VITTA_CHECK_LAUNCH();
+  } else if (p->n_blocks_nhwc) {
     VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
                        p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
@@ -500,6 +521,33 @@ int vitta_moments_partials_f32(const vitta_plan* p, const void* const* h_x, void
   if (!p || !h_x) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
   return launch_partials(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream));
+}
+
+int vitta_moments_partials_timed_f32(const vitta_plan* p, const void* const* h_x, void* d_ws, size_t ws_bytes,
+                                     void* stream, void* ev_start, void* ev_stop) {
+  if (!p || !h_x || !ev_start || !ev_stop) return VITTA_ERR_INVALID_ARG;
+  if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
+  return launch_partials(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream),
+                         static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
+}
+
+int vitta_event_create(void** out_event) {
+  if (!out_event) return VITTA_ERR_INVALID_ARG;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return VITTA_ERR_LAUNCH;
+  *out_event = e;
+  return VITTA_OK;
+}
+
+void vitta_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy(static_cast<hipEvent_t>(event));
+}
+
+int vitta_event_elapsed_ms(void* ev_start, void* ev_stop, float* out_ms) {
+  if (!ev_start || !ev_stop || !out_ms) return VITTA_ERR_INVALID_ARG;
+  if (hipEventSynchronize(static_cast<hipEvent_t>(ev_stop)) != hipSuccess) return VITTA_ERR_LAUNCH;
+  return hipEventElapsedTime(out_ms, static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)) == hipSuccess
+             ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
 int vitta_moments_finalize_f32(const vitta_plan* p, const float* d_shift, float* d_cnt, float* d_s1,

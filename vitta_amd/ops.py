@@ -193,8 +193,8 @@ class StatPlan:
 
     def moments(self, feats, shift=None, events=None):
         """feats: list of contiguous CUDA fp32 tensors (one per layer) -> fills cnt/s1/s2.
-        `events=(start, stop)`: torch.cuda.Events recorded on the launch stream around the streaming
-        (partials) kernel only -- bench.py's live kernel timing."""
+        `events`: a KernelEventPair attached to the dispatch of the streaming (partials) kernel -- bench.py's
+        live kernel timing."""
         if len(feats) != self.n_layers:
             raise ValueError("one feature per planned layer expected")
         for i, t in enumerate(feats):
@@ -210,10 +210,8 @@ class StatPlan:
                                                   _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
                   "vitta_moments_batched_f32")
         else:
-            events[0].record()
-            check(lib().vitta_moments_partials_f32(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream()),
-                  "vitta_moments_partials_f32")
-            events[1].record()
+            check(lib().vitta_moments_partials_timed_f32(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream(),
+                                                         events.start, events.stop), "vitta_moments_partials_timed_f32")
             check(lib().vitta_moments_finalize_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2),
                                                    _p(self.ws), self.ws_bytes, _stream()),
                   "vitta_moments_finalize_f32")
@@ -255,6 +253,29 @@ class StatPlan:
                                              _p(self.total_loss), _p(self.mu), _p(self.coef_a), _p(self.coef_b),
                                              _p(self.ws), self.ws_bytes, _stream()), "vitta_stat_align_fwd_f32")
         return self.total_loss, self.layer_loss
+
+
+class KernelEventPair:
+    """Two hipEvents the library attaches to ONE kernel dispatch (vitta_moments_partials_timed_f32): elapsed_ms()
+    is that kernel's own duration, the figure rocprofv3 --kernel-trace reports for the launch."""
+
+    def __init__(self):
+        a, b = C.c_void_p(), C.c_void_p()
+        check(lib().vitta_event_create(C.byref(a)), "vitta_event_create")
+        check(lib().vitta_event_create(C.byref(b)), "vitta_event_create")
+        self.start, self.stop = a, b
+
+    def elapsed_ms(self):
+        ms = C.c_float()
+        check(lib().vitta_event_elapsed_ms(self.start, self.stop, C.byref(ms)), "vitta_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            lib().vitta_event_destroy(self.start)
+            lib().vitta_event_destroy(self.stop)
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------------------------------------
