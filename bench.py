@@ -63,6 +63,8 @@ def parse():
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
                         "the tail of a rocprofv3 trace is the shipped hipGraph replay and nothing else")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo: rehearse the multi-rank code path with all ranks sharing one GPU (not a measurement)")
     p.add_argument("--sequential", action="store_true",
                    help="adapt(i); eval(i) back to back on one stream instead of eval(i-1) beside adapt(i)")
     p.add_argument("--segmented-graph", action="store_true",
@@ -298,11 +300,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if opt.dist_backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:  # rehearsal of the data-parallel path with several ranks on ONE GPU (RCCL refuses duplicate devices)
+            torch.distributed.init_process_group(opt.dist_backend)
     if opt.miopen_find:
         torch.backends.cudnn.benchmark = True
     # corpus/main_eval.py:77 sets cudnn.benchmark (an exhaustive MIOpen find on ROCm: minutes of search

@@ -35,6 +35,9 @@ BACKEND_FACTORY = None
 
 # tta_standard runs this many videos eagerly, then captures the step into hipGraphs (None: never)
 GRAPH_AFTER_STEPS = 3
+# hipStreamCaptureModeThreadLocal: other threads of the process (the RCCL watchdog of a data-parallel run, data-loader
+# pin-memory threads) may keep calling into the runtime while this thread captures
+CAPTURE_MODE = "thread_local"
 
 NUM_CLASSES = {"ucf101": 101, "hmdb51": 51, "kinetics": 400, "somethingv2": 174, "kth": 6, "u2h": 12, "h2u": 12}
 
@@ -494,7 +497,7 @@ class ViTTAAdapter:
         actual_bz = x.shape[0] // self.n_views if a.arch == "tanet" else x.shape[0]
         pool = torch.cuda.graph_pool_handle()
         g["seg_fwd"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["seg_fwd"], pool=pool):
+        with torch.cuda.graph(g["seg_fwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
             if overlap_eval:  # the evaluation of the previous video rides beside the adaptation forward
                 g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
             self.arena.zero_grad()
@@ -502,11 +505,11 @@ class ViTTAAdapter:
             if overlap_eval:
                 torch.cuda.current_stream().wait_stream(side)
         g["seg_bwd"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["seg_bwd"], pool=pool):
+        with torch.cuda.graph(g["seg_bwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
             loss_reg = self.engine.finish_global()
             self.total_loss(loss_reg, loss_consis).backward()
         g["seg_opt"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["seg_opt"], pool=pool):
+        with torch.cuda.graph(g["seg_opt"], pool=pool, capture_error_mode=CAPTURE_MODE):
             self.optimizer.step()
         g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
 
@@ -533,16 +536,16 @@ class ViTTAAdapter:
                 g["step"] = None  # step() replays the three segments
         elif overlap_eval:
             g["step"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["step"]):
+            with torch.cuda.graph(g["step"], capture_error_mode=CAPTURE_MODE):
                 g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
                 g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
         else:
             g["adapt"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["adapt"]):
+            with torch.cuda.graph(g["adapt"], capture_error_mode=CAPTURE_MODE):
                 g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True)
         self.close_hooks()
         g["eval"] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g["eval"]):
+        with torch.cuda.graph(g["eval"], capture_error_mode=CAPTURE_MODE):
             g["eval_out"] = self._evaluate_eager(g["eval_in"])
         self.add_hooks_back()
         torch.cuda.synchronize()
