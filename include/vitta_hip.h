@@ -277,14 +277,21 @@ int vitta_plan_layer_geometry(const vitta_plan* plan, int layer, int64_t* out5);
  * token coordinates; code[t] = (t_d*(2wh-1) + t_h)*(2ww-1) + t_w) and the shift mask is -100 where
  * region[b % nW][q] != region[b % nW][k] (swin_transformer.py:316-329).  No [N x N] operand exists.
  *   d_table [T, nH] (the module's parameter as stored), T <= 4096; d_code int32 [N];
- *   d_region int32 [nW, N] or NULL; d_dtable [T, nH] or NULL (accumulated: zero it first). */
+ *   d_region int32 [nW, N] or NULL; d_dtable [T, nH] or NULL (accumulated: zero it first).
+ *   d_rowmap int32 [map_windows, N] or NULL.  NULL: window b, token n is row b*N + n of qkv / out / dqkv (the
+ *   partitioned layout of swin_transformer.py:233).  Otherwise it is row (b / map_windows)*tokens_per_sample +
+ *   rowmap[b % map_windows][n] of the natural [B, D*H*W] token order: torch.roll + window_partition and their
+ *   inverses (swin_transformer.py:222-243) become address arithmetic (qkv / proj are per token and commute with
+ *   the permutation); tokens_per_sample == map_windows * N (no padding). */
 int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code,
                            int32_t code_off, const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH,
-                           int32_t head_dim, float scale, float* d_out, float* d_lse, void* stream);
+                           int32_t head_dim, float scale, const int32_t* d_rowmap, int32_t map_windows,
+                           int64_t tokens_per_sample, float* d_out, float* d_lse, void* stream);
 int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code,
                            int32_t code_off, const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH,
-                           int32_t head_dim, float scale, const float* d_out, const float* d_dout,
-                           const float* d_lse, float* d_delta, float* d_dqkv, float* d_dtable, void* stream);
+                           int32_t head_dim, float scale, const int32_t* d_rowmap, int32_t map_windows,
+                           int64_t tokens_per_sample, const float* d_out, const float* d_dout, const float* d_lse,
+                           float* d_delta, float* d_dqkv, float* d_dtable, void* stream);
 
 /* --------------------------------------------------------------------------
  * A7 -- optimizer update on the flat parameter arena, one launch.

@@ -386,3 +386,27 @@ def test_tta_loop_overlapped_schedule_logs_the_same_run_on_gpu(tmp_path):
             spread = abs(rows_s[i][k] - rows_s2[i][k])
             assert abs(rows_o[i][k] - rows_s[i][k]) <= max(4 * spread, rel * abs(rows_s[i][k]) + floor), (i, k)
     assert abs(acc_o[0] - acc_s[0]) <= max(abs(acc_s[0] - acc_s2[0]), 100.0 / 8 + 1e-6)
+
+
+def test_swin_row_mapped_attention_equals_roll_and_partition_copies_on_gpu():
+    """Whole Swin-B forward + backward (224^2 and a 112^2 input, whose stage-3 windows clamp): shift + window
+    partition folded into the attention kernel's addressing (natural token order end to end) vs torch.roll +
+    window_partition / window_reverse copies around the same kernel."""
+    from vitta_amd import swin
+    model = H.build_swin(11, 0).to(_dev())
+    for size in (224, 112):
+        x = H.seeded_randn((1, 2, 3, 16, size, size), 31).to(_dev())
+        outs = []
+        for mapped in (True, False):
+            swin.FUSED_PARTITION = mapped
+            model.zero_grad()
+            vid, view = model(x)
+            view.square().sum().backward()
+            outs.append((view.detach().cpu(), model.backbone.layers[2].blocks[3].attn.qkv.weight.grad.cpu().clone(),
+                         model.backbone.layers[0].blocks[1].attn.relative_position_bias_table.grad.cpu().clone(),
+                         model.backbone.layers[1].blocks[1].norm1.weight.grad.cpu().clone(),
+                         model.backbone.patch_embed.proj.weight.grad.cpu().clone()))
+        swin.FUSED_PARTITION = True
+        assert_logits_close(outs[0][0], outs[1][0], 1e-4)
+        for a, b in zip(outs[0][1:], outs[1][1:]):
+            assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-9

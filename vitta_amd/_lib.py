@@ -65,9 +65,10 @@ SIGNATURES = {
     "vitta_plan_layer_geometry": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "vitta_wmsa_supported": (C.c_int, [_i32, _i32]),
     "vitta_wmsa_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p]),
-    "vitta_wmsa_rel_fwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p]),
-    "vitta_wmsa_rel_bwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p,
+    "vitta_wmsa_rel_fwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _i32, _i64,
                                          _p, _p, _p]),
+    "vitta_wmsa_rel_bwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _i32, _i64,
+                                         _p, _p, _p, _p, _p, _p, _p]),
     "vitta_wmsa_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "vitta_moments_partials_timed_f32": (C.c_int, [_p, C.POINTER(_p), _p, _sz, _p, _p, _p]),
     "vitta_event_create": (C.c_int, [C.POINTER(_p)]),

@@ -8,7 +8,11 @@
 // 4 accumulators), nothing of size N x N ever reaches HBM.  fp32 in / fp32 accumulate on
 // v_mfma_f32_16x16x4_f32 (exact f32, the reference is fp32 end to end).
 //
-// Layouts: qkv [B_, N, 3, nH, 32] exactly as the qkv Linear writes it; out [B_, N, nH*32] as the proj
+// Token rows: window b, token n lives at row b*N + n of qkv / out (the reference's partitioned layout), or -- with a
+// row map -- at row (b / nWm)*L + rowmap[b % nWm][n] of the NATURAL [B, D*H*W] token order: the cyclic shift and the
+// window partition of swin_transformer.py:222-243 (and their inverses) become address arithmetic, the four copies
+// per shifted block disappear (qkv / proj are per-token, so they commute with the permutation).
+// Layouts: qkv [rows, 3, nH, 32] exactly as the qkv Linear writes it; out [B_, N, nH*32] as the proj
 // Linear reads it (the reference's reshape/permute/transpose copies disappear); bias [nH, N, N];
 // mask [nW, N, N] or null (window b uses mask[b % nW]); lse [B_, nH, N] = row max + log row sum.
 //
@@ -39,7 +43,7 @@ __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
 // 4 x 16 B per lane are in flight (a load->store loop serialises on every HBM/L2 round trip; the staging of the
 // two 50 KB operands was longer than the MFMA work of a workgroup at the late stages).
 __device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const float* __restrict__ src_base,
-                                                 int64_t row_stride, int N, int nt) {
+                                                 int64_t row_stride, int N, int nt, const int* __restrict__ rows) {
   const int total = 16 * nt * (HD / 4);
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * WMSA_THREADS) {
     float4 v[4];
@@ -48,7 +52,7 @@ __device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const 
       const int i = i0 + u * WMSA_THREADS;
       const int row = i / (HD / 4), c4 = i % (HD / 4);
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src_base + row * row_stride + 4 * c4);
+      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src_base + (int64_t)rows[row] * row_stride + 4 * c4);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -58,11 +62,25 @@ __device__ __forceinline__ void stage_rows_dense(float* __restrict__ dst, const 
   }
 }
 
-// rows of one of q/k/v (sel) of (b, h): qkv is [B_, N, 3, nH, 32]
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ qkv, int64_t b, int h,
-                                           int sel, int N, int nH, int nt) {
+// rows of one of q/k/v (sel) of head h: qkv is [rows, 3, nH, 32]
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float* __restrict__ qkv, int h, int sel, int N,
+                                           int nH, int nt, const int* __restrict__ rows) {
   const int64_t rs = 3 * (int64_t)nH * HD;  // floats per token
-  stage_rows_dense(dst, qkv + b * N * rs + (int64_t)sel * nH * HD + (int64_t)h * HD, rs, N, nt);
+  stage_rows_dense(dst, qkv + (int64_t)sel * nH * HD + (int64_t)h * HD, rs, N, nt, rows);
+}
+
+// where the tokens of window b live (see the header): rows[n] for n < 16*nt (clamped past N), then a barrier
+struct RowMap {
+  const int* map;  // [nWm, N] sample-local rows, or null
+  int nWm;
+  int64_t L;       // tokens per sample
+};
+__device__ __forceinline__ void fill_rows(int* __restrict__ rows, const RowMap& rm, int64_t b, int N, int nt) {
+  for (int i = threadIdx.x; i < 16 * nt; i += blockDim.x) {
+    const int n = i < N ? i : N - 1;
+    rows[i] = rm.map ? (int)((b / rm.nWm) * rm.L + rm.map[(b % rm.nWm) * (int64_t)N + n]) : (int)(b * N + n);
+  }
+  __syncthreads();
 }
 
 // 8 contiguous floats of a row (d = 8*kk .. 8*kk+7)
@@ -149,7 +167,7 @@ __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, con
 
 // LDS carve shared by the three kernels: [buf0 | buf1 | extra floats | tab | code | region]
 struct Carve {
-  float* buf0; float* buf1; float* extra; float* tab; int* code; int* region;
+  float* buf0; float* buf1; float* extra; float* tab; int* code; int* region; int* rows;
 };
 __device__ __forceinline__ Carve carve(float* smem, int nt, int extra_floats, int T) {
   Carve c;
@@ -159,6 +177,7 @@ __device__ __forceinline__ Carve carve(float* smem, int nt, int extra_floats, in
   c.tab = c.extra + extra_floats;
   c.code = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
   c.region = c.code + 16 * nt;
+  c.rows = c.region + 16 * nt;
   return c;
 }
 
@@ -193,23 +212,26 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
                                                                 const int* __restrict__ code_g,
                                                                 const int* __restrict__ region_g, int T, int off,
                                                                 int nW, int N, int nH, float scale, int qsplit,
-                                                                float* __restrict__ out, float* __restrict__ lse) {
+                                                                RowMap rm, float* __restrict__ out,
+                                                                float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
   const Carve cv = carve(smem, nt, 0, T);
   float* k_lds = cv.buf0;                   // [16*nt][KPAD]
   float* v_lds = cv.buf1;                   // [16*nt][KPAD]
+  const int* rows = cv.rows;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
-  stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
-  stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  fill_rows(cv.rows, rm, b, N, nt);
+  stage_rows(k_lds, qkv, h, 1, N, nH, nt, rows);
+  stage_rows(v_lds, qkv, h, 2, N, nH, nt, rows);
   const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 15, kk = lane >> 4;
   const int64_t rs = 3 * (int64_t)nH * HD;
-  const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
+  const float* q_base = qkv + (int64_t)h * HD;
   const int C = nH * HD;
 
   // row tiles of this workgroup: [rt0, rt1) of the nt tiles, split over `qsplit` workgroups
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
   for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
     const int q = min(16 * rt + i, N - 1);  // clamped: rows >= N are computed but never stored
     float qf[8];
-    load8(qf, q_base + q * rs + 8 * kk);
+    load8(qf, q_base + (int64_t)rows[q] * rs + 8 * kk);
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] *= scale;
 
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
       const int qrow = 16 * rt + 4 * kk + r;
       const float il = __shfl(inv_l, 4 * kk + r, 64);
       if (qrow < N) {
-        float* o = out + (b * N + qrow) * C + h * HD;
+        float* o = out + (int64_t)rows[qrow] * C + h * HD;
         o[i] = o0[r] * il;
         o[16 + i] = o1[r] * il;
       }
@@ -285,7 +307,7 @@ template <bool REL>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
     const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
     const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
-    float scale, int qsplit, const float* __restrict__ out, const float* __restrict__ dout,
+    float scale, int qsplit, RowMap rm, const float* __restrict__ out, const float* __restrict__ dout,
     const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
@@ -295,10 +317,12 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   float* k_lds = cv.buf0;
   float* v_lds = cv.buf1;
   float* dtab = cv.extra;
+  const int* rows = cv.rows;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
-  stage_rows(k_lds, qkv, b, h, 1, N, nH, nt);
-  stage_rows(v_lds, qkv, b, h, 2, N, nH, nt);
+  fill_rows(cv.rows, rm, b, N, nt);
+  stage_rows(k_lds, qkv, h, 1, N, nH, nt, rows);
+  stage_rows(v_lds, qkv, h, 2, N, nH, nt, rows);
   const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   if (REL && dbias)
     for (int i = threadIdx.x; i < T; i += WMSA_THREADS) dtab[i] = 0.f;
@@ -308,16 +332,16 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   const int i = lane & 15, kk = lane >> 4;
   const int64_t rs = 3 * (int64_t)nH * HD;
   const int C = nH * HD;
-  const float* q_base = qkv + b * N * rs + (int64_t)h * HD;
+  const float* q_base = qkv + (int64_t)h * HD;
   const int per = (nt + qsplit - 1) / qsplit;
   const int rt0 = blockIdx.x * per, rt1 = min(nt, rt0 + per);
   for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
     const bool qvalid = 16 * rt + i < N;
     const int q = min(16 * rt + i, N - 1);
     float qf[8], gf[8], of[8];
-    load8(qf, q_base + q * rs + 8 * kk);
-    load8(gf, dout + (b * N + q) * C + h * HD + 8 * kk);
-    load8(of, out + (b * N + q) * C + h * HD + 8 * kk);
+    load8(qf, q_base + (int64_t)rows[q] * rs + 8 * kk);
+    load8(gf, dout + (int64_t)rows[q] * C + h * HD + 8 * kk);
+    load8(of, out + (int64_t)rows[q] * C + h * HD + 8 * kk);
     float dl = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
     for (int r = 0; r < 4; ++r) {
       const int qrow = 16 * rt + 4 * kk + r;
       if (qrow < N) {
-        float* o = dqkv + (b * N + qrow) * rs + (int64_t)h * HD;  // sel 0 = q
+        float* o = dqkv + (int64_t)rows[qrow] * rs + (int64_t)h * HD;  // sel 0 = q
         o[i] = dq0[r] * scale;
         o[16 + i] = dq1[r] * scale;
       }
@@ -389,7 +413,7 @@ template <bool REL>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
     const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
-    float scale, int qsplit, const float* __restrict__ dout, const float* __restrict__ lse,
+    float scale, int qsplit, RowMap rm, const float* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta, float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
@@ -401,8 +425,10 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int C = nH * HD;
-  stage_rows(q_lds, qkv, b, h, 0, N, nH, nt);
-  stage_rows_dense(g_lds, dout + b * N * C + h * HD, C, N, nt);
+  const int* rows = cv.rows;
+  fill_rows(cv.rows, rm, b, N, nt);
+  stage_rows(q_lds, qkv, h, 0, N, nH, nt, rows);
+  stage_rows_dense(g_lds, dout + h * HD, C, N, nt, rows);
   const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   for (int r = threadIdx.x; r < 16 * nt; r += WMSA_THREADS) {
     l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
@@ -413,16 +439,16 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = lane & 15, kk = lane >> 4;
   const int64_t rs = 3 * (int64_t)nH * HD;
-  const float* k_base = qkv + b * N * rs + (int64_t)(nH + h) * HD;
-  const float* v_base = qkv + b * N * rs + (int64_t)(2 * nH + h) * HD;
+  const float* k_base = qkv + (int64_t)(nH + h) * HD;
+  const float* v_base = qkv + (int64_t)(2 * nH + h) * HD;
   const int per = (nt + qsplit - 1) / qsplit;
   const int kt0 = blockIdx.x * per, kt1 = min(nt, kt0 + per);
   for (int kt = kt0 + wave; kt < kt1; kt += WMSA_WAVES) {
     const int key = min(16 * kt + i, N - 1);
     const bool kvalid = 16 * kt + i < N;
     float kf[8], vf[8];
-    load8(kf, k_base + key * rs + 8 * kk);
-    load8(vf, v_base + key * rs + 8 * kk);
+    load8(kf, k_base + (int64_t)rows[key] * rs + 8 * kk);
+    load8(vf, v_base + (int64_t)rows[key] * rs + 8 * kk);
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
     for (int qt = 0; qt < nt; ++qt) {
       // S tile [query][key]: A = Q tile (LDS), B = K^T (registers); C layout: col = key i, row = query 4kk + r
@@ -459,8 +485,8 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
     for (int r = 0; r < 4; ++r) {
       const int krow = 16 * kt + 4 * kk + r;
       if (krow < N) {
-        float* ok = dqkv + (b * N + krow) * rs + (int64_t)(nH + h) * HD;
-        float* ov = dqkv + (b * N + krow) * rs + (int64_t)(2 * nH + h) * HD;
+        float* ok = dqkv + (int64_t)rows[krow] * rs + (int64_t)(nH + h) * HD;
+        float* ov = dqkv + (int64_t)rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
         ok[i] = dk0[r] * scale;
         ok[16 + i] = dk1[r] * scale;
         ov[i] = dv0[r];
@@ -483,12 +509,13 @@ constexpr int T_MAX = 4096;  // (2wd-1)(2wh-1)(2ww-1): 2535 for the (8,7,7) wind
 
 inline size_t lds_bytes(int N, int extra_floats, int T) {
   const int nt = (N + 15) / 16;
-  return sizeof(float) * ((size_t)2 * 16 * nt * KPAD + extra_floats + ((T + 3) & ~3) + 2 * 16 * nt);
+  return sizeof(float) * ((size_t)2 * 16 * nt * KPAD + extra_floats + ((T + 3) & ~3) + 3 * 16 * nt);
 }
 
 struct WmsaArgs {
   const float* qkv; const float* bias; const float* mask; const int* code; const int* region;
   int T, off, nW; int64_t B_; int N, nH; float scale;
+  RowMap rm;
 };
 
 template <bool REL>
@@ -500,7 +527,7 @@ int launch_fwd(const WmsaArgs& a, float* out, float* lse, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return VITTA_ERR_LAUNCH;
   VITTA_LAUNCH(wmsa_fwd_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds, st, a.qkv, a.bias, a.mask,
-               a.code, a.region, REL ? a.T : 0, a.off, a.nW, a.N, a.nH, a.scale, qs, out, lse);
+               a.code, a.region, REL ? a.T : 0, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, lse);
   return VITTA_OK;
 }
 
@@ -517,9 +544,9 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
     return VITTA_ERR_LAUNCH;
   VITTA_LAUNCH(wmsa_bwd_dq_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, a.mask,
-               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, out, dout, lse, delta, dqkv, dbias);
+               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dbias);
   VITTA_LAUNCH(wmsa_bwd_dkv_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, a.mask,
-               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, dout, lse, delta, dqkv);
+               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, dout, lse, delta, dqkv);
   return VITTA_OK;
 }
 
@@ -540,7 +567,7 @@ int vitta_wmsa_fwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out, d_bias, d_mask)) return VITTA_ERR_INVALID_ARG;
-  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale};
+  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale, RowMap{nullptr, 1, 0}};
   return launch_fwd<false>(a, d_out, d_lse, static_cast<hipStream_t>(stream));
 }
 
@@ -552,33 +579,41 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_mask && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out, d_dout, d_dqkv) || misaligned(d_bias, d_mask)) return VITTA_ERR_INVALID_ARG;
-  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale};
+  const WmsaArgs a{d_qkv, d_bias, d_mask, nullptr, nullptr, 0, 0, d_mask ? nW : 1, B_, N, nH, scale, RowMap{nullptr, 1, 0}};
   return launch_bwd<false>(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dbias, static_cast<hipStream_t>(stream));
 }
 
 int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
-                           float scale, float* d_out, float* d_lse, void* stream) {
+                           float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                           float* d_out, float* d_lse, void* stream) {
   if (!d_qkv || !d_table || !d_code || !d_out || !d_lse || B_ <= 0 || nH <= 0 || T <= 0 || T > T_MAX)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if (d_rowmap && (map_windows <= 0 || B_ % map_windows || tokens_per_sample != (int64_t)map_windows * N))
+    return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
-  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale};
+  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
+                   RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
   return launch_fwd<true>(a, d_out, d_lse, static_cast<hipStream_t>(stream));
 }
 
 int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
-                           float scale, const float* d_out, const float* d_dout, const float* d_lse, float* d_delta,
+                           float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                           const float* d_out, const float* d_dout, const float* d_lse, float* d_delta,
                            float* d_dqkv, float* d_dtable, void* stream) {
   if (!d_qkv || !d_table || !d_code || !d_out || !d_dout || !d_lse || !d_delta || !d_dqkv || B_ <= 0 || nH <= 0 ||
       T <= 0 || T > T_MAX)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
   if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
+  if (d_rowmap && (map_windows <= 0 || B_ % map_windows || tokens_per_sample != (int64_t)map_windows * N))
+    return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
-  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale};
+  const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
+                   RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
   return launch_bwd<true>(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dtable, static_cast<hipStream_t>(stream));
 }
 

@@ -404,38 +404,51 @@ class WindowAttention(torch.autograd.Function):
 
 class WindowAttentionRel(torch.autograd.Function):
     """WindowAttention with the relative-position bias looked up from the [T, nH] table and the shift
-    mask derived from region ids inside the kernel (nothing of size N x N in memory)."""
+    mask derived from region ids inside the kernel (nothing of size N x N in memory).
+
+    `rowmap` None: qkv (B_, N, 3C) in the partitioned layout -> (B_, N, C).
+    `rowmap` int32 (nW, N): qkv (B, L, 3C) in the NATURAL token order, L = nW * N; window w of sample s gathers its
+    tokens at rows s*L + rowmap[w] and scatters its output to the same rows -> (B, L, C): the cyclic shift and the
+    window partition / reverse never touch memory."""
 
     @staticmethod
-    def forward(ctx, qkv, table, code, code_off, region, scale, num_heads):
+    def forward(ctx, qkv, table, code, code_off, region, scale, num_heads, rowmap=None):
         _require_cuda_f32(qkv, "qkv")
         qkv, table = qkv.contiguous(), table.contiguous()
-        b_, n, c3 = qkv.shape
-        c = c3 // 3
+        c = qkv.shape[-1] // 3
         hd = c // num_heads
-        out = torch.empty(b_, n, c, dtype=torch.float32, device=qkv.device)
+        if rowmap is None:
+            b_, n, _ = qkv.shape
+            nwm, tokens = 1, 0
+            out = torch.empty(b_, n, c, dtype=torch.float32, device=qkv.device)
+        else:
+            bsz, tokens, _ = qkv.shape
+            nwm, n = rowmap.shape
+            if tokens != nwm * n or rowmap.dtype != torch.int32 or not rowmap.is_contiguous():
+                raise ValueError("rowmap must be a contiguous int32 [nW, N] with nW * N tokens per sample")
+            b_ = bsz * nwm
+            out = torch.empty(bsz, tokens, c, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
         nw = region.shape[0] if region is not None else 1
         check(lib().vitta_wmsa_rel_fwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
-                                           b_, n, num_heads, hd, float(scale), _p(out), _p(lse), _stream()),
-              "vitta_wmsa_rel_fwd_f32")
-        ctx.save_for_backward(qkv, table, code, region, out, lse)
-        ctx.meta = (int(code_off), float(scale), num_heads, hd, nw)
+                                           b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
+                                           _stream()), "vitta_wmsa_rel_fwd_f32")
+        ctx.save_for_backward(qkv, table, code, region, rowmap, out, lse)
+        ctx.meta = (int(code_off), float(scale), num_heads, hd, nw, b_, n, nwm, tokens)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, table, code, region, out, lse = ctx.saved_tensors
-        off, scale, nh, hd, nw = ctx.meta
-        b_, n, _ = qkv.shape
+        qkv, table, code, region, rowmap, out, lse = ctx.saved_tensors
+        off, scale, nh, hd, nw, b_, n, nwm, tokens = ctx.meta
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        dtable = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         check(lib().vitta_wmsa_rel_bwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
-                                           hd, scale, _p(out), _p(dout), _p(lse), _p(delta), _p(dqkv), _p(dtable),
-                                           _stream()), "vitta_wmsa_rel_bwd_f32")
-        return dqkv, dtable, None, None, None, None, None
+                                           hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
+                                           _p(dqkv), _p(dtable), _stream()), "vitta_wmsa_rel_bwd_f32")
+        return dqkv, r_table, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

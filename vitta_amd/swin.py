@@ -109,6 +109,18 @@ def compute_region(D, H, W, window_size, shift_size, device):
     return window_partition(region.view(1, D, H, W, 1), window_size).squeeze(-1).to(torch.int32).contiguous().to(device)
 
 
+@lru_cache()
+def compute_rowmap(D, H, W, window_size, shift_size, device):
+    """(nW, N) int32: natural row d*H*W + h*W + w of token n of window w, after the cyclic shift by -shift_size and
+    the window partition (swin_transformer.py:222-233).  window_reverse + the inverse roll send window outputs back
+    to exactly these rows, so the fused attention kernel gathers and scatters through this map and the activations
+    never leave their natural order."""
+    idx = torch.arange(D * H * W).view(1, D, H, W, 1)
+    if any(s > 0 for s in shift_size):
+        idx = torch.roll(idx, shifts=tuple(-s for s in shift_size), dims=(1, 2, 3))
+    return window_partition(idx, window_size).squeeze(-1).to(torch.int32).contiguous().to(device)
+
+
 def relative_position_code(window_size):
     """code[t] with relative_position_index[q, k] == code[q] - code[k] + offset (the index is linear in
     the token coordinates): lets a kernel index the bias table without any (N, N) operand."""
@@ -129,6 +141,7 @@ def relative_position_index(window_size):
 
 
 FUSED_ATTENTION = True  # tests flip this to compare the fused kernel with the composed ops on the GPU
+FUSED_PARTITION = True  # ... and this to compare the row-mapped kernel with roll + window_partition copies
 
 
 def window_attention(qkv, bias, mask, scale, num_heads):
@@ -212,6 +225,18 @@ class SwinTransformerBlock3D(nn.Module):
             x = F.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
         Dp, Hp, Wp = D + pad[0], H + pad[1], W + pad[2]
         shifted = any(s > 0 for s in ss)
+        attn = self.attn
+        n_tok = ws[0] * ws[1] * ws[2]
+        if (x.is_cuda and FUSED_ATTENTION and FUSED_PARTITION and not any(pad) and (not shifted or region is not None)
+                and attn.relative_position_bias_table.shape[0] <= 4096):
+            from . import ops
+            if ops.wmsa_supported(n_tok, C // attn.num_heads):
+                # shift + partition + reverse + inverse shift as address arithmetic inside the attention kernel
+                rowmap = compute_rowmap(D, H, W, ws, ss, x.device)
+                out = ops.WindowAttentionRel.apply(attn.qkv(x.view(B, D * H * W, C)), attn.relative_position_bias_table,
+                                                   attn.relative_position_code[:n_tok], attn.code_offset,
+                                                   region if shifted else None, attn.scale, attn.num_heads, rowmap)
+                return attn.proj_drop(attn.proj(out)).view(B, D, H, W, C)
         if shifted:
             x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
         windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None,
