@@ -309,6 +309,14 @@ int vitta_adam_step_f32(float* d_param, const float* d_grad, float* d_exp_avg, f
 int vitta_sgd_step_f32(float* d_param, const float* d_grad, float* d_momentum_buf, float lr, float momentum,
                        float weight_decay, int64_t n, void* stream);
 
+/* --------------------------------------------------------------------------
+ * A10 -- residual update with per-sample stochastic depth (Video Swin blocks, swin_transformer.py:268-275 with timm's
+ * DropPath): out[b] = x[b] + scale[b] * branch[b], one pass.  d_scale [samples] device array or NULL (= 1);
+ * d_x NULL: out[b] = scale[b] * branch[b] (the backward of the branch).  per_sample % 4 == 0, 16-byte aligned.
+ * -------------------------------------------------------------------------- */
+int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_scale, int64_t samples,
+                        int64_t per_sample, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -542,3 +542,30 @@ def test_fused_bn_act_forked_output_sums_both_gradients():
         fused_bn.ENABLED = True
         for a, b in zip(*res):
             assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
+
+
+def test_residual_drop_path_one_pass_equals_torch_ops():
+    """ops.ResidualDropPath (x + scale_b * branch, vitta_scale_add_f32) == x + branch * mask of timm's DropPath,
+    forward and both gradients, with and without a scale; and the batched mask draw feeds each module's two uses."""
+    from vitta_amd import ops, swin
+    torch.manual_seed(4)
+    x0 = torch.randn(3, 4, 7, 7, 32, device=_dev())
+    b0 = torch.randn_like(x0)
+    gout = torch.randn_like(x0)
+    for scale in (torch.tensor([0.0, 1.25, 1.25], device=_dev()), None):
+        x, b = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        out = ops.ResidualDropPath.apply(x, b, scale)
+        out.backward(gout)
+        xr, br = x0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        ref = xr + (br * scale.view(3, 1, 1, 1, 1) if scale is not None else br)
+        ref.backward(gout)
+        torch.testing.assert_close(out.detach(), ref.detach(), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(x.grad, xr.grad, rtol=0, atol=0)
+        torch.testing.assert_close(b.grad, br.grad, rtol=1e-6, atol=1e-6)
+    mods = [swin.DropPath(0.2).train(), swin.DropPath(0.0).train(), swin.DropPath(0.5).train()]
+    swin.draw_drop_path_masks(mods, 64, _dev())
+    assert len(mods[0]._next) == 2 and len(mods[2]._next) == 2 and not getattr(mods[1], "_next", None)
+    m0 = mods[0].sample(64, _dev())
+    assert set(m0.unique().tolist()) <= {0.0, 1.25} and len(mods[0]._next) == 1
+    m2 = mods[2].sample(64, _dev())
+    assert set(m2.unique().tolist()) <= {0.0, 2.0}

@@ -296,6 +296,7 @@ def _grad_sink(param, needed, zero=True):
     g = param.grad
     if (DIRECT_PARAM_GRAD and param.is_leaf and g is not None and g.dtype == torch.float32 and g.is_contiguous()
             and g.device == param.device and g.shape == param.shape):
+        param._vitta_direct_grad = True  # tta.FlatArena keeps the live view attached for this parameter
         return g, None
     buf = torch.zeros_like(param, memory_format=torch.contiguous_format) if zero \
         else torch.empty_like(param, memory_format=torch.contiguous_format)
@@ -608,3 +609,30 @@ class TamFused(torch.autograd.Function):
               "vitta_tam_branch_bwd_f32")
         check(lib().vitta_tam_pool_bwd_f32(_p(gbuf), n, t, c, hw, _p(gx), st), "vitta_tam_pool_bwd_f32")
         return (gx, None, r_wg1, r_gw, r_gb, r_wg3, r_w0, r_lw, r_lb, r_w3, None, None, None, None, None, None)
+
+
+class ResidualDropPath(torch.autograd.Function):
+    """out = x + scale_b * branch in one pass (scale: one value per sample on the device, bernoulli(keep)/keep of
+    timm's DropPath; None = 1).  Backward: dx = g (the same tensor), dbranch = scale_b * g."""
+
+    @staticmethod
+    def forward(ctx, x, branch, scale):
+        _require_cuda_f32(x, "x")
+        x, branch = x.contiguous(), branch.contiguous()
+        out = torch.empty_like(x)
+        b = x.shape[0]
+        check(lib().vitta_scale_add_f32(_p(x), _p(branch), _p(scale), b, x.numel() // b, _p(out), _stream()),
+              "vitta_scale_add_f32")
+        ctx.save_for_backward(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        if scale is None:
+            return g, g, None
+        g = g.contiguous()
+        gb = torch.empty_like(g)
+        b = g.shape[0]
+        check(lib().vitta_scale_add_f32(None, _p(g), _p(scale), b, g.numel() // b, _p(gb), _stream()), "vitta_scale_add_f32")
+        return g, gb, None

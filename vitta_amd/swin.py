@@ -31,14 +31,63 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
 
-    def forward(self, x):
-        if self.drop_prob == 0.0 or not self.training:
-            return x
+    def active(self):
+        return self.drop_prob > 0.0 and self.training
+
+    def sample(self, batch, device):
+        """Per-sample scale bernoulli(keep)/keep, shape (batch,).  SwinTransformer3D.forward draws the masks of all
+        its DropPath modules in ONE launch and parks each module's row in `_next`; stand-alone use draws here."""
+        queue = getattr(self, "_next", None)
+        if queue:
+            mask = queue.pop(0)
+            if mask.shape[0] == batch and mask.device == device:
+                return mask
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        mask = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
-        return x * mask
+        return mask
+
+    def forward(self, x):
+        if not self.active():
+            return x
+        return x * self.sample(x.shape[0], x.device).view((x.shape[0],) + (1,) * (x.ndim - 1))
+
+
+_DP_CACHE = {}
+
+
+def draw_drop_path_masks(modules, batch, device, uses=2):
+    """One bernoulli + one scale launch for all DropPath modules of a forward (instead of two per use); a block
+    applies its module `uses` times (attention and MLP residual).  The keep probabilities live on the device
+    (cached per configuration: no host-to-device copy inside a captured graph)."""
+    mods = [m for m in modules if isinstance(m, DropPath) and m.active() for _ in range(uses)]
+    for m in mods:
+        m._next = []
+    if not mods:
+        return
+    key = (tuple((m.drop_prob, m.scale_by_keep) for m in mods), batch, str(device))
+    if key not in _DP_CACHE:
+        keep = torch.tensor([1.0 - m.drop_prob for m in mods], dtype=torch.float32).clamp_(min=0.0)
+        scale = torch.tensor([1.0 / k if (k > 0 and m.scale_by_keep) else 1.0 for k, m in zip(keep.tolist(), mods)],
+                             dtype=torch.float32)
+        _DP_CACHE[key] = (keep.unsqueeze(1).expand(len(mods), batch).contiguous().to(device), scale.unsqueeze(1).to(device))
+    keep_dev, scale_dev = _DP_CACHE[key]
+    masks = torch.bernoulli(keep_dev) * scale_dev
+    for m, row in zip(mods, masks):
+        m._next.append(row)
+
+
+def residual(x, branch, drop_path):
+    """x + drop_path(branch); on the GPU one pass (vitta_scale_add_f32) for this module's own DropPath / Identity."""
+    if x.is_cuda and FUSED_RESIDUAL and x.dtype == torch.float32 and (x.numel() // x.shape[0]) % 4 == 0:
+        from . import ops
+        if isinstance(drop_path, DropPath):
+            scale = drop_path.sample(x.shape[0], x.device) if drop_path.active() else None
+            return ops.ResidualDropPath.apply(x, branch, scale)
+        if isinstance(drop_path, nn.Identity):
+            return ops.ResidualDropPath.apply(x, branch, None)
+    return x + drop_path(branch)
 
 
 class Mlp(nn.Module):
@@ -141,6 +190,7 @@ def relative_position_index(window_size):
 
 
 FUSED_ATTENTION = True  # tests flip this to compare the fused kernel with the composed ops on the GPU
+FUSED_RESIDUAL = True   # x + DropPath(branch) as one pass
 FUSED_PARTITION = True  # ... and this to compare the row-mapped kernel with roll + window_partition copies
 
 
@@ -249,8 +299,8 @@ class SwinTransformerBlock3D(nn.Module):
         return x
 
     def forward(self, x, mask_matrix, region=None):
-        x = x + self.drop_path(self.attention_branch(x, mask_matrix, region))
-        return x + self.drop_path(self.mlp(self.norm2(x)))
+        x = residual(x, self.attention_branch(x, mask_matrix, region), self.drop_path)
+        return residual(x, self.mlp(self.norm2(x)), self.drop_path)
 
 
 class PatchMerging(nn.Module):
@@ -355,6 +405,8 @@ class SwinTransformer3D(nn.Module):
 
     def forward(self, x):
         x = self.pos_drop(self.patch_embed(x))
+        if x.is_cuda and self.training:
+            draw_drop_path_masks([blk.drop_path for layer in self.layers for blk in layer.blocks], x.shape[0], x.device)
         for layer in self.layers:
             x = layer(x)
         return self.norm(x)

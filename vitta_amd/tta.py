@@ -161,18 +161,50 @@ class FlatArena:
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        self._all_views, self._views, self._indirect = [], None, None
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
                 flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
+                self._all_views.append(p.grad)
                 off += pad(k)
         self.flat_param = nn.Parameter(flat)  # shares storage with every p.data view
         self.flat_param.grad = self.grad
 
     def zero_grad(self):
         self.grad.zero_()
+
+    # Gradients our backward kernels do not write themselves (LayerNorm affine under torch's LN backward, every
+    # weight in SGD-all mode) reach a parameter through autograd's AccumulateGrad.  With a live `.grad` view that is one
+    # in-place add launch per tensor (100 per Swin step); with `.grad = None` AccumulateGrad just keeps the incoming
+    # tensor, and ONE multi-tensor copy moves them all into the arena afterwards.  Which parameters are written
+    # directly (`ops._grad_sink` marks them) is learnt during the first backward pass.
+    def before_backward(self):
+        if self._indirect is None:
+            return
+        for p in self._indirect:
+            p.grad = None
+
+    def after_backward(self):
+        if self._indirect is None:
+            self._indirect = [p for p in self.params if not getattr(p, "_vitta_direct_grad", False)]
+            return
+        src, dst = [], []
+        for p, view in zip(self._indirect, self._indirect_views):
+            if p.grad is not None:
+                src.append(p.grad.reshape(view.shape))
+                dst.append(view)
+            p.grad = view
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    @property
+    def _indirect_views(self):
+        if self._views is None:
+            self._views = {id(p): v for p, v in zip(self.params, self._all_views)}
+        return [self._views[id(p)] for p in self._indirect]
 
     def all_reduce(self):
         torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
@@ -465,7 +497,9 @@ class ViTTAAdapter:
         if has_video:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
             output, loss_reg, loss_consis = self.forward_losses(input, actual_bz)
+            self.arena.before_backward()
             self.total_loss(loss_reg, loss_consis).backward()
+            self.arena.after_backward()
         else:
             if self.engine is None:
                 raise RuntimeError("ragged data-parallel steps need the batched engine")
@@ -507,7 +541,9 @@ class ViTTAAdapter:
         g["seg_bwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_bwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
             loss_reg = self.engine.finish_global()
+            self.arena.before_backward()
             self.total_loss(loss_reg, loss_consis).backward()
+            self.arena.after_backward()
         g["seg_opt"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_opt"], pool=pool, capture_error_mode=CAPTURE_MODE):
             self.optimizer.step()
