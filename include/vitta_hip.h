@@ -317,6 +317,19 @@ int vitta_sgd_step_f32(float* d_param, const float* d_grad, float* d_momentum_bu
 int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_scale, int64_t samples,
                         int64_t per_sample, float* d_out, void* stream);
 
+/* --------------------------------------------------------------------------
+ * A8 -- pointwise convolution + eval-mode BatchNorm (+ residual) (+ ReLU) as one fp32 MFMA GEMM.
+ * Replaces conv1 -> bn1 -> relu and conv3 -> bn3 -> (+identity) -> relu of a ResNet-50 bottleneck
+ * (models/tanet_models/tanet.py:129 via torchvision's Bottleneck.forward; temporal_module.py:85-106).
+ *   d_x [N, C, HW] (NCHW frames), d_weight [K, C] (the conv weight [K, C, 1, 1] as stored),
+ *   h_bn = {gamma, beta, running_mean, running_var} device pointers [K], d_res [N, K, HW] or NULL,
+ *   d_z [N, K, HW] = act(bn(conv(x)) (+ res)).  C % 16 == 0, HW % 4 == 0 (else VITTA_ERR_UNSUPPORTED).
+ * -------------------------------------------------------------------------- */
+int vitta_conv1x1_bn_act_supported(int32_t C, int32_t K, int64_t HW);
+int vitta_conv1x1_bn_act_fwd_f32(const float* d_x, const float* d_weight, const float* const* h_bn, float eps,
+                                 const float* d_res, int32_t relu, float* d_z, int64_t N, int32_t C, int32_t K, int64_t HW,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif
