@@ -330,6 +330,33 @@ int vitta_conv1x1_bn_act_fwd_f32(const float* d_x, const float* d_weight, const 
                                  const float* d_res, int32_t relu, float* d_z, int64_t N, int32_t C, int32_t K, int64_t HW,
                                  void* stream);
 
+/* --------------------------------------------------------------------------
+ * A2 / A10 -- LayerNorm over the channel axis of channels-last rows [rows, C], fused with its surroundings in a Video
+ * Swin block (swin_transformer.py:245-275) and with the ViTTA statistics of a hooked LayerNorm
+ * (utils/norm_stats_utils.py:222-230).  C in {128, 256, 512, 1024, 2048}.
+ *   forward : x' = x + scale[row / rows_per_sample] * branch   (d_branch/d_xnew NULL: x' = x, nothing written)
+ *             y = LN(x') * gamma + beta ; d_mean / d_rstd [rows] saved for the backward;
+ *             hooked: d_shift [C] (source mean) and d_partial [vitta_ln_num_partials(rows)][2][C] receive per-workgroup
+ *             sums of (y - shift), (y - shift)^2; vitta_colsum2_f32 adds them into the s1 / s2 statistics.
+ *   backward: g = g_y (+ gscale (a_c + b_c (y - mu_c)) when d_mu != NULL);  d_gx = LN-backward(g) (+ d_gxnew);
+ *             d_gbranch (optional) = scale * d_gx;  d_partial [..][2][C] = per-workgroup sums of g*xhat | g
+ *             (-> vitta_colsum2_f32 -> d gamma, d beta).
+ * vitta_colsum2_f32: out_a[c] += sum_b partial[b][0][c], out_b[c] += sum_b partial[b][1][c] (row-parallel, one fp32
+ *             atomic per column and 32 partial rows: zero the outputs for a fresh sum, or hand live gradient storage);
+ *             d_cnt (optional) <- cnt_value (the plan's per-layer sample count).
+ * -------------------------------------------------------------------------- */
+int vitta_ln_supported(int32_t C);
+int64_t vitta_ln_num_partials(int64_t rows);
+int vitta_ln_fwd_f32(const float* d_x, const float* d_branch, const float* d_scale, int64_t rows, int64_t rows_per_sample,
+                     int32_t C, const float* d_gamma, const float* d_beta, float eps, float* d_xnew, float* d_y,
+                     float* d_mean, float* d_rstd, const float* d_shift, float* d_partial, void* stream);
+int vitta_ln_bwd_f32(const float* d_gy, const float* d_gxnew, const float* d_x, const float* d_mean, const float* d_rstd,
+                     const float* d_gamma, const float* d_beta, const float* d_scale, const float* d_mu,
+                     const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int64_t rows,
+                     int64_t rows_per_sample, int32_t C, float* d_gx, float* d_gbranch, float* d_partial, void* stream);
+int vitta_colsum2_f32(const float* d_partial, int64_t n_partials, int32_t C, float* d_out_a, float* d_out_b, float* d_cnt,
+                      float cnt_value, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -596,3 +596,36 @@ def test_conv1x1_bn_act_mfma_gemm_matches_conv_plus_bn(cin, cout, hw, nfr, res, 
     got = ops.conv1x1_bn_act_forward(x.to(d), w.to(d), gam.to(d), bet.to(d), rm.to(d), rv.to(d), 1e-5,
                                      r.to(d) if res else None, relu)
     assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("c", [128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize("with_branch", [False, True])
+def test_fused_layernorm_matches_torch(c, with_branch):
+    """ops.FusedLayerNorm (no statistics site) == F.layer_norm(x + scale_b * branch): outputs, saved x', and every
+    gradient (x, branch, gamma, beta), including the residual path's own gradient arriving at x'."""
+    import torch.nn.functional as F
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(c)
+    shape = (3, 2, 5, 7, c)
+    x, br = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    scale = torch.tensor([0.0, 1.25, 1.25])
+    gy, gx2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (x, br, w, b)]
+    xn = leaves[0] + leaves[1] * scale.double().view(3, 1, 1, 1, 1) if with_branch else leaves[0]
+    y = F.layer_norm(xn, (c,), leaves[2], leaves[3], 1e-5)
+    ((y * gy.double()).sum() + ((xn * gx2.double()).sum() if with_branch else 0.0)).backward()
+    d = _dev()
+    dl = [t.to(d).requires_grad_(True) for t in (x, br, w, b)]
+    if with_branch:
+        xn_d, y_d = ops.FusedLayerNorm.apply(dl[0], dl[1], scale.to(d), dl[2], dl[3], 1e-5, None)
+        ((y_d * gy.to(d)).sum() + (xn_d * gx2.to(d)).sum()).backward()
+        torch.testing.assert_close(xn_d.detach().cpu().double(), xn.detach(), rtol=1e-6, atol=1e-6)
+    else:
+        y_d = ops.FusedLayerNorm.apply(dl[0], None, None, dl[2], dl[3], 1e-5, None)
+        (y_d * gy.to(d)).sum().backward()
+    torch.testing.assert_close(y_d.detach().cpu().double(), y.detach(), rtol=1e-5, atol=1e-5)
+    for i, (a, ref) in enumerate(zip(dl, leaves)):
+        if i == 1 and not with_branch:
+            continue
+        assert (a.grad.cpu().double() - ref.grad).abs().max().item() <= 1e-4 * ref.grad.abs().max().item() + 1e-6, i

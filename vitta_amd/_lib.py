@@ -76,6 +76,11 @@ SIGNATURES = {
     "vitta_event_elapsed_ms": (C.c_int, [_p, _p, C.POINTER(_f32)]),
     "vitta_conv1x1_bn_act_supported": (C.c_int, [_i32, _i32, _i64]),
     "vitta_conv1x1_bn_act_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _i32, _p, _i64, _i32, _i32, _i64, _p]),
+    "vitta_ln_supported": (C.c_int, [_i32]),
+    "vitta_ln_num_partials": (_i64, [_i64]),
+    "vitta_ln_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _p]),
+    "vitta_ln_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "vitta_colsum2_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p]),
     "vitta_scale_add_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "vitta_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
     "vitta_sgd_step_f32": (C.c_int, [_p, _p, _p, _f32, _f32, _f32, _i64, _p]),

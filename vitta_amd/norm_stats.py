@@ -138,6 +138,29 @@ class FusedSite:
         return e.plan.mu[sl], e.plan.coef_a[sl], e.plan.coef_b[sl], e.gscale
 
 
+class FusedLNSite:
+    """The same for a hooked LayerNorm on the fused pass (ops.FusedLayerNorm): the kernel's channel sums go straight
+    into the engine's [cnt | s1 | s2] statistics (no partial triples, no finalize launch)."""
+
+    def __init__(self, engine, index):
+        self.engine, self.index = engine, index
+
+    def begin(self, rows, c):
+        e = self.engine
+        plan = e.plan
+        outer, pc, inner, _ = plan.shapes[self.index]
+        if (rows, c) != (outer * inner, pc):
+            raise RuntimeError("fused statistics pass: feature shape differs from the planned one")
+        if not e._fused_seen:  # first fused layer of the step: the column sums ADD into [s1 | s2]
+            plan.stats.zero_()
+        e._fused_seen.add(self.index)
+        e._fused_direct = True
+        sl = plan.channel_slice(self.index)
+        return e.src_mean[sl], plan.s1[sl], plan.s2[sl], plan.cnt[self.index:self.index + 1]
+
+    coefficients = FusedSite.coefficients
+
+
 class _Inject(torch.autograd.Function):
     """Identity in the forward; adds the stat-loss gradient of its layer in the backward."""
 
@@ -194,6 +217,7 @@ class StatAlignEngine:
         self.gscale = None
         self._gscale_set = False
         self._fused_seen = set()
+        self._fused_direct = False
         self.timing_events = None  # bench.py: callable returning (start, stop) events per step
 
     # -- registration -------------------------------------------------------------------------
@@ -225,6 +249,23 @@ class StatAlignEngine:
         if (x.shape[0], x.shape[1], x.shape[2] * x.shape[3]) != (outer, c, inner) or self._feats:
             return None
         return FusedSite(self, index)
+
+    def fused_ln_site(self, index, x):
+        """A FusedLNSite if this step can take the fused LayerNorm path for hooked layer `index`: a plan for exactly
+        these shapes exists and EVERY hooked layer of the plan is a channels-last LayerNorm the kernel covers (a step is
+        all-fused or all-recorded)."""
+        if not self._built or self.plan is None or not torch.is_grad_enabled() or self._feats \
+                or not hasattr(self.plan, "s1"):
+            return None
+        ok = getattr(self.plan, "_ln_direct_ok", None)
+        if ok is None:
+            from . import ops
+            ok = self.plan._ln_direct_ok = all(layout == _lib.LAYOUT_NHWC and inner == 1 and ops.ln_supported(c)
+                                               for _, c, inner, layout in self.plan.shapes)
+        outer, c, inner, _ = self.plan.shapes[index]
+        if not ok or (x.numel() // x.shape[-1], x.shape[-1]) != (outer * inner, c):
+            return None
+        return FusedLNSite(self, index)
 
     def collect(self, index, feature, kind):
         """Called by hook `index` during the forward; returns the tensor that replaces the output."""
@@ -263,7 +304,10 @@ class StatAlignEngine:
             if len(self._fused_seen) != n or self._feats:
                 raise RuntimeError("a step must be either all-fused or all-recorded")
             self._fused_seen = set()
-            self.plan.finalize(self.src_mean)
+            if self._fused_direct:  # fused LayerNorm passes wrote [cnt | s1 | s2] themselves
+                self._fused_direct = False
+            else:
+                self.plan.finalize(self.src_mean)
             return
         if len(self._feats) != n:
             missing = [i for i in range(n) if i not in self._feats]

@@ -657,3 +657,80 @@ def conv1x1_bn_act_forward(x, weight, bn_w, bn_b, bn_rm, bn_rv, eps, residual, r
                                              int(bool(relu)), _p(z), n, c, k, h * w, _stream()),
           "vitta_conv1x1_bn_act_fwd_f32")
     return z
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (+ residual / stochastic depth) (+ ViTTA statistics), channels-last rows
+# ------------------------------------------------------------------------------------------------
+def ln_supported(c):
+    return bool(lib().vitta_ln_supported(int(c)))
+
+
+class FusedLayerNorm(torch.autograd.Function):
+    """y = LayerNorm_C(x') with x' = x + scale_b * branch (branch optional), one pass; a hooked layer (`site`) leaves the
+    shifted channel sums of y in the engine's statistics buffer, and its backward adds the statistics-loss gradient.
+    Returns y, or (x', y) with a branch.  Backward: one pass for dx (+ the gradient arriving at x'), d branch, and
+    per-workgroup d gamma / d beta partials, then one column sum."""
+
+    @staticmethod
+    def forward(ctx, x, branch, scale, weight, bias, eps, site):
+        ctx.set_materialize_grads(False)
+        _require_cuda_f32(x, "x")
+        x = x.contiguous()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        rps = rows // x.shape[0]
+        f = dict(dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(rows, **f), torch.empty(rows, **f)
+        xnew = None
+        if branch is not None:
+            branch = branch.contiguous()
+            xnew = torch.empty_like(x)
+        shift = partial = None
+        nb = int(lib().vitta_ln_num_partials(rows))
+        if site is not None:
+            shift, s1, s2, cnt = site.begin(rows, c)
+            partial = torch.empty(nb * 2 * c, **f)
+        check(lib().vitta_ln_fwd_f32(_p(x), _p(branch), _p(scale), rows, rps, c, _p(weight), _p(bias), float(eps), _p(xnew),
+                                     _p(y), _p(mean), _p(rstd), _p(shift), _p(partial), _stream()), "vitta_ln_fwd_f32")
+        if site is not None:
+            check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(s1), _p(s2), _p(cnt), float(rows), _stream()),
+                  "vitta_colsum2_f32")
+        ctx.save_for_backward(xnew if xnew is not None else x, mean, rstd, weight, bias, scale)
+        ctx.meta = (rows, rps, c, site, nb, branch is not None)
+        return (xnew, y) if branch is not None else y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xn, mean, rstd, weight, bias, scale = ctx.saved_tensors
+        rows, rps, c, site, nb, has_branch = ctx.meta
+        g_xnew, gy = (grads[0], grads[1]) if has_branch else (None, grads[0])
+        if gy is None:  # the normalised output took no part in the loss: only the residual path carries a gradient
+            gb = None
+            if has_branch and g_xnew is not None:
+                gb = g_xnew if scale is None else g_xnew * scale.view((-1,) + (1,) * (g_xnew.dim() - 1))
+            return g_xnew, gb, None, None, None, None, None
+        f = dict(dtype=torch.float32, device=xn.device)
+        gy = gy.contiguous()
+        g_xnew = g_xnew.contiguous() if g_xnew is not None else None
+        gx = torch.empty_like(xn)
+        gbranch = torch.empty_like(xn) if (has_branch and scale is not None) else None
+        partial = torch.empty(nb * 2 * c, **f)
+        mu = ca = cb = gs = None
+        if site is not None:
+            mu, ca, cb, gs = site.coefficients()
+        check(lib().vitta_ln_bwd_f32(_p(gy), _p(g_xnew), _p(xn), _p(mean), _p(rstd), _p(weight), _p(bias), _p(scale), _p(mu),
+                                     _p(ca), _p(cb), _p(gs), rows, rps, c, _p(gx), _p(gbranch), _p(partial), _stream()),
+              "vitta_ln_bwd_f32")
+        r_w = r_b = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            dw, r_w = _grad_sink(weight, True)   # live .grad storage, or a zeroed buffer: the column sum adds into it
+            db, r_b = _grad_sink(bias, True)
+            check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(dw), _p(db), None, 0.0, _stream()), "vitta_colsum2_f32")
+            if not ctx.needs_input_grad[3]:
+                r_w = None
+            if not ctx.needs_input_grad[4]:
+                r_b = None
+        g_branch = (gbranch if gbranch is not None else gx) if has_branch else None
+        return gx, g_branch, None, r_w, r_b, None, None

@@ -267,9 +267,9 @@ class SwinTransformerBlock3D(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def attention_branch(self, x, mask_matrix, region=None):
+        """x: the NORMALISED block input (norm1 already applied)."""
         B, D, H, W, C = x.shape
         ws, ss = get_window_size((D, H, W), self.window_size, self.shift_size)
-        x = self.norm1(x)
         pad = [(w - n % w) % w for n, w in zip((D, H, W), ws)]
         if any(pad):
             x = F.pad(x, (0, 0, 0, pad[2], 0, pad[1], 0, pad[0]))
@@ -299,8 +299,10 @@ class SwinTransformerBlock3D(nn.Module):
         return x
 
     def forward(self, x, mask_matrix, region=None):
-        x = residual(x, self.attention_branch(x, mask_matrix, region), self.drop_path)
-        return residual(x, self.mlp(self.norm2(x)), self.drop_path)
+        from .fused_ln import ln, ln_residual
+        a = self.attention_branch(ln(self.norm1, x), mask_matrix, region)
+        x, y = ln_residual(self.norm2, x, a, self.drop_path)  # x = x + drop_path(a); y = norm2(x): one pass
+        return residual(x, self.mlp(y), self.drop_path)
 
 
 class PatchMerging(nn.Module):
@@ -315,7 +317,8 @@ class PatchMerging(nn.Module):
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
-        return self.reduction(self.norm(x))
+        from .fused_ln import ln
+        return self.reduction(ln(self.norm, x))
 
 
 class BasicLayer(nn.Module):
@@ -409,7 +412,8 @@ class SwinTransformer3D(nn.Module):
             draw_drop_path_masks([blk.drop_path for layer in self.layers for blk in layer.blocks], x.shape[0], x.device)
         for layer in self.layers:
             x = layer(x)
-        return self.norm(x)
+        from .fused_ln import ln
+        return ln(self.norm, x)
 
 
 class I3DHead(nn.Module):
