@@ -294,6 +294,8 @@ def _grad_sink(param, needed, zero=True):
     if not needed:
         return None, None
     g = param.grad
+    if g is None:
+        g = getattr(param, "_vitta_arena_view", None)  # tta.FlatArena detached `.grad` for this backward
     if (DIRECT_PARAM_GRAD and param.is_leaf and g is not None and g.dtype == torch.float32 and g.is_contiguous()
             and g.device == param.device and g.shape == param.shape):
         param._vitta_direct_grad = True  # tta.FlatArena keeps the live view attached for this parameter

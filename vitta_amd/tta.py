@@ -161,13 +161,14 @@ class FlatArena:
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
-        self._all_views, self._views, self._indirect = [], None, None
+        self._all_views, self._learnt = [], False
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
                 flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
+                p._vitta_arena_view = p.grad  # found by ops._grad_sink even while `.grad` is detached
                 self._all_views.append(p.grad)
                 off += pad(k)
         self.flat_param = nn.Parameter(flat)  # shares storage with every p.data view
@@ -176,35 +177,31 @@ class FlatArena:
     def zero_grad(self):
         self.grad.zero_()
 
-    # Gradients our backward kernels do not write themselves (LayerNorm affine under torch's LN backward, every
-    # weight in SGD-all mode) reach a parameter through autograd's AccumulateGrad.  With a live `.grad` view that is one
-    # in-place add launch per tensor (100 per Swin step); with `.grad = None` AccumulateGrad just keeps the incoming
-    # tensor, and ONE multi-tensor copy moves them all into the arena afterwards.  Which parameters are written
-    # directly (`ops._grad_sink` marks them) is learnt during the first backward pass.
+    # Gradients our backward kernels do not write themselves (every weight in SGD-all mode, norm layers on the torch
+    # fallback) reach a parameter through autograd's AccumulateGrad.  With a live `.grad` view that is one in-place add
+    # launch per tensor; with `.grad = None` AccumulateGrad just keeps the incoming tensor, and ONE multi-tensor copy
+    # moves them all into the arena afterwards.  Parameters whose kernels accumulate straight into the arena
+    # (`ops._grad_sink` finds the view through `_vitta_arena_view` and marks them) keep their view attached.
     def before_backward(self):
-        if self._indirect is None:
+        if not self._learnt:
             return
-        for p in self._indirect:
-            p.grad = None
+        for p in self.params:
+            if not getattr(p, "_vitta_direct_grad", False):
+                p.grad = None
 
     def after_backward(self):
-        if self._indirect is None:
-            self._indirect = [p for p in self.params if not getattr(p, "_vitta_direct_grad", False)]
+        if not self._learnt:  # first backward: every view was attached (plain AccumulateGrad adds)
+            self._learnt = True
             return
         src, dst = [], []
-        for p, view in zip(self._indirect, self._indirect_views):
-            if p.grad is not None:
-                src.append(p.grad.reshape(view.shape))
+        for p, view in zip(self.params, self._all_views):
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                src.append(g.reshape(view.shape))
                 dst.append(view)
             p.grad = view
         if src:
             torch._foreach_copy_(dst, src)
-
-    @property
-    def _indirect_views(self):
-        if self._views is None:
-            self._views = {id(p): v for p, v in zip(self.params, self._all_views)}
-        return [self._views[id(p)] for p in self._indirect]
 
     def all_reduce(self):
         torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
