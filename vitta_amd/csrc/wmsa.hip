@@ -263,6 +263,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
       if (NTC || t < nt) {
         acc[t] = score_tile<REL>(k_lds, qf, t, lane, terms, q, N);
         m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
+        if (NTC) __builtin_amdgcn_sched_barrier(0);  // keep one tile's loads from being hoisted over the previous tiles
       }
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
           o0 = mfma(acc[t][r], vrow[i], o0);
           o1 = mfma(acc[t][r], vrow[16 + i], o1);
         }
+        if (NTC) __builtin_amdgcn_sched_barrier(0);
       }
     }
     // C layout: row = query 4*kk + r, col = d = i; the row's 1/l lives in lane (4*kk + r)
@@ -551,8 +553,8 @@ int launch_fwd(const WmsaArgs& a, float* out, float* lse, hipStream_t st) {
   } while (0)
   // the compile-time variant (NTC = 25) lets the scheduler hoist every tile's loads: 256 VGPRs + 1.4 KB of scratch per
   // lane and 15 % slower end to end (measured); the per-tile guard of the run-time variant keeps live ranges short
-  (void)nt;
-  WMSA_FWD(0);
+  if (nt == NT_MAX) WMSA_FWD(NT_MAX);
+  else WMSA_FWD(0);
 #undef WMSA_FWD
   return VITTA_OK;
 }
