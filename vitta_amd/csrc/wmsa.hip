@@ -133,9 +133,15 @@ __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, con
   const int j = lane & 15, kk = lane >> 4;
   float kf[8];
   load8(kf, k_lds + (16 * t + j) * KPAD + 8 * kk);
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // two accumulator chains: a dependent v_mfma_f32_16x16x4_f32 waits 40 cycles for its predecessor while the pipe could
+  // issue every 32 (PMC: SQ_WAIT_INST_ANY was the largest share of the forward kernel's wave cycles)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int s = 0; s < 8; ++s) acc = mfma(kf[s], qf[s], acc);
+  for (int s = 0; s < 8; s += 2) {
+    acc = mfma(kf[s], qf[s], acc);
+    acc2 = mfma(kf[s + 1], qf[s + 1], acc2);
+  }
+  acc += acc2;
   const int key0 = 16 * t + 4 * kk;
   if constexpr (REL) {
     // the four keys of this lane are consecutive: one 16-byte LDS read brings their packed code | region, then four
