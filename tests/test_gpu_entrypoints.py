@@ -1,0 +1,86 @@
+"""The reference's entry points end to end on the GPU with synthetic videos (default flags: batched engine, hipGraph
+replay after three eager videos, overlapped evaluation): compute_statistics -> files -> eval() -> tta_standard."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+from vitta_amd import scripts, tta
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(tmp_path, **over):
+    a = scripts.tanet_ucf101_args([])
+    a.datatype, a.clip_length, a.input_size, a.workers, a.device = "synthetic", 8, 64, 0, "cuda"
+    a.synthetic_n_videos = 10
+    a.val_vid_list = os.path.join(str(tmp_path), "lists", "{}.txt")
+    a.result_dir = os.path.join(str(tmp_path), "results", "{}_{}", "tta_{}")
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+@pytest.mark.parametrize("affine_only", [True, False])
+def test_eval_statistics_then_tta_online_on_gpu(tmp_path, affine_only):
+    from corpus.main_eval import eval as run_eval
+    model = H.build_tanet(101, 8, 0)
+    ckpt = os.path.join(str(tmp_path), "tanet_synth.pth.tar")
+    torch.save({"state_dict": tta.SingleDeviceParallel(model).state_dict(), "epoch": 1, "best_prec1": 0.0}, ckpt)
+    # 1. source statistics through the reference's compute_stats entry
+    sargs = scripts.compute_stats(_args(tmp_path, model_path=ckpt))
+    sargs.batch_size = 2
+    sargs.val_vid_list, sargs.result_dir = "unused", os.path.join(str(tmp_path), "stats_run")
+    res, _ = run_eval(args=sargs)
+    assert res is None
+    mean_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_mean_*.npy"))[0]
+    var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
+    assert len(np.load(mean_file, allow_pickle=True)) == 53
+    # 2. online TTA over 10 videos: 3 eager, then graph replay, evaluation overlapped with the next adaptation
+    targs = _args(tmp_path, model_path=ckpt, spatiotemp_mean_clean_file=mean_file, spatiotemp_var_clean_file=var_file,
+                  verbose=True, update_only_bn_affine=affine_only)
+    targs.val_vid_list, targs.result_dir = "unused", os.path.join(str(tmp_path), "tta_run")
+    res, returned = run_eval(args=targs)
+    assert returned is None and len(res) == 1 and 0.0 <= res[0] <= 100.0
+    text = open(glob.glob(os.path.join(targs.result_dir, "*"))[0]).read()
+    for i in range(10):
+        assert f"TTA Epoch1: [{i}/10]" in text
+    assert "nan" not in text.lower()
+
+
+def test_eval_statistics_then_tta_online_swin_on_gpu(tmp_path):
+    """Same for Video Swin-B (tta_swin_ucf101.py overrides, 112^2 clips): LayerNorm statistics file -> TTA with the
+    fused LayerNorm / row-mapped attention path, graph replay and overlapped evaluation."""
+    from corpus.main_eval import eval as run_eval
+    model = H.build_swin(101, 0)
+    ckpt = os.path.join(str(tmp_path), "swin_synth.pth")
+    torch.save({"state_dict": model.state_dict()}, ckpt)
+
+    def args_for(**over):
+        a = scripts.swin_ucf101_args([])
+        a.datatype, a.input_size, a.scale_size, a.workers, a.device = "synthetic", 112, 112, 0, "cuda"
+        a.synthetic_n_videos, a.model_path = 8, ckpt
+        for k, v in over.items():
+            setattr(a, k, v)
+        return a
+
+    sargs = scripts.compute_stats(args_for())
+    sargs.batch_size = 2
+    sargs.val_vid_list, sargs.result_dir = "unused", os.path.join(str(tmp_path), "stats_run")
+    res, _ = run_eval(args=sargs)
+    assert res is None
+    mean_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_mean_*.npy"))[0]
+    var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
+    assert len(np.load(mean_file, allow_pickle=True)) == 52
+    targs = args_for(spatiotemp_mean_clean_file=mean_file, spatiotemp_var_clean_file=var_file, verbose=True,
+                     update_only_bn_affine=True)
+    targs.val_vid_list, targs.result_dir = "unused", os.path.join(str(tmp_path), "tta_run")
+    res, returned = run_eval(args=targs)
+    assert returned is None and len(res) == 1 and 0.0 <= res[0] <= 100.0
+    text = open(glob.glob(os.path.join(targs.result_dir, "*"))[0]).read()
+    for i in range(8):
+        assert f"TTA Epoch1: [{i}/8]" in text
+    assert "nan" not in text.lower()

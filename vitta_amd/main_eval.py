@@ -25,7 +25,10 @@ from .utils_ import make_dir, model_analysis, path_logger
 def pick_device(args):
     dev = getattr(args, "device", None)
     if dev is not None:
-        return torch.device(dev)
+        dev = torch.device(dev)
+        if dev.type == "cuda" and dev.index is None:  # "cuda": this rank's GPU
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+        return dev
     if torch.cuda.is_available():
         return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     return torch.device("cpu")
