@@ -84,3 +84,25 @@ def test_eval_statistics_then_tta_online_swin_on_gpu(tmp_path):
     for i in range(8):
         assert f"TTA Epoch1: [{i}/8]" in text
     assert "nan" not in text.lower()
+
+
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with both
+    ranks on the one GPU of the test box over gloo (RCCL refuses duplicate devices): data-parallel engine, the three
+    captured graph segments with the two exchanges between them, overlapped evaluation, the max-over-ranks timing and
+    the single JSON line of rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "4",
+           "--dist-backend", "gloo", "--no-cpu-baseline", "--no-streaming", "--size", "112"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["value"] > 0
+    assert rec["config"]["parallelism"] == "dp2" and "3 segments" in rec["launch_mode"]
