@@ -71,8 +71,14 @@ def parse():
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
     p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
     p.add_argument("--size", type=int, default=224)
-    p.add_argument("--clip-length", type=int, default=8)
-    return p.parse_args()
+    p.add_argument("--clip-length", type=int, default=None, help="frames per view (default 8 TANet / 16 Swin)")
+    p.add_argument("--arch", default="tanet", choices=["tanet", "swin"],
+                   help="tanet: BASELINE.json's metric (default); swin: the same iteration on Video Swin-B "
+                        "(BASELINE config 2 shape: 2 views x 16 frames x 224^2, LN-affine Adam)")
+    opt = p.parse_args()
+    if opt.clip_length is None:
+        opt.clip_length = 8 if opt.arch == "tanet" else 16
+    return opt
 
 
 def make_args(tmp, size, clip_length, optimizer, device, n_videos):
@@ -117,18 +123,56 @@ def build_model_and_stats(tmp, size, T, device):
     return model, mp, vp
 
 
+def build_swin_and_stats(tmp, size, T, device):
+    """Seeded Video Swin-B; source statistics = moments of a calibration pass (seed 1000) on the 52 LayerNorm outputs
+    after the first one (what compute_statistics writes for the arch)."""
+    from vitta_amd import synthetic as S
+    from vitta_amd.bns_utils import choose_layers
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    model = S.build_swin(101, 0).to(device)
+    lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
+    hooks = [ComputeNormStatsHook(m, clip_len=T, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+    with torch.no_grad():
+        model(S.seeded_randn((1, 2, 3, T, size, size), 1000, device))
+    means = [h.batch_mean.cpu().numpy() for h in hooks]
+    vars_ = [h.batch_var.cpu().numpy() for h in hooks]
+    for h in hooks:
+        h.close()
+    mp, vp = S.write_stat_files(tmp, means, vars_, tag="swin")
+    return model, mp, vp
+
+
+def make_swin_args(tmp, size, clip_length, optimizer, device, n_videos):
+    from vitta_amd import scripts
+    a = scripts.swin_ucf101_args([])
+    a.datatype, a.input_size, a.scale_size, a.workers, a.verbose = "synthetic", size, size, 0, False
+    a.clip_length, a.result_dir, a.num_classes, a.batch_size = clip_length, tmp, 101, 1
+    a.update_only_bn_affine = optimizer == "adam_affine"
+    a.synthetic_n_videos, a.synthetic_device = n_videos, device
+    return a
+
+
 def run_gpu(opt, rank, world, device):
     from vitta_amd import data, tta
     tmp = tempfile.mkdtemp(prefix="vitta_bench_")
     n_videos = max(16, min(64, opt.steps + opt.warmup))
-    model, mp, vp = build_model_and_stats(tmp, opt.size, opt.clip_length, device)
-    args = make_args(tmp, opt.size, opt.clip_length, opt.optimizer, device, n_videos)
+    if opt.arch == "swin":
+        n_videos = min(n_videos, 16)  # 77 MB per clip pair
+        model, mp, vp = build_swin_and_stats(tmp, opt.size, opt.clip_length, device)
+        args = make_swin_args(tmp, opt.size, opt.clip_length, opt.optimizer, device, n_videos)
+    else:
+        model, mp, vp = build_model_and_stats(tmp, opt.size, opt.clip_length, device)
+        args = make_args(tmp, opt.size, opt.clip_length, opt.optimizer, device, n_videos)
     args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
     args.synthetic_seed = 10000 * rank  # every rank adapts to its own videos (weak scaling)
     log("model + source statistics ready")
     adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
-    tta_set = data.build_tanet_dataset(args, "val", "tta")
-    eval_set = data.build_tanet_dataset(args, "val", "eval")
+    if opt.arch == "swin":
+        tta_set = data.build_videoswin_dataset(args, "val", "tta")
+        eval_set = data.build_videoswin_dataset(args, "val", "eval")
+    else:
+        tta_set = data.build_tanet_dataset(args, "val", "tta")
+        eval_set = data.build_tanet_dataset(args, "val", "eval")
     torch.cuda.synchronize()
 
     # live timing of the moments kernel: one (start, stop) event pair per step, on the launch stream
@@ -202,8 +246,8 @@ def run_gpu(opt, rank, world, device):
         # In the shipped step the moments of the hooked layers ride on the fused BN pass (no launch of their
         # own, no extra traffic); for the roofline line the stand-alone kernel is timed on the same features,
         # so the repeat runs with the BN fusion off.
-        from vitta_amd import fused_bn
-        fused_bn.ENABLED = False
+        from vitta_amd import fused_bn, fused_ln
+        fused_bn.ENABLED = fused_ln.ENABLED = False
         graph, adapter._graph = adapter._graph, None
         adapter.engine.timing_events = new_events
         barrier()
@@ -213,7 +257,7 @@ def run_gpu(opt, rank, world, device):
         barrier()
         eager_elapsed = time.perf_counter() - te
         adapter._graph = graph
-        fused_bn.ENABLED = True
+        fused_bn.ENABLED = fused_ln.ENABLED = True
         log(f"eager repeat of the timed steps (kernel events): {eager_elapsed:.3f}s")
     adapter.engine.timing_events = None
     torch.cuda.synchronize()
@@ -316,14 +360,17 @@ def main():
     elapsed, kern_ms, adapt_only, streaming, adapter = run_gpu(opt, rank, world, device)
     videos = opt.steps * world
     value = videos / elapsed
-    algo_bytes = 4 * HOOKED_ELEMENTS_PER_VIDEO * (opt.size / 224.0) ** 2 * (opt.clip_length / 8.0)
+    if opt.arch == "swin":
+        algo_bytes = 4.0 * sum(o * c * i for o, c, i, _ in adapter.engine.plan.shapes)  # 253.7 MB at 2x16x224^2
+    else:
+        algo_bytes = 4 * HOOKED_ELEMENTS_PER_VIDEO * (opt.size / 224.0) ** 2 * (opt.clip_length / 8.0)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
 
     # HBM traffic of the moments launch from the PMC passes committed under profiles/ (bench.py itself
     # cannot run rocprofv3 --pmc): corrected read bytes + write bytes of the in-step (1 video) launch
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r1_moments_pmc.json")
-    if os.path.exists(pmc_file) and opt.size == 224 and opt.clip_length == 8:
+    if os.path.exists(pmc_file) and opt.size == 224 and opt.clip_length == 8 and opt.arch == "tanet":
         pmc = json.load(open(pmc_file))["in_step_1_video"]
         traffic = pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]
 
@@ -351,7 +398,20 @@ def main():
                              "BN pass (bn_act_fwd_kernel) at zero extra traffic",
                      "streaming": streaming},
     }
-    if rank == 0 and world == 1 and not opt.no_cpu_baseline:
+    if opt.arch == "swin":
+        n_ln = len(adapter.engine.hooks)
+        line["metric"] = f"videos/sec TTA step (Video Swin-B, 2x{opt.clip_length}x{opt.size}^2), whole job"
+        line["config"]["workload"] = (f"Video Swin-B UCF101 ViTTA online TTA, per-video iteration = adapt step (2 views x "
+                                      f"{opt.clip_length} frames x {opt.size}^2, {n_ln} hooked LayerNorm layers, l1 stat "
+                                      "alignment + prediction consistency, backward, optimizer) + eval forward (1 view)")
+        line["config"]["optimizer"] = "Adam on LN affine (update_only_bn_affine)" if opt.optimizer == "adam_affine" \
+            else "SGD all parameters"
+        line["config"]["exchanges"] = "moments all-reduce + gradient all-reduce" if world > 1 else "none"
+        line["roofline"]["kernel"] = f"moments_nhwc_partial_kernel ({n_ln} layers, 1 launch)"
+        line["roofline"]["traffic_source"] = None
+        line["roofline"]["note"] = ("stand-alone batched kernel timed on the step's own hooked LayerNorm outputs; in the "
+                                    "shipped step these moments ride on the fused LayerNorm pass (ln_fwd_kernel)")
+    if rank == 0 and world == 1 and not opt.no_cpu_baseline and opt.arch == "tanet":
         del adapter
         torch.cuda.empty_cache()
         log("cpu baseline ...")

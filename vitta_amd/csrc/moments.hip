@@ -156,6 +156,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
 // ----------------------------------------------------------------------------
 // NHWC partial kernel
 // ----------------------------------------------------------------------------
+template <bool NT>
 __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
     const LayerInfo* __restrict__ linfo, const BlockEnt* __restrict__ tab, PtrPack ptrs,
     float* __restrict__ ws) {
@@ -185,14 +186,14 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
       const float4* p = reinterpret_cast<const float4*>(x + (r0 + ty) * C + c0);
       const int64_t stride4 = ((int64_t)TY * C) >> 2;
       const int64_t nn = (r1 - r0 - ty + TY - 1) / TY;
-      const float4 f = *p;
+      const float4 f = ld4<NT>(p);
       x0[0] = f.x; x0[1] = f.y; x0[2] = f.z; x0[3] = f.w;
       cnt = (float)nn;
       int64_t n = 0;
       for (; n + kUnroll <= nn; n += kUnroll) {
         float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = p[(n + u) * stride4];
+        for (int u = 0; u < kUnroll; ++u) v[u] = ld4<NT>(p + (n + u) * stride4);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
           const float d0 = v[u].x - x0[0], d1 = v[u].y - x0[1], d2 = v[u].z - x0[2], d3 = v[u].w - x0[3];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
         }
       }
       for (; n < nn; ++n) {
-        const float4 v = p[n * stride4];
+        const float4 v = ld4<NT>(p + n * stride4);
         const float d0 = v.x - x0[0], d1 = v.y - x0[1], d2 = v.z - x0[2], d3 = v.w - x0[3];
         s[0] += d0; s[1] += d1; s[2] += d2; s[3] += d3;
         q[0] = fmaf(d0, d0, q[0]); q[1] = fmaf(d1, d1, q[1]);
@@ -505,12 +506,20 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
   }
   if (p->n_blocks_nhwc && ev_start) {  // channels-last plan (Swin): the events go to its kernel
     (void)hipGetLastError();
-    hipExtLaunchKernelGGL(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start, ev_stop, 0,
-                          p->d_info, p->d_tab_nhwc, pack, ws);
+    if (p->nt_loads)
+      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<true>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
+                            ev_stop, 0, p->d_info, p->d_tab_nhwc, pack, ws);
+    else
+      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<false>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
+                            ev_stop, 0, p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
   } else if (p->n_blocks_nhwc) {
-    VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
-                       p->d_info, p->d_tab_nhwc, pack, ws);
+    if (p->nt_loads)
+      VITTA_LAUNCH(moments_nhwc_partial_kernel<true>, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
+                   p->d_info, p->d_tab_nhwc, pack, ws);
+    else
+      VITTA_LAUNCH(moments_nhwc_partial_kernel<false>, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
+                   p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
   return VITTA_OK;
@@ -661,7 +670,7 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
     VITTA_LAUNCH(moments_nchw_partial_kernel<false>, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                  d_tab, pack, d_part);
   else
-    VITTA_LAUNCH(moments_nhwc_partial_kernel, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+    VITTA_LAUNCH(moments_nhwc_partial_kernel<false>, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
   VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(moments_finalize_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK),
