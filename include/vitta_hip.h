@@ -68,6 +68,12 @@ typedef struct vitta_plan vitta_plan;
 
 int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
                       vitta_plan** out_plan);
+/* Same with the frame split of NCHW layers fixed by the caller (h_nsplit[l] > 0; 0 / NULL: the library's choice).
+ * A plan whose per-workgroup triples are written by fused BatchNorm passes (vitta_bn_act_fwd_f32, one launch PER
+ * LAYER) wants each layer split over enough workgroups to fill the GPU on its own; the batched kernel (ONE launch
+ * for all layers) wants few, long walks. */
+int vitta_plan_create_split(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
+                            const int32_t* h_nsplit, vitta_plan** out_plan);
 /* The plan itself is a host object.  Its device tables live in a CALLER-OWNED device buffer of
  * vitta_plan_table_bytes() bytes (256-byte aligned) that must outlive the plan's launches;
  * vitta_plan_upload copies them there (stream-ordered) and must precede the first launch.  The

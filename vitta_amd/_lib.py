@@ -30,6 +30,7 @@ SIGNATURES = {
     "vitta_abi_version": (C.c_int, []),
     "vitta_status_string": (C.c_char_p, [C.c_int]),
     "vitta_plan_create": (C.c_int, [C.POINTER(LayerShape), C.c_int, C.c_int, C.POINTER(_p)]),
+    "vitta_plan_create_split": (C.c_int, [C.POINTER(LayerShape), C.c_int, C.c_int, C.POINTER(_i32), C.POINTER(_p)]),
     "vitta_plan_set_option": (C.c_int, [_p, C.c_int, C.c_int]),
     "vitta_plan_table_bytes": (_sz, [_p]),
     "vitta_plan_upload": (C.c_int, [_p, _p, _sz, _p]),

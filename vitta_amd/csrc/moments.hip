@@ -354,6 +354,11 @@ const char* vitta_status_string(int status) {
 
 int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
                       vitta_plan** out_plan) {
+  return vitta_plan_create_split(h_shapes, n_layers, target_blocks, nullptr, out_plan);
+}
+
+int vitta_plan_create_split(const vitta_layer_shape* h_shapes, int n_layers, int target_blocks,
+                            const int32_t* h_nsplit, vitta_plan** out_plan) {
   if (!h_shapes || !out_plan || n_layers <= 0 || n_layers > VITTA_MAX_LAYERS) return VITTA_ERR_INVALID_ARG;
   vitta_plan* p = new (std::nothrow) vitta_plan();
   if (!p) return VITTA_ERR_ALLOC;
@@ -392,6 +397,7 @@ int vitta_plan_create(const vitta_layer_shape* h_shapes, int n_layers, int targe
     L->ws_off = ws;
     if (L->layout == VITTA_LAYOUT_NCHW) {
       int64_t ns = (int64_t)((double)L->outer / goal_nchw + 0.999);
+      if (h_nsplit && h_nsplit[l] > 0) ns = h_nsplit[l];  // the caller's frame split (fused BN passes write the triples)
       ns = std::max<int64_t>(1, std::min<int64_t>(ns, L->outer));
       L->nsplit = (int32_t)ns;
       ws += ns * L->nchunks * L->slots;

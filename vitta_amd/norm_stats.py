@@ -104,6 +104,14 @@ class HipBackend:
         from . import ops
         return ops.StatPlan(shapes, device)
 
+    def make_fused_plan(self, shapes, device):
+        """Plan for steps whose per-layer triples come from fused BatchNorm passes: every NCHW layer is split over the
+        frames like an un-hooked fused BN launch would be (ops._bn_nsplit: >= 1024 workgroups per layer if the frame
+        count allows)."""
+        from . import ops
+        ns = [ops._bn_nsplit(outer, c, inner) if layout == _lib.LAYOUT_NCHW else 0 for outer, c, inner, layout in shapes]
+        return ops.StatPlan(shapes, device, nsplit=ns)
+
     def layout(self, feature, kind):
         from . import ops
         return ops.feature_layout(feature, kind)
@@ -218,6 +226,7 @@ class StatAlignEngine:
         self._gscale_set = False
         self._fused_seen = set()
         self._fused_direct = False
+        self._fused_plans = {}
         self.timing_events = None  # bench.py: callable returning (start, stop) events per step
 
     # -- registration -------------------------------------------------------------------------
@@ -248,6 +257,14 @@ class StatAlignEngine:
         outer, c, inner, _ = self.plan.shapes[index]
         if (x.shape[0], x.shape[1], x.shape[2] * x.shape[3]) != (outer, c, inner) or self._feats:
             return None
+        if not self._fused_seen and hasattr(self.backend, "make_fused_plan"):
+            # first fused layer of the step: switch to the plan whose frame splits suit one launch PER layer (the
+            # batched-kernel plan walks all 16 frames in one workgroup: 49 workgroups for a 256 x 14 x 14 layer)
+            key = tuple(self.plan.shapes)
+            fused = self._fused_plans.get(key)
+            if fused is None:
+                fused = self._fused_plans[key] = self.backend.make_fused_plan(self.plan.shapes, self.device)
+            self.plan = fused
         return FusedSite(self, index)
 
     def fused_ln_site(self, index, x):

@@ -140,8 +140,8 @@ def pred_consis(preds):
 class StatPlan:
     """Owns a vitta_plan plus the packed per-channel device buffers of the batched path."""
 
-    def __init__(self, shapes, device, target_blocks=0, nt_loads=None):
-        # shapes: list of (outer, C, inner, layout)
+    def __init__(self, shapes, device, target_blocks=0, nt_loads=None, nsplit=None):
+        # shapes: list of (outer, C, inner, layout); nsplit: optional per-layer frame split (0 = library's choice)
         self.device = torch.device(device)
         self.shapes = [tuple(int(v) for v in s) for s in shapes]
         n = len(self.shapes)
@@ -149,8 +149,9 @@ class StatPlan:
             raise ValueError(f"number of hooked layers must be in 1..{_lib.MAX_LAYERS}, got {n}")
         arr = (_lib.LayerShape * n)(*[_lib.LayerShape(*s) for s in self.shapes])
         handle = C.c_void_p()
+        ns = (C.c_int32 * n)(*[int(v) for v in nsplit]) if nsplit is not None else None
         with torch.cuda.device(self.device):
-            check(lib().vitta_plan_create(arr, n, target_blocks, C.byref(handle)), "vitta_plan_create")
+            check(lib().vitta_plan_create_split(arr, n, target_blocks, ns, C.byref(handle)), "vitta_plan_create_split")
         self._h = handle
         L = lib()
         if nt_loads is not None:  # default: the library decides (non-temporal beyond the Infinity Cache size)
