@@ -258,6 +258,7 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  *   d_triples: NULL, or the layer's (n, mean, M2) partial area of a plan workspace
  *              (float* workspace + 3*ws_off, geometry from vitta_plan_layer_geometry; nsplit must match)
  *   backward: d_gres NULL iff no residual; d_mu/d_coef_a/d_coef_b/d_gscale NULL iff not hooked;
+ *             d_gx NULL: the BN input needs no gradient (first layer behind a frozen conv): only d gamma / d beta;
  *             d_gz2: NULL, or a second gradient of z (z feeds the next block's conv AND its identity path; summing
  *             the two here saves autograd's add pass over the largest tensors of the network);
  *             d_z needed only for relu+residual; d_partial: vitta_bn_act_partial_floats() floats of scratch;
@@ -362,6 +363,19 @@ int vitta_ln_bwd_f32(const float* d_gy, const float* d_gxnew, const float* d_x, 
                      int64_t rows_per_sample, int32_t C, float* d_gx, float* d_gbranch, float* d_partial, void* stream);
 int vitta_colsum2_f32(const float* d_partial, int64_t n_partials, int32_t C, float* d_out_a, float* d_out_b, float* d_cnt,
                       float cnt_value, void* stream);
+
+/* --------------------------------------------------------------------------
+ * A8 -- ResNet stem tail in one pass: eval BatchNorm -> ReLU -> MaxPool2d(3, stride 2, pad 1) over the 7x7 convolution's
+ * output (torchvision ResNet.forward: bn1, relu, maxpool).  d_x [N, C, H, W] -> d_out [N, C, PH, PW],
+ * PH = (H - 1) / 2 + 1.  The backward produces ONLY d gamma / d beta (ACCUMULATED with atomics; affine-only adaptation:
+ * the stem convolution is frozen, nothing flows below the BatchNorm), recomputing each window's maximum from d_x:
+ * max-pool's scatter becomes a reduction.  N * C <= 65535.
+ * -------------------------------------------------------------------------- */
+int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, float eps, int64_t N, int32_t C, int32_t H,
+                                    int32_t W, float* d_out, void* stream);
+int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps,
+                                           int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
+                                           void* stream);
 
 #ifdef __cplusplus
 }

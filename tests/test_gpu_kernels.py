@@ -629,3 +629,28 @@ def test_fused_layernorm_matches_torch(c, with_branch):
         if i == 1 and not with_branch:
             continue
         assert (a.grad.cpu().double() - ref.grad).abs().max().item() <= 1e-4 * ref.grad.abs().max().item() + 1e-6, i
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 112, 112), (3, 16, 15, 23), (2, 8, 8, 8)])
+def test_fused_stem_pool_matches_torch(shape):
+    """ops.FusedStemPool == max_pool2d(relu(batch_norm_eval(x)), 3, 2, 1): output and the affine gradients (the
+    max-pool scatter recomputed as a reduction), accumulated into live .grad storage; odd sizes exercise the padding."""
+    import torch.nn.functional as F
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(shape[2])
+    c = shape[1]
+    x = torch.randn(shape, generator=g)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rm, rv = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.max_pool2d(torch.relu(F.batch_norm(x.double(), rm.double(), rv.double(), wd, bd, False, 0.0, 1e-5)), 3, 2, 1)
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout.double())
+    d = _dev()
+    wg, bg = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    wg.grad, bg.grad = torch.full_like(wg, 0.5), torch.full_like(bg, -0.25)  # live storage: the kernel adds into it
+    out = ops.FusedStemPool.apply(x.to(d), wg, bg, rm.to(d), rv.to(d), 1e-5)
+    out.backward(gout.to(d))
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert (wg.grad.cpu().double() - 0.5 - wd.grad).abs().max().item() <= 1e-4 * wd.grad.abs().max().item() + 1e-5
+    assert (bg.grad.cpu().double() + 0.25 - bd.grad).abs().max().item() <= 1e-4 * bd.grad.abs().max().item() + 1e-5

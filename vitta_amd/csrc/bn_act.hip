@@ -187,7 +187,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
     const float4* pz = (RELU && RES) ? reinterpret_cast<const float4*>(z + j) : nullptr;
     const float4* pg = reinterpret_cast<const float4*>(gz + j);
     const float4* pg2 = gz2 ? reinterpret_cast<const float4*>(gz2 + j) : nullptr;
-    float4* pgx = reinterpret_cast<float4*>(gx + j);
+    float4* pgx = gx ? reinterpret_cast<float4*>(gx + j) : nullptr;  // null: the input needs no gradient (stem, frozen conv)
     float4* pgr = RES ? reinterpret_cast<float4*>(gres + j) : nullptr;
 #pragma unroll 4
     for (int64_t n = n0; n < n1; ++n) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
         dg[k] = fmaf(gy, (v[k] - rm[k]) * is[k], dg[k]);
         db[k] += gy;
       }
-      pgx[n * stride4] = make_float4(o[0], o[1], o[2], o[3]);
+      if (pgx) pgx[n * stride4] = make_float4(o[0], o[1], o[2], o[3]);
       if (RES) pgr[n * stride4] = make_float4(gg[0], gg[1], gg[2], gg[3]);
     }
   }
@@ -317,8 +317,8 @@ int vitta_bn_act_bwd_f32(const float* d_x, const float* d_z, const float* d_gz, 
   BnGeom g;
   const int rc = make_geom(outer, C, HW, nsplit, &g);
   if (rc != VITTA_OK) return rc;
-  if (!d_x || !d_gz || !d_gx || !d_weight || !d_bias || !d_rmean || !d_rvar || !d_dgamma || !d_dbeta)
-    return VITTA_ERR_INVALID_ARG;
+  if (!d_x || !d_gz || !d_weight || !d_bias || !d_rmean || !d_rvar || !d_dgamma || !d_dbeta)
+    return VITTA_ERR_INVALID_ARG;  // d_gx may be NULL: the BN input needs no gradient
   if (!accumulate && !d_partial) return VITTA_ERR_INVALID_ARG;
   // accumulate: every workgroup adds its per-channel sums straight into the live gradient (fp32 atomics, no partial
   // buffer, no second launch); otherwise partials + a deterministic fp64 finalize

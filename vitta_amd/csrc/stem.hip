@@ -1,0 +1,142 @@
+// ResNet stem tail: eval-mode BatchNorm -> ReLU -> MaxPool2d(3, stride 2, pad 1) in one pass over the 7x7 convolution's
+// output (torchvision ResNet.forward: bn1, relu, maxpool; the largest activation of the network: 16 x 64 x 112 x 112).
+//
+//   forward : pooled[n,c,ph,pw] = max over the 3x3 window of relu(x * s_c + t_c)     (zero padding == -inf padding after ReLU)
+//   backward: ONLY the affine gradients (update_only_bn_affine: the stem convolution is frozen and its input is the
+//             video, so no gradient flows below the BN).  The window maximum is recomputed per pooled element, which turns
+//             MaxPool's scatter into a plain reduction:  d beta_c = sum g * [ymax > 0],  d gamma_c = sum g * xhat(argmax).
+// Unfused this is BN+ReLU pass (102 MB) + max-pool (64 MB) forward and max-pool backward (atomics, 92 us) + BN backward
+// (154 MB) per adaptation step; fused 64 MB forward and 64 MB backward.
+#include <algorithm>
+
+#include "common.h"
+
+using namespace vitta;
+
+namespace {
+
+struct StemGeom {
+  int64_t N; int C, H, W, PH, PW;
+};
+
+// y values of the window of pooled pixel (ph, pw); returns the maximum, *arg = its x value (pre-BN) for the backward
+__device__ __forceinline__ float window_max(const float* __restrict__ xp, int H, int W, int ph, int pw, float sc, float sh,
+                                            float* arg_x) {
+  float best = 0.f, bx = 0.f;  // relu(.) >= 0 and padding contributes 0: starting at 0 is exact
+  bool found = false;
+  const int h0 = 2 * ph - 1, w0 = 2 * pw - 1;
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh) {
+    const int h = h0 + dh;
+    if (h < 0 || h >= H) continue;
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int w = w0 + dw;
+      if (w < 0 || w >= W) continue;
+      const float xv = xp[(int64_t)h * W + w];
+      const float y = fmaxf(fmaf(xv, sc, sh), 0.f);
+      if (!found || y > best) {  // first maximum in scan order, like aten::max_pool2d_with_indices
+        best = y; bx = xv; found = true;
+      }
+    }
+  }
+  *arg_x = bx;
+  return best;
+}
+
+__global__ __launch_bounds__(VITTA_BLOCK) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                               const float* __restrict__ rvar, float eps, StemGeom g,
+                                                               float* __restrict__ out) {
+  const int64_t plane_out = (int64_t)g.PH * g.PW;
+  const int64_t nc = blockIdx.y;  // (n, c) plane
+  const int c = (int)(nc % g.C);
+  const float sc = gamma[c] * rsqrtf(rvar[c] + eps);
+  const float sh = beta[c] - rmean[c] * sc;
+  const float* xp = x + nc * (int64_t)g.H * g.W;
+  float* op = out + nc * plane_out;
+  for (int64_t i = (int64_t)blockIdx.x * VITTA_BLOCK + threadIdx.x; i < plane_out; i += (int64_t)gridDim.x * VITTA_BLOCK) {
+    float ax;
+    op[i] = window_max(xp, g.H, g.W, (int)(i / g.PW), (int)(i % g.PW), sc, sh, &ax);
+  }
+}
+
+__global__ __launch_bounds__(VITTA_BLOCK) void stem_bwd_affine_kernel(const float* __restrict__ x, const float* __restrict__ gpool,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                                      float eps, StemGeom g, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta) {
+  __shared__ float red[2][VITTA_BLOCK / VITTA_WAVE];
+  const int64_t plane_out = (int64_t)g.PH * g.PW;
+  const int64_t nc = blockIdx.y;
+  const int c = (int)(nc % g.C);
+  const float is = rsqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * is;
+  const float rm = rmean[c];
+  const float sh = beta[c] - rm * sc;
+  const float* xp = x + nc * (int64_t)g.H * g.W;
+  const float* gp = gpool + nc * plane_out;
+  float a = 0.f, b = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * VITTA_BLOCK + threadIdx.x; i < plane_out; i += (int64_t)gridDim.x * VITTA_BLOCK) {
+    float ax;
+    const float ymax = window_max(xp, g.H, g.W, (int)(i / g.PW), (int)(i % g.PW), sc, sh, &ax);
+    const float gy = ymax > 0.f ? gp[i] : 0.f;  // ReLU mask of the routed gradient
+    a = fmaf(gy, (ax - rm) * is, a);
+    b += gy;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ta = 0.f, tb = 0.f;
+    for (int w = 0; w < VITTA_BLOCK / VITTA_WAVE; ++w) { ta += red[0][w]; tb += red[1][w]; }
+    atomicAdd(dgamma + c, ta);
+    atomicAdd(dbeta + c, tb);
+  }
+}
+
+inline int geom(int64_t N, int C, int H, int W, StemGeom* g) {
+  if (N <= 0 || C <= 0 || H < 2 || W < 2) return VITTA_ERR_INVALID_ARG;
+  g->N = N; g->C = C; g->H = H; g->W = W;
+  g->PH = (H + 2 - 3) / 2 + 1;
+  g->PW = (W + 2 - 3) / 2 + 1;
+  return VITTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, float eps, int64_t N, int32_t C, int32_t H,
+                                    int32_t W, float* d_out, void* stream) {
+  StemGeom g;
+  if (!d_x || !h_bn || !h_bn[0] || !h_bn[1] || !h_bn[2] || !h_bn[3] || !d_out) return VITTA_ERR_INVALID_ARG;
+  const int rc = geom(N, C, H, W, &g);
+  if (rc != VITTA_OK) return rc;
+  if (N * C > 65535) return VITTA_ERR_UNSUPPORTED;
+  const int64_t po = (int64_t)g.PH * g.PW;
+  const dim3 grid((unsigned)std::min<int64_t>((po + VITTA_BLOCK - 1) / VITTA_BLOCK, 64), (unsigned)(N * C));
+  VITTA_LAUNCH(stem_fwd_kernel, grid, dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream), d_x, h_bn[0], h_bn[1], h_bn[2],
+               h_bn[3], eps, g, d_out);
+  return VITTA_OK;
+}
+
+int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps,
+                                           int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
+                                           void* stream) {
+  StemGeom g;
+  if (!d_x || !d_gpool || !h_bn || !h_bn[0] || !h_bn[1] || !h_bn[2] || !h_bn[3] || !d_dgamma || !d_dbeta)
+    return VITTA_ERR_INVALID_ARG;
+  const int rc = geom(N, C, H, W, &g);
+  if (rc != VITTA_OK) return rc;
+  if (N * C > 65535) return VITTA_ERR_UNSUPPORTED;
+  const int64_t po = (int64_t)g.PH * g.PW;
+  const dim3 grid((unsigned)std::min<int64_t>((po + VITTA_BLOCK - 1) / VITTA_BLOCK, 64), (unsigned)(N * C));
+  VITTA_LAUNCH(stem_bwd_affine_kernel, grid, dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream), d_x, d_gpool, h_bn[0],
+               h_bn[1], h_bn[2], h_bn[3], eps, g, d_dgamma, d_dbeta);
+  return VITTA_OK;
+}
+
+}  // extern "C"

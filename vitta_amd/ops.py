@@ -511,7 +511,7 @@ class FusedBNAct(torch.autograd.Function):
             gz = torch.zeros_like(x)
         gz = gz.contiguous()
         gz2 = gz2.contiguous() if gz2 is not None else None
-        gx = torch.empty_like(x)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gres = torch.empty_like(x) if has_res else None
         dgamma, ret_gamma = _grad_sink(weight, ctx.needs_input_grad[1], zero=False)
         dbeta, ret_beta = _grad_sink(bias, ctx.needs_input_grad[2], zero=False)
@@ -737,3 +737,36 @@ class FusedLayerNorm(torch.autograd.Function):
                 r_b = None
         g_branch = (gbranch if gbranch is not None else gx) if has_branch else None
         return gx, g_branch, None, r_w, r_b, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNet stem tail: eval BN -> ReLU -> MaxPool(3, 2, 1) in one pass (affine-only backward)
+# ------------------------------------------------------------------------------------------------
+class FusedStemPool(torch.autograd.Function):
+    """pooled = maxpool3x3s2p1(relu(bn_eval(x))) for an x that needs NO gradient (the stem convolution is frozen and
+    its input is the video): the backward only accumulates d gamma / d beta, recomputing the window maxima."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps):
+        _require_cuda_f32(x, "x")
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+        check(lib().vitta_stem_bn_relu_pool_fwd_f32(_p(x), _ptr4(weight, bias, running_mean, running_var), float(eps), n, c, h,
+                                                    w, _p(out), _stream()), "vitta_stem_bn_relu_pool_fwd_f32")
+        ctx.save_for_backward(x, weight, bias, running_mean, running_var)
+        ctx.eps = float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, bias, running_mean, running_var = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("FusedStemPool has no input gradient: use the unfused stem when the convolution below trains")
+        n, c, h, w = x.shape
+        dw, r_w = _grad_sink(weight, True)
+        db, r_b = _grad_sink(bias, True)
+        check(lib().vitta_stem_bn_relu_pool_bwd_affine_f32(_p(x), _p(gout.contiguous()), _ptr4(weight, bias, running_mean,
+                                                                                               running_var), ctx.eps, n, c, h, w,
+                                                           _p(dw), _p(db), _stream()), "vitta_stem_bn_relu_pool_bwd_affine_f32")
+        return (None, r_w if ctx.needs_input_grad[1] else None, r_b if ctx.needs_input_grad[2] else None, None, None, None)

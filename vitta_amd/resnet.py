@@ -80,8 +80,26 @@ class ResNet(nn.Module):
         stage += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*stage)
 
+    def _stem_fusable(self, y):
+        """bn1 -> relu -> maxpool as one pass (vitta_stem_bn_relu_pool_*): eval-mode affine BN without hooks, the stock
+        3/2/1 max-pool, and a convolution output that needs no gradient (frozen stem under update_only_bn_affine,
+        or no_grad) -- the fused backward only produces d gamma / d beta."""
+        from . import fused_bn
+        bn, mp = self.bn1, self.maxpool
+        return (fused_bn.ENABLED and y.is_cuda and y.dtype == torch.float32 and not y.requires_grad
+                and isinstance(bn, nn.BatchNorm2d) and not bn.training and bn.affine
+                and not bn._forward_hooks and not bn._forward_pre_hooks and not mp._forward_hooks and not self.relu._forward_hooks
+                and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) ==
+                (3, 2, 1, 1, False) and y.shape[0] * y.shape[1] <= 65535)
+
     def forward(self, x):
-        x = self.maxpool(bn_act(self.bn1, self.conv1(x), relu=True, act=self.relu))
+        y = self.conv1(x)
+        if self._stem_fusable(y):
+            from . import ops
+            bn = self.bn1
+            x = ops.FusedStemPool.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        else:
+            x = self.maxpool(bn_act(self.bn1, y, relu=True, act=self.relu))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = torch.flatten(self.avgpool(x), 1)
         return self.fc(x)
