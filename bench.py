@@ -249,6 +249,7 @@ def run_gpu(opt, rank, world, device):
         from vitta_amd import fused_bn, fused_ln
         fused_bn.ENABLED = fused_ln.ENABLED = False
         graph, adapter._graph = adapter._graph, None
+        plan_of_graph = adapter.engine.plan  # the captured graphs write this plan's buffers (the eager exchanges read them)
         adapter.engine.timing_events = new_events
         barrier()
         te = time.perf_counter()
@@ -257,6 +258,7 @@ def run_gpu(opt, rank, world, device):
         barrier()
         eager_elapsed = time.perf_counter() - te
         adapter._graph = graph
+        adapter.engine.plan = plan_of_graph
         fused_bn.ENABLED = fused_ln.ENABLED = True
         log(f"eager repeat of the timed steps (kernel events): {eager_elapsed:.3f}s")
     adapter.engine.timing_events = None
