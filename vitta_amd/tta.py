@@ -426,6 +426,7 @@ class ViTTAAdapter:
                 and eval_input.shape == g["eval_in"].shape):
             g["tta_in"].copy_(tta_input)
             g["eval_in"].copy_(eval_input)
+            self.engine.plan = g["plan"]  # the buffers the captured launches (and the eager exchanges between them) use
             if g["step"] is not None:
                 g["step"].replay()
             else:
@@ -475,6 +476,7 @@ class ViTTAAdapter:
         g = self._graph
         if g is not None and has_video and input.shape == g["tta_in"].shape and "step" not in g:
             g["tta_in"].copy_(input)
+            self.engine.plan = g["plan"]
             if "adapt" in g:
                 g["adapt"].replay()
             else:  # data-parallel: three graph segments with the two exchanges launched eagerly in between
@@ -582,6 +584,7 @@ class ViTTAAdapter:
             g["eval_out"] = self._evaluate_eager(g["eval_in"])
         self.add_hooks_back()
         torch.cuda.synchronize()
+        g["plan"] = self.engine.plan  # an eager step on other shapes in between may switch the engine to another plan
         self._graph = g
 
     @torch.no_grad()
