@@ -298,11 +298,17 @@ class SwinTransformerBlock3D(nn.Module):
             x = x[:, :D, :H, :W, :].contiguous()
         return x
 
-    def forward(self, x, mask_matrix, region=None):
+    def forward(self, x, mask_matrix, region=None, normed=None, next_norm=None):
+        """`normed`: norm1(x) if the caller already has it; `next_norm`: the LayerNorm that consumes this block's
+        output (the next block's norm1) -- then the closing residual update and that normalisation are one pass and
+        the block returns (x_out, next_norm(x_out)) instead of x_out."""
         from .fused_ln import ln, ln_residual
-        a = self.attention_branch(ln(self.norm1, x), mask_matrix, region)
+        a = self.attention_branch(ln(self.norm1, x) if normed is None else normed, mask_matrix, region)
         x, y = ln_residual(self.norm2, x, a, self.drop_path)  # x = x + drop_path(a); y = norm2(x): one pass
-        return residual(x, self.mlp(y), self.drop_path)
+        m = self.mlp(y)
+        if next_norm is not None:
+            return ln_residual(next_norm, x, m, self.drop_path)
+        return residual(x, m, self.drop_path)
 
 
 class PatchMerging(nn.Module):
@@ -345,8 +351,11 @@ class BasicLayer(nn.Module):
         Dp, Hp, Wp = (int(np.ceil(n / w)) * w for n, w in zip((D, H, W), ws))
         attn_mask = compute_mask(Dp, Hp, Wp, ws, ss, x.device)
         region = compute_region(Dp, Hp, Wp, ws, ss, x.device) if x.is_cuda else None
-        for blk in self.blocks:
-            x = blk(x, attn_mask, region)
+        normed = None
+        for i, blk in enumerate(self.blocks):
+            nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
+            out = blk(x, attn_mask, region, normed=normed, next_norm=nxt)
+            x, normed = out if nxt is not None else (out, None)
         return self.downsample(x) if self.downsample is not None else x
 
 
