@@ -377,7 +377,8 @@ def main():
         traffic = pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]
 
     line = {
-        "metric": "videos/sec TTA step (TANet-R50, 2x8x224^2), whole job", "value": value, "unit": "videos/s",
+        "metric": f"videos/sec TTA step (TANet-R50, 2x{opt.clip_length}x{opt.size}^2), whole job", "value": value,
+        "unit": "videos/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "TANet-R50 UCF101 ViTTA online TTA, per-video iteration = adapt step (2 views x "
