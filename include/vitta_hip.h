@@ -290,6 +290,9 @@ int vitta_plan_layer_geometry(const vitta_plan* plan, int layer, int64_t* out5);
  *   rowmap[b % map_windows][n] of the natural [B, D*H*W] token order: torch.roll + window_partition and their
  *   inverses (swin_transformer.py:222-243) become address arithmetic (qkv / proj are per token and commute with
  *   the permutation); tokens_per_sample == map_windows * N (no padding). */
+/* the relative-position form also covers windows of 401..800 tokens (e.g. (16,7,7) = 784: keys / queries walked in
+ * chunks through LDS, online softmax), table T <= 8192; the dense form and T stay at N <= 400, T <= 4096 otherwise */
+int vitta_wmsa_rel_supported(int32_t N, int32_t head_dim);
 int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code,
                            int32_t code_off, const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH,
                            int32_t head_dim, float scale, const int32_t* d_rowmap, int32_t map_windows,

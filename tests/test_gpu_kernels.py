@@ -267,9 +267,13 @@ def test_wmsa_unsupported_shapes_are_reported():
 
 
 @pytest.mark.parametrize("ws,clamp,B,nh,shift", [((8, 7, 7), (8, 7, 7), 2, 4, True), ((8, 7, 7), (4, 7, 7), 3, 2, False),
-                                               ((8, 7, 7), (8, 4, 4), 2, 2, True), ((2, 3, 3), (2, 3, 3), 5, 1, True)])
+                                               ((8, 7, 7), (8, 4, 4), 2, 2, True), ((2, 3, 3), (2, 3, 3), 5, 1, True),
+                                               ((16, 7, 7), (16, 7, 7), 1, 2, True), ((16, 7, 7), (16, 7, 7), 1, 1, False),
+                                               ((16, 7, 7), (9, 7, 7), 1, 2, True), ((16, 7, 7), (16, 7, 5), 1, 1, True)])
 def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
-    """On-chip bias/mask variant == dense variant semantics: table[index[:N,:N]] and compute_mask."""
+    """On-chip bias/mask variant == dense variant semantics: table[index[:N,:N]] and compute_mask.  The (16,7,7)
+    cases (N = 784, 441, 560 tokens; table of 5239 rows) run the chunked kernels (keys / queries walked in chunks of
+    400 through LDS, online softmax)."""
     from vitta_amd import ops, swin
     g = torch.Generator().manual_seed(23)
     N = clamp[0] * clamp[1] * clamp[2]

@@ -19,15 +19,17 @@ p.add_argument("--size", type=int, default=224)
 p.add_argument("--frames", type=int, default=16)
 p.add_argument("--no-graph", action="store_true")
 p.add_argument("--sgd", action="store_true")
+p.add_argument("--views", type=int, default=2)
+p.add_argument("--window-depth", type=int, default=8, help="temporal window (16 = the SSv2 recipe of BASELINE config 4)")
 p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
 dev = torch.device("cuda:0")
 tmp = tempfile.mkdtemp()
-model = S.build_swin(101, 0).to(dev)
+model = S.build_swin(101, 0, window_size=(opt.window_depth, 7, 7)).to(dev)
 lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
 hooks = [ComputeNormStatsHook(m, clip_len=opt.frames, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
 with torch.no_grad():
-    model(S.seeded_randn((1, 2, 3, opt.frames, opt.size, opt.size), 1000, dev))
+    model(S.seeded_randn((1, opt.views, 3, opt.frames, opt.size, opt.size), 1000, dev))
 means = [h.batch_mean.cpu().numpy() for h in hooks]
 vars_ = [h.batch_var.cpu().numpy() for h in hooks]
 for h in hooks:
@@ -38,6 +40,7 @@ args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "s
 args.clip_length, args.result_dir, args.num_classes = opt.frames, tmp, 101
 args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
 args.update_only_bn_affine = not opt.sgd
+args.n_augmented_views, args.window_size = opt.views, (opt.window_depth, 7, 7)
 args.synthetic_n_videos, args.synthetic_device = 8, dev
 adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
 tta_set = data.build_videoswin_dataset(args, "val", "tta")
@@ -74,5 +77,5 @@ for i in range(opt.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
 print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph,
-                      frames=opt.frames, size=opt.size, schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
+                      frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

@@ -65,6 +65,7 @@ SIGNATURES = {
                                        _i32, _p, _p, _p, _i32, _p]),
     "vitta_plan_layer_geometry": (C.c_int, [_p, C.c_int, C.POINTER(_i64)]),
     "vitta_wmsa_supported": (C.c_int, [_i32, _i32]),
+    "vitta_wmsa_rel_supported": (C.c_int, [_i32, _i32]),
     "vitta_wmsa_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p]),
     "vitta_wmsa_rel_fwd_f32": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _i32, _i64,
                                          _p, _p, _p]),

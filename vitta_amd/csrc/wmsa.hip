@@ -522,6 +522,407 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Windows of 401 .. 800 tokens (the (16,7,7) window of the 32-frame SSv2 recipe: N = 784).  K and V of one (window, head)
+// no longer fit LDS together (226 KB), so keys (forward, dQ) / queries (dK dV) are walked in CHUNKS of 25 tiles that are
+// re-staged into the same two LDS buffers; a wave keeps the running state of at most TPW = 2 of its tiles in registers
+// across the chunks (forward: online softmax m, l, O; backward: plain accumulation, P = exp(S - lse) needs no rescale).
+// Relative-position form only (table <= 8192 entries: 5239 for (16,7,7)).
+// ------------------------------------------------------------------------------------------------
+constexpr int CT = NT_MAX;        // tiles per chunk
+constexpr int NTB_MAX = 50;       // N <= 800
+constexpr int TPW = 2;            // tiles of state per wave
+constexpr int T_MAX_BIG = 8192;
+
+struct CarveC {
+  float* buf0; float* buf1; float* extra; float* tab; int* cr; int* rows;
+};
+__device__ __forceinline__ CarveC carve_c(float* smem, int ntN, int extra_floats, int T) {
+  CarveC c;
+  c.buf0 = smem;
+  c.buf1 = c.buf0 + 16 * CT * KPAD;
+  c.extra = c.buf1 + 16 * CT * KPAD;
+  c.tab = c.extra + extra_floats;
+  c.cr = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
+  c.rows = c.cr + 16 * ntN;
+  return c;
+}
+
+// rows / packed codes of ALL tokens of window b, the table column of head h; ends with a barrier
+__device__ __forceinline__ AddTerms setup_chunked(const CarveC& c, const float* table, const int* code_g, const int* region_g,
+                                                  int T, int off, int nW, int N, int nH, int h, int64_t b, int ntN,
+                                                  const RowMap& rm) {
+  for (int i = threadIdx.x; i < T; i += WMSA_THREADS) c.tab[i] = table[(int64_t)i * nH + h];
+  for (int i = threadIdx.x; i < 16 * ntN; i += WMSA_THREADS) {
+    const int n = i < N ? i : N - 1;
+    const int reg = region_g ? region_g[(b % nW) * (int64_t)N + n] : 0;
+    c.cr[i] = code_g[n] | (reg << 16);
+    c.rows[i] = rm.map ? (int)((b / rm.nWm) * rm.L + rm.map[(b % rm.nWm) * (int64_t)N + n]) : (int)(b * N + n);
+  }
+  __syncthreads();
+  AddTerms a;
+  a.bias_h = nullptr; a.mask_b = nullptr; a.tab = c.tab; a.cr = c.cr; a.off = off;
+  return a;
+}
+
+// S^T tile t of a chunk whose first key is `kbase`: keys 16t + 4kk + r of the chunk, query with packed code pq
+__device__ __forceinline__ f32x4 score_tile_chunk(const float* __restrict__ k_lds, const float (&qf)[8], int t, int lane,
+                                                  const AddTerms& a, int pq, int kbase, int N) {
+  const int j = lane & 15, kk = lane >> 4;
+  float kf[8];
+  load8(kf, k_lds + (16 * t + j) * KPAD + 8 * kk);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; s += 2) {
+    acc = mfma(kf[s], qf[s], acc);
+    acc2 = mfma(kf[s + 1], qf[s + 1], acc2);
+  }
+  acc += acc2;
+  const int key0 = kbase + 16 * t + 4 * kk;
+  const int4 ck = *reinterpret_cast<const int4*>(a.cr + key0);
+  const int cq = pk_code(pq) + a.off, rq = pk_region(pq);
+  const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
+  float tv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tv[r] = a.tab[cq - pk_code(kc[r])];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = pk_region(kc[r]) != rq ? tv[r] - 100.f : tv[r];
+    acc[r] = key0 + r < N ? acc[r] + v : -INFINITY;
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_chunked_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ table, const int* __restrict__ code_g,
+    const int* __restrict__ region_g, int T, int off, int nW, int N, int nH, float scale, int qsplit, RowMap rm,
+    float* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ntN = (N + 15) / 16;
+  const CarveC cv = carve_c(smem, ntN, 0, T);
+  float* k_lds = cv.buf0;
+  float* v_lds = cv.buf1;
+  const int* rows = cv.rows;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const AddTerms terms = setup_chunked(cv, table, code_g, region_g, T, off, nW, N, nH, h, b, ntN, rm);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  const float* q_base = qkv + (int64_t)h * HD;
+  const int per = (ntN + qsplit - 1) / qsplit;
+  const int rt0 = blockIdx.x * per, rt1 = min(ntN, rt0 + per);
+
+  float qf[TPW][8], m[TPW], l[TPW];
+  int pq[TPW];
+  bool has[TPW];
+  f32x4 o0[TPW], o1[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int rt = rt0 + wave + WMSA_WAVES * j;
+    has[j] = rt < rt1;
+    const int q = min(16 * rt + i, N - 1);
+    load8(qf[j], q_base + (int64_t)rows[q] * rs + 8 * kk);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[j][s] *= scale;
+    pq[j] = cv.cr[q];
+    m[j] = -INFINITY;
+    l[j] = 0.f;
+    o0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    o1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int kbase = 0; kbase < N; kbase += 16 * CT) {
+    const int nk = min(N - kbase, 16 * CT), ntk = (nk + 15) / 16;
+    __syncthreads();  // every wave is done with the previous chunk
+    stage_rows(k_lds, qkv, h, 1, nk, nH, ntk, rows + kbase);
+    stage_rows(v_lds, qkv, h, 2, nk, nH, ntk, rows + kbase);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (!has[j]) continue;  // wave-uniform
+      f32x4 acc[CT];
+      float mc = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (t < ntk) {
+          acc[t] = score_tile_chunk(k_lds, qf[j], t, lane, terms, pq[j], kbase, N);
+          mc = fmaxf(mc, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
+        }
+      }
+      mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+      const float m_new = fmaxf(m[j], mc);
+      const float alpha = __expf(m[j] - m_new);  // 0 on the first chunk (m = -inf)
+      float ls = 0.f;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (t < ntk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __expf(acc[t][r] - m_new);
+            acc[t][r] = p;
+            ls += p;
+          }
+        }
+      }
+      ls += __shfl_xor(ls, 16, 64);
+      ls += __shfl_xor(ls, 32, 64);
+      l[j] = l[j] * alpha + ls;
+      m[j] = m_new;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {  // O rows are queries 4kk + r: their rescale factor lives in lane 4kk + r
+        const float ar = __shfl(alpha, 4 * kk + r, 64);
+        o0[j][r] *= ar;
+        o1[j][r] *= ar;
+      }
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        if (t < ntk) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* vrow = v_lds + (16 * t + 4 * kk + r) * KPAD;
+            o0[j] = mfma(acc[t][r], vrow[i], o0[j]);
+            o1[j] = mfma(acc[t][r], vrow[16 + i], o1[j]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (!has[j]) continue;
+    const int rt = rt0 + wave + WMSA_WAVES * j;
+    const float inv_l = 1.f / l[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * kk + r;
+      const float il = __shfl(inv_l, 4 * kk + r, 64);
+      if (qrow < N) {
+        float* o = out + (int64_t)rows[qrow] * C + h * HD;
+        o[i] = o0[j][r] * il;
+        o[16 + i] = o1[j][r] * il;
+      }
+    }
+    if (kk == 0 && 16 * rt + i < N) lse[(b * nH + h) * N + 16 * rt + i] = m[j] + __logf(l[j]);
+  }
+}
+
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_chunked_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ table, const int* __restrict__ code_g,
+    const int* __restrict__ region_g, int T, int off, int nW, int N, int nH, float scale, int qsplit, RowMap rm,
+    const float* __restrict__ out, const float* __restrict__ dout, const float* __restrict__ lse,
+    float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dtable) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ntN = (N + 15) / 16;
+  const CarveC cv = carve_c(smem, ntN, 0, T);
+  float* k_lds = cv.buf0;
+  float* v_lds = cv.buf1;
+  const int* rows = cv.rows;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const AddTerms terms = setup_chunked(cv, table, code_g, region_g, T, off, nW, N, nH, h, b, ntN, rm);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  const float* q_base = qkv + (int64_t)h * HD;
+  const int per = (ntN + qsplit - 1) / qsplit;
+  const int rt0 = blockIdx.x * per, rt1 = min(ntN, rt0 + per);
+
+  float qf[TPW][8], gf[TPW][8], L[TPW], dl[TPW];
+  int pq[TPW], qi[TPW];
+  bool has[TPW], qvalid[TPW];
+  f32x4 dq0[TPW], dq1[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int rt = rt0 + wave + WMSA_WAVES * j;
+    has[j] = rt < rt1;
+    qvalid[j] = has[j] && 16 * rt + i < N;
+    const int q = min(16 * rt + i, N - 1);
+    qi[j] = q;
+    float of[8];
+    load8(qf[j], q_base + (int64_t)rows[q] * rs + 8 * kk);
+    load8(gf[j], dout + (int64_t)rows[q] * C + h * HD + 8 * kk);
+    load8(of, out + (int64_t)rows[q] * C + h * HD + 8 * kk);
+    float d = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      qf[j][s] *= scale;
+      d = fmaf(gf[j][s], of[s], d);
+    }
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    dl[j] = d;
+    L[j] = lse[(b * nH + h) * N + q];
+    if (kk == 0 && qvalid[j]) delta[(b * nH + h) * N + q] = d;
+    pq[j] = cv.cr[q];
+    dq0[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dq1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int kbase = 0; kbase < N; kbase += 16 * CT) {
+    const int nk = min(N - kbase, 16 * CT), ntk = (nk + 15) / 16;
+    __syncthreads();
+    stage_rows(k_lds, qkv, h, 1, nk, nH, ntk, rows + kbase);
+    stage_rows(v_lds, qkv, h, 2, nk, nH, ntk, rows + kbase);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (!has[j]) continue;
+      for (int t = 0; t < ntk; ++t) {
+        const f32x4 s = score_tile_chunk(k_lds, qf[j], t, lane, terms, pq[j], kbase, N);
+        float vf[8];
+        load8(vf, v_lds + (16 * t + i) * KPAD + 8 * kk);
+        f32x4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dp = mfma(vf[u], gf[j][u], dp);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = __expf(s[r] - L[j]) * (dp[r] - dl[j]);  // exp(-inf) = 0 for padded keys
+        if (dtable && qvalid[j]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kbase + 16 * t + 4 * kk + r;
+            if (key < N)
+              atomicAdd(dtable + (int64_t)(pk_code(pq[j]) - pk_code(terms.cr[key]) + terms.off) * nH + h, ds[r]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* krow = k_lds + (16 * t + 4 * kk + r) * KPAD;
+          dq0[j] = mfma(ds[r], krow[i], dq0[j]);
+          dq1[j] = mfma(ds[r], krow[16 + i], dq1[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (!has[j]) continue;
+    const int rt = rt0 + wave + WMSA_WAVES * j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * kk + r;
+      if (qrow < N) {
+        float* o = dqkv + (int64_t)rows[qrow] * rs + (int64_t)h * HD;
+        o[i] = dq0[j][r] * scale;
+        o[16 + i] = dq1[j][r] * scale;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_chunked_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ table, const int* __restrict__ code_g,
+    const int* __restrict__ region_g, int T, int off, int nW, int N, int nH, float scale, int qsplit, RowMap rm,
+    const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ntN = (N + 15) / 16;
+  const CarveC cv = carve_c(smem, ntN, 2 * 16 * CT, T);
+  float* q_lds = cv.buf0;
+  float* g_lds = cv.buf1;
+  float* l_lds = cv.extra;
+  float* d_lds = l_lds + 16 * CT;
+  const int* rows = cv.rows;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int C = nH * HD;
+  const AddTerms terms = setup_chunked(cv, table, code_g, region_g, T, off, nW, N, nH, h, b, ntN, rm);
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = lane & 15, kk = lane >> 4;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const float* k_base = qkv + (int64_t)(nH + h) * HD;
+  const float* v_base = qkv + (int64_t)(2 * nH + h) * HD;
+  const int per = (ntN + qsplit - 1) / qsplit;
+  const int kt0 = blockIdx.x * per, kt1 = min(ntN, kt0 + per);
+
+  float kf[TPW][8], vf[TPW][8];
+  int pkey[TPW];
+  bool has[TPW], kvalid[TPW];
+  f32x4 dk0[TPW], dk1[TPW], dv0[TPW], dv1[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int kt = kt0 + wave + WMSA_WAVES * j;
+    has[j] = kt < kt1;
+    const int key = min(16 * kt + i, N - 1);
+    kvalid[j] = has[j] && 16 * kt + i < N;
+    pkey[j] = cv.cr[key];
+    load8(kf[j], k_base + (int64_t)rows[key] * rs + 8 * kk);
+    load8(vf[j], v_base + (int64_t)rows[key] * rs + 8 * kk);
+    dk0[j] = dk1[j] = dv0[j] = dv1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int qbase = 0; qbase < N; qbase += 16 * CT) {
+    const int nq = min(N - qbase, 16 * CT), ntq = (nq + 15) / 16;
+    __syncthreads();
+    stage_rows(q_lds, qkv, h, 0, nq, nH, ntq, rows + qbase);
+    stage_rows_dense(g_lds, dout + h * HD, C, nq, ntq, rows + qbase);
+    for (int r = threadIdx.x; r < 16 * ntq; r += WMSA_THREADS) {
+      l_lds[r] = r < nq ? lse[(b * nH + h) * N + qbase + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
+      d_lds[r] = r < nq ? delta[(b * nH + h) * N + qbase + r] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (!has[j]) continue;
+      for (int qt = 0; qt < ntq; ++qt) {
+        float qf[8], gf[8];
+        load8(qf, q_lds + (16 * qt + i) * KPAD + 8 * kk);
+        load8(gf, g_lds + (16 * qt + i) * KPAD + 8 * kk);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s = mfma(qf[u], kf[j][u], s);
+          dp = mfma(gf[u], vf[j][u], dp);
+        }
+        f32x4 p, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * qt + 4 * kk + r, q = qbase + ql;
+          const float term = rel_term(terms, terms.cr[q < N ? q : N - 1], pkey[j]);
+          const float sv = (q < N && kvalid[j]) ? fmaf(s[r], scale, term) : -INFINITY;
+          p[r] = __expf(sv - l_lds[ql]);
+          ds[r] = p[r] * (dp[r] - d_lds[ql]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float* grow = g_lds + (16 * qt + 4 * kk + r) * KPAD;
+          const float* qrow = q_lds + (16 * qt + 4 * kk + r) * KPAD;
+          dv0[j] = mfma(p[r], grow[i], dv0[j]);
+          dv1[j] = mfma(p[r], grow[16 + i], dv1[j]);
+          dk0[j] = mfma(ds[r], qrow[i], dk0[j]);
+          dk1[j] = mfma(ds[r], qrow[16 + i], dk1[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (!has[j]) continue;
+    const int kt = kt0 + wave + WMSA_WAVES * j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = 16 * kt + 4 * kk + r;
+      if (krow < N) {
+        float* ok = dqkv + (int64_t)rows[krow] * rs + (int64_t)(nH + h) * HD;
+        float* ov = dqkv + (int64_t)rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
+        ok[i] = dk0[j][r] * scale;
+        ok[16 + i] = dk1[j][r] * scale;
+        ov[i] = dv0[j][r];
+        ov[16 + i] = dv1[j][r];
+      }
+    }
+  }
+}
+
+inline size_t lds_bytes_chunked(int N, int extra_floats, int T) {
+  const int ntN = (N + 15) / 16;
+  return sizeof(float) * ((size_t)2 * 16 * CT * KPAD + extra_floats + ((T + 3) & ~3) + 2 * 16 * ntN);
+}
+
 inline int pick_qsplit(int64_t pairs, int nt) {
   // One workgroup per CU at a time (the staged operands take ~115 KB of LDS) and every workgroup re-stages
   // K and V: split the query tiles of a (window, head) pair only until every CU has one workgroup (256),
@@ -584,6 +985,40 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
   return VITTA_OK;
 }
 
+inline int chunked_qsplit(int N) {
+  const int ntN = (N + 15) / 16;
+  return (ntN + WMSA_WAVES * TPW - 1) / (WMSA_WAVES * TPW);
+}
+
+template <typename K>
+inline bool set_dyn_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) ==
+         hipSuccess;
+}
+
+int launch_fwd_chunked(const WmsaArgs& a, float* out, float* lse, hipStream_t st) {
+  const int qs = chunked_qsplit(a.N);
+  const size_t lds = lds_bytes_chunked(a.N, 0, a.T);
+  if (lds > 160 * 1024) return VITTA_ERR_UNSUPPORTED;
+  if (!set_dyn_lds(wmsa_fwd_chunked_kernel, lds)) return VITTA_ERR_LAUNCH;
+  VITTA_LAUNCH(wmsa_fwd_chunked_kernel, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds, st, a.qkv, a.bias, a.code,
+               a.region, a.T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, lse);
+  return VITTA_OK;
+}
+
+int launch_bwd_chunked(const WmsaArgs& a, const float* out, const float* dout, const float* lse, float* delta, float* dqkv,
+                       float* dtable, hipStream_t st) {
+  const int qs = chunked_qsplit(a.N);
+  const size_t lds1 = lds_bytes_chunked(a.N, 0, a.T), lds2 = lds_bytes_chunked(a.N, 2 * 16 * CT, a.T);
+  if (lds2 > 160 * 1024) return VITTA_ERR_UNSUPPORTED;
+  if (!set_dyn_lds(wmsa_bwd_dq_chunked_kernel, lds1) || !set_dyn_lds(wmsa_bwd_dkv_chunked_kernel, lds2)) return VITTA_ERR_LAUNCH;
+  VITTA_LAUNCH(wmsa_bwd_dq_chunked_kernel, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, a.code,
+               a.region, a.T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dtable);
+  VITTA_LAUNCH(wmsa_bwd_dkv_chunked_kernel, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, a.code,
+               a.region, a.T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, dout, lse, delta, dqkv);
+  return VITTA_OK;
+}
+
 inline bool misaligned(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
   return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
            reinterpret_cast<uintptr_t>(d)) & 15u) != 0;
@@ -594,6 +1029,11 @@ inline bool misaligned(const void* a, const void* b = nullptr, const void* c = n
 extern "C" {
 
 int vitta_wmsa_supported(int32_t N, int32_t head_dim) { return (head_dim == HD && N >= 1 && N <= 16 * NT_MAX) ? 1 : 0; }
+
+/* relative-position form: additionally windows of up to 800 tokens (key / query chunks re-staged through LDS) */
+int vitta_wmsa_rel_supported(int32_t N, int32_t head_dim) {
+  return (head_dim == HD && N >= 1 && N <= 16 * NTB_MAX) ? 1 : 0;
+}
 
 int vitta_wmsa_fwd_f32(const float* d_qkv, const float* d_bias, const float* d_mask, int32_t nW, int64_t B_, int32_t N,
                        int32_t nH, int32_t head_dim, float scale, float* d_out, float* d_lse, void* stream) {
@@ -621,15 +1061,18 @@ int vitta_wmsa_rel_fwd_f32(const float* d_qkv, const float* d_table, int32_t T, 
                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                            float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                            float* d_out, float* d_lse, void* stream) {
-  if (!d_qkv || !d_table || !d_code || !d_out || !d_lse || B_ <= 0 || nH <= 0 || T <= 0 || T > T_MAX)
+  if (!d_qkv || !d_table || !d_code || !d_out || !d_lse || B_ <= 0 || nH <= 0 || T <= 0 || T > T_MAX_BIG)
     return VITTA_ERR_INVALID_ARG;
-  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (!vitta_wmsa_rel_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  const bool chunked = N > 16 * NT_MAX;
+  if (!chunked && T > T_MAX) return VITTA_ERR_UNSUPPORTED;
   if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
   if (d_rowmap && (map_windows <= 0 || B_ % map_windows || tokens_per_sample != (int64_t)map_windows * N))
     return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
   const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
                    RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+  if (chunked) return launch_fwd_chunked(a, d_out, d_lse, static_cast<hipStream_t>(stream));
   return launch_fwd<true>(a, d_out, d_lse, static_cast<hipStream_t>(stream));
 }
 
@@ -639,15 +1082,19 @@ int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, 
                            const float* d_out, const float* d_dout, const float* d_lse, float* d_delta,
                            float* d_dqkv, float* d_dtable, void* stream) {
   if (!d_qkv || !d_table || !d_code || !d_out || !d_dout || !d_lse || !d_delta || !d_dqkv || B_ <= 0 || nH <= 0 ||
-      T <= 0 || T > T_MAX)
+      T <= 0 || T > T_MAX_BIG)
     return VITTA_ERR_INVALID_ARG;
-  if (!vitta_wmsa_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  if (!vitta_wmsa_rel_supported(N, head_dim)) return VITTA_ERR_UNSUPPORTED;
+  const bool chunked = N > 16 * NT_MAX;
+  if (!chunked && T > T_MAX) return VITTA_ERR_UNSUPPORTED;
   if (d_region && (nW <= 0 || B_ % nW)) return VITTA_ERR_INVALID_ARG;
   if (d_rowmap && (map_windows <= 0 || B_ % map_windows || tokens_per_sample != (int64_t)map_windows * N))
     return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
   const WmsaArgs a{d_qkv, d_table, nullptr, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
                    RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+  if (chunked)
+    return launch_bwd_chunked(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dtable, static_cast<hipStream_t>(stream));
   return launch_bwd<true>(a, d_out, d_dout, d_lse, d_delta, d_dqkv, d_dtable, static_cast<hipStream_t>(stream));
 }
 

@@ -371,6 +371,12 @@ def wmsa_supported(n_tokens, head_dim):
     return bool(lib().vitta_wmsa_supported(int(n_tokens), int(head_dim)))
 
 
+def wmsa_rel_supported(n_tokens, head_dim, table_rows):
+    """relative-position-table form: windows up to 800 tokens; tables up to 4096 rows (8192 beyond 400 tokens)"""
+    ok = bool(lib().vitta_wmsa_rel_supported(int(n_tokens), int(head_dim)))
+    return ok and table_rows <= (8192 if n_tokens > 400 else 4096)
+
+
 class WindowAttention(torch.autograd.Function):
     """softmax(scale q k^T + bias (+ mask)) v per (window, head) in one launch; the N x N matrix never
     reaches HBM (swin_transformer.py:144-168).  qkv (B_, N, 3C) -> (B_, N, C)."""

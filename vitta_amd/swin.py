@@ -240,7 +240,7 @@ class WindowAttention3D(nn.Module):
         B_, N, C = x.shape
         if x.is_cuda and FUSED_ATTENTION and (mask is None or region is not None):
             from . import ops
-            if ops.wmsa_supported(N, C // self.num_heads) and self.relative_position_bias_table.shape[0] <= 4096:
+            if ops.wmsa_rel_supported(N, C // self.num_heads, self.relative_position_bias_table.shape[0]):
                 out = ops.WindowAttentionRel.apply(self.qkv(x), self.relative_position_bias_table,
                                                    self.relative_position_code[:N], self.code_offset, region, self.scale,
                                                    self.num_heads)
@@ -277,10 +277,9 @@ class SwinTransformerBlock3D(nn.Module):
         shifted = any(s > 0 for s in ss)
         attn = self.attn
         n_tok = ws[0] * ws[1] * ws[2]
-        if (x.is_cuda and FUSED_ATTENTION and FUSED_PARTITION and not any(pad) and (not shifted or region is not None)
-                and attn.relative_position_bias_table.shape[0] <= 4096):
+        if x.is_cuda and FUSED_ATTENTION and FUSED_PARTITION and not any(pad) and (not shifted or region is not None):
             from . import ops
-            if ops.wmsa_supported(n_tok, C // attn.num_heads):
+            if ops.wmsa_rel_supported(n_tok, C // attn.num_heads, attn.relative_position_bias_table.shape[0]):
                 # shift + partition + reverse + inverse shift as address arithmetic inside the attention kernel
                 rowmap = compute_rowmap(D, H, W, ws, ss, x.device)
                 out = ops.WindowAttentionRel.apply(attn.qkv(x.view(B, D * H * W, C)), attn.relative_position_bias_table,
