@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _rank_main(rank, world, port, tmp, mode):
+def _rank_main(rank, world, port, tmp, mode, device="cpu"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -50,8 +50,10 @@ def _rank_main(rank, world, port, tmp, mode):
     for i in range(3):
         m = H.unpack_mask(g[f"sgd_step{i}_dropmask"], g[f"sgd_step{i}_dropmask_shape"])
         masks.append(m[rank * 2 * Tn:(rank + 1) * 2 * Tn])
-    tta.BACKEND_FACTORY = OracleBackend
-    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+    dev = torch.device(device)
+    if dev.type == "cpu":
+        tta.BACKEND_FACTORY = OracleBackend  # host logic over the oracle; on the GPU the product's HIP backend runs
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(dev), args)
     tta.BACKEND_FACTORY = None
     assert adapter.world == 2 and adapter.bucket is not None and adapter.engine.distributed
     adapter.model.module.base_model.fc = H.ReplayDropout(0.8, masks)
@@ -63,27 +65,27 @@ def _rank_main(rank, world, port, tmp, mode):
         vid = 2 * step + rank
         has_video = not (mode == "ragged" and step == 1 and rank == 1)  # rank 1 runs dry on the last step
         adapter.set_adapt_mode()
-        x = adapter.shape_tta_input(tta_set[vid][0].unsqueeze(0)) if has_video else None
+        x = adapter.shape_tta_input(tta_set[vid][0].unsqueeze(0).to(dev)) if has_video else None
         _, loss_reg, loss_consis = adapter.adapt_step(x, has_video)
         named = dict(adapter.model.named_parameters())
         adapter.close_hooks()
-        logits = adapter.evaluate(adapter.shape_eval_input(eval_set[vid][0].unsqueeze(0)))
+        logits = adapter.evaluate(adapter.shape_eval_input(eval_set[vid][0].unsqueeze(0).to(dev)))
         adapter.add_hooks_back()
         out[f"step{step}_loss_reg"] = float(loss_reg)
         out[f"step{step}_loss_consis"] = float(loss_consis) if loss_consis is not None else float("nan")
-        out[f"step{step}_logits"] = logits.numpy()
+        out[f"step{step}_logits"] = logits.detach().cpu().numpy()
         out[f"step{step}_ema_sum"] = float(adapter.engine.ema_mean.double().sum())
         out[f"step{step}_param_sum"] = float(sum(float(p.double().sum()) for p in named.values()))
         for name in map(str, g["sampled_params"]):
-            out[f"step{step}_param::{name}"] = named[name].detach().numpy()[:int(g["sample_rows"])].copy()
-            out[f"step{step}_grad::{name}"] = named[name].grad.detach().numpy()[:int(g["sample_rows"])].copy()
+            out[f"step{step}_param::{name}"] = named[name].detach().cpu().numpy()[:int(g["sample_rows"])].copy()
+            out[f"step{step}_grad::{name}"] = named[name].grad.detach().cpu().numpy()[:int(g["sample_rows"])].copy()
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **out)
     torch.distributed.destroy_process_group()
 
 
-def _run(tmp_path, mode):
+def _run(tmp_path, mode, device="cpu"):
     port = _free_port()
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path), mode, device), nprocs=2, join=True)
     return [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(2)]
 
 

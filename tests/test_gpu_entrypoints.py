@@ -106,3 +106,29 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 6 and rec["value"] > 0
     assert rec["config"]["parallelism"] == "dp2" and "3 segments" in rec["launch_mode"]
+
+
+def test_two_ranks_on_one_gpu_equal_reference_batch_of_two(tmp_path):
+    """The data-parallel numerics ON THE GPU (fused BN passes feeding the packed moments, the two exchanges, the flat
+    gradient arena): 2 ranks sharing the test box's GPU over gloo reproduce the reference's own batch-of-two run, the
+    same golden tests/test_dist_cpu.py checks the host logic against."""
+    import test_dist_cpu as D
+    g = H.golden("tta3_bz2.npz")
+    r0, r1 = D._run(tmp_path, "full", device="cuda:0")
+    for i in range(3):
+        k = f"sgd_step{i}_"
+        ref_reg, ref_con = float(g[k + "loss_reg"]), float(g[k + "loss_consis"])
+        assert r0[f"step{i}_loss_reg"] == pytest.approx(float(r1[f"step{i}_loss_reg"]), rel=1e-6)
+        assert abs(float(r0[f"step{i}_loss_reg"]) - ref_reg) <= max(1e-4 * ref_reg, 4 * float(g[k + "noise_loss_reg"])) + 1e-6
+        total_con = float(r0[f"step{i}_loss_consis"]) + float(r1[f"step{i}_loss_consis"])
+        assert abs(total_con - ref_con) <= max(5e-3 * ref_con, 4 * float(g[k + "noise_loss_consis"])) + 1e-6
+        assert float(r0[f"step{i}_ema_sum"]) == pytest.approx(float(r1[f"step{i}_ema_sum"]), rel=1e-6)
+        assert float(r0[f"step{i}_param_sum"]) == pytest.approx(float(r1[f"step{i}_param_sum"]), rel=1e-9)
+        ref_logits = g[k + "eval_logits"]
+        got = np.concatenate([r0[f"step{i}_logits"], r1[f"step{i}_logits"]])
+        assert np.abs(got - ref_logits).max() <= max(2e-3 * np.abs(ref_logits).max(), 4 * float(g[k + "noise_eval_logits"]))
+        for name in map(str, g["sampled_params"]):
+            ref_g = g[k + f"grad::{name}"]
+            bound = max(2e-2 * np.abs(ref_g).max(), 4 * float(g[k + f"noise_grad::{name}"])) + 1e-9
+            assert np.abs(r0[f"step{i}_grad::{name}"] - ref_g).max() <= bound, (i, name)
+            np.testing.assert_allclose(r0[f"step{i}_grad::{name}"], r1[f"step{i}_grad::{name}"], rtol=0, atol=0)
