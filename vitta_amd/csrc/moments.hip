@@ -414,6 +414,12 @@ int vitta_plan_create_split(const vitta_layer_shape* h_shapes, int n_layers, int
         for (int k = 0; k < L->nchunks; ++k) tab_nhwc.push_back(BlockEnt{l, k, sp, 0});
     }
   }
+  // workgroups are dispatched in table order: walk the layers LAST FIRST.  In a training step the hooked features were
+  // written in layer order, so the last layers are the ones still in the Infinity Cache; reading the oldest (evicted)
+  // ones first would push them out before they are reached.
+  // (measured in the TANet step: 35.5-38 us against 41 us in layer order, r1p)
+  std::stable_sort(tab_nchw.begin(), tab_nchw.end(), [](const BlockEnt& a, const BlockEnt& b) { return a.layer > b.layer; });
+  std::stable_sort(tab_nhwc.begin(), tab_nhwc.end(), [](const BlockEnt& a, const BlockEnt& b) { return a.layer > b.layer; });
   p->ws_triples = ws;
   p->n_blocks_nchw = (int)tab_nchw.size();
   p->n_blocks_nhwc = (int)tab_nhwc.size();
