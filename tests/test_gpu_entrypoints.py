@@ -40,14 +40,18 @@ def test_eval_statistics_then_tta_online_on_gpu(tmp_path, affine_only):
     var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
     assert len(np.load(mean_file, allow_pickle=True)) == 53
     # 2. online TTA over 10 videos: 3 eager, then graph replay, evaluation overlapped with the next adaptation
+    # lr: the seeded toy model on noise clips is an unstable optimisation problem at the shipped 5e-5 with momentum SGD
+    # over all weights (the loss explodes after ~6 videos, in some runs to NaN): this test is about the plumbing
     targs = _args(tmp_path, model_path=ckpt, spatiotemp_mean_clean_file=mean_file, spatiotemp_var_clean_file=var_file,
-                  verbose=True, update_only_bn_affine=affine_only)
+                  verbose=True, update_only_bn_affine=affine_only, lr=2e-6)
     targs.val_vid_list, targs.result_dir = "unused", os.path.join(str(tmp_path), "tta_run")
     res, returned = run_eval(args=targs)
     assert returned is None and len(res) == 1 and 0.0 <= res[0] <= 100.0
     text = open(glob.glob(os.path.join(targs.result_dir, "*"))[0]).read()
     for i in range(10):
         assert f"TTA Epoch1: [{i}/10]" in text
+    if "nan" in text.lower():
+        print("\n".join(l[:220] for l in text.splitlines() if "TTA Epoch1" in l))
     assert "nan" not in text.lower()
 
 
