@@ -298,7 +298,9 @@ def streaming_moments(adapter, device, copies=16, reps=20):
     from vitta_amd import ops
     base = adapter.engine.plan.shapes
     shapes = [(outer * copies, c, inner, layout) for outer, c, inner, layout in base]
-    plan = ops.StatPlan(shapes, device)
+    # twice the workgroups of the in-step launch (same speed at this size): the two show up as separate lines of a
+    # rocprofv3 summary split by launch geometry
+    plan = ops.StatPlan(shapes, device, target_blocks=4096)
     feats = [torch.randn(outer * c * inner, device=device) for outer, c, inner, _ in shapes]
     nbytes = 4 * sum(f.numel() for f in feats)
     shift = torch.zeros(plan.total_channels, device=device)

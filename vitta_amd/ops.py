@@ -154,7 +154,7 @@ class StatPlan:
             check(lib().vitta_plan_create_split(arr, n, target_blocks, ns, C.byref(handle)), "vitta_plan_create_split")
         self._h = handle
         L = lib()
-        if nt_loads is not None:  # default: the library decides (non-temporal beyond the Infinity Cache size)
+        if nt_loads is not None:  # default: the library's (non-temporal loads: every feature is read once)
             check(L.vitta_plan_set_option(self._h, 1, int(bool(nt_loads))), "vitta_plan_set_option")
         # device tables of the plan: a torch-owned buffer (the library never allocates device memory)
         self.tables = torch.empty(int(L.vitta_plan_table_bytes(self._h)), dtype=torch.uint8, device=self.device)
