@@ -16,6 +16,26 @@ using namespace vitta;
 
 namespace {
 
+// streaming load: every operand of these passes is read exactly once per pass and not again before the far end of the
+// step (the conv output x only in the backward), so the loads carry the non-temporal hint -- what has to stay in the
+// Infinity Cache is what the pass WRITES (the next convolution reads z / gx right away).  VITTA_BN_NT=0 at compile
+// time restores plain loads.
+#ifndef VITTA_BN_NT
+#define VITTA_BN_NT 1
+#endif
+__device__ __forceinline__ float4 ldnt(const float4* p) {
+#if VITTA_BN_NT
+  float4 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  v.z = __builtin_nontemporal_load(&p->z);
+  v.w = __builtin_nontemporal_load(&p->w);
+  return v;
+#else
+  return *p;
+#endif
+}
+
 // one wave per channel touched by the chunk: sum the per-slot values staged in LDS
 __device__ __forceinline__ void segmented_sum2(const float* lds_a, const float* lds_b, int64_t base, int64_t plane,
                                                int64_t HW, float* out2 /* [slots][2] of this (split, chunk) */,
@@ -102,13 +122,13 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_fwd_kernel(const float* __
     const float4* pr = RES ? reinterpret_cast<const float4*>(res + j) : nullptr;
     float4* pz = reinterpret_cast<float4*>(z + j);
     if (STATS) {
-      const float4 f = px[n0 * stride4];
+      const float4 f = px[n0 * stride4];  // (re-read below: plain load)
       y0[0] = fmaf(f.x, sc[0], sh[0]); y0[1] = fmaf(f.y, sc[1], sh[1]);
       y0[2] = fmaf(f.z, sc[2], sh[2]); y0[3] = fmaf(f.w, sc[3], sh[3]);
     }
 #pragma unroll 4
     for (int64_t n = n0; n < n1; ++n) {
-      const float4 v = px[n * stride4];
+      const float4 v = ldnt(px + n * stride4);
       float y[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3])};
       if (STATS) {
 #pragma unroll
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_fwd_kernel(const float* __
         }
       }
       if (RES) {
-        const float4 r = pr[n * stride4];
+        const float4 r = ldnt(pr + n * stride4);
         y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
       }
       if (RELU) {
@@ -191,17 +211,17 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_act_bwd_kernel(
     float4* pgr = RES ? reinterpret_cast<float4*>(gres + j) : nullptr;
 #pragma unroll 4
     for (int64_t n = n0; n < n1; ++n) {
-      const float4 v4 = px[n * stride4];
-      const float4 g4 = pg[n * stride4];
+      const float4 v4 = ldnt(px + n * stride4);
+      const float4 g4 = ldnt(pg + n * stride4);
       const float v[4] = {v4.x, v4.y, v4.z, v4.w};
       float gg[4] = {g4.x, g4.y, g4.z, g4.w};
       if (pg2) {
-        const float4 h4 = pg2[n * stride4];
+        const float4 h4 = ldnt(pg2 + n * stride4);
         gg[0] += h4.x; gg[1] += h4.y; gg[2] += h4.z; gg[3] += h4.w;
       }
       float zz[4] = {1.f, 1.f, 1.f, 1.f};
       if (RELU && RES) {
-        const float4 z4 = pz[n * stride4];
+        const float4 z4 = ldnt(pz + n * stride4);
         zz[0] = z4.x; zz[1] = z4.y; zz[2] = z4.z; zz[3] = z4.w;
       }
       float o[4];
