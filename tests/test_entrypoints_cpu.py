@@ -98,6 +98,11 @@ def test_episodic_mode_matches_reference(tmp_path, monkeypatch):
     """if_tta_standard='tta_standard' -- model, optimizer, hooks and EMA re-initialised for
     every video, momentum_mvg = 1, two gradient steps per video; the product's tta_standard driven end to end
     against the reference's own run (dropout masks replayed)."""
+    run_episodic(tmp_path, monkeypatch, "cpu")
+
+
+def run_episodic(tmp_path, monkeypatch, device):
+    """Shared with tests/test_gpu_entrypoints.py (device 'cuda:0': the product's HIP backend instead of the oracle's)."""
     g = H.golden("episodic.npz")
     ch = g["src_channels"]
     offs = np.concatenate([[0], np.cumsum(ch)])
@@ -105,10 +110,12 @@ def test_episodic_mode_matches_reference(tmp_path, monkeypatch):
                                 [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
     args = H.tanet_args(tmp_path, clip_length=8, input_size=64, spatiotemp_mean_clean_file=mp,
                         spatiotemp_var_clean_file=vp, lr=5e-5, if_tta_standard="tta_standard", momentum_mvg=1.0,
-                        n_gradient_steps=2, synthetic_n_videos=2, synthetic_seed=500, device="cpu")
+                        n_gradient_steps=2, synthetic_n_videos=2, synthetic_seed=500, device=device)
     masks = [H.unpack_mask(g[f"step{i}_dropmask"], g[f"step{i}_dropmask_shape"]) for i in range(4)]
-    model = tta.SingleDeviceParallel(H.build_tanet(101, 8, 0))
-    monkeypatch.setattr(tta, "BACKEND_FACTORY", OracleBackend)
+    model = tta.SingleDeviceParallel(H.build_tanet(101, 8, 0)).to(device)
+    gpu = torch.device(device).type == "cuda"
+    if not gpu:
+        monkeypatch.setattr(tta, "BACKEND_FACTORY", OracleBackend)
     seen = {"losses": [], "adapters": []}
     real_init = tta.ViTTAAdapter.__init__
 
@@ -130,19 +137,20 @@ def test_episodic_mode_matches_reference(tmp_path, monkeypatch):
 
     def evaluate(self, x):
         o = real_eval(self, x)
-        logits.append(o.clone())
+        logits.append(o.detach().cpu().clone())
         return o
 
     monkeypatch.setattr(tta.ViTTAAdapter, "__init__", init)
     monkeypatch.setattr(tta.ViTTAAdapter, "adapt_step", step)
     monkeypatch.setattr(tta.ViTTAAdapter, "evaluate", evaluate)
     import logging
-    res = tta.tta_standard(model, torch.nn.CrossEntropyLoss(), args=args, logger=logging.getLogger("t"), writer=None)
+    res = tta.tta_standard(model, torch.nn.CrossEntropyLoss().to(device), args=args, logger=logging.getLogger("t"), writer=None)
     assert len(seen["adapters"]) == 2 and len(seen["losses"]) == 4  # re-initialised per video, 2 steps each
     for i, (lr_, lc_) in enumerate(seen["losses"]):
         first = i % 2 == 0  # first step of a video starts from the pristine model: tight; second: after one update
-        assert lr_ == pytest.approx(float(g[f"step{i}_loss_reg"]), rel=1e-5 if first else 1e-3)
-        assert lc_ == pytest.approx(float(g[f"step{i}_loss_consis"]), rel=1e-5 if first else 5e-3)
+        tight = 1e-4 if gpu else 1e-5  # (library reduction orders on the GPU)
+        assert lr_ == pytest.approx(float(g[f"step{i}_loss_reg"]), rel=tight if first else 2e-3)
+        assert lc_ == pytest.approx(float(g[f"step{i}_loss_consis"]), rel=tight if first else 1e-2)
     for v in range(2):
         ref = torch.from_numpy(g[f"video{v}_eval_logits"])
         # momentum_mvg = 1 and two steps make this regime chaotic: the reference re-run with inputs perturbed

@@ -136,3 +136,10 @@ def test_two_ranks_on_one_gpu_equal_reference_batch_of_two(tmp_path):
             bound = max(2e-2 * np.abs(ref_g).max(), 4 * float(g[k + f"noise_grad::{name}"])) + 1e-9
             assert np.abs(r0[f"step{i}_grad::{name}"] - ref_g).max() <= bound, (i, name)
             np.testing.assert_allclose(r0[f"step{i}_grad::{name}"], r1[f"step{i}_grad::{name}"], rtol=0, atol=0)
+
+
+def test_episodic_mode_matches_reference_on_gpu(tmp_path, monkeypatch):
+    """SURVEY 8f row N4 on the GPU: if_tta_standard='tta_standard' (fresh adapter per video, momentum_mvg = 1, two
+    gradient steps) through the HIP path against the reference's own run -- the golden of tests/test_entrypoints_cpu.py."""
+    from test_entrypoints_cpu import run_episodic
+    run_episodic(tmp_path, monkeypatch, "cuda:0")
