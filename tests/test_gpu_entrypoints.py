@@ -143,3 +143,48 @@ def test_episodic_mode_matches_reference_on_gpu(tmp_path, monkeypatch):
     gradient steps) through the HIP path against the reference's own run -- the golden of tests/test_entrypoints_cpu.py."""
     from test_entrypoints_cpu import run_episodic
     run_episodic(tmp_path, monkeypatch, "cuda:0")
+
+
+def test_ragged_last_batch_with_captured_graphs_on_gpu(tmp_path, monkeypatch):
+    """batch_size 2 over 7 videos: steps of 2, 2, 2 and a ragged last step of 1.  The graphs are captured on a
+    2-video step; the 1-video step has other shapes, so it runs eagerly on another statistics plan and the engine must
+    come back to the captured graphs' plan afterwards (here: the drained evaluation).  Same losses as the plain eager,
+    sequential loop."""
+    import json
+    import re
+    from vitta_amd import tta as T
+    g = H.golden("tta3.npz")
+    cfg = json.loads(str(g["config"]))
+    Tn, size = cfg["T"], cfg["size"]
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    model = H.build_tanet(101, Tn, 0)
+    model.base_model.fc = torch.nn.Identity()
+    monkeypatch.setattr(T, "GRAPH_AFTER_STEPS", 2)  # (every convolution shape must have run eagerly once before a capture)
+
+    def run(fast):
+        a = H.tanet_args(tmp_path, clip_length=Tn, input_size=size, spatiotemp_mean_clean_file=mp,
+                         spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=1e-4, synthetic_n_videos=7,
+                         synthetic_seed=700, verbose=True, batch_size=2, overlap_eval=fast, hip_graph=fast)
+        lines = []
+
+        class Log:
+            def debug(self, msg):
+                lines.append(msg)
+        res = T.tta_standard(T.SingleDeviceParallel(model).to("cuda:0"), torch.nn.CrossEntropyLoss().to("cuda:0"), args=a,
+                             logger=Log(), writer=None)
+        rows = {}
+        for l in lines:
+            m = re.match(r"TTA Epoch1: \[(\d+)/4\].*Loss reg ([\d.]+) .*Loss consis ([\d.]+) ", l)
+            if m:
+                rows[int(m.group(1))] = (float(m.group(2)), float(m.group(3)))
+        return res, rows
+
+    (acc_f, fast), (acc_s, slow), (_, slow2) = run(True), run(False), run(False)
+    assert sorted(fast) == sorted(slow) == [0, 1, 2, 3]
+    for i in range(4):
+        for k, (rel, floor) in enumerate(((2e-3, 2e-4), (2e-2, 2e-4))):
+            spread = abs(slow[i][k] - slow2[i][k])
+            assert abs(fast[i][k] - slow[i][k]) <= max(4 * spread, rel * abs(slow[i][k]) + floor), (i, k, fast[i], slow[i])
