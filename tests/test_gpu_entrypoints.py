@@ -188,3 +188,25 @@ def test_ragged_last_batch_with_captured_graphs_on_gpu(tmp_path, monkeypatch):
         for k, (rel, floor) in enumerate(((2e-3, 2e-4), (2e-2, 2e-4))):
             spread = abs(slow[i][k] - slow2[i][k])
             assert abs(fast[i][k] - slow[i][k]) <= max(4 * spread, rel * abs(slow[i][k]) + floor), (i, k, fast[i], slow[i])
+
+
+def test_two_ranks_swin_equal_one_process_batch_of_two_on_gpu(tmp_path):
+    """Video Swin-B, LayerNorm statistics from the fused LayerNorm passes: 2 ranks x 1 video (packed-moments and
+    gradient all-reduce, gloo on the shared GPU) == 1 process x 2 videos -- the statistics loss, the EMA state and the
+    summed consistency loss over three steps; the replicas stay identical."""
+    import torch.multiprocessing as mp
+    import swin_dp_worker as W
+    from test_dist_cpu import _free_port
+    mp.spawn(W.run, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    W.run(0, 1, 0, str(tmp_path))
+    r0, r1, one = (np.load(os.path.join(str(tmp_path), f)) for f in ("w2r0.npz", "w2r1.npz", "w1r0.npz"))
+    for i in range(3):
+        assert float(r0[f"step{i}_loss_reg"]) == pytest.approx(float(r1[f"step{i}_loss_reg"]), rel=1e-6)
+        np.testing.assert_allclose(r0[f"step{i}_ema"], r1[f"step{i}_ema"], rtol=1e-6, atol=1e-7)
+        assert float(r0[f"step{i}_param_sum"]) == pytest.approx(float(r1[f"step{i}_param_sum"]), rel=1e-9)
+        tol = 1e-4 if i == 0 else 5e-3  # later steps: Adam's sign-like updates amplify round-off differences
+        assert float(r0[f"step{i}_loss_reg"]) == pytest.approx(float(one[f"step{i}_loss_reg"]), rel=tol)
+        total = float(r0[f"step{i}_loss_consis"]) + float(r1[f"step{i}_loss_consis"])
+        assert total == pytest.approx(float(one[f"step{i}_loss_consis"]), rel=10 * tol, abs=1e-4)
+        scale = np.abs(one[f"step{i}_ema"]).max()
+        assert np.abs(r0[f"step{i}_ema"] - one[f"step{i}_ema"]).max() <= (1e-4 if i == 0 else 5e-3) * scale
