@@ -109,9 +109,37 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
   for (int i = threadIdx.x; i < rows * len; i += TBW) dst[i] = src[(int64_t)(i / len) * stride + i % len];
 }
 
-// pooled [C][T] of clip n -> LDS [C][T+2], zero padded in t
+// pooled [C][T] of clip n -> LDS [C][T+2], zero padded in t.  T % 4 == 0 (the shipped 8 / 16 frames): the rows are read
+// as 16-byte vectors, SU of them in flight per lane (the scalar loop was 20 dependent L2 round trips per lane at C = 512:
+// most of F1's 9-11 us)
 __device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, int c0, int nc, float* pl) {
   const int C = a.C, T = a.T, TP = T + 2;
+  const float* src = a.pooled + ((int64_t)n * C + c0) * T;
+  const int ncv = min(nc, C - c0);  // valid channels of the tile
+  if ((T & 3) == 0 && aligned16(src)) {
+    const int t4 = T >> 2, n4 = ncv * t4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += SU * TBW) {
+      float4 v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) v[u] = s4[min(i0 + u * TBW, n4 - 1)];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * TBW;
+        if (i < n4) {
+          float* d = pl + (i / t4) * TP + 1 + 4 * (i % t4);
+          d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+      }
+    }
+    for (int c = threadIdx.x; c < nc; c += TBW) {  // the two pad columns; whole rows of channels past C
+      pl[c * TP] = 0.f;
+      pl[c * TP + T + 1] = 0.f;
+      if (c >= ncv)
+        for (int t = 0; t < T; ++t) pl[c * TP + 1 + t] = 0.f;
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < nc * TP; i += TBW) {
     const int c = c0 + i / TP, t = i % TP - 1;
     pl[i] = (c < C && t >= 0 && t < T) ? a.pooled[((int64_t)n * C + c) * T + t] : 0.f;
@@ -206,6 +234,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   const int item = threadIdx.x / CS, cs = threadIdx.x % CS;
   float acc = 0.f;
   const int o = tile * OBF + item / T, t = item % T;
+  // eval-BN parameters of this item's channel: issued now, consumed after the reduction (a dependent chain of global
+  // loads at the very end of a 7 us kernel is a fifth of its run time)
+  float bw = 0.f, brv = 1.f, brm = 0.f, bb = 0.f;
+  if (cs == 0 && item < items && o < O) { bw = a.bnl.w[o]; brv = a.bnl.rv[o]; brm = a.bnl.rm[o]; bb = a.bnl.b[o]; }
   if (item < items && o < O) {
     const float* w = wl + (item / T) * C * 3;
     for (int c = cs; c < C; c += CS) {
@@ -220,10 +252,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
   if (cs == 0 && item < items && o < O) {
     float pre = 0.f;
     for (int k = 0; k < CS; ++k) pre += red[item * CS + k];
-    const float sc = a.bnl.w[o] * rsqrtf(a.bnl.rv[o] + a.bnl.eps);
+    const float sc = bw * rsqrtf(brv + a.bnl.eps);
     const int64_t idx = ((int64_t)n * O + o) * T + t;
     h_pre[idx] = pre;
-    h_act[idx] = fmaxf(fmaf(pre - a.bnl.rm[o], sc, a.bnl.b[o]), 0.f);
+    h_act[idx] = fmaxf(fmaf(pre - brm, sc, bb), 0.f);
   }
 }
 
@@ -289,6 +321,13 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   const int CS = TBW / items > 0 ? TBW / items : 1;
   const int item = threadIdx.x / CS, cs = threadIdx.x % CS;
   const int o = tile * OBB + item / T, t = item % T;
+  // operands of the item's epilogue, issued before the reduction (see F1)
+  float bw = 0.f, brv = 1.f, brm = 0.f, hact = 0.f, hpre = 0.f;
+  if (cs == 0 && item < items && o < O) {
+    const int64_t idx0 = ((int64_t)n * O + o) * T + t;
+    bw = a.bnl.w[o]; brv = a.bnl.rv[o]; brm = a.bnl.rm[o];
+    hact = h_act[idx0]; hpre = h_pre[idx0];
+  }
   float acc = 0.f;
   if (item < items && o < O)
     for (int c = cs; c < C; c += CS) acc = fmaf(wl[c * OBB + item / T], dz[c * T + t], acc);
@@ -298,10 +337,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
     float dh = 0.f;
     for (int k = 0; k < CS; ++k) dh += red[item * CS + k];
     const int64_t idx = ((int64_t)n * O + o) * T + t;
-    const float is = rsqrtf(a.bnl.rv[o] + a.bnl.eps);
-    const float gy = h_act[idx] > 0.f ? dh : 0.f;
-    dpre_g[idx] = gy * a.bnl.w[o] * is;
-    atomicAdd(g.dbnl_w + o, gy * (h_pre[idx] - a.bnl.rm[o]) * is);
+    const float is = rsqrtf(brv + a.bnl.eps);
+    const float gy = hact > 0.f ? dh : 0.f;
+    dpre_g[idx] = gy * bw * is;
+    atomicAdd(g.dbnl_w + o, gy * (hpre - brm) * is);
     atomicAdd(g.dbnl_b + o, gy);
   }
   if (g.dw3) {  // dW3[c, o] += sum_t dz[c,t] h[o,t] for this tile's o
@@ -337,9 +376,11 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
       wl[i] = r < cw ? a.w0[((int64_t)o * C + c0) * 3 + r] : 0.f;
     }
   }
-  for (int i = threadIdx.x; i < O * TP; i += TBW) {
-    const int o = i / TP, t = i % TP - 1;
-    dpre[i] = (t >= 0 && t < T) ? dpre_g[((int64_t)n * O + o) * T + t] : 0.f;
+  {  // d(conv1 output) [O][T] of the clip -> [O][T+2]: the same padded staging as the pooled rows
+    TamBranchArgs tmp = a;
+    tmp.pooled = dpre_g;
+    tmp.C = O;
+    load_pooled_t(tmp, n, 0, O, dpre);
   }
   load_pooled_t(a, n, c0, CBB, pl);
   for (int i = threadIdx.x; i < 5 * M + M * T; i += TBW) gacc[i] = 0.f;
