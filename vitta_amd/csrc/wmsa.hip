@@ -203,7 +203,16 @@ __device__ __forceinline__ AddTerms setup_terms(const Carve& c, const float* bia
   AddTerms a;
   a.bias_h = nullptr; a.mask_b = nullptr; a.tab = nullptr; a.cr = nullptr; a.off = off;
   if constexpr (REL) {
-    for (int i = threadIdx.x; i < T; i += WMSA_THREADS) c.tab[i] = bias_or_table[(int64_t)i * nH + h];
+    // the table column is a strided gather of T (2535) floats: all of a lane's loads in flight together (a plain loop
+    // is five dependent L2 round trips at the head of every workgroup)
+    for (int i0 = threadIdx.x; i0 < T; i0 += 8 * WMSA_THREADS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = bias_or_table[(int64_t)min(i0 + u * WMSA_THREADS, T - 1) * nH + h];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * WMSA_THREADS < T) c.tab[i0 + u * WMSA_THREADS] = v[u];
+    }
     for (int i = threadIdx.x; i < 16 * nt; i += WMSA_THREADS) {
       const int n = i < N ? i : N - 1;
       const int reg = region_g ? region_g[(b % nW) * (int64_t)N + n] : 0;
@@ -552,7 +561,14 @@ __device__ __forceinline__ CarveC carve_c(float* smem, int ntN, int extra_floats
 __device__ __forceinline__ AddTerms setup_chunked(const CarveC& c, const float* table, const int* code_g, const int* region_g,
                                                   int T, int off, int nW, int N, int nH, int h, int64_t b, int ntN,
                                                   const RowMap& rm) {
-  for (int i = threadIdx.x; i < T; i += WMSA_THREADS) c.tab[i] = table[(int64_t)i * nH + h];
+  for (int i0 = threadIdx.x; i0 < T; i0 += 8 * WMSA_THREADS) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = table[(int64_t)min(i0 + u * WMSA_THREADS, T - 1) * nH + h];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * WMSA_THREADS < T) c.tab[i0 + u * WMSA_THREADS] = v[u];
+  }
   for (int i = threadIdx.x; i < 16 * ntN; i += WMSA_THREADS) {
     const int n = i < N ? i : N - 1;
     const int reg = region_g ? region_g[(b % nW) * (int64_t)N + n] : 0;
