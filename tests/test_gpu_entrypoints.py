@@ -145,6 +145,13 @@ def test_episodic_mode_matches_reference_on_gpu(tmp_path, monkeypatch):
     run_episodic(tmp_path, monkeypatch, "cuda:0")
 
 
+def test_epoch_style_test_time_adapt_matches_reference_on_gpu(tmp_path, monkeypatch):
+    """SURVEY 8f row N4, second half, on the GPU: the epoch-style test_time_adapt (adapt over the list two videos per
+    step, close the hooks, validate_brief over the list) through the HIP path against the reference's own run."""
+    from test_entrypoints_cpu import run_epoch
+    run_epoch(tmp_path, monkeypatch, "cuda:0")
+
+
 def test_ragged_last_batch_with_captured_graphs_on_gpu(tmp_path, monkeypatch):
     """batch_size 2 over 7 videos: steps of 2, 2, 2 and a ragged last step of 1.  The graphs are captured on a
     2-video step; the 1-video step has other shapes, so it runs eagerly on another statistics plan and the engine must

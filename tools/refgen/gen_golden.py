@@ -22,8 +22,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import refimport  # noqa: E402
 
+os.chdir(HERE)  # reference modules append the working directory to sys.path: it must not be the repo root (see below)
 ARGV = sys.argv[1:]  # refimport.install() resets sys.argv (the reference parses it at import time)
 refimport.install()
+# the repo root carries drop-in packages with the reference's names (corpus/, utils/, models/): bind those names to
+# the REFERENCE before anything puts the repo root on sys.path
+import corpus.basics as _ref_basics  # noqa: E402
+import utils.opts as _ref_opts  # noqa: E402
+assert _ref_basics.__file__.startswith(refimport.REFERENCE) and _ref_opts.__file__.startswith(refimport.REFERENCE)
 sys.path.insert(0, os.path.join(refimport.REPO, "tests"))
 import helpers as H  # noqa: E402
 
@@ -217,21 +223,25 @@ class _Perturbed(torch.utils.data.Dataset):
         return x * (1 + self.eps * H.seeded_randn(tuple(x.shape), self.seed + i)), y
 
 
-def run_reference_tta(args, model_origin, n_videos, batch_size, capture, perturb=0.0, perturb_seed=90000):
+def run_reference_tta(args, model_origin, n_videos, batch_size, capture, perturb=0.0, perturb_seed=90000,
+                      entry="tta_standard"):
     import corpus.basics as B
     import copy as _copy
 
     real_deepcopy = _copy.deepcopy
 
+    def instrument(c):
+        capture.model = c
+        for m in c.modules():
+            if isinstance(m, nn.Dropout):
+                m.register_forward_hook(lambda mod, i, o: capture.drop_masks.append(t2n(o != 0)) if mod.training else None)
+        c.register_forward_hook(lambda mod, i, o: capture.eval_logits.append(t2n(o)) if not mod.training else None)
+
     def spy_deepcopy(obj, *a, **k):
         c = real_deepcopy(obj, *a, **k)
         if isinstance(obj, nn.Module) and (capture.model is None or getattr(capture, "episodic", False)) \
                 and isinstance(obj, Wrap):
-            capture.model = c
-            for m in c.modules():
-                if isinstance(m, nn.Dropout):
-                    m.register_forward_hook(lambda mod, i, o: capture.drop_masks.append(t2n(o != 0)) if mod.training else None)
-            c.register_forward_hook(lambda mod, i, o: capture.eval_logits.append(t2n(o)) if not mod.training else None)
+            instrument(c)
         return c
 
     B.cp.deepcopy = spy_deepcopy
@@ -286,7 +296,12 @@ def run_reference_tta(args, model_origin, n_videos, batch_size, capture, perturb
     logger = logging.getLogger("refgen")
     logger.addHandler(logging.NullHandler())
     try:
-        res = B.tta_standard(Wrap(model_origin), nn.CrossEntropyLoss(), args=args, logger=logger, writer=None)
+        if entry == "tta_standard":
+            res = B.tta_standard(Wrap(model_origin), nn.CrossEntropyLoss(), args=args, logger=logger, writer=None)
+        else:  # the epoch-style function adapts the model it is given: hand it a private, instrumented copy
+            own = real_deepcopy(Wrap(model_origin))
+            instrument(own)
+            res, _ = B.test_time_adapt(own, nn.CrossEntropyLoss(), args=args, logger=logger, writer=None)
     finally:
         B.cp.deepcopy = real_deepcopy
         B.compute_pred_consis = real_consis
@@ -426,6 +441,49 @@ def gen_episodic():
     out["src_channels"] = np.array([len(m) for m in means])
     out["top1"] = np.array(res)
     save("episodic.npz", **out)
+
+
+def gen_epoch():
+    """N4, second half: the epoch-style `test_time_adapt` (if_tta_standard falsy): four videos adapted two per
+    step (Adam on the BN affine parameters), hooks closed, then `validate_brief` over the list in one batch."""
+    from utils.opts import get_opts
+    T, size, n_videos, bz = 8, 64, 4, 2
+    ref, _ = ref_tanet(101, T, 0)
+    means, vars_ = source_stats_for(ref, T, size)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        mp, vp = H.write_stat_files(tmp, means, vars_)
+        args = get_opts()
+        args.arch, args.dataset, args.clip_length, args.workers = "tanet", "ucf101", T, 0
+        args.input_size, args.verbose, args.batch_size, args.batch_size_eval = size, False, bz, n_videos
+        args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+        args.num_classes, args.gpus, args.result_dir, args.lr = 101, [0], tmp, 1e-3
+        args.if_tta_standard, args.update_only_bn_affine, args.n_epoch_adapat = False, True, 1
+        cap = _Capture()
+        torch.manual_seed(77)
+        res = run_reference_tta(args, ref, n_videos, bz, cap, entry="test_time_adapt")
+        floor = 0.0
+        for trial in range(3):
+            c2 = _Capture()
+            torch.manual_seed(77)
+            run_reference_tta(args, ref, n_videos, bz, c2, perturb=1e-7, perturb_seed=90000 + 1000 * trial,
+                              entry="test_time_adapt")
+            floor = max(floor, float(np.abs(cap.eval_logits[0] - c2.eval_logits[0]).max()))
+        out["noise_eval_logits"] = np.array(floor)
+    assert len(cap.steps) == 2 and len(cap.eval_logits) == 1, (len(cap.steps), len(cap.eval_logits))
+    for i, rec in enumerate(cap.steps):
+        out[f"step{i}_loss_reg"] = np.array(rec["loss_reg"])
+        out[f"step{i}_loss_consis"] = cap.consis[i]
+        bits, shape = H.pack_mask(cap.drop_masks[i])
+        out[f"step{i}_dropmask"], out[f"step{i}_dropmask_shape"] = bits, shape
+        for key in SAMPLED_PARAMS:
+            out[f"step{i}_param::{key}"] = rec[f"param::{key}"]
+    out["eval_logits"] = cap.eval_logits[0]
+    out["src_means"], out["src_vars"] = np.concatenate(means), np.concatenate(vars_)
+    out["src_channels"] = np.array([len(m) for m in means])
+    out["sampled_params"] = np.array(SAMPLED_PARAMS)
+    out["top1"] = np.array(res)
+    save("epoch.npz", **out)
 
 
 def synthetic_frames(n, w, h, seed):
@@ -733,7 +791,7 @@ def gen_bns():
 
 
 SECTIONS = dict(l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
-                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic, data=gen_data)
+                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic, data=gen_data, epoch=gen_epoch)
 
 if __name__ == "__main__":
     for n in (ARGV or list(SECTIONS)):

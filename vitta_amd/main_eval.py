@@ -17,7 +17,7 @@ import time
 
 import torch
 
-from .tta import NUM_CLASSES, SingleDeviceParallel, _loader, compute_statistics, get_dataset_tanet, \
+from .tta import NUM_CLASSES, SingleDeviceParallel, _loader, compute_statistics, test_time_adapt, get_dataset_tanet, \
     get_dataset_videoswin, get_model, tta_standard, validate
 from .utils_ import make_dir, model_analysis, path_logger
 
@@ -79,10 +79,11 @@ def eval(args=None, model=None):
         if args.compute_stat == "mean_var":
             compute_statistics(model, args=args, log_time=log_time)
         elif args.compute_stat is False:
-            if not args.if_tta_standard:
-                raise NotImplementedError("the epoch-style test_time_adapt variant is outside the ViTTA path")
-            epoch_result_list = tta_standard(model, criterion, args=args, logger=logger, writer=None)
-            model = None
+            if args.if_tta_standard:
+                epoch_result_list = tta_standard(model, criterion, args=args, logger=logger, writer=None)
+                model = None
+            else:  # epoch-style: returns the adapted model (main_eval.py:96-98)
+                epoch_result_list, model = test_time_adapt(model, criterion, args=args, logger=logger, writer=None)
         else:
             raise NotImplementedError(f"compute_stat={args.compute_stat!r} is outside the ViTTA path")
     elif args.evaluate_baselines:

@@ -213,9 +213,9 @@ class DeferredLog:
 
     FIELDS = 5  # loss_reg, loss_consis, loss_ce, prec1, prec5
 
-    def __init__(self, device, logger, total, verbose, lag=8):
+    def __init__(self, device, logger, total, verbose, lag=8, epoch=1, print_freq=1):
         self.logger, self.total, self.verbose, self.lag = logger, total, verbose, lag
-        self.device = device
+        self.device, self.epoch, self.print_freq = device, epoch, print_freq
         self.pending = []
         self.meters = dict(batch_time=AverageMeter(), loss_reg=AverageMeter(), loss_consis=AverageMeter(),
                            loss_ce=AverageMeter(), top1=AverageMeter(), top5=AverageMeter())
@@ -248,14 +248,14 @@ class DeferredLog:
         m["loss_ce"].update(ce, bz)
         m["top1"].update(p1, bz)
         m["top5"].update(p5, bz)
-        if self.verbose and self.logger is not None:
+        if self.verbose and self.logger is not None and batch_id % self.print_freq == 0:
             self.logger.debug(("TTA Epoch{epoch}: [{0}/{1}]\t"
                                "Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t"
                                "Loss reg {loss_reg.val:.4f} ({loss_reg.avg:.4f})\t"
                                "Loss consis {loss_consis.val:.4f} ({loss_consis.avg:.4f})\t"
                                "Prec@1 {top1.val:.3f} ({top1.avg:.3f})\t"
                                "Prec@5 {top5.val:.3f} ({top5.avg:.3f})").format(
-                batch_id, self.total, epoch=1, batch_time=m["batch_time"], loss_reg=m["loss_reg"],
+                batch_id, self.total, epoch=self.epoch, batch_time=m["batch_time"], loss_reg=m["loss_reg"],
                 loss_consis=m["loss_consis"], top1=m["top1"], top5=m["top5"]))
 
 
@@ -266,9 +266,10 @@ class ViTTAAdapter:
     """Everything `tta_standard` sets up before the first video (corpus/basics.py:525-601), plus the
     adapt / evaluate steps of the loop body so bench.py and the tests can drive them directly."""
 
-    def __init__(self, model_origin, args, engine_backend=None, use_engine=None):
+    def __init__(self, model_origin, args, engine_backend=None, use_engine=None, copy=True):
         self.args = args
-        self.model = cp.deepcopy(model_origin)
+        # tta_standard adapts a copy (basics.py:527); the epoch-style test_time_adapt adapts the caller's model
+        self.model = cp.deepcopy(model_origin) if copy else model_origin
         model = self.model
         self.device = _device_of(model)
         self.rank, self.world = _dist()
@@ -724,6 +725,137 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
         torch.distributed.all_reduce(t)
         return [float(t[0] / t[1])]
     return [top1.avg]
+
+
+# ------------------------------------------------------------------------------------------------
+# the epoch-style variant (if_tta_standard falsy): adapt over the whole list, then evaluate the whole list
+# ------------------------------------------------------------------------------------------------
+def _shard(dataset, n_total, rank, world, batch_size):
+    """Rank r of R takes videos r, R+r, ...; returns (dataset, steps every rank must take)."""
+    if world == 1:
+        return dataset, -(-n_total // batch_size)
+    mine = list(range(rank, n_total, world))
+    per_rank = -(-n_total // world)
+    return torch.utils.data.Subset(dataset, mine), -(-per_rank // batch_size)
+
+
+def test_time_adapt(model, criterion, args=None, logger=None, writer=None):
+    """corpus/basics.py:760-1084: one pass of gradient steps over the test list (`batch_size` videos per step, the
+    caller's model adapted in place, statistics hooks closed afterwards), then `validate_brief` over the same list
+    with the adapted weights.  Returns ([top-1 after the epoch], model).
+
+    Same per-step arithmetic as the online loop (the adapter's adapt step); what differs is the protocol: no per-video
+    evaluation, accuracy meters of the adaptation pass use the TRAIN-mode view-averaged logits (basics.py:1036), the
+    eval loader batches `batch_size_eval` videos.  The reference's other branches of this function are not reachable
+    as shipped: `stat_reg='BNS'` fails on an undefined name at basics.py:1015, a second epoch backpropagates through
+    the closed hooks' stale `r_feature` graphs (basics.py:1013-1028 after :1065-1067), `cossim` is outside the ViTTA
+    path."""
+    if args.stat_reg != "mean_var":
+        raise NotImplementedError(f"test_time_adapt: stat_reg={args.stat_reg!r} is not a working branch of the reference")
+    if int(args.n_epoch_adapat) != 1:
+        raise NotImplementedError("test_time_adapt: the reference cannot run a second epoch (hooks are closed after the first)")
+    if not hasattr(args, "moving_avg"):
+        args.moving_avg = False
+    if not hasattr(args, "momentum_mvg"):
+        args.momentum_mvg = 0.1
+    device = _device_of(model)
+    rank, world = _dist()
+    if args.arch == "tanet":
+        tta_set = get_dataset_tanet(args, split="val", dataset_type="tta")
+        eval_set = get_dataset_tanet(args, split="val", dataset_type="eval")
+    elif args.arch == "videoswintransformer":
+        tta_set = get_dataset_videoswin(args, split="val", dataset_type="tta")
+        eval_set = get_dataset_videoswin(args, split="val", dataset_type="eval")
+    else:
+        raise NotImplementedError(f"Incorrect model type {args.arch}")
+    tta_set, n_steps = _shard(tta_set, len(tta_set), rank, world, args.batch_size)
+    adapter = ViTTAAdapter(model, args, copy=False)
+    if_sample = args.if_sample_tta_aug_views
+    if if_sample:
+        assert adapter.n_clips == 1
+
+    epoch = 0
+    log = DeferredLog(device, logger, n_steps, args.verbose, epoch=epoch, print_freq=args.print_freq)
+    tta_iter = iter(_loader(tta_set, args))
+    end = time.time()
+    for i in range(n_steps):
+        try:
+            input, target = next(tta_iter)
+            has_video = True
+        except StopIteration:  # ragged tail of a data-parallel run
+            input = target = None
+            has_video = False
+        adapter.set_adapt_mode()
+        row = torch.zeros(DeferredLog.FIELDS, dtype=torch.float32, device=device)
+        actual_bz = 0
+        if has_video:
+            actual_bz = input.shape[0]
+            input = adapter.shape_tta_input(input.to(device, non_blocking=True))
+            target = target.to(device, non_blocking=True)
+        output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
+        now = time.time()
+        if has_video:
+            row[0] = loss_reg
+            if loss_consis is not None:
+                row[1] = loss_consis
+            row[2] = criterion(output, target)
+            prec1, prec5 = accuracy(output.data, target, topk=(1, 5))
+            row[3], row[4] = prec1, prec5
+            log.push(i, row, actual_bz, now - end)
+            if writer is not None:
+                writer.add_scalars("loss", {"loss_reg": float(loss_reg)}, global_step=i + 1)
+                if loss_consis is not None:
+                    writer.add_scalars("loss", {"loss_consis": float(loss_consis)}, global_step=i + 1)
+                writer.add_scalars("loss", {"loss_ce": float(row[2])}, global_step=i + 1)
+        end = now
+    log.flush()
+    adapter.close_hooks()
+    top1_acc = validate_brief(eval_set, adapter, global_iter=n_steps, epoch=epoch, args=args, logger=logger, writer=writer)
+    return [top1_acc], adapter.model
+
+
+def validate_brief(eval_set, adapter, global_iter, epoch=None, args=None, logger=None, writer=None):
+    """corpus/basics.py:1105-1186: top-1 of the (adapted) model over the evaluation views of the whole list,
+    `batch_size_eval` videos at a time; data-parallel runs split the list and add up the counts."""
+    device = adapter.device
+    rank, world = _dist()
+    bz_eval = getattr(args, "batch_size_eval", args.batch_size)
+    eval_set, _ = _shard(eval_set, len(eval_set), rank, world, bz_eval)
+    workers = 0 if getattr(eval_set, "on_device", False) else args.workers
+    loader = torch.utils.data.DataLoader(eval_set, batch_size=bz_eval, shuffle=False, num_workers=workers,
+                                         pin_memory=workers > 0)
+    batch_time, top1, top5 = AverageMeter(), AverageMeter(), AverageMeter()
+    counts = torch.zeros(3, dtype=torch.float64, device=device)  # sum prec1*bz, sum prec5*bz, videos
+    with torch.no_grad():
+        end = time.time()
+        for i, (input, target) in enumerate(loader):
+            actual_bz = input.shape[0]
+            input = adapter.shape_eval_input(input.to(device, non_blocking=True))
+            target = target.to(device, non_blocking=True)
+            output = adapter._evaluate_eager(input)
+            prec1, prec5 = accuracy(output.data, target, topk=(1, 5))
+            counts += torch.stack([prec1.reshape(()) * actual_bz, prec5.reshape(()) * actual_bz,
+                                   torch.full_like(prec1.reshape(()), actual_bz)]).double()
+            if args.verbose and i % args.print_freq == 0:  # the only place the host waits for the stream
+                top1.update(prec1.item(), actual_bz)
+                top5.update(prec5.item(), actual_bz)
+                batch_time.update(time.time() - end)
+                logger.debug(("  \tTest Epoch {epoch}: [{0}/{1}]\t"
+                              "Time {batch_time.val:.3f} ({batch_time.avg:.3f})\t"
+                              "Prec@1 {top1.val:.3f} ({top1.avg:.3f})\t"
+                              "Prec@5 {top5.val:.3f} ({top5.avg:.3f})").format(
+                    i, len(loader), epoch=epoch, batch_time=batch_time, top1=top1, top5=top5))
+            end = time.time()
+    if world > 1:
+        torch.distributed.all_reduce(counts)
+    s1, s5, n = counts.tolist()
+    acc1, acc5 = s1 / max(n, 1.0), s5 / max(n, 1.0)
+    if logger is not None:
+        logger.debug("  \tTesting Results Epoch {epoch}: Prec@1 {0:.3f} Prec@5 {1:.3f}".format(acc1, acc5, epoch=epoch))
+        logger.debug(f"  \tTest Epoch {epoch} acc {acc1} ")
+    if writer is not None:
+        writer.add_scalars("acc", {"test_acc": acc1}, global_step=global_iter)
+    return acc1
 
 
 # ------------------------------------------------------------------------------------------------
