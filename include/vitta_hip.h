@@ -380,6 +380,24 @@ int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpoo
                                            int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
                                            void* stream);
 
+/* --------------------------------------------------------------------------
+ * N1 -- decoded RGB frames -> network input, bit-identical to the reference's PIL pipeline
+ * (models/tanet_models/transforms.py:277-384 per-view multi-scale crop + Image.resize(BILINEAR); :46-54, :170-184
+ * short-edge scale + centre crop; :637-678 stack + ToTorchFormatTensor(div 255); :140-152 GroupNormalize).
+ * d_frames [n_frames][in_h][in_w][3] bytes (decoder layout); frame f belongs to view f / frames_per_view.  Per view:
+ * d_origin (x0, y0) of its crop; per OUTPUT column x the taps of Pillow's 8-bit resampler: d_xbounds[v][x] = (first
+ * input column relative to the crop, tap count), d_xcoef[v][x][0..kx) 22-bit fixed-point weights; same for rows.  The
+ * horizontal pass is rounded to bytes before the vertical pass (as Pillow does).  d_lut [3][256] = the normalised fp32
+ * value of each byte per channel.  d_out [n_frames * 3][out_h][out_w] (frames stacked on the channel axis).
+ * One workgroup = one frame x tile_rows output rows; lds_rows >= the input rows any tile's taps span (the caller built
+ * the tables and knows; rows beyond it are dropped, never written out of bounds); lds_rows * 3 * out_w <= 64 KiB.
+ * -------------------------------------------------------------------------- */
+int vitta_frames_resample_norm_f32(const uint8_t* d_frames, int32_t n_frames, int32_t in_h, int32_t in_w,
+                                   int32_t frames_per_view, const int32_t* d_origin, const int32_t* d_xbounds,
+                                   const int32_t* d_xcoef, int32_t kx, const int32_t* d_ybounds, const int32_t* d_ycoef,
+                                   int32_t ky, const float* d_lut, float* d_out, int32_t out_h, int32_t out_w,
+                                   int32_t tile_rows, int32_t lds_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

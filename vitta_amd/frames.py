@@ -1,0 +1,149 @@
+"""Device-side crop + resize + normalise of decoded frames, bit-identical to the reference's
+PIL pipeline (models/tanet_models/transforms.py:277-384, :46-54, :170-184, :637-678, :140-152).
+
+The host builds, per view, what depends only on (crop size, output size): the tap windows and 22-bit fixed-point
+weights of Pillow's 8-bit BILINEAR resampler (Pillow's Resample.c `precompute_coeffs` + `normalize_coeffs_8bpc`, in
+double precision, same operation order) and the 3 x 256 table `(byte / 255 - mean_c) / std_c` (with the reference's own
+float32 ops, so every entry is the value the host pipeline would produce).  `vitta_frames_resample_norm_f32` does the two
+integer passes, the byte rounding between them and the table look-up for all frames of all views in ONE launch, reading
+the uploaded uint8 frames (a quarter of the PCIe bytes of a float clip) and writing the [V*T*3, H, W] input directly.
+
+No CPU fallback: `resample_normalise` raises VittaHipError for host tensors (the host pipeline is vitta_amd.data_video).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+PRECISION_BITS = 32 - 8 - 2
+TILE_ROWS = 8
+LDS_BYTES = 64 * 1024
+
+
+def bilinear_taps(in_size, out_size):
+    """Pillow's tap windows for resizing `in_size` samples to `out_size` with the BILINEAR (triangle) filter:
+    bounds int32 [out_size, 2] = (first input sample, tap count), coefs int32 [out_size, ksize] fixed point."""
+    scale = in_size / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / filterscale
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coefs = np.zeros((out_size, ksize), dtype=np.int32)
+    one = float(1 << PRECISION_BITS)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws, ww = [], 0.0
+        for x in range(xmax):
+            a = (x + xmin - center + 0.5) * ss
+            if a < 0.0:
+                a = -a
+            w = 1.0 - a if a < 1.0 else 0.0
+            ws.append(w)
+            ww += w
+        for x in range(xmax):
+            w = ws[x] / ww if ww != 0.0 else ws[x]
+            coefs[xx, x] = int(-0.5 + w * one) if w < 0 else int(0.5 + w * one)
+        bounds[xx] = (xmin, xmax)
+    return bounds, coefs
+
+
+def normalise_table(mean, std):
+    """[3, 256] float32: ToTorchFormatTensor(div=True) then GroupNormalize on every possible byte."""
+    v = torch.arange(256, dtype=torch.uint8).float().div(255)
+    m = torch.tensor(list(mean), dtype=torch.float32).view(-1, 1)
+    s = torch.tensor(list(std), dtype=torch.float32).view(-1, 1)
+    return v.unsqueeze(0).repeat(len(mean), 1).sub_(m).div_(s)
+
+
+class ViewSpec:
+    """One view: crop `box` = (x0, y0, w, h) of the frame, resized to `resize` = (W, H), of which the `window`
+    (left, top) + the plan's output size is kept.  tta view: window (0, 0) and resize == output size; eval: box = whole
+    frame, resize = short edge to scale_size, window = the centre crop."""
+
+    def __init__(self, box, resize, window=(0, 0)):
+        self.box, self.resize, self.window = tuple(box), tuple(resize), tuple(window)
+
+
+class FramePlan:
+    """Tap tables of a list of views for one launch (host-built, uploaded once per clip: a few KB)."""
+
+    def __init__(self, views, out_size, device, mean, std, lut=None):
+        out_w, out_h = out_size
+        xs, ys = [], []
+        for v in views:
+            x0, y0, w, h = v.box
+            rw, rh = v.resize
+            left, top = v.window
+            if not (0 <= left and left + out_w <= rw and 0 <= top and top + out_h <= rh):
+                raise ValueError(f"output window {v.window}+{out_size} outside the resized view {v.resize}")
+            bx, cx = bilinear_taps(w, rw)
+            by, cy = bilinear_taps(h, rh)
+            xs.append((bx[left:left + out_w], cx[left:left + out_w]))
+            ys.append((by[top:top + out_h], cy[top:top + out_h]))
+        self.kx, self.ky = max(c.shape[1] for _, c in xs), max(c.shape[1] for _, c in ys)
+        pad = lambda c, k: np.pad(c, ((0, 0), (0, k - c.shape[1])))
+        tile, rows = TILE_ROWS, None
+        while True:  # the input rows one tile of output rows spans must fit the workgroup's LDS
+            rows = max(int((b[t:t + tile, 0] + b[t:t + tile, 1]).max() - b[t, 0]) for b, _ in ys for t in range(0, out_h, tile))
+            if rows * 3 * out_w <= LDS_BYTES or tile == 1:
+                break
+            tile //= 2
+        if rows * 3 * out_w > LDS_BYTES:
+            raise _lib.VittaHipError(f"a single output row spans {rows} input rows of {out_w} columns: beyond the kernel's LDS tile")
+        self.tile_rows, self.lds_rows = tile, rows
+        host = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)
+        self.origin = host(np.array([[v.box[0], v.box[1]] for v in views], dtype=np.int32))
+        self.xb, self.xc = host(np.stack([b for b, _ in xs])), host(np.stack([pad(c, self.kx) for _, c in xs]))
+        self.yb, self.yc = host(np.stack([b for b, _ in ys])), host(np.stack([pad(c, self.ky) for _, c in ys]))
+        self.lut = lut if lut is not None else normalise_table(mean, std).to(device)
+        self.out_w, self.out_h, self.n_views = out_w, out_h, len(views)
+        self.boxes = [v.box for v in views]
+
+
+def resample_normalise(frames, plan, frames_per_view, out=None):
+    """frames: uint8 [F, H, W, 3] on the GPU -> float32 [F*3, out_h, out_w] (the reference's stacked clip layout)."""
+    if not frames.is_cuda:
+        raise _lib.VittaHipError(f"frames must live on the GPU (got {frames.device}); the HIP path has no CPU fallback")
+    if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3:
+        raise _lib.VittaHipError(f"frames must be uint8 [F, H, W, 3] (got {frames.dtype} {tuple(frames.shape)})")
+    frames = frames.contiguous()
+    f, h, w, _ = frames.shape
+    if f != plan.n_views * frames_per_view:
+        raise ValueError(f"{f} frames for {plan.n_views} views of {frames_per_view}")
+    for x0, y0, bw, bh in plan.boxes:
+        if not (0 <= x0 and x0 + bw <= w and 0 <= y0 and y0 + bh <= h):
+            raise ValueError(f"crop box {(x0, y0, bw, bh)} outside the {w}x{h} frame")
+    if out is None:
+        out = torch.empty(f * 3, plan.out_h, plan.out_w, dtype=torch.float32, device=frames.device)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    check(lib().vitta_frames_resample_norm_f32(p(frames), f, h, w, frames_per_view, p(plan.origin), p(plan.xb), p(plan.xc),
+                                               plan.kx, p(plan.yb), p(plan.yc), plan.ky, p(plan.lut), p(out), plan.out_h,
+                                               plan.out_w, plan.tile_rows, plan.lds_rows,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "vitta_frames_resample_norm_f32")
+    return out
+
+
+def eval_view(frame_size, scale_size, input_size):
+    """GroupScale(scale_size) + GroupCenterCrop(input_size) as one ViewSpec (torchvision 0.8.2 Resize / CenterCrop)."""
+    w, h = frame_size
+    if (w <= h and w == scale_size) or (h <= w and h == scale_size):
+        rw, rh = w, h
+    elif w < h:
+        rw, rh = scale_size, int(scale_size * h / w)
+    else:
+        rw, rh = int(scale_size * w / h), scale_size
+    top, left = int(round((rh - input_size) / 2.0)), int(round((rw - input_size) / 2.0))
+    return ViewSpec((0, 0, w, h), (rw, rh), (left, top))
