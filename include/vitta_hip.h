@@ -389,6 +389,7 @@ int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpoo
  * input column relative to the crop, tap count), d_xcoef[v][x][0..kx) 22-bit fixed-point weights; same for rows.  The
  * horizontal pass is rounded to bytes before the vertical pass (as Pillow does).  d_lut [3][256] = the normalised fp32
  * value of each byte per channel.  d_out [n_frames * 3][out_h][out_w] (frames stacked on the channel axis).
+ * kx / ky = row strides of the weight tables >= every window's tap count, zero padded (4 / 4 selects the unrolled path).
  * One workgroup = one frame x tile_rows output rows; lds_rows >= the input rows any tile's taps span (the caller built
  * the tables and knows; rows beyond it are dropped, never written out of bounds); lds_rows * 3 * out_w <= 64 KiB.
  * -------------------------------------------------------------------------- */

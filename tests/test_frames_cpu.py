@@ -99,7 +99,9 @@ def test_frame_plan_tiles_fit_lds_and_refuse_host_tensors():
     views = [FR.ViewSpec((0, 0, 1920, 1080), (398, 224)), FR.ViewSpec((100, 50, 168, 192), (398, 224), (0, 0))]
     plan = FR.FramePlan(views, (224, 224), "cpu", MEAN, STD)
     assert plan.lds_rows * 3 * 224 <= FR.LDS_BYTES and plan.tile_rows >= 1
-    assert plan.xc.shape[0] == 2 and plan.kx == max(FR.bilinear_taps(1920, 398)[1].shape[1], 3)
+    assert plan.xc.shape[0] == 2 and plan.kx == int(FR.bilinear_taps(1920, 398)[0][:, 1].max()) and plan.xc.shape[2] == plan.kx
+    small = FR.FramePlan([FR.ViewSpec((0, 0, 256, 240), (224, 256))], (224, 224), "cpu", MEAN, STD)
+    assert small.kx == 4 and small.ky == 4 and small.xc.shape == (1, 224, 4)  # 3-tap windows padded to the unrolled path
     with pytest.raises(Exception, match="GPU"):
         FR.resample_normalise(torch.zeros(2, 1080, 1920, 3, dtype=torch.uint8), plan, 1)
     with pytest.raises(ValueError):

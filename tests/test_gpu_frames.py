@@ -86,3 +86,21 @@ def test_out_buffer_and_argument_checks():
         FR.resample_normalise(frames[:, :40], plan, 2)  # crop box outside the frame
     with pytest.raises(Exception, match="uint8"):
         FR.resample_normalise(frames.float(), plan, 2)
+
+
+@pytest.mark.parametrize("mode", ["tta", "eval"])
+def test_dataset_transform_chain_on_device_is_the_host_chain(mode):
+    """`tanet_clip_on_device` (what VideoTANetDataset runs with --device_preprocess) against the host PIL chain of the
+    same dataset on the same decoded frames and the same `random` draws: equal bit for bit."""
+    from PIL import Image
+    T, views = 8, 2
+    frames = byte_frames(views * T if mode == "tta" else T, 320, 240, seed=33)
+    pil = [Image.fromarray(f) for f in frames]
+    random.seed(17)
+    if mode == "tta":
+        host = DV.stack_to_tensor(DV.subgroup_multiscale_crop(pil, views, T, 224), MEAN, STD)
+    else:
+        host = DV.stack_to_tensor([DV.center_crop(DV.scale_short_edge(f, 256), 224) for f in pil], MEAN, STD)
+    random.seed(17)
+    dev = DV.tanet_clip_on_device(frames, DEV, T, 224, 256, MEAN, STD, tta_views=views if mode == "tta" else None)
+    assert dev.is_cuda and torch.equal(dev.cpu(), host)

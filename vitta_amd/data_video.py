@@ -6,8 +6,11 @@ TANet (models/tanet_models/video_dataset.py:305-341 + transforms.py):
             resized to input_size with PIL BILINEAR
     'eval': resize smaller edge to scale_size (BILINEAR) + centre crop input_size (transforms.py:46-54,170-184)
     -> stack frames on the channel axis, /255, normalise per channel -> [V*T*3, H, W] float32.
-  The PIL steps are kept on the host ON PURPOSE: PIL's BILINEAR (with its reducing filter) is what defines
-  "identical inputs"; tests/test_data_video.py checks every step against the reference's own transform classes.
+  PIL's BILINEAR (with its reducing filter) is what defines "identical inputs"; tests/test_data_video.py checks every
+  host step against the reference's own transform classes.  With `device_preprocess` (extension, --device_preprocess)
+  the decoded uint8 frames are uploaded as they are and crop + resize + stack + normalise run in ONE HIP launch that is
+  bit-identical to the PIL path (vitta_amd/frames.py, tests/test_gpu_frames.py): a quarter of the PCIe bytes, no
+  per-frame PIL work on the host.
   The crop/offset draws consume `random` exactly like the reference (one choice of the (w, h) pair, one choice
   of the offset, per view), so a seeded run reproduces the reference's crops.
 
@@ -110,12 +113,41 @@ def stack_to_tensor(images, mean, std):
     return t.sub_(m).div_(s)
 
 
+def tanet_clip_on_device(frames_u8, device, clip_len, input_size, scale_size, mean, std, tta_views=None, rng=random,
+                         lut=None):
+    """The transform chain of `VideoTANetDataset.__getitem__` on the device: frames_u8 = the decoded uint8 frames
+    [F, H, W, 3] (numpy or tensor).  tta_views: per-view multi-scale crop (same `random` draws, in the same order, as
+    the host pipeline) resized to input_size; None: short edge -> scale_size, centre crop.  -> [F*3, S, S] float32 on
+    `device`, bit-identical to stack_to_tensor(PIL path)."""
+    from . import frames as FR
+    t = torch.as_tensor(frames_u8)
+    f, h, w, _ = t.shape
+    size = (input_size, input_size) if isinstance(input_size, int) else tuple(input_size)
+    if tta_views:
+        assert f == tta_views * clip_len
+        views = []
+        for _ in range(tta_views):
+            cw, ch, ow, oh = sample_multiscale_crop((w, h), size, rng=rng)
+            views.append(FR.ViewSpec((ow, oh, cw, ch), size))
+        per_view = clip_len
+    else:
+        views, per_view = [FR.eval_view((w, h), scale_size, size[0])], f
+    plan = FR.FramePlan(views, size, device, mean, std, lut=lut)
+    return FR.resample_normalise(t.to(device, non_blocking=True), plan, per_view)
+
+
 class VideoTANetDataset(torch.utils.data.Dataset):
     def __init__(self, list_file, num_segments, video_data_dir, vid_format="", input_size=224, scale_size=256,
                  input_mean=(0.485, 0.456, 0.406), input_std=(0.229, 0.224, 0.225), test_sample="uniform-1",
-                 tta_views=None, tta_styles=None, spatial_rand_cropping=True, test_crops=1, debug=False):
+                 tta_views=None, tta_styles=None, spatial_rand_cropping=True, test_crops=1, debug=False,
+                 device_preprocess=None):
         if test_crops != 1:
             raise NotImplementedError(f"{test_crops} spatial crops not implemented!")
+        # device_preprocess = a torch device: samples come back device-resident (the loader then runs without workers,
+        # tta._loader); None: the host PIL pipeline
+        self.device = torch.device(device_preprocess) if device_preprocess is not None else None
+        self.on_device = self.device is not None
+        self._lut = None
         self.records = data.parse_video_list(list_file, remove_missing=True, debug=debug)
         self.T, self.dir, self.fmt = num_segments, video_data_dir, vid_format
         self.input_size, self.scale_size, self.mean, self.std = input_size, scale_size, input_mean, input_std
@@ -139,12 +171,27 @@ class VideoTANetDataset(torch.utils.data.Dataset):
         rec = self.records[i]
         reader = self._decord.VideoReader(osp.join(self.dir, f"{rec.path}{self.fmt}"))
         idx = np.minimum(self.frame_indices(rec.num_frames), len(reader) - 1).astype(np.int64)
+        if self.on_device:
+            if self._lut is None:
+                from . import frames as FR
+                self._lut = FR.normalise_table(self.mean, self.std).to(self.device)
+            tta = self.tta_views if (self.tta_views and self.spatial_rand_cropping) else None
+            clip = tanet_clip_on_device(reader.get_batch(idx).asnumpy(), self.device, self.T, self.input_size,
+                                        self.scale_size, self.mean, self.std, tta_views=tta, lut=self._lut)
+            return clip, rec.label
         frames = [Image.fromarray(f).convert("RGB") for f in reader.get_batch(idx).asnumpy()]
         if self.tta_views and self.spatial_rand_cropping:
             frames = subgroup_multiscale_crop(frames, self.tta_views, self.T, self.input_size)
         else:
             frames = [center_crop(scale_short_edge(f, self.scale_size), self.input_size) for f in frames]
         return stack_to_tensor(frames, self.mean, self.std), rec.label
+
+
+def _preprocess_device(args):
+    if not getattr(args, "device_preprocess", False):
+        return None
+    dev = getattr(args, "device", None)
+    return torch.device(dev) if dev is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def tanet_video_dataset(args, dataset_type):
@@ -156,7 +203,8 @@ def tanet_video_dataset(args, dataset_type):
                              tta_views=args.n_augmented_views if tta else None,
                              tta_styles=args.tta_view_sample_style_list if tta else None,
                              spatial_rand_cropping=args.if_spatial_rand_cropping if tta else False,
-                             test_crops=args.test_crops, debug=args.debug)
+                             test_crops=args.test_crops, debug=args.debug,
+                             device_preprocess=_preprocess_device(args))
 
 
 # ------------------------------------------------------------------------------------------------

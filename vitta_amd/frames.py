@@ -11,6 +11,7 @@ the uploaded uint8 frames (a quarter of the PCIe bytes of a float clip) and writ
 No CPU fallback: `resample_normalise` raises VittaHipError for host tensors (the host pipeline is vitta_amd.data_video).
 """
 import ctypes as C
+import functools
 import math
 
 import numpy as np
@@ -21,9 +22,11 @@ from ._lib import check, lib
 
 PRECISION_BITS = 32 - 8 - 2
 TILE_ROWS = 8
+FAST_TAPS = 4
 LDS_BYTES = 64 * 1024
 
 
+@functools.lru_cache(maxsize=256)
 def bilinear_taps(in_size, out_size):
     """Pillow's tap windows for resizing `in_size` samples to `out_size` with the BILINEAR (triangle) filter:
     bounds int32 [out_size, 2] = (first input sample, tap count), coefs int32 [out_size, ksize] fixed point."""
@@ -56,6 +59,8 @@ def bilinear_taps(in_size, out_size):
             w = ws[x] / ww if ww != 0.0 else ws[x]
             coefs[xx, x] = int(-0.5 + w * one) if w < 0 else int(0.5 + w * one)
         bounds[xx] = (xmin, xmax)
+    bounds.setflags(write=False)  # cached: shared between plans
+    coefs.setflags(write=False)
     return bounds, coefs
 
 
@@ -92,15 +97,19 @@ class FramePlan:
             by, cy = bilinear_taps(h, rh)
             xs.append((bx[left:left + out_w], cx[left:left + out_w]))
             ys.append((by[top:top + out_h], cy[top:top + out_h]))
-        self.kx, self.ky = max(c.shape[1] for _, c in xs), max(c.shape[1] for _, c in ys)
-        pad = lambda c, k: np.pad(c, ((0, 0), (0, k - c.shape[1])))
+        # row stride of the weight tables = the longest window actually used (Pillow's ksize is an upper bound); windows
+        # of up to FAST_TAPS taps take the kernel's unrolled path, which wants exactly that stride (zero padded)
+        longest = lambda tabs: max(int(b[:, 1].max()) for b, _ in tabs)
+        stride = lambda n: FAST_TAPS if n <= FAST_TAPS else n
+        self.kx, self.ky = stride(longest(xs)), stride(longest(ys))
+        pad = lambda c, k: np.pad(c, ((0, 0), (0, max(k - c.shape[1], 0))))[:, :k]
         tile, rows = TILE_ROWS, None
         while True:  # the input rows one tile of output rows spans must fit the workgroup's LDS
             rows = max(int((b[t:t + tile, 0] + b[t:t + tile, 1]).max() - b[t, 0]) for b, _ in ys for t in range(0, out_h, tile))
-            if rows * 3 * out_w <= LDS_BYTES or tile == 1:
+            if rows * 4 * out_w + 3072 <= LDS_BYTES or tile == 1:  # one dword per (row, column) + the byte table
                 break
             tile //= 2
-        if rows * 3 * out_w > LDS_BYTES:
+        if rows * 4 * out_w + 3072 > LDS_BYTES:
             raise _lib.VittaHipError(f"a single output row spans {rows} input rows of {out_w} columns: beyond the kernel's LDS tile")
         self.tile_rows, self.lds_rows = tile, rows
         host = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=True)

@@ -7,6 +7,8 @@
 * `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py;
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 * `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
+* `--device_preprocess` (extension, default False) uploads the decoded uint8 frames and runs crop / resize / normalise
+  of the TANet pipeline in one HIP launch (bit-identical to the PIL path, vitta_amd/frames.py).
 """
 import argparse
 
@@ -98,6 +100,9 @@ _FLAGS = [
     (("--overlap_eval",), dict(type=_bool, default=True,
                                help="(extension) evaluate video i on a second stream beside the adaptation forward of "
                                     "video i+1 (same weights, same results)")),
+    (("--device_preprocess",), dict(type=_bool, default=False,
+                                    help="(extension) TANet real-video pipeline: crop + PIL-BILINEAR resize + normalise on "
+                                         "the GPU from the uploaded uint8 frames (bit-identical to the host PIL path)")),
     (("--n_gradient_steps",), dict(type=int, default=1, help="number of gradient steps per sample")),
     # input / optimiser
     (("--full_res",), dict(action="store_true")),
