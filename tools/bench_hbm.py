@@ -1,0 +1,58 @@
+"""What this box's HBM delivers to plain vendor kernels, beside the moments kernel on the same bytes (SURVEY 8d:
+"verify the 8 TB/s with a device-to-device copy test on the box").
+
+    python tools/bench_hbm.py
+
+(a) device-to-device copy of a 2.85 GB fp32 buffer (bytes moved = 2 x size), (b) a read-only reduction of it
+(torch.sum: rocPRIM), (c) `vitta_moments_batched_f32` on the C2 layer shapes x 16 videos (the bench's streaming launch:
+2.85 GB read once).  All timed with events over 20 launches after 3 warm-ups; GB/s of bytes moved."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vitta_amd import ops  # noqa: E402
+
+
+def timed(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    dev = torch.device("cuda:0")
+    # hooked BN2d outputs of TANet-R50 layer3 / layer4 for 2 x 8 frames at 224^2, 16 videos' worth of frames
+    shapes = []
+    for blocks, planes, hw in ((6, 256, 14), (3, 512, 7)):
+        for b in range(blocks):
+            first_hw = hw * 2 if b == 0 else hw  # conv1/bn1 of a stage's first block still runs at the input resolution
+            shapes += [(16 * 16, planes, first_hw * first_hw, 0), (16 * 16, planes, hw * hw, 0), (16 * 16, planes * 4, hw * hw, 0)]
+            if b == 0:
+                shapes.append((16 * 16, planes * 4, hw * hw, 0))
+    numel = sum(o * c * i for o, c, i, _ in shapes)
+    feats = [torch.randn(o, c, i, device=dev) for o, c, i, _ in shapes]
+    plan = ops.StatPlan(shapes, dev, target_blocks=4096)
+    flat = torch.empty(numel, device=dev)
+    dst = torch.empty_like(flat)
+    out = {"bytes": numel * 4}
+    ms = timed(lambda: dst.copy_(flat))
+    out["d2d_copy"] = dict(ms=ms, GBps_moved=2 * numel * 4 / ms * 1e-6)
+    ms = timed(lambda: flat.sum())
+    out["torch_sum_read_only"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6)
+    ms = timed(lambda: plan.partials(feats))
+    out["moments_batched"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6, frac_of_8TBps=numel * 4 / ms * 1e-6 / 8000.0)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
