@@ -51,6 +51,12 @@ def main():
     out["torch_sum_read_only"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6)
     ms = timed(lambda: plan.partials(feats))
     out["moments_batched"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6, frac_of_8TBps=numel * 4 / ms * 1e-6 / 8000.0)
+    if "--sweep" in sys.argv:
+        out["sweep_target_blocks"] = {}
+        for tb in (1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 32768):
+            pl = ops.StatPlan(shapes, dev, target_blocks=tb)
+            ms = timed(lambda: pl.partials(feats))
+            out["sweep_target_blocks"][tb] = round(numel * 4 / ms * 1e-6)
     print(json.dumps(out))
 
 
