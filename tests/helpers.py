@@ -107,3 +107,38 @@ def tanet_args(tmpdir, num_classes_dataset="ucf101", **over):
     for k, v in over.items():
         setattr(args, k, v)
     return args
+
+
+class FakeDecord:
+    """Stand-in for the `decord` module in dataset tests (decord is not installed in the image): every video is a
+    seeded stack of uint8 frames; `VideoReader(path)` / `len` / `get_batch(idx).asnumpy()` as the datasets use them."""
+
+    def __init__(self, n_frames=40, w=320, h=240, seed=0):
+        self.n_frames, self.w, self.h, self.seed = n_frames, w, h, seed
+        self.opened = []
+
+    def VideoReader(self, path):
+        import zlib
+        import numpy as np
+        owner = self
+        owner.opened.append(path)
+        rng = np.random.RandomState((self.seed + zlib.crc32(path.encode())) % (2 ** 31))
+        base = rng.randint(0, 256, size=(self.n_frames, self.h // 16 + 1, self.w // 16 + 1, 3)).astype(np.uint8)
+        frames = np.repeat(np.repeat(base, 16, axis=1), 16, axis=2)[:, :self.h, :self.w]
+        frames = (frames.astype(np.int32) + rng.randint(-8, 9, size=frames.shape)).clip(0, 255).astype(np.uint8)
+
+        class Batch:
+            def __init__(self, arr):
+                self.arr = arr
+
+            def asnumpy(self):
+                return self.arr
+
+        class Reader:
+            def __len__(self):
+                return owner.n_frames
+
+            def get_batch(self, idx):
+                return Batch(frames[np.asarray(idx)])
+
+        return Reader()

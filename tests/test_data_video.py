@@ -77,3 +77,31 @@ def test_real_video_datasets_need_decord(tmp_path):
         pass
     with pytest.raises(ImportError):
         DV.VideoTANetDataset(str(lst), 8, str(tmp_path))
+
+
+def _list_file(tmp_path):
+    lst = tmp_path / "list.txt"
+    lst.write_text("clipA 40 3\nclipB 33 7\n")
+    return str(lst)
+
+
+def test_tanet_dataset_host_pipeline_with_a_stand_in_decoder(tmp_path, monkeypatch):
+    """The dataset class end to end on the host (index sampling -> decode -> PIL transforms -> stacked clip) with a
+    stand-in for the uninstalled decoder: shapes, labels, the frames asked of the decoder, determinism under a seed."""
+    fake = H.FakeDecord(n_frames=33)  # the list says 40 for clipA: indices are clamped to the decoder's own length
+    monkeypatch.setattr(DV, "_decord", lambda: fake)
+    tta = DV.VideoTANetDataset(_list_file(tmp_path), 8, str(tmp_path), vid_format=".mp4", tta_views=2,
+                               tta_styles=["uniform_equidist"])
+    ev = DV.VideoTANetDataset(_list_file(tmp_path), 8, str(tmp_path), vid_format=".mp4")
+    assert len(tta) == 2 and not tta.on_device
+    random.seed(3)
+    x, y = tta[0]
+    assert x.shape == (2 * 8 * 3, 224, 224) and x.dtype == torch.float32 and y == 3
+    assert fake.opened[-1].endswith("clipA.mp4")
+    random.seed(3)
+    x2, _ = tta[0]
+    assert torch.equal(x, x2)
+    e, y = ev[1]
+    assert e.shape == (8 * 3, 224, 224) and y == 7
+    idx = tta.frame_indices(40)
+    assert len(idx) == 16 and idx.max() == 40  # 1-based; the dataset clamps to the decoder's last frame (video_dataset.py:328)

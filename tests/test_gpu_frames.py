@@ -104,3 +104,31 @@ def test_dataset_transform_chain_on_device_is_the_host_chain(mode):
     random.seed(17)
     dev = DV.tanet_clip_on_device(frames, DEV, T, 224, 256, MEAN, STD, tta_views=views if mode == "tta" else None)
     assert dev.is_cuda and torch.equal(dev.cpu(), host)
+
+
+def test_dataset_with_device_preprocess_equals_the_host_dataset(tmp_path, monkeypatch):
+    """`VideoTANetDataset(device_preprocess=...)` end to end (index sampling -> decode -> upload -> one launch) against
+    the same dataset on the host PIL pipeline, with a stand-in for the uninstalled decoder: equal bit for bit, sample
+    resident on the GPU, loader without worker processes."""
+    from vitta_amd import tta as T
+    fake = H.FakeDecord(n_frames=33)
+    monkeypatch.setattr(DV, "_decord", lambda: fake)
+    lst = tmp_path / "list.txt"
+    lst.write_text("clipA 40 3\nclipB 33 7\n")
+    kw = dict(vid_format=".mp4")
+    for views in (2, None):
+        extra = dict(tta_views=views, tta_styles=["uniform_equidist"]) if views else {}
+        host = DV.VideoTANetDataset(str(lst), 8, str(tmp_path), **kw, **extra)
+        dev = DV.VideoTANetDataset(str(lst), 8, str(tmp_path), device_preprocess=DEV, **kw, **extra)
+        assert dev.on_device
+        for i in range(2):
+            random.seed(11 + i)
+            xh, yh = host[i]
+            random.seed(11 + i)
+            xd, yd = dev[i]
+            assert xd.is_cuda and yd == yh and torch.equal(xd.cpu(), xh)
+    args = H.tanet_args(tmp_path, workers=4, batch_size=2)
+    loader = T._loader(dev, args)
+    assert loader.num_workers == 0
+    xb, yb = next(iter(loader))
+    assert xb.is_cuda and xb.shape == (2, 24, 224, 224) and yb.tolist() == [3, 7]
