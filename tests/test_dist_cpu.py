@@ -125,3 +125,76 @@ def test_ragged_tail_keeps_replicas_in_sync(tmp_path):
     assert float(r0["step1_ema_sum"]) == pytest.approx(float(r1["step1_ema_sum"]), rel=1e-9)
     assert float(r0["step1_param_sum"]) == pytest.approx(float(r1["step1_param_sum"]), rel=1e-12)
     assert float(r0["step1_loss_reg"]) == pytest.approx(float(r1["step1_loss_reg"]), rel=1e-6)
+
+
+def _epoch_rank_main(rank, world, port, tmp):
+    """Epoch-style test_time_adapt (N4) on 2 ranks, one video per rank and step = the reference's batch of two."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import logging
+    from oracle.oracle_backend import OracleBackend
+    from vitta_amd import tta
+    g = H.golden("epoch.npz")
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    rdir = os.path.join(tmp, f"r{rank}")
+    os.makedirs(rdir, exist_ok=True)
+    mp_, vp_ = H.write_stat_files(rdir, [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                  [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(rdir, clip_length=8, input_size=64, spatiotemp_mean_clean_file=mp_, spatiotemp_var_clean_file=vp_,
+                        lr=1e-3, if_tta_standard=False, update_only_bn_affine=True, batch_size=1, batch_size_eval=2,
+                        synthetic_n_videos=4, synthetic_seed=500, device="cpu")
+    masks = []
+    for i in range(2):  # rank r = rows [16 r, 16 r + 16) of the reference's batch-of-two dropout mask
+        m = H.unpack_mask(g[f"step{i}_dropmask"], g[f"step{i}_dropmask_shape"])
+        masks.append(m[rank * 16:(rank + 1) * 16])
+    model = tta.SingleDeviceParallel(H.build_tanet(101, 8, 0))
+    model.module.base_model.fc = H.ReplayDropout(0.8, masks)
+    tta.BACKEND_FACTORY = OracleBackend
+    seen, logits = [], []
+    real_step, real_eval = tta.ViTTAAdapter.adapt_step, tta.ViTTAAdapter._evaluate_eager
+
+    def step(self, *a, **k):
+        out = real_step(self, *a, **k)
+        seen.append((float(out[1]), float(out[2])))
+        return out
+
+    def evaluate(self, x):
+        o = real_eval(self, x)
+        logits.append(o.detach().numpy().copy())
+        return o
+
+    tta.ViTTAAdapter.adapt_step, tta.ViTTAAdapter._evaluate_eager = step, evaluate
+    res, adapted = tta.test_time_adapt(model, torch.nn.CrossEntropyLoss(), args=args, logger=logging.getLogger("t"), writer=None)
+    named = dict(adapted.named_parameters())
+    out = {"top1": np.array(res), "logits": np.concatenate(logits), "loss_reg": np.array([s[0] for s in seen]),
+           "loss_consis": np.array([s[1] for s in seen])}
+    for name in map(str, g["sampled_params"]):
+        out[f"param::{name}"] = named[name].detach().numpy()[:4].copy()
+    np.savez(os.path.join(tmp, f"epoch_rank{rank}.npz"), **out)
+    torch.distributed.destroy_process_group()
+
+
+def test_epoch_style_on_two_ranks_equals_reference_batch_of_two(tmp_path):
+    """test_time_adapt data-parallel: videos (0, 1) then (2, 3) adapted one per rank = the reference's two steps of
+    batch size two; validate_brief splits the list and adds up the counts."""
+    port = _free_port()
+    mp.spawn(_epoch_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [np.load(os.path.join(str(tmp_path), f"epoch_rank{r}.npz")) for r in range(2)]
+    g = H.golden("epoch.npz")
+    for i in range(2):
+        assert float(r0["loss_reg"][i]) == pytest.approx(float(r1["loss_reg"][i]), rel=1e-6)
+        assert float(r0["loss_reg"][i]) == pytest.approx(float(g[f"step{i}_loss_reg"]), rel=1e-5 if i == 0 else 2e-3)
+        total = float(r0["loss_consis"][i]) + float(r1["loss_consis"][i])  # a SUM over the batch's videos
+        assert total == pytest.approx(float(g[f"step{i}_loss_consis"]), rel=1e-5 if i == 0 else 1e-2)
+    for name in map(str, g["sampled_params"]):
+        np.testing.assert_array_equal(r0[f"param::{name}"], r1[f"param::{name}"])  # replicas identical
+        ref = g[f"step1_param::{name}"]
+        assert np.abs(r0[f"param::{name}"] - ref).max() <= 2.5e-3 + 1e-5 * np.abs(ref).max()
+    ref = g["eval_logits"]
+    got = np.stack([r0["logits"][0], r1["logits"][0], r0["logits"][1], r1["logits"][1]])  # rank r evaluated videos r, 2 + r
+    assert np.abs(got - ref).max() <= max(2e-3 * np.abs(ref).max(), float(g["noise_eval_logits"]))
+    assert r0["top1"].tolist() == r1["top1"].tolist() == pytest.approx(g["top1"].tolist())
