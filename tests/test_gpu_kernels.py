@@ -75,6 +75,51 @@ def test_moments_large_mean_small_var():
     torch.testing.assert_close(v.cpu().double(), v_ref, rtol=1e-3, atol=0)
 
 
+@pytest.mark.parametrize("shape", BN2D_SHAPES[:7])
+def test_moments_nchw_single_bf16(shape):
+    """bfloat16 features (`_bf16` input variants with fp32 accumulate): the result is the fp32 path's on the
+    widened values -- checked against the oracle on exactly those values, same tolerances as fp32."""
+    from vitta_amd import ops
+    xb = _feat(shape, 1, 1).to(torch.bfloat16)
+    clip = 8 if shape[0] % 8 == 0 else shape[0]
+    m_ref, v_ref = O.moments(xb.double(), "bn2d", clip)
+    m, v = ops.moments(xb.to(_dev()), "bn2d")
+    assert m.dtype == torch.float32 and v.dtype == torch.float32
+    torch.testing.assert_close(m.cpu().double(), m_ref, rtol=RTOL_MEAN, atol=ATOL_MEAN)
+    torch.testing.assert_close(v.cpu().double(), v_ref, rtol=RTOL_VAR, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", LN_SHAPES)
+def test_moments_nhwc_single_bf16(shape):
+    from vitta_amd import ops
+    xb = _feat(shape, 2, 4).to(torch.bfloat16)
+    m_ref, v_ref = O.moments(xb.double(), "ln")
+    m, v = ops.moments(xb.to(_dev()), "ln")
+    torch.testing.assert_close(m.cpu().double(), m_ref, rtol=RTOL_MEAN, atol=ATOL_MEAN)
+    torch.testing.assert_close(v.cpu().double(), v_ref, rtol=RTOL_VAR, atol=1e-7)
+
+
+def test_moments_batched_bf16_equals_fp32_on_widened_values():
+    """One batched launch over mixed layouts with bfloat16 features: same (cnt, s1, s2) as the fp32 launch on the
+    widened copies -- bit for bit (same plan, same order of operations) -- and mixed element types are refused."""
+    from vitta_amd import _lib, ops
+    feats = _mixed_plan_inputs()
+    shapes = [ops.feature_layout(f, k) for f, k in feats]
+    plan = ops.StatPlan(shapes, _dev())
+    fb = [f.to(torch.bfloat16).to(_dev()) for f, _ in feats]
+    ff = [t.float() for t in fb]
+    shift = torch.cat([O.moments(f.double(), k, 8)[0].float() + 0.1 for f, k in feats]).to(_dev())
+    plan.moments(fb, shift)
+    got = [t.clone() for t in (plan.cnt, plan.s1, plan.s2)]
+    plan.moments(ff, shift)
+    for a, b in zip(got, (plan.cnt, plan.s1, plan.s2)):
+        assert torch.equal(a, b)
+    with pytest.raises(_lib.VittaHipError):
+        plan.moments([fb[0]] + ff[1:], shift)
+    with pytest.raises(_lib.VittaHipError):
+        ops.moments(fb[0].half(), "bn2d")
+
+
 def _mixed_plan_inputs():
     feats = [(_feat((16, 256, 14, 14), 10, 1), "bn2d"), (_feat((16, 512, 7, 7), 11, 1), "bn2d"),
              (_feat((2, 8, 7, 7, 128), 12, 4), "ln"), (_feat((16, 6, 5, 5), 13, 1), "bn2d"),

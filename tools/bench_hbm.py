@@ -5,7 +5,7 @@
 
 (a) device-to-device copy of a 2.85 GB fp32 buffer (bytes moved = 2 x size), (b) a read-only reduction of it
 (torch.sum: rocPRIM), (c) `vitta_moments_batched_f32` on the C2 layer shapes x 16 videos (the bench's streaming launch:
-2.85 GB read once).  All timed with events over 20 launches after 3 warm-ups; GB/s of bytes moved."""
+2.85 GB read once; and the same launch on bfloat16 features, 1.43 GB).  All timed with events over 20 launches after 3 warm-ups; GB/s of bytes moved."""
 import json
 import os
 import sys
@@ -51,6 +51,11 @@ def main():
     out["torch_sum_read_only"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6)
     ms = timed(lambda: plan.partials(feats))
     out["moments_batched"] = dict(ms=ms, GBps=numel * 4 / ms * 1e-6, frac_of_8TBps=numel * 4 / ms * 1e-6 / 8000.0)
+    fb = [f.to(torch.bfloat16) for f in feats]
+    ms = timed(lambda: plan.partials(fb))
+    out["moments_batched_bf16"] = dict(ms=ms, bytes=numel * 2, GBps=numel * 2 / ms * 1e-6,
+                                       frac_of_8TBps=numel * 2 / ms * 1e-6 / 8000.0)
+    del fb
     if "--sweep" in sys.argv:
         out["sweep_target_blocks"] = {}
         for tb in (1024, 2048, 3072, 4096, 6144, 8192, 12288, 16384, 32768):

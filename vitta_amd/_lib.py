@@ -41,11 +41,15 @@ SIGNATURES = {
     "vitta_plan_num_blocks": (_i64, [_p]),
     "vitta_moments_batched_f32": (C.c_int, [_p, C.POINTER(_p), _p, _p, _p, _p, _p, _sz, _p]),
     "vitta_moments_partials_f32": (C.c_int, [_p, C.POINTER(_p), _p, _sz, _p]),
+    "vitta_moments_batched_bf16": (C.c_int, [_p, C.POINTER(_p), _p, _p, _p, _p, _p, _sz, _p]),
+    "vitta_moments_partials_bf16": (C.c_int, [_p, C.POINTER(_p), _p, _sz, _p]),
     "vitta_moments_finalize_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _sz, _p]),
     "vitta_moments_to_meanvar_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "vitta_moments_workspace_bytes": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_moments_nchw_f32": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
     "vitta_moments_nhwc_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "vitta_moments_nchw_bf16": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
+    "vitta_moments_nhwc_bf16": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
     "vitta_stat_align_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, C.c_int,
                                            _p, _p, _p, _p, _p, _p, _sz, _p]),
     "vitta_stat_align_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p]),

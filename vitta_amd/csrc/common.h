@@ -89,7 +89,7 @@ struct BlockEnt {
 };
 
 struct PtrPack {
-  const float* x[VITTA_MAX_LAYERS];
+  const void* x[VITTA_MAX_LAYERS];  // fp32 or bf16 features, as the launch's element type says
 };
 
 }  // namespace vitta

@@ -39,7 +39,15 @@ constexpr int kUnroll = 8;
 // ----------------------------------------------------------------------------
 // NCHW partial kernel
 // ----------------------------------------------------------------------------
-// streaming load: NT = non-temporal hint (the features are read exactly once by this kernel)
+// streaming load: NT = non-temporal hint (the features are read exactly once by this kernel).  T = element type as
+// stored: float, or uint16_t holding bfloat16 (widened to fp32 in registers: accumulation is always fp32).
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<uint16_t> { using type = uint2; };  // four bf16 = 8 bytes
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
 template <bool NT>
 __device__ __forceinline__ float4 ld4(const float4* p) {
   if constexpr (NT) {
@@ -55,6 +63,21 @@ __device__ __forceinline__ float4 ld4(const float4* p) {
 }
 
 template <bool NT>
+__device__ __forceinline__ float4 ld4(const uint2* p) {
+  uint2 w;
+  if constexpr (NT) {
+    w.x = __builtin_nontemporal_load(&p->x);
+    w.y = __builtin_nontemporal_load(&p->y);
+  } else {
+    w = *p;
+  }
+  return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+}
+
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+
+template <bool NT, typename T = float>
 __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
     const LayerInfo* __restrict__ linfo, const BlockEnt* __restrict__ tab, PtrPack ptrs,
     float* __restrict__ ws) {
@@ -63,7 +86,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
 
   const BlockEnt e = tab[blockIdx.x];
   const LayerInfo L = linfo[e.layer];
-  const float* __restrict__ x = ptrs.x[e.layer];
+  const T* __restrict__ x = static_cast<const T*>(ptrs.x[e.layer]);
+  using V4 = typename Vec4<T>::type;
   const int tid = threadIdx.x;
   const int64_t plane = L.plane;
   const int64_t base = (int64_t)e.chunk * VITTA_CHUNK;
@@ -77,7 +101,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
   if (L.vec == 4) {
     const int64_t j = base + 4 * (int64_t)tid;
     if (j < plane && n1 > n0) {
-      const float4* p = reinterpret_cast<const float4*>(x + n0 * plane + j);
+      const V4* p = reinterpret_cast<const V4*>(x + n0 * plane + j);
       const int64_t stride4 = plane >> 2;
       const float4 f = ld4<NT>(p);
       x0[0] = f.x; x0[1] = f.y; x0[2] = f.z; x0[3] = f.w;
@@ -116,10 +140,10 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
       const int64_t j = base + tid + (int64_t)VITTA_BLOCK * k;
       float sk = 0.f, qk = 0.f, xk = 0.f;
       if (j < plane && n1 > n0) {
-        const float* p = x + n0 * plane + j;
-        xk = *p;
+        const T* p = x + n0 * plane + j;
+        xk = ld1(p);
         for (int64_t n = 0; n < n1 - n0; ++n) {
-          const float d = p[n * plane] - xk;
+          const float d = ld1(p + n * plane) - xk;
           sk += d;
           qk = fmaf(d, d, qk);
         }
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nchw_partial_kernel(
 // ----------------------------------------------------------------------------
 // NHWC partial kernel
 // ----------------------------------------------------------------------------
-template <bool NT>
+template <bool NT, typename T = float>
 __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
     const LayerInfo* __restrict__ linfo, const BlockEnt* __restrict__ tab, PtrPack ptrs,
     float* __restrict__ ws) {
@@ -166,7 +190,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
 
   const BlockEnt e = tab[blockIdx.x];
   const LayerInfo L = linfo[e.layer];
-  const float* __restrict__ x = ptrs.x[e.layer];
+  const T* __restrict__ x = static_cast<const T*>(ptrs.x[e.layer]);
+  using V4 = typename Vec4<T>::type;
   const int tid = threadIdx.x;
   const int C = L.C;
   const int TX = L.tx;
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
   const bool active = ty < TY && c0 < C;
   if (active && r0 + ty < r1) {
     if (W == 4) {
-      const float4* p = reinterpret_cast<const float4*>(x + (r0 + ty) * C + c0);
+      const V4* p = reinterpret_cast<const V4*>(x + (r0 + ty) * C + c0);
       const int64_t stride4 = ((int64_t)TY * C) >> 2;
       const int64_t nn = (r1 - r0 - ty + TY - 1) / TY;
       const float4 f = ld4<NT>(p);
@@ -210,13 +235,13 @@ __global__ __launch_bounds__(VITTA_BLOCK) void moments_nhwc_partial_kernel(
         q[2] = fmaf(d2, d2, q[2]); q[3] = fmaf(d3, d3, q[3]);
       }
     } else {
-      const float* p = x + (r0 + ty) * C + c0;
+      const T* p = x + (r0 + ty) * C + c0;
       const int64_t stride = (int64_t)TY * C;
       const int64_t nn = (r1 - r0 - ty + TY - 1) / TY;
-      x0[0] = *p;
+      x0[0] = ld1(p);
       cnt = (float)nn;
       for (int64_t n = 0; n < nn; ++n) {
-        const float d = p[n * stride] - x0[0];
+        const float d = ld1(p + n * stride) - x0[0];
         s[0] += d;
         q[0] = fmaf(d, d, q[0]);
       }
@@ -483,70 +508,79 @@ int64_t vitta_plan_num_blocks(const vitta_plan* p) { return p ? p->n_blocks_nchw
 // ev_start / ev_stop (optional): hipEvents attached to the DISPATCH of the streaming kernel (hipExtLaunchKernelGGL):
 // they take the kernel's own begin / end timestamps, like a profiler, instead of bracketing it with barrier packets
 // (an event pair around a lone launch measured 50 us for a kernel rocprofv3 times at 40 us, r1j).
+extern "C++" {
+template <typename T>
 static int launch_partials(const vitta_plan* p, const void* const* h_x, float* ws, hipStream_t st,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   if (!p->d_info) return VITTA_ERR_INVALID_ARG;  // vitta_plan_upload not called
   PtrPack pack;
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   for (int l = 0; l < p->n_layers; ++l) {
-    const float* x = static_cast<const float*>(h_x[l]);
+    const void* x = h_x[l];
     if (!x) return VITTA_ERR_INVALID_ARG;
-    if (p->h_info[l].vec == 4 && (reinterpret_cast<uintptr_t>(x) & 15u)) return VITTA_ERR_INVALID_ARG;
+    if (p->h_info[l].vec == 4 && (reinterpret_cast<uintptr_t>(x) & (4 * sizeof(T) - 1))) return VITTA_ERR_INVALID_ARG;
     pack.x[l] = x;
   }
   if (p->n_blocks_nchw && ev_start) {
     (void)hipGetLastError();
     if (p->nt_loads)
-      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<true>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
+      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<true, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nchw, pack, ws);
     else
-      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<false>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
+      hipExtLaunchKernelGGL((moments_nchw_partial_kernel<false, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nchw, pack, ws);
     VITTA_CHECK_LAUNCH();
     ev_start = ev_stop = nullptr;
   } else if (p->n_blocks_nchw) {
     if (p->nt_loads)
-      VITTA_LAUNCH(moments_nchw_partial_kernel<true>, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
+      VITTA_LAUNCH((moments_nchw_partial_kernel<true, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nchw, pack, ws);
     else
-      VITTA_LAUNCH(moments_nchw_partial_kernel<false>, dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
+      VITTA_LAUNCH((moments_nchw_partial_kernel<false, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nchw, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
   if (p->n_blocks_nhwc && ev_start) {  // channels-last plan (Swin): the events go to its kernel
     (void)hipGetLastError();
     if (p->nt_loads)
-      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<true>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
+      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<true, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nhwc, pack, ws);
     else
-      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<false>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
+      hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<false, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
   } else if (p->n_blocks_nhwc) {
     if (p->nt_loads)
-      VITTA_LAUNCH(moments_nhwc_partial_kernel<true>, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
+      VITTA_LAUNCH((moments_nhwc_partial_kernel<true, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nhwc, pack, ws);
     else
-      VITTA_LAUNCH(moments_nhwc_partial_kernel<false>, dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
+      VITTA_LAUNCH((moments_nhwc_partial_kernel<false, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nhwc, pack, ws);
     VITTA_CHECK_LAUNCH();
   }
   return VITTA_OK;
 }
+}  // extern "C++"
 
 int vitta_moments_partials_f32(const vitta_plan* p, const void* const* h_x, void* d_ws, size_t ws_bytes,
                                void* stream) {
   if (!p || !h_x) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
-  return launch_partials(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream));
+  return launch_partials<float>(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream));
+}
+
+int vitta_moments_partials_bf16(const vitta_plan* p, const void* const* h_x, void* d_ws, size_t ws_bytes, void* stream) {
+  if (!p || !h_x) return VITTA_ERR_INVALID_ARG;
+  if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
+  return launch_partials<uint16_t>(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream));
 }
 
 int vitta_moments_partials_timed_f32(const vitta_plan* p, const void* const* h_x, void* d_ws, size_t ws_bytes,
                                      void* stream, void* ev_start, void* ev_stop) {
   if (!p || !h_x || !ev_start || !ev_stop) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
-  return launch_partials(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream),
-                         static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
+  return launch_partials<float>(p, h_x, static_cast<float*>(d_ws), static_cast<hipStream_t>(stream),
+                                static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop));
 }
 
 int vitta_event_create(void** out_event) {
@@ -580,20 +614,37 @@ int vitta_moments_finalize_f32(const vitta_plan* p, const float* d_shift, float*
   return VITTA_OK;
 }
 
-int vitta_moments_batched_f32(const vitta_plan* p, const void* const* h_x, const float* d_shift,
+}  // extern "C"
+
+template <typename T>
+static int moments_batched_t(const vitta_plan* p, const void* const* h_x, const float* d_shift,
                               float* d_cnt, float* d_s1, float* d_s2, void* d_ws, size_t ws_bytes,
                               void* stream) {
   if (!p || !h_x || !d_cnt || !d_s1 || !d_s2) return VITTA_ERR_INVALID_ARG;
   if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* ws = static_cast<float*>(d_ws);
-  const int rc = launch_partials(p, h_x, ws, st);
+  const int rc = launch_partials<T>(p, h_x, ws, st);
   if (rc != VITTA_OK) return rc;
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
   VITTA_LAUNCH(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info,
                      p->d_chan2layer, p->total_channels, ws, d_shift, 0, d_cnt, d_s1, d_s2);
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
+}
+
+extern "C" {
+
+int vitta_moments_batched_f32(const vitta_plan* p, const void* const* h_x, const float* d_shift,
+                              float* d_cnt, float* d_s1, float* d_s2, void* d_ws, size_t ws_bytes,
+                              void* stream) {
+  return moments_batched_t<float>(p, h_x, d_shift, d_cnt, d_s1, d_s2, d_ws, ws_bytes, stream);
+}
+
+int vitta_moments_batched_bf16(const vitta_plan* p, const void* const* h_x, const float* d_shift,
+                               float* d_cnt, float* d_s1, float* d_s2, void* d_ws, size_t ws_bytes,
+                               void* stream) {
+  return moments_batched_t<uint16_t>(p, h_x, d_shift, d_cnt, d_s1, d_s2, d_ws, ws_bytes, stream);
 }
 
 int vitta_moments_to_meanvar_f32(const vitta_plan* p, const float* d_shift, const float* d_cnt,
@@ -653,7 +704,9 @@ __global__ void single_tables_kernel(BlockEnt* tab, int32_t* c2l, LayerInfo* d_i
   if (i < C) c2l[i] = 0;
 }
 
-int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, int32_t layout,
+extern "C++" {
+template <typename T>
+int moments_single(const T* d_x, int64_t outer, int32_t C, int64_t inner, int32_t layout,
                    float* d_mean, float* d_var, void* d_ws, size_t ws_bytes, void* stream) {
   if (!d_x || !d_mean || !d_var) return VITTA_ERR_INVALID_ARG;
   SinglePlan sp;
@@ -661,7 +714,7 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
   if (st != VITTA_OK) return st;
   const size_t need = sp.bytes_info + sp.bytes_tab + sp.bytes_c2l + sp.bytes_part;
   if (!d_ws || ws_bytes < need) return VITTA_ERR_WORKSPACE;
-  if (sp.info.vec == 4 && (reinterpret_cast<uintptr_t>(d_x) & 15u)) return VITTA_ERR_INVALID_ARG;
+  if (sp.info.vec == 4 && (reinterpret_cast<uintptr_t>(d_x) & (4 * sizeof(T) - 1))) return VITTA_ERR_INVALID_ARG;
   hipStream_t s = static_cast<hipStream_t>(stream);
   char* base = static_cast<char*>(d_ws);
   LayerInfo* d_info = reinterpret_cast<LayerInfo*>(base);
@@ -676,10 +729,10 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   pack.x[0] = d_x;
   if (layout == VITTA_LAYOUT_NCHW)
-    VITTA_LAUNCH(moments_nchw_partial_kernel<false>, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+    VITTA_LAUNCH((moments_nchw_partial_kernel<false, T>), dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                  d_tab, pack, d_part);
   else
-    VITTA_LAUNCH(moments_nhwc_partial_kernel<false>, dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
+    VITTA_LAUNCH((moments_nhwc_partial_kernel<false, T>), dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
   VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(moments_finalize_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK),
@@ -688,6 +741,7 @@ int moments_single(const float* d_x, int64_t outer, int32_t C, int64_t inner, in
   VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
+}  // extern "C++"
 }  // namespace
 
 size_t vitta_moments_workspace_bytes(int64_t outer, int32_t C, int64_t inner, int32_t layout) {
@@ -703,6 +757,16 @@ int vitta_moments_nchw_f32(const float* d_x, int64_t NT, int32_t C, int64_t HW, 
 
 int vitta_moments_nhwc_f32(const float* d_x, int64_t rows, int32_t C, float* d_mean, float* d_var,
                            void* d_ws, size_t ws_bytes, void* stream) {
+  return moments_single(d_x, rows, C, 1, VITTA_LAYOUT_NHWC, d_mean, d_var, d_ws, ws_bytes, stream);
+}
+
+int vitta_moments_nchw_bf16(const uint16_t* d_x, int64_t NT, int32_t C, int64_t HW, float* d_mean,
+                            float* d_var, void* d_ws, size_t ws_bytes, void* stream) {
+  return moments_single(d_x, NT, C, HW, VITTA_LAYOUT_NCHW, d_mean, d_var, d_ws, ws_bytes, stream);
+}
+
+int vitta_moments_nhwc_bf16(const uint16_t* d_x, int64_t rows, int32_t C, float* d_mean, float* d_var,
+                            void* d_ws, size_t ws_bytes, void* stream) {
   return moments_single(d_x, rows, C, 1, VITTA_LAYOUT_NHWC, d_mean, d_var, d_ws, ws_bytes, stream);
 }
 

@@ -20,6 +20,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def _require_cuda_feature(t, name):
+    """Hooked features may be fp32 or bfloat16 (widened to fp32 in registers by the moments kernels)."""
+    if not t.is_cuda:
+        raise _lib.VittaHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.VittaHipError(f"{name} must be float32 or bfloat16 (got {t.dtype})")
+
+
 def _require_cuda_f32(t, name):
     if not t.is_cuda:
         raise _lib.VittaHipError(f"{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback")
@@ -56,8 +64,9 @@ def feature_layout(feature, kind):
 # single-layer moments (drop-in for one hook invocation)
 # ------------------------------------------------------------------------------------------------
 def moments(feature, kind):
-    """Per-channel (mean, biased var) over (N, T, H, W) of one hooked feature; no autograd."""
-    _require_cuda_f32(feature, "feature")
+    """Per-channel (mean, biased var) over (N, T, H, W) of one hooked feature (fp32 or bfloat16, fp32 accumulation and
+    results); no autograd."""
+    _require_cuda_feature(feature, "feature")
     x = feature if feature.is_contiguous() else feature.contiguous()
     outer, c, inner, layout = feature_layout(x, kind)
     L = lib()
@@ -65,12 +74,13 @@ def moments(feature, kind):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     var = torch.empty(c, dtype=torch.float32, device=x.device)
+    sfx = "bf16" if x.dtype == torch.bfloat16 else "f32"
     if layout == LAYOUT_NCHW:
-        check(L.vitta_moments_nchw_f32(_p(x), outer, c, inner, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
-              "vitta_moments_nchw_f32")
+        check(getattr(L, f"vitta_moments_nchw_{sfx}")(_p(x), outer, c, inner, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
+              f"vitta_moments_nchw_{sfx}")
     else:
-        check(L.vitta_moments_nhwc_f32(_p(x), outer, c, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
-              "vitta_moments_nhwc_f32")
+        check(getattr(L, f"vitta_moments_nhwc_{sfx}")(_p(x), outer, c, _p(mean), _p(var), _p(ws), ws_bytes, _stream()),
+              f"vitta_moments_nhwc_{sfx}")
     return mean, var
 
 
@@ -193,20 +203,29 @@ class StatPlan:
         return slice(o, o + self.shapes[layer][1])
 
     def moments(self, feats, shift=None, events=None):
-        """feats: list of contiguous CUDA fp32 tensors (one per layer) -> fills cnt/s1/s2.
+        """feats: list of contiguous CUDA tensors (one per layer), all fp32 or all bfloat16 -> fills cnt/s1/s2.
         `events`: a KernelEventPair attached to the dispatch of the streaming (partials) kernel -- bench.py's
         live kernel timing."""
         if len(feats) != self.n_layers:
             raise ValueError("one feature per planned layer expected")
+        bf16 = len(feats) > 0 and feats[0].dtype == torch.bfloat16
         for i, t in enumerate(feats):
-            _require_cuda_f32(t, f"feature {i}")
+            _require_cuda_feature(t, f"feature {i}")
+            if (t.dtype == torch.bfloat16) != bf16:
+                raise _lib.VittaHipError("one launch reads features of one element type (all fp32 or all bfloat16)")
             if not t.is_contiguous():
                 raise _lib.VittaHipError(f"feature {i} must be contiguous")
             outer, c, inner, _ = self.shapes[i]
             if t.numel() != outer * c * inner:
                 raise _lib.VittaHipError(f"feature {i} has {t.numel()} elements, plan expects {outer * c * inner}")
             self._ptr_arr[i] = t.data_ptr()
-        if events is None:
+        if bf16:
+            if events is not None:
+                raise _lib.VittaHipError("dispatch-timed launches exist for fp32 features only")
+            check(lib().vitta_moments_batched_bf16(self._h, self._ptr_arr, _p(shift), _p(self.cnt), _p(self.s1),
+                                                   _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
+                  "vitta_moments_batched_bf16")
+        elif events is None:
             check(lib().vitta_moments_batched_f32(self._h, self._ptr_arr, _p(shift), _p(self.cnt), _p(self.s1),
                                                   _p(self.s2), _p(self.ws), self.ws_bytes, _stream()),
                   "vitta_moments_batched_f32")
@@ -222,8 +241,8 @@ class StatPlan:
         """First stage only (the streaming kernel), for micro-benchmarks."""
         for i, t in enumerate(feats):
             self._ptr_arr[i] = t.data_ptr()
-        check(lib().vitta_moments_partials_f32(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream()),
-              "vitta_moments_partials_f32")
+        name = "vitta_moments_partials_bf16" if feats[0].dtype == torch.bfloat16 else "vitta_moments_partials_f32"
+        check(getattr(lib(), name)(self._h, self._ptr_arr, _p(self.ws), self.ws_bytes, _stream()), name)
 
     def layer_geometry(self, layer):
         """(nsplit, nchunks, slots, ws_off) of a layer: where a fused BN pass deposits its partial triples."""
