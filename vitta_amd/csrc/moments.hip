@@ -34,7 +34,7 @@ using namespace vitta;
 
 namespace {
 
-constexpr int kUnroll = 8;
+constexpr int kUnroll = 16;
 
 // ----------------------------------------------------------------------------
 // NCHW partial kernel
