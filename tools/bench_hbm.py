@@ -62,6 +62,16 @@ def main():
             pl = ops.StatPlan(shapes, dev, target_blocks=tb)
             ms = timed(lambda: pl.partials(feats))
             out["sweep_target_blocks"][tb] = round(numel * 4 / ms * 1e-6)
+        del feats, flat, dst
+        # channels-last (Video Swin-B, C3): 42 hooked LayerNorm outputs, 16 videos' worth of rows
+        ln = [(16 * 3136, 512, 1, 1)] * 36 + [(16 * 784, 2048, 1, 1)] + [(16 * 784, 1024, 1, 1)] * 5
+        n_ln = sum(o * c for o, c, _, _ in ln)
+        f_ln = [torch.randn(o, c, device=dev) for o, c, _, _ in ln]
+        out["sweep_target_blocks_nhwc"] = {"bytes": n_ln * 4}
+        for tb in (1024, 2048, 4096, 8192, 16384, 32768):
+            pl = ops.StatPlan(ln, dev, target_blocks=tb)
+            ms = timed(lambda: pl.partials(f_ln))
+            out["sweep_target_blocks_nhwc"][tb] = (pl.num_blocks, round(n_ln * 4 / ms * 1e-6))
     print(json.dumps(out))
 
 
