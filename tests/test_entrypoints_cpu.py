@@ -154,8 +154,10 @@ def run_episodic(tmp_path, monkeypatch, device):
     for v in range(2):
         ref = torch.from_numpy(g[f"video{v}_eval_logits"])
         # momentum_mvg = 1 and two steps make this regime chaotic: the reference re-run with inputs perturbed
-        # by 1e-7 relative moves its own adapted logits by `noise_eval_logits` (0.66 on a scale of 7.7)
-        assert (logits[v] - ref).abs().max().item() <= max(2e-3 * ref.abs().max().item(), float(g["noise_eval_logits"]))
+        # by 1e-7 relative moves its own adapted logits by `noise_eval_logits` (0.66 on a scale of 7.7) -- the largest
+        # of only THREE perturbed reruns, i.e. a lower bound of its spread: twice that is the bound here (the GPU
+        # path's own run-to-run spread, from the order of its gradient atomics, reaches 0.82)
+        assert (logits[v] - ref).abs().max().item() <= max(2e-3 * ref.abs().max().item(), 2 * float(g["noise_eval_logits"]))
     assert res == pytest.approx(g["top1"].tolist())
 
 
