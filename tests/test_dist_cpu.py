@@ -196,5 +196,5 @@ def test_epoch_style_on_two_ranks_equals_reference_batch_of_two(tmp_path):
         assert np.abs(r0[f"param::{name}"] - ref).max() <= 2.5e-3 + 1e-5 * np.abs(ref).max()
     ref = g["eval_logits"]
     got = np.stack([r0["logits"][0], r1["logits"][0], r0["logits"][1], r1["logits"][1]])  # rank r evaluated videos r, 2 + r
-    assert np.abs(got - ref).max() <= max(2e-3 * np.abs(ref).max(), float(g["noise_eval_logits"]))
+    assert np.abs(got - ref).max() <= max(2e-3 * np.abs(ref).max(), 2 * float(g["noise_eval_logits"]))
     assert r0["top1"].tolist() == r1["top1"].tolist() == pytest.approx(g["top1"].tolist())

@@ -219,7 +219,8 @@ def run_epoch(tmp_path, monkeypatch, device):
             # round-off sized gradient flips sign
             assert (params[k] - ref).abs().max().item() <= (1e-6 if i == 0 else 2.5e-3) + 1e-5 * ref.abs().max().item(), (i, k)
     ref = torch.from_numpy(g["eval_logits"])
-    assert (logits[0] - ref).abs().max().item() <= max(2e-3 * ref.abs().max().item(), float(g["noise_eval_logits"]))
+    # (noise floor = the largest of three perturbed reruns of the reference: a lower bound of its spread, hence the 2)
+    assert (logits[0] - ref).abs().max().item() <= max(2e-3 * ref.abs().max().item(), 2 * float(g["noise_eval_logits"]))
     assert res == pytest.approx(g["top1"].tolist())
     assert _hooks_of(model) == []  # the statistics hooks were closed before the evaluation pass and stay closed
 
