@@ -69,6 +69,9 @@ def parse():
                    help="adapt(i); eval(i) back to back on one stream instead of eval(i-1) beside adapt(i)")
     p.add_argument("--segmented-graph", action="store_true",
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
+    p.add_argument("--force-exchanges", action="store_true",
+                   help="single process: form a ONE-rank RCCL group and run the data-parallel step (segmented graphs, both "
+                        "all-reduces) anyway -- exercises the RCCL calls on a one-GPU box")
     p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
     p.add_argument("--size", type=int, default=224)
     p.add_argument("--clip-length", type=int, default=None, help="frames per view (default 8 TANet / 16 Swin)")
@@ -272,7 +275,7 @@ def run_gpu(opt, rank, world, device):
 
     # adapt-only timing (no evaluation forward), same videos, for the report
     adapt_only = float("nan")
-    if not opt.sequential and use_graph and world == 1:
+    if not opt.sequential and use_graph and world == 1 and not opt.force_exchanges:
         # the overlapped capture is one graph holding adaptation and evaluation: for SURVEY 8d's "(i) adapt step only"
         # capture the plain adapt / eval graphs as well (after the timed region; a failure only drops this figure)
         try:
@@ -362,6 +365,12 @@ def run_cpu_baseline(opt):
 
 def main():
     opt = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner through
+    # C stdio when a communicator is created, flushed at exit -- after the JSON line): hand file descriptor 1 to stderr
+    # for the run and keep the real stdout for the line alone.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -369,6 +378,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    if world == 1 and opt.force_exchanges:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        from vitta_amd import tta as _tta
+        _tta.FORCE_EXCHANGES = True
+        opt.segmented_graph = True
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if opt.dist_backend == "nccl":
@@ -407,7 +424,7 @@ def main():
                                "prediction consistency, backward, optimizer) + eval forward (1 view)",
                    "optimizer": "Adam on BN affine (update_only_bn_affine)" if opt.optimizer == "adam_affine" else "SGD all parameters",
                    "videos_per_gpu_per_step": 1, "parallelism": f"dp{world}",
-                   "exchanges": "moments all-reduce (43k floats) + gradient all-reduce" if world > 1 else "none",
+                   "exchanges": "moments all-reduce (43k floats) + gradient all-reduce" if (world > 1 or opt.force_exchanges) else "none",
                    "schedule": "sequential: adapt(i); eval(i)" if opt.sequential else
                                "overlapped: eval(i-1) on a second stream beside adapt(i), optimizer update after both "
                                "(same weights and results as the sequential order)"},
@@ -441,10 +458,11 @@ def main():
         log("cpu baseline ...")
         line["cpu_baseline"] = run_cpu_baseline(opt)
         log("cpu baseline done")
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or opt.force_exchanges:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

@@ -217,3 +217,23 @@ def test_two_ranks_swin_equal_one_process_batch_of_two_on_gpu(tmp_path):
         assert total == pytest.approx(float(one[f"step{i}_loss_consis"]), rel=10 * tol, abs=1e-4)
         scale = np.abs(one[f"step{i}_ema"]).max()
         assert np.abs(r0[f"step{i}_ema"] - one[f"step{i}_ema"]).max() <= (1e-4 if i == 0 else 5e-3) * scale
+
+
+def test_rccl_exchanges_between_graph_segments_with_a_one_rank_group():
+    """The RCCL calls themselves (torch.distributed backend "nccl"), which the two-rank rehearsals above cannot reach on
+    a one-GPU box: bench.py --force-exchanges forms a ONE-rank RCCL group and runs the data-parallel step -- three
+    captured graph segments with the packed-moments and flat-gradient all-reduces launched eagerly between them, the
+    evaluation overlapped on the side stream -- and must report the same kind of line at about the single-process rate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "8", "--warmup", "4",
+           "--no-cpu-baseline", "--no-streaming", "--size", "112"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines  # RCCL's version banner (C stdio, flushed at exit) must not follow the JSON line
+    rec = json.loads(lines[0])
+    assert "3 segments" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0

@@ -94,6 +94,11 @@ def _n_clips(args):
     return int(args.sample_style.split("-")[-1]) if args.arch == "tanet" else args.num_clips
 
 
+# test / rehearsal switch: run the two data-parallel exchanges (and the segmented graphs around them) even in a process
+# group of ONE rank -- the only way to drive the RCCL calls themselves on a single-GPU box (bench.py --force-exchanges)
+FORCE_EXCHANGES = False
+
+
 def _dist():
     d = torch.distributed
     if d.is_available() and d.is_initialized() and d.get_world_size() > 1:
@@ -296,7 +301,7 @@ class ViTTAAdapter:
                 self.optimizer = torch.optim.SGD(params=[self.arena.flat_param], lr=args.lr, momentum=args.momentum,
                                                  weight_decay=args.weight_decay)
         self.params = self.arena.params
-        self.bucket = self.arena if self.world > 1 else None
+        self.bucket = self.arena if (self.world > 1 or FORCE_EXCHANGES) else None
 
         self.n_clips = _n_clips(args)
         self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
@@ -324,7 +329,8 @@ class ViTTAAdapter:
         if engine_backend is None and BACKEND_FACTORY is not None:
             engine_backend = BACKEND_FACTORY()
         self.backend = engine_backend
-        self.engine = StatAlignEngine(args.reg_type, args.momentum_mvg, backend=engine_backend) if use_engine else None
+        self.engine = StatAlignEngine(args.reg_type, args.momentum_mvg, backend=engine_backend,
+                                      distributed=True if FORCE_EXCHANGES else None) if use_engine else None
         self.hooked = select_hooked(args, self.chosen_layers)
         self.stat_reg_hooks = [
             CombineNormStatsRegHook_onereg(layer, clip_len=args.clip_length,
@@ -566,7 +572,7 @@ class ViTTAAdapter:
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
         self.set_adapt_mode()
-        if self.world > 1 or segmented:
+        if self.world > 1 or segmented or self.bucket is not None:
             self._capture_segments(g, overlap_eval)
             if overlap_eval:
                 g["step"] = None  # step() replays the three segments
