@@ -69,6 +69,9 @@ def parse():
                    help="adapt(i); eval(i) back to back on one stream instead of eval(i-1) beside adapt(i)")
     p.add_argument("--segmented-graph", action="store_true",
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
+    p.add_argument("--tuned-gemms", action="store_true",
+                   help="--arch swin: the measured GEMM selection table (vitta_amd/tuning) instead of the library default; "
+                        "off by default (see vitta_amd/tuning/__init__.py)")
     p.add_argument("--force-exchanges", action="store_true",
                    help="single process: form a ONE-rank RCCL group and run the data-parallel step (segmented graphs, both "
                         "all-reduces) anyway -- exercises the RCCL calls on a one-GPU box")
@@ -392,6 +395,10 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:  # rehearsal of the data-parallel path with several ranks on ONE GPU (RCCL refuses duplicate devices)
             torch.distributed.init_process_group(opt.dist_backend)
+    want_tuned, opt.tuned_gemms = opt.tuned_gemms, False
+    if opt.arch == "swin" and want_tuned and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+        from vitta_amd import tuning
+        opt.tuned_gemms = tuning.enable_tuned_gemms()
     if opt.miopen_find:
         torch.backends.cudnn.benchmark = True
     # corpus/main_eval.py:77 sets cudnn.benchmark (an exhaustive MIOpen find on ROCm: minutes of search
@@ -450,6 +457,8 @@ def main():
         line["config"]["exchanges"] = "moments all-reduce + gradient all-reduce" if world > 1 else "none"
         line["roofline"]["kernel"] = f"moments_nhwc_partial_kernel ({n_ln} layers, 1 launch)"
         line["roofline"]["traffic_source"] = None
+        line["config"]["gemm_selection"] = ("measured table vitta_amd/tuning (hipBLASLt / rocBLAS solution per shape, no search at "
+                                            "run time)") if opt.tuned_gemms else "library default"
         line["roofline"]["note"] = ("stand-alone batched kernel timed on the step's own hooked LayerNorm outputs; in the "
                                     "shipped step these moments ride on the fused LayerNorm pass (ln_fwd_kernel)")
     if rank == 0 and world == 1 and not opt.no_cpu_baseline and opt.arch == "tanet":

@@ -21,8 +21,16 @@ p.add_argument("--no-graph", action="store_true")
 p.add_argument("--sgd", action="store_true")
 p.add_argument("--views", type=int, default=2)
 p.add_argument("--window-depth", type=int, default=8, help="temporal window (16 = the SSv2 recipe of BASELINE config 4)")
+p.add_argument("--tuned-gemms", action="store_true", help="measured GEMM selection table (vitta_amd/tuning); off by default")
+p.add_argument("--blas", default=None, choices=["hipblaslt", "hipblas", "default"], help="torch.backends.cuda.preferred_blas_library")
 p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
+if opt.blas:
+    torch.backends.cuda.preferred_blas_library(opt.blas)
+tuned = False
+if opt.tuned_gemms and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+    from vitta_amd import tuning
+    tuned = tuning.enable_tuned_gemms()
 dev = torch.device("cuda:0")
 tmp = tempfile.mkdtemp()
 model = S.build_swin(101, 0, window_size=(opt.window_depth, 7, 7)).to(dev)
@@ -76,6 +84,6 @@ for i in range(opt.steps):
     one(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
-print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph,
+print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph, tuned_gemms=tuned,
                       frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine",
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

@@ -63,6 +63,9 @@ def eval(args=None, model=None):
     device = pick_device(args)
     if device.type == "cuda":
         torch.cuda.set_device(device)
+        if getattr(args, "tuned_gemms", False) and args.arch == "videoswintransformer":
+            from . import tuning
+            logger.debug(f"tuned GEMM table loaded: {tuning.enable_tuned_gemms()}")
 
     if model is None:
         model = load_checkpoint_into(get_model(args, num_classes, logger), args, logger, device)

@@ -7,6 +7,7 @@
 * `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py;
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 * `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
+* `--tuned_gemms` (extension, default False) loads the measured GEMM-solution table for the Video Swin-B step.
 * `--device_preprocess` (extension, default False) uploads the decoded uint8 frames and runs crop / resize / normalise
   of the TANet pipeline in one HIP launch (bit-identical to the PIL path, vitta_amd/frames.py).
 """
@@ -103,6 +104,9 @@ _FLAGS = [
     (("--device_preprocess",), dict(type=_bool, default=False,
                                     help="(extension) TANet real-video pipeline: crop + PIL-BILINEAR resize + normalise on "
                                          "the GPU from the uploaded uint8 frames (bit-identical to the host PIL path)")),
+    (("--tuned_gemms",), dict(type=_bool, default=False,
+                              help="(extension) Video Swin-B: take the measured hipBLASLt / rocBLAS solution per GEMM shape "
+                                   "(vitta_amd/tuning) instead of the library's default heuristic")),
     (("--n_gradient_steps",), dict(type=int, default=1, help="number of gradient steps per sample")),
     # input / optimiser
     (("--full_res",), dict(action="store_true")),
