@@ -15,9 +15,13 @@ them and ignores the file otherwise).  Measured: 24.8 -> 21.3 ms per video (sequ
 
 OFF BY DEFAULT everywhere (`bench.py --arch swin --tuned-gemms`, `tools/bench_swin.py --tuned-gemms`, `--tuned_gemms` of
 the entry points): of seven runs with TunableOp enabled on the round's GPU boxes, three did not finish within their
-250-300 s limit (the other four took 12 s and produced the figures above).  The stall was not diagnosed in the round
-(it needs GPU time the round no longer had): until it is, the table is evidence of what the library's default
-heuristic leaves on the table for these shapes (8-14 % of the step), not a shipped setting.
+250-300 s limit (the other four took 12 s and produced the figures above).  A watchdog run
+(`tools/debug/stall_trace.py`) places the stall on the DEVICE: the host sits in `torch.cuda.synchronize()` after the first
+replay of the captured step -- the graph never completes.  Suspected, not proven: some of the selected solutions
+coordinate their workgroups through flags in a workspace (split-K / stream-K style) and do not tolerate the replayed
+graph's concurrency (two branches issuing GEMMs that share the library workspace).  Until that is settled the table is
+evidence of what the library's default heuristic leaves on the table for these shapes (8-14 % of the step), not a
+shipped setting.
 """
 import os
 
