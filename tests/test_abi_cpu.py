@@ -79,3 +79,15 @@ def test_product_ops_refuse_host_tensors():
     plan = frames.FramePlan([frames.ViewSpec((0, 0, 8, 8), (4, 4))], (4, 4), "cpu", (0.5,) * 3, (0.25,) * 3)
     with pytest.raises(_lib.VittaHipError, match="GPU"):
         frames.resample_normalise(torch.zeros(1, 8, 8, 3, dtype=torch.uint8), plan, 1)
+
+
+def test_bench_refuses_to_run_without_a_gpu_and_keeps_stdout_clean():
+    """bench.py measures the HIP path only: on a box without a GPU it stops with a message on stderr, nothing on stdout
+    (the driver reads stdout for the one JSON line), no CPU fallback number."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and out.stdout == "" and "no CPU fallback" in out.stderr
