@@ -10,10 +10,10 @@
 // An output window inside a larger resize (eval: short edge -> 256, centre 224) is just a table slice.
 //
 // One workgroup = one frame x `tile_rows` output rows, one lane per output column: the horizontal pass of the input rows
-// that tile needs goes to LDS as bytes (planar [row][channel][x]; a lane's taps stay in registers over the rows, its three
-// channels are adjacent bytes), the vertical pass reads LDS and writes coalesced fp32 rows through the LDS copy of the
-// normalisation table.  HBM traffic = the
-// crop's bytes once + the fp32 output once.
+// that tile needs stays in LDS (one packed R|G|B dword per (row, column) in the unrolled path, planar bytes in the general
+// one; a lane's taps stay in registers over the rows), the vertical pass reads LDS and writes coalesced fp32 rows through
+// the LDS copy of the normalisation table.  HBM traffic = the crop's bytes once + the fp32 output once
+// (profiles/r1p_frames_pmc.json: writes 1.000 x, total <= 1.08 x algorithmic).
 #include <algorithm>
 
 #include "common.h"
