@@ -41,7 +41,12 @@ class BNFeatureHook:
     """`stat_reg='BNS'`: align the statistics of a BatchNorm layer's INPUT with the layer's own running
     statistics (the source model's BN statistics); zero-initialised EMA when `running_manner`.
     The reductions run on the HIP moment kernels (BN2d: over (N*T, H, W); BN3d: over (N, T, H, W);
-    BatchNorm1d: over the rows of (N*C, T) or over (N, T) of (N, C, T)); backward is analytic."""
+    BatchNorm1d: over the rows of (N*C, T) or over (N, T) of (N, C, T)); backward is analytic.
+
+    Deviation from the reference, on purpose: with `use_src_stat_in_reg` the reference keeps
+    `module.running_mean.data` -- a live ALIAS (BNS_utils.py:33-34) -- so under --fix_BNS False its "source" statistics
+    drift with the train-mode BN layer.  Here the source statistics are a snapshot taken at construction (what the
+    name says); with frozen BN buffers (--fix_BNS True, the shipped default) the two are identical."""
 
     def __init__(self, module, reg_type="l2norm", running_manner=False, use_src_stat_in_reg=True, momentum=0.1,
                  backend=None):

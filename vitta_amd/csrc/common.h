@@ -121,6 +121,3 @@ struct vitta_plan {
     if (hipGetLastError() != hipSuccess) return VITTA_ERR_LAUNCH;  \
   } while (0)
 
-#define VITTA_CHECK_LAUNCH() \
-  do {                       \
-  } while (0)

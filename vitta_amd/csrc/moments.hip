@@ -529,7 +529,6 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     else
       hipExtLaunchKernelGGL((moments_nchw_partial_kernel<false, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nchw, pack, ws);
-    VITTA_CHECK_LAUNCH();
     ev_start = ev_stop = nullptr;
   } else if (p->n_blocks_nchw) {
     if (p->nt_loads)
@@ -538,7 +537,6 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     else
       VITTA_LAUNCH((moments_nchw_partial_kernel<false, T>), dim3(p->n_blocks_nchw), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nchw, pack, ws);
-    VITTA_CHECK_LAUNCH();
   }
   if (p->n_blocks_nhwc && ev_start) {  // channels-last plan (Swin): the events go to its kernel
     (void)hipGetLastError();
@@ -548,7 +546,6 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     else
       hipExtLaunchKernelGGL((moments_nhwc_partial_kernel<false, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st, ev_start,
                             ev_stop, 0, p->d_info, p->d_tab_nhwc, pack, ws);
-    VITTA_CHECK_LAUNCH();
   } else if (p->n_blocks_nhwc) {
     if (p->nt_loads)
       VITTA_LAUNCH((moments_nhwc_partial_kernel<true, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
@@ -556,7 +553,6 @@ static int launch_partials(const vitta_plan* p, const void* const* h_x, float* w
     else
       VITTA_LAUNCH((moments_nhwc_partial_kernel<false, T>), dim3(p->n_blocks_nhwc), dim3(VITTA_BLOCK), 0, st,
                    p->d_info, p->d_tab_nhwc, pack, ws);
-    VITTA_CHECK_LAUNCH();
   }
   return VITTA_OK;
 }
@@ -610,7 +606,6 @@ int vitta_moments_finalize_f32(const vitta_plan* p, const float* d_shift, float*
   VITTA_LAUNCH(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream),
                      p->d_info, p->d_chan2layer, p->total_channels, static_cast<const float*>(d_ws), d_shift, 0,
                      d_cnt, d_s1, d_s2);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -629,7 +624,6 @@ static int moments_batched_t(const vitta_plan* p, const void* const* h_x, const 
   const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
   VITTA_LAUNCH(moments_finalize_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info,
                      p->d_chan2layer, p->total_channels, ws, d_shift, 0, d_cnt, d_s1, d_s2);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -655,7 +649,6 @@ int vitta_moments_to_meanvar_f32(const vitta_plan* p, const float* d_shift, cons
   VITTA_LAUNCH(moments_to_meanvar_kernel, dim3(grid), dim3(VITTA_BLOCK), 0,
                      static_cast<hipStream_t>(stream), p->d_info, p->d_chan2layer, p->total_channels,
                      d_shift, d_cnt, d_s1, d_s2, d_mean, d_var);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -724,7 +717,6 @@ int moments_single(const T* d_x, int64_t outer, int32_t C, int64_t inner, int32_
   // tables + the layer record are written by a small kernel (stream ordered, no host staging)
   VITTA_LAUNCH(single_tables_kernel, dim3((std::max(sp.n_blocks, (int)C) + 255) / 256), dim3(256),
                      0, s, d_tab, d_c2l, d_info, sp.info, sp.info.nchunks, sp.n_blocks, (int)C);
-  VITTA_CHECK_LAUNCH();
   PtrPack pack;
   for (int l = 0; l < VITTA_MAX_LAYERS; ++l) pack.x[l] = nullptr;
   pack.x[0] = d_x;
@@ -734,11 +726,9 @@ int moments_single(const T* d_x, int64_t outer, int32_t C, int64_t inner, int32_
   else
     VITTA_LAUNCH((moments_nhwc_partial_kernel<false, T>), dim3(sp.n_blocks), dim3(VITTA_BLOCK), 0, s, d_info,
                        d_tab, pack, d_part);
-  VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(moments_finalize_kernel, dim3((C + VITTA_BLOCK - 1) / VITTA_BLOCK), dim3(VITTA_BLOCK),
                      0, s, d_info, d_c2l, (int64_t)C, d_part, (const float*)nullptr, 1, (float*)nullptr,
                      d_mean, d_var);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 }  // extern "C++"

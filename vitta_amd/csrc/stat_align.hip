@@ -273,13 +273,10 @@ int vitta_stat_align_fwd_f32(const vitta_plan* p, const float* d_shift, const fl
   VITTA_LAUNCH(stat_align_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info, p->d_chan2layer,
                      p->total_channels, d_shift, d_cnt, d_s1, d_s2, d_ema_mean, d_ema_var, d_src_mean,
                      d_src_var, momentum, reg_type, term, d_mu, d_coef_a, d_coef_b);
-  VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(layer_loss_kernel, dim3(p->n_layers), dim3(VITTA_BLOCK), 0, st, p->d_info, term,
                      d_layer_loss);
-  VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(total_loss_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, d_layer_loss, p->n_layers,
                      d_total_loss);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -315,7 +312,6 @@ int vitta_stat_align_bwd_f32(const float* d_x, const float* d_gout, float* d_gin
   } else {
     return VITTA_ERR_INVALID_ARG;
   }
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -329,9 +325,7 @@ int vitta_pred_consis_f32(const float* d_logits, int32_t B, int32_t V, int32_t K
   float* part = d_loss + 1;
   VITTA_LAUNCH(pred_consis_kernel, dim3(B), dim3(VITTA_BLOCK), lds, st, d_logits, (int)V, (int)K, part,
                      d_grad);
-  VITTA_CHECK_LAUNCH();
   VITTA_LAUNCH(pred_consis_total_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, part, (int)B, d_loss);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 

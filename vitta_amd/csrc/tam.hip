@@ -237,7 +237,6 @@ int vitta_tam_pool_f32(const float* d_x, int32_t N, int32_t T, int32_t C, int32_
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)N * T * C;
   TAM_DISPATCH(tam_pool_kernel, rows, HW, st, d_x, (int)N, (int)T, (int)C, (int)HW, d_pool);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -249,7 +248,6 @@ int vitta_tam_agg_fwd_f32(const float* d_x, const float* d_gate, const float* d_
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)N * T * C;
   TAM_DISPATCH(tam_agg_fwd_kernel, rows, HW, st, d_x, d_gate, d_kern, (int)N, (int)T, (int)C, (int)HW, d_out);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -268,11 +266,9 @@ int vitta_tam_agg_bwd_f32(const float* d_x, const float* d_gate, const float* d_
   float* dots = d_ggate + (int64_t)N * C * T;
   TAM_DISPATCH(tam_agg_bwd_kernel, rows, HW, st, d_x, d_gate, d_kern, d_gout, (int)N, (int)T, (int)C, (int)HW,
                d_gx, dots);
-  VITTA_CHECK_LAUNCH();
   const int64_t NC = (int64_t)N * C;
   VITTA_LAUNCH(tam_finish_bwd_kernel, dim3((unsigned)((NC + VITTA_BLOCK - 1) / VITTA_BLOCK)),
                      dim3(VITTA_BLOCK), 0, st, d_gate, d_kern, dots, NC, (int)T, d_ggate, d_gkern);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 
@@ -283,7 +279,6 @@ int vitta_tam_pool_bwd_f32(const float* d_gpool, int32_t N, int32_t T, int32_t C
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t rows = (int64_t)N * T * C;
   TAM_DISPATCH(tam_pool_bwd_kernel, rows, HW, st, d_gpool, (int)N, (int)T, (int)C, (int)HW, d_gx_accum);
-  VITTA_CHECK_LAUNCH();
   return VITTA_OK;
 }
 

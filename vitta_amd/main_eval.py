@@ -34,6 +34,23 @@ def pick_device(args):
     return torch.device("cpu")
 
 
+def init_distributed(device):
+    """One process per GPU under torchrun (RANK / WORLD_SIZE in the environment): join the job's process group -- RCCL
+    ('nccl') for GPU ranks, gloo for host ranks -- so that tta_standard / test_time_adapt shard the videos and run their
+    two exchanges.  Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    d = torch.distributed
+    if world > 1 and d.is_available() and not d.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if device.type == "cuda":
+            d.init_process_group("nccl", device_id=device)
+        else:
+            d.init_process_group("gloo")
+    if d.is_available() and d.is_initialized():
+        return d.get_rank(), d.get_world_size()
+    return 0, 1
+
+
 def load_checkpoint_into(model, args, logger, device):
     """Both checkpoint layouts of the reference (main_eval.py:55-65): keys with a `module.` prefix
     (TANet) are loaded into the wrapped model, keys without (Swin) into the bare model."""
@@ -54,15 +71,18 @@ def load_checkpoint_into(model, args, logger, device):
 def eval(args=None, model=None):
     log_time = time.strftime("%Y%m%d_%H%M%S")
     make_dir(args.result_dir)
-    logger = path_logger(args.result_dir, log_time)
+    device = pick_device(args)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    rank, _ = init_distributed(device)
+    # every rank keeps its own log file (rank 0 under the reference's name); the *_all_result line is rank 0's
+    logger = path_logger(args.result_dir, log_time if rank == 0 else f"{log_time}_rank{rank}")
     if args.verbose:
         for arg in dir(args):
             if arg[0] != "_":
                 logger.debug(f"{arg} {getattr(args, arg)}")
     args.num_classes = num_classes = NUM_CLASSES[args.dataset]
-    device = pick_device(args)
     if device.type == "cuda":
-        torch.cuda.set_device(device)
         if getattr(args, "tuned_gemms", False) and args.arch == "videoswintransformer":
             from . import tuning
             logger.debug(f"tuned GEMM table loaded: {tuning.enable_tuned_gemms()}")

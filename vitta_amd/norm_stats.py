@@ -191,15 +191,19 @@ class _LossReg(torch.autograd.Function):
     before any of them."""
 
     @staticmethod
-    def forward(ctx, anchor, engine, value):
+    def forward(ctx, anchor, engine, value, tie=None):
         ctx.engine = engine
+        ctx.tie = None if tie is None else (tie.shape, tie.dtype, tie.device)
         return value.clone()
 
     @staticmethod
     def backward(ctx, g):
         ctx.engine.gscale.copy_(g.reshape(1))
         ctx.engine._gscale_set = True
-        return None, None, None
+        # `tie` (the model output) receives a zero gradient: its only purpose is to make this backward walk the model's
+        # graph -- the injection nodes hang off it -- when loss_reg is the WHOLE loss (no consistency term)
+        gt = None if ctx.tie is None else torch.zeros(ctx.tie[0], dtype=ctx.tie[1], device=ctx.tie[2])
+        return None, None, None, gt
 
 
 class StatAlignEngine:
@@ -297,20 +301,22 @@ class StatAlignEngine:
         self._kinds[index] = kind
         return out
 
-    def finish(self):
+    def finish(self, tie=None):
         """Batched moments -> (all-reduce) -> EMA + loss + coefficients.  Returns loss_reg."""
         self.reduce_local()
         self.exchange()
-        return self.finish_global()
+        return self.finish_global(tie)
 
     def exchange(self):
         """The moments all-reduce (data-parallel only): one SUM over the packed [cnt | s1 | s2] buffer."""
         if self.distributed:
             torch.distributed.all_reduce(self.plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
 
-    def finish_global(self):
-        """EMA update + loss + backward coefficients from the (reduced) statistics."""
-        return self._align_and_wrap(self.plan)
+    def finish_global(self, tie=None):
+        """EMA update + loss + backward coefficients from the (reduced) statistics.  `tie`: the model output of this
+        step when loss_reg alone is backpropagated (prediction consistency off): the statistics gradient is injected by
+        nodes of the MODEL's graph, which a backward from loss_reg reaches only through that output."""
+        return self._align_and_wrap(self.plan, tie)
 
     def reduce_local(self):
         """This rank's additive statistics of the step into plan.stats (no communication)."""
@@ -342,7 +348,7 @@ class StatAlignEngine:
         plan.moments(feats, self.src_mean, **({"events": self.timing_events()} if self.timing_events else {}))
         self._feats, self._kinds = {}, {}
 
-    def _align_and_wrap(self, plan):
+    def _align_and_wrap(self, plan, tie=None):
         total, layer = plan.align(self.src_mean, self.ema_mean, self.ema_var, self.src_mean, self.src_var,
                                   self.momentum, self.reg_type)
         for i, h in enumerate(self.hooks):
@@ -350,7 +356,9 @@ class StatAlignEngine:
         self._feats, self._kinds = {}, {}
         self.gscale.zero_()
         self._gscale_set = False
-        return _LossReg.apply(self._anchor, self, total[0])
+        if tie is not None and not tie.requires_grad:
+            tie = None
+        return _LossReg.apply(self._anchor, self, total[0], tie)
 
     def finish_empty(self):
         """Ragged tail of a data-parallel run: this rank has no video in the step but still joins the

@@ -17,6 +17,12 @@ CORRUPTIONS = ["gauss_shuffled", "pepper_shuffled", "salt_shuffled", "shot_shuff
                "rain_shuffled", "h265_abr_shuffled"]
 
 
+def _rank():
+    import torch
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
+
+
 def run_over_corruptions(args, corruptions=CORRUPTIONS):
     """eval() once per corruption; one line of rounded top-1 per corruption in <result_dir>/<time>_all_result."""
     list_template, dir_template = args.val_vid_list, args.result_dir
@@ -26,9 +32,9 @@ def run_over_corruptions(args, corruptions=CORRUPTIONS):
         args.val_vid_list = list_template.format(args.corruptions)
         args.result_dir = dir_template.format(args.arch, args.dataset, args.corruptions)
         epoch_result_list, _ = run_eval(args=args)
-        if f_write is None:
+        if f_write is None and _rank() == 0:  # data-parallel runs: one result file, written by rank 0
             f_write = get_writer_to_all_result(args)
-        if epoch_result_list is not None:
+        if epoch_result_list is not None and f_write is not None:
             f_write.write(" ".join(str(round(float(x), 3)) for x in epoch_result_list) + "\n")
             f_write.flush()
         results.append(epoch_result_list)

@@ -387,7 +387,7 @@ class ViTTAAdapter:
         output, loss_consis = self.forward_local(input, actual_bz)
         if self.engine is not None:
             self.engine.exchange()
-            loss_reg = self.engine.finish_global()
+            loss_reg = self.engine.finish_global(tie=None if self.if_pred_consistency else output)
         else:
             loss_reg = torch.zeros((), dtype=torch.float32, device=output.device)
             for h in self.stat_reg_hooks:
@@ -546,7 +546,7 @@ class ViTTAAdapter:
                 torch.cuda.current_stream().wait_stream(side)
         g["seg_bwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_bwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
-            loss_reg = self.engine.finish_global()
+            loss_reg = self.engine.finish_global(tie=None if self.if_pred_consistency else output)
             self.arena.before_backward()
             self.total_loss(loss_reg, loss_consis).backward()
             self.arena.after_backward()
@@ -650,7 +650,12 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
     adapter = None
     # overlapped schedule (extension, --overlap_eval): the evaluation of video i runs beside the adaptation forward
     # of video i+1 on a second stream -- same weights, same numbers, one iteration later (ViTTAAdapter.step)
-    overlap = (bool(getattr(args, "overlap_eval", True)) and device.type == "cuda"
+    # Only with frozen BatchNorm buffers: under --fix_BNS False the adaptation forward of video i+1 UPDATES running_mean /
+    # running_var while the evaluation of video i would read them on the other stream (a race, and a different protocol:
+    # the reference evaluates video i before adapt(i+1) touches the buffers).  LayerNorm models have no such buffers.
+    bn_buffers_frozen = bool(args.fix_BNS) or not any(isinstance(m, nn.modules.batchnorm._BatchNorm)
+                                                      for m in model_origin.modules())
+    overlap = (bool(getattr(args, "overlap_eval", True)) and device.type == "cuda" and bn_buffers_frozen
                and args.if_tta_standard == "tta_online" and args.n_gradient_steps == 1)
     waiting = None  # (batch_id, row, actual_bz, ev_input, ev_target): adapted, not evaluated yet
     end = time.time()
