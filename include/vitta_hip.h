@@ -343,17 +343,81 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
                         int64_t per_sample, float* d_out, void* stream);
 
 /* --------------------------------------------------------------------------
- * A8 -- pointwise convolution + eval-mode BatchNorm (+ residual) (+ ReLU) as one fp32 MFMA GEMM.
- * Replaces conv1 -> bn1 -> relu and conv3 -> bn3 -> (+identity) -> relu of a ResNet-50 bottleneck
- * (models/tanet_models/tanet.py:129 via torchvision's Bottleneck.forward; temporal_module.py:85-106).
- *   d_x [N, C, HW] (NCHW frames), d_weight [K, C] (the conv weight [K, C, 1, 1] as stored),
- *   h_bn = {gamma, beta, running_mean, running_var} device pointers [K], d_res [N, K, HW] or NULL,
- *   d_z [N, K, HW] = act(bn(conv(x)) (+ res)).  C % 16 == 0, HW % 4 == 0 (else VITTA_ERR_UNSUPPORTED).
+ * A8 -- the 2D convolutions of the TANet trunk (torchvision ResNet-50 Bottleneck under models/tanet_models/tanet.py:125-150,
+ * wrapped by TemporalBottleneck, temporal_module.py:85-106: conv1x1 -> BN -> ReLU -> TAM -> conv3x3 -> BN -> ReLU ->
+ * conv1x1 -> BN -> (+identity) -> ReLU) as ONE implicit-GEMM kernel family on v_mfma_f32_32x32x2_f32 (exact fp32).
+ *
+ * Activations are "channel-major planes": tensor[c][p], p = frame * H*W + h * W + w over ALL frames of the clip, so a
+ * pointwise convolution is one GEMM  D[p][k] = sum_c X[c][p] W[c][k]  with pixels on the MFMA row axis (every epilogue
+ * access is 4 consecutive pixels of one channel per lane = 16 bytes) and a 3x3 / strided / transposed convolution the
+ * same GEMM with a gathered A operand (tap table below).  Weights are PACKED [tap][C][K] (K contiguous):
+ *   forward 1x1 : W^T of the [K, C, 1, 1] parameter;  dgrad 1x1: the [K, C] parameter itself (roles of C and K swap);
+ *   forward 3x3 : w[k][c][dh][dw] -> [dh*3+dw][c][k];  dgrad 3x3: [tap'][k][c] = w[k][c][2-dh'][2-dw'].
+ *
+ * The M axis walks a grid of (n, i, j), i < Hg, j < Wg, per frame.  Source pixel of tap t: (i*sstride + dh[t],
+ * j*sstride + dw[t]) in the Hs x Ws planes of x (zero outside); destination pixel (i*ostride + oa, j*ostride + ob) in
+ * the Hy x Wy planes of y.  ostride 2 (one launch per parity class) is the data gradient of a stride-2 convolution.
+ *
+ * Epilogue (flags):
+ *   forward : raw = acc                                   -> y_raw (optional second output)
+ *             z = raw * s_k + t_k  (epi_bn, eval-mode BatchNorm2d: s = gamma / sqrt(var + eps), t = beta - mean * s)
+ *             VITTA_CONV_STATS: st_s1[k] += sum(z - shift_k), st_s2[k] += sum (z - shift_k)^2 over the tile's pixels
+ *                               (the hooked-layer moments of utils/norm_stats_utils.py:185-253, additive form)
+ *             o = (VITTA_CONV_EPI_APPLY ? z : raw) (+ res) ; VITTA_CONV_EPI_RELU: max(o, 0)          -> y
+ *   backward (VITTA_CONV_BWD_BN; acc = gradient w.r.t. the ACTIVATED input a = relu(bn(bwd_x)) of the forward conv):
+ *             g = acc (+ res: the gradient arriving over the identity path)
+ *             z = bwd_x * s + t ; m = relu mask (z > 0, or bwd_mask > 0 when given; 1 without VITTA_CONV_BWD_RELU)
+ *             dz = g * m + gscale * (a_k + b_k (z - mu_k))   (statistics-loss gradient, A6; inj_* NULL: none)
+ *             dgamma_k += sum dz * (bwd_x - mean_k) * rstd_k ; dbeta_k += sum dz   (atomics, may point into .grad)
+ *             y = dz * s_k ; y_raw (optional) = g * m
+ *   VITTA_CONV_PRO_BN_RELU: x is the RAW output of the previous convolution; relu(bn(x)) (pro_bn) is applied on load.
+ * All pointers are device pointers; bn arrays are {gamma, beta, running_mean, running_var}.
  * -------------------------------------------------------------------------- */
-int vitta_conv1x1_bn_act_supported(int32_t C, int32_t K, int64_t HW);
-int vitta_conv1x1_bn_act_fwd_f32(const float* d_x, const float* d_weight, const float* const* h_bn, float eps,
-                                 const float* d_res, int32_t relu, float* d_z, int64_t N, int32_t C, int32_t K, int64_t HW,
-                                 void* stream);
+#define VITTA_CONV_PRO_BN_RELU 1
+#define VITTA_CONV_EPI_APPLY 2
+#define VITTA_CONV_EPI_RELU 4
+#define VITTA_CONV_STATS 8
+#define VITTA_CONV_RES 16
+#define VITTA_CONV_RES_HALF 32 /* res is a half-resolution tensor [K][N * ceil(Hy/2) * ceil(Wy/2)] added at even (h, w) */
+#define VITTA_CONV_BWD_BN 64
+#define VITTA_CONV_BWD_RELU 128
+#define VITTA_CONV_MAX_TAPS 9
+
+typedef struct vitta_conv_desc {
+  const float* x;      /* [C][x_pixels]   x_pixels = N * Hs * Ws */
+  const float* w;      /* packed [n_wtaps][C][K] */
+  float* y;            /* [K][y_pixels]   y_pixels = N * Hy * Wy */
+  float* y_raw;        /* optional second output, same shape as y */
+  const float* res;    /* optional addend, same shape as y (or half resolution, VITTA_CONV_RES_HALF) */
+  const float* pro_bn[4];
+  const float* epi_bn[4];
+  const float* bwd_bn[4];
+  float pro_eps, epi_eps, bwd_eps;
+  const float* st_shift; /* [K] */
+  float* st_s1;          /* [K] */
+  float* st_s2;          /* [K] */
+  const float* bwd_x;    /* [K][y_pixels] raw convolution output whose BatchNorm is differentiated */
+  const float* bwd_mask; /* [K][y_pixels] or NULL */
+  const float* inj_mu;   /* [K] or NULL */
+  const float* inj_a;
+  const float* inj_b;
+  const float* inj_gscale; /* device scalar */
+  float* dgamma;         /* [K] accumulated */
+  float* dbeta;
+  int32_t C, K, N;
+  int32_t Hs, Ws, Hg, Wg, Hy, Wy;
+  int32_t sstride, ostride, oa, ob;
+  int32_t ntaps;
+  int8_t dh[VITTA_CONV_MAX_TAPS], dw[VITTA_CONV_MAX_TAPS], wt[VITTA_CONV_MAX_TAPS]; /* wt: tap slot in w */
+  int32_t flags;
+  int32_t tile; /* 0: library's choice; else (BM << 16) | BN, see vitta_conv_tiles */
+} vitta_conv_desc;
+
+/* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */
+int vitta_conv_supported(const vitta_conv_desc* h_desc);
+int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream);
+/* Workgroups the launch of this descriptor would use (for tile selection / tests). */
+int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
 
 /* --------------------------------------------------------------------------
  * A2 / A10 -- LayerNorm over the channel axis of channels-last rows [rows, C], fused with its surroundings in a Video

@@ -1,0 +1,186 @@
+"""vitta_conv_f32 (hand-written fp32-MFMA implicit GEMM, vitta_amd/csrc/conv.hip) against fp64 torch CPU convolutions:
+every geometry the TANet trunk uses (pointwise, 3x3, stride 2, their data gradients) and every epilogue.
+
+Tolerance: fp32 accumulation in k order (v_mfma_f32_32x32x2_f32 is an fmaf chain) against an fp64 reference:
+|err| <= 2e-5 * max|ref| for K up to 4608 terms per output."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, tol=TOL, what=""):
+    err = (got.detach().cpu().double() - ref).abs().max().item()
+    bound = tol * max(ref.abs().max().item(), 1e-6)
+    assert err <= bound, (what, err, bound)
+
+
+def _bn(c, g):
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3, torch.randn(c, generator=g) * 0.2,
+            torch.rand(c, generator=g) + 0.5)
+
+
+def _bn_apply(x, bn, eps=1e-5):
+    gam, bet, rm, rv = (t.double() for t in bn)
+    return F.batch_norm(x, rm, rv, gam, bet, False, 0.0, eps)
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz,stride,tile", [
+    (4, 64, 64, 56, 1, 1, 0), (2, 256, 64, 56, 1, 1, 0), (16, 64, 256, 56, 1, 1, 0), (8, 512, 128, 28, 1, 1, 0),
+    (16, 1024, 256, 14, 1, 1, 0), (16, 2048, 512, 7, 1, 1, 0), (8, 512, 2048, 7, 1, 1, 0), (8, 48, 96, 10, 1, 1, 0),
+    (4, 64, 64, 56, 3, 1, 0), (8, 128, 128, 28, 3, 1, 0), (16, 256, 256, 14, 3, 1, 0), (16, 512, 512, 7, 3, 1, 0),
+    (4, 128, 128, 56, 3, 2, 0), (8, 256, 256, 28, 3, 2, 0), (8, 512, 512, 14, 3, 2, 0), (4, 256, 512, 56, 1, 2, 0),
+    (8, 1024, 2048, 14, 1, 2, 0), (4, 64, 64, 13, 3, 1, 0), (4, 32, 32, 9, 3, 2, 0),
+    (4, 128, 128, 28, 1, 1, (128 << 16) | 128), (4, 128, 128, 28, 3, 1, (128 << 16) | 64), (4, 128, 128, 28, 3, 1, (64 << 16) | 64),
+    (4, 128, 128, 28, 1, 1, (64 << 16) | 32), (4, 128, 128, 28, 3, 1, (128 << 16) | 128)])
+def test_forward_matches_fp64_conv(n, c, k, h, ksz, stride, tile):
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n * 1000 + c + k + h + ksz)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    pad = ksz // 2
+    ref = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    d = _dev()
+    geom = CV.Geometry.forward(n, h, h, ksz, stride, pad)
+    y = torch.full((k, n * geom.hy * geom.wy), float("nan"), device=d)
+    CV.launch(geom, CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k, tile=tile)
+    _close(CV.from_cm(y, n, geom.hy, geom.wy), ref)
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz,stride", [(4, 64, 256, 28, 1, 1), (8, 1024, 256, 14, 1, 1), (4, 64, 64, 28, 3, 1),
+                                                (8, 256, 256, 14, 3, 1), (8, 512, 512, 7, 3, 1), (4, 128, 128, 28, 3, 2),
+                                                (8, 512, 512, 14, 3, 2), (4, 32, 64, 7, 3, 2), (4, 32, 64, 9, 3, 2),
+                                                (4, 256, 512, 28, 1, 2), (4, 64, 128, 7, 1, 2)])
+def test_data_gradient_matches_fp64_autograd(n, c, k, h, ksz, stride):
+    """d input of conv(k x k, stride, pad k // 2): stride 1 = one launch with the flipped tap table; stride 2 (3x3) =
+    one launch per parity class of the input pixel; strided pointwise = a half-resolution GEMM added at even
+    positions by the consumer (RES_HALF on a following launch, here an identity 1x1)."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n + c + k + h + 7 * ksz + stride)
+    x = torch.randn(n, c, h, h, generator=g).double().requires_grad_(True)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    pad = ksz // 2
+    out = F.conv2d(x, w.double(), stride=stride, padding=pad)
+    gy = torch.randn(out.shape, generator=g)
+    out.backward(gy.double())
+    d = _dev()
+    wp = CV.pack_bwd(w.to(d))
+    gy_cm = CV.to_cm(gy.to(d))
+    geoms = CV.Geometry.dgrad(n, h, h, ksz, stride, pad)
+    if stride == 2 and ksz == 1:
+        ho = geoms[0].hy
+        half = torch.full((c, n * ho * ho), float("nan"), device=d)
+        CV.launch(geoms[0], gy_cm, wp, half, k, c)
+        # consumer: an identity pointwise convolution on a zero tensor with the half-resolution addend
+        eye = torch.eye(32, device=d).reshape(1, 32, 32).contiguous()
+        zero = torch.zeros(32, n * h * h, device=d)
+        for c0 in range(0, c, 32):
+            got = torch.full((32, n * h * h), float("nan"), device=d)
+            CV.launch(CV.Geometry.forward(n, h, h), zero, eye, got, 32, 32, flags=CV.CONV_RES_HALF,
+                      res=half[c0:c0 + 32].contiguous())
+            _close(CV.from_cm(got, n, h, h), x.grad[:, c0:c0 + 32])
+        return
+    gx = torch.full((c, n * h * h), float("nan"), device=d)
+    for geom in geoms:
+        CV.launch(geom, gy_cm, wp, gx, k, c)
+    _close(CV.from_cm(gx, n, h, h), x.grad)
+
+
+@pytest.mark.parametrize("n,c,k,h,hooked", [(8, 256, 1024, 14, True), (16, 512, 2048, 7, True), (4, 64, 256, 28, False)])
+def test_bottleneck_tail_epilogue(n, c, k, h, hooked):
+    """conv3 of a bottleneck in one launch: x2 raw -> relu(bn2(.)) on load -> 1x1 -> raw x3 (second output), moments of
+    z3 = bn3(x3) (hooked layer), out = relu(z3 + identity)."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(h * c + k)
+    x2 = torch.randn(n, c, h, h, generator=g)
+    ident = torch.randn(n, k, h, h, generator=g)
+    w = torch.randn(k, c, 1, 1, generator=g) * c ** -0.5
+    bn2, bn3 = _bn(c, g), _bn(k, g)
+    shift = torch.randn(k, generator=g) * 0.1
+    a = torch.relu(_bn_apply(x2.double(), bn2))
+    x3 = F.conv2d(a, w.double())
+    z3 = _bn_apply(x3, bn3)
+    out = torch.relu(z3 + ident.double())
+    d = _dev()
+    P = n * h * h
+    y, yraw = torch.full((k, P), float("nan"), device=d), torch.full((k, P), float("nan"), device=d)
+    s1, s2 = torch.zeros(k, device=d), torch.zeros(k, device=d)
+    flags = CV.CONV_PRO_BN_RELU | CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if hooked else 0)
+    CV.launch(CV.Geometry.forward(n, h, h), CV.to_cm(x2.to(d)), CV.pack_fwd(w.to(d)), y, c, k, flags=flags, y_raw=yraw,
+              res=CV.to_cm(ident.to(d)), pro_bn=[t.to(d) for t in bn2], epi_bn=[t.to(d) for t in bn3],
+              stats=(shift.to(d), s1, s2) if hooked else None)
+    _close(CV.from_cm(yraw, n, h, h), x3, what="raw")
+    _close(CV.from_cm(y, n, h, h), out, what="out")
+    if hooked:
+        dz = z3 - shift.double().view(1, -1, 1, 1)
+        r1, r2 = dz.sum((0, 2, 3)), (dz * dz).sum((0, 2, 3))
+        assert (s1.cpu().double() - r1).abs().max().item() <= 1e-5 * dz.abs().sum((0, 2, 3)).max().item()
+        _close(s2, r2, tol=1e-5, what="s2")
+
+
+@pytest.mark.parametrize("n,c,k,h,relu,inject,mask", [(8, 1024, 256, 14, True, True, False), (8, 256, 256, 14, True, False, False),
+                                                       (4, 256, 64, 28, True, True, True), (8, 2048, 512, 7, False, True, False)])
+def test_data_gradient_with_batchnorm_backward_epilogue(n, c, k, h, relu, inject, mask):
+    """conv dgrad whose epilogue differentiates the BatchNorm (+ReLU) that FED the forward convolution:
+        a = relu(bn(xr)), y = conv1x1(a);  given gy (+ a second gradient g2 arriving at a):
+        g = W^T gy + g2 ; dz = g * [mask] + gscale (a_k + b_k (z - mu_k)) ; d gamma, d beta ; d xr = dz * s
+    against fp64 autograd of the same composition."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(c + k + h)
+    xr = torch.randn(n, k, h, h, generator=g)
+    bn = _bn(k, g)
+    # keep every pre-activation away from the ReLU kink (an fp32 / fp64 sign flip there is an O(1) gradient difference)
+    z0 = _bn_apply(xr.double(), bn)
+    xr = torch.where(z0.abs() < 1e-3, xr + 0.01, xr).double().requires_grad_(True)
+    gam, bet = bn[0].double().requires_grad_(True), bn[1].double().requires_grad_(True)
+    z = F.batch_norm(xr, bn[2].double(), bn[3].double(), gam, bet, False, 0.0, 1e-5)
+    other = torch.randn(n, k, h, h, generator=g)  # a tensor whose sign decides the mask when `mask`
+    if relu:
+        a = z * (other.double() > 0) if mask else torch.relu(z)
+    else:
+        a = z
+    w = torch.randn(c, k, 1, 1, generator=g) * k ** -0.5
+    y = F.conv2d(a, w.double())
+    gy = torch.randn(y.shape, generator=g)
+    g2 = torch.randn(a.shape, generator=g)
+    mu, ca, cb = torch.randn(k, generator=g) * 0.1, torch.randn(k, generator=g) * 1e-3, torch.randn(k, generator=g) * 1e-3
+    gscale = 0.7
+    loss = (y * gy.double()).sum() + (a * g2.double()).sum()
+    if inject:
+        v = lambda t: t.double().view(1, -1, 1, 1)
+        loss = loss + gscale * ((v(ca) - v(cb) * v(mu)) * z + 0.5 * v(cb) * z * z).sum()
+    loss.backward()
+    d = _dev()
+    P = n * h * h
+    gx = torch.full((k, P), float("nan"), device=d)
+    gm = torch.full((k, P), float("nan"), device=d)
+    dgam, dbet = torch.full((k,), 0.25, device=d), torch.full((k,), -0.5, device=d)
+    flags = CV.CONV_BWD_BN | CV.CONV_RES | (CV.CONV_BWD_RELU if relu else 0)
+    CV.launch(CV.Geometry.dgrad(n, h, h)[0], CV.to_cm(gy.to(d)), CV.pack_bwd(w.to(d)), gx, c, k, flags=flags, y_raw=gm,
+              res=CV.to_cm(g2.to(d)), bwd_bn=[t.to(d) for t in bn], bwd_x=CV.to_cm(xr.detach().float().to(d)),
+              bwd_mask=CV.to_cm(other.to(d)) if mask else None,
+              inj=(mu.to(d), ca.to(d), cb.to(d), torch.tensor([gscale], device=d)) if inject else None, dgamma=dgam, dbeta=dbet)
+    _close(CV.from_cm(gx, n, h, h), xr.grad, what="dx")
+    _close(dgam - 0.25, gam.grad, tol=1e-4, what="dgamma")
+    _close(dbet + 0.5, bet.grad, tol=1e-4, what="dbeta")
+    gref = F.conv_transpose2d(gy.double(), w.double()) + g2.double()
+    if relu:
+        gref = gref * ((other.double() > 0) if mask else (z.detach() > 0))
+    _close(CV.from_cm(gm, n, h, h), gref, what="masked gradient")
+
+
+def test_unsupported_shapes_are_refused_not_miscomputed():
+    from vitta_amd import _lib, conv as CV
+    d = _dev()
+    x = torch.zeros(24, 4 * 36, device=d)
+    with pytest.raises(_lib.VittaHipError):
+        CV.launch(CV.Geometry.forward(4, 6, 6), x, torch.zeros(1, 24, 32, device=d), torch.zeros(32, 4 * 36, device=d), 24, 32)
+    with pytest.raises(_lib.VittaHipError):
+        CV.launch(CV.Geometry.forward(4, 6, 6), x.cpu(), torch.zeros(1, 24, 32), torch.zeros(32, 4 * 36), 24, 32)

@@ -620,32 +620,6 @@ def test_residual_drop_path_one_pass_equals_torch_ops():
     assert set(m2.unique().tolist()) <= {0.0, 2.0}
 
 
-@pytest.mark.parametrize("cin,cout,hw,nfr,res,relu", [(64, 64, 56, 4, False, True), (256, 64, 56, 2, False, True),
-                                                      (64, 256, 56, 2, True, True), (128, 512, 28, 3, True, True),
-                                                      (512, 128, 28, 2, False, False), (1024, 256, 14, 5, False, True),
-                                                      (32, 40, 6, 2, True, False)])
-def test_conv1x1_bn_act_mfma_gemm_matches_conv_plus_bn(cin, cout, hw, nfr, res, relu):
-    """vitta_conv1x1_bn_act_fwd_f32 (pointwise conv + eval BN (+ residual) (+ ReLU) as one fp32 MFMA GEMM) ==
-    F.conv2d followed by batch_norm / add / relu, incl. ragged pixel tiles (HW = 3136, 784, 196, 36) and K % 32 != 0."""
-    import torch.nn.functional as F
-    from vitta_amd import ops
-    g = torch.Generator().manual_seed(cin + cout)
-    x = torch.randn(nfr, cin, hw, hw, generator=g)
-    w = torch.randn(cout, cin, 1, 1, generator=g) * (cin ** -0.5)
-    gam, bet = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
-    rm, rv = torch.randn(cout, generator=g), torch.rand(cout, generator=g) + 0.3
-    r = torch.randn(nfr, cout, hw, hw, generator=g) if res else None
-    ref = F.batch_norm(F.conv2d(x.double(), w.double()), rm.double(), rv.double(), gam.double(), bet.double(), False, 0.0, 1e-5)
-    if res:
-        ref = ref + r.double()
-    if relu:
-        ref = torch.relu(ref)
-    d = _dev()
-    assert ops.conv1x1_bn_act_supported(x.to(d), w.to(d))
-    got = ops.conv1x1_bn_act_forward(x.to(d), w.to(d), gam.to(d), bet.to(d), rm.to(d), rv.to(d), 1e-5,
-                                     r.to(d) if res else None, relu)
-    assert (got.cpu().double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
-
 
 @pytest.mark.parametrize("c", [128, 256, 512, 1024, 2048])
 @pytest.mark.parametrize("with_branch", [False, True])

@@ -1,0 +1,108 @@
+"""Per-layer timing of the hand-written convolutions on the TANet-R50 shapes (adapt pass: 16 frames of 224^2), forward
+and data gradient, beside the vendor library's forward on the same shape (reference point, not product).
+
+    python tools/bench_conv.py [--frames 16] [--out gpurun_out/conv_bench.json]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vitta_amd import conv as CV  # noqa: E402
+
+PEAK = 157.3  # TFLOP/s fp32 matrix (MI355X_MICROARCH.md)
+
+
+def trunk_convs():
+    """(name, C, K, H_in, k, stride, count) of the bottleneck convolutions of ResNet-50 at 224^2 (after the stem: 56^2)."""
+    out = []
+    h, inpl = 56, 64
+    for li, (planes, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)], 1):
+        for b in range(blocks):
+            s = stride if b == 0 else 1
+            out.append((f"layer{li}.{b}.conv1", inpl, planes, h, 1, 1))
+            out.append((f"layer{li}.{b}.conv2", planes, planes, h, 3, s))
+            ho = CV.out_size(h, 3, s, 1)
+            out.append((f"layer{li}.{b}.conv3", planes, planes * 4, ho, 1, 1))
+            if b == 0:
+                out.append((f"layer{li}.{b}.downsample", inpl, planes * 4, h, 1, s))
+            h, inpl = ho, planes * 4
+    return out
+
+
+def time_it(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--out", default="gpurun_out/conv_bench.json")
+    ap.add_argument("--tiles", default="", help="comma list of BMxBN to sweep instead of the library's choice")
+    ap.add_argument("--no-vendor", action="store_true")
+    opt = ap.parse_args()
+    d = torch.device("cuda:0")
+    n = opt.frames
+    rows, seen = [], {}
+    tiles = [0] + [(int(t.split("x")[0]) << 16) | int(t.split("x")[1]) for t in opt.tiles.split(",") if t]
+    for name, c, k, h, ksz, s in trunk_convs():
+        key = (c, k, h, ksz, s)
+        if key in seen:
+            seen[key]["count"] += 1
+            continue
+        pad = ksz // 2
+        gf = CV.Geometry.forward(n, h, h, ksz, s, pad)
+        ho = gf.hy
+        x = torch.randn(c, n * h * h, device=d)
+        w = torch.randn(k, c, ksz, ksz, device=d) * (c * ksz * ksz) ** -0.5
+        wf, wb = CV.pack_fwd(w), CV.pack_bwd(w)
+        y = torch.empty(k, n * ho * ho, device=d)
+        gx = torch.empty(c, n * h * h, device=d)
+        flops = 2.0 * n * ho * ho * c * k * ksz * ksz
+        row = dict(name=name, C=c, K=k, H=h, k=ksz, stride=s, count=1, gflop=flops / 1e9)
+        for tile in tiles:
+            tag = "" if tile == 0 else f"_{tile >> 16}x{tile & 0xffff}"
+            if tile and k % (tile & 0xffff):
+                continue
+            t_f = time_it(lambda: CV.launch(gf, x, wf, y, c, k, tile=tile), opt.reps)
+            geoms = CV.Geometry.dgrad(n, h, h, ksz, s, pad)
+            gdst = torch.empty(c, n * ho * ho, device=d) if (s == 2 and ksz == 1) else gx
+
+            def dgrad():
+                for g in geoms:
+                    CV.launch(g, y, wb, gdst, k, c, tile=tile)
+            t_b = time_it(dgrad, opt.reps)
+            row[f"fwd_us{tag}"], row[f"fwd_tf{tag}"] = t_f, flops / t_f / 1e6
+            row[f"dgrad_us{tag}"], row[f"dgrad_tf{tag}"] = t_b, flops / t_b / 1e6
+        if not opt.no_vendor:
+            xn = torch.randn(n, c, h, h, device=d)
+            t_v = time_it(lambda: F.conv2d(xn, w, stride=s, padding=pad), opt.reps)
+            row["vendor_fwd_us"], row["vendor_fwd_tf"] = t_v, flops / t_v / 1e6
+        seen[key] = row
+        rows.append(row)
+        print({kk: (round(v, 1) if isinstance(v, float) else v) for kk, v in row.items()}, flush=True)
+    tot = lambda f: sum(r[f] * r["count"] for r in rows if f in r)
+    summary = dict(frames=n, fwd_ms=tot("fwd_us") / 1e3, dgrad_ms=tot("dgrad_us") / 1e3, vendor_fwd_ms=tot("vendor_fwd_us") / 1e3,
+                   gflop=tot("gflop"), fwd_tf=tot("gflop") / tot("fwd_us") * 1e3, dgrad_tf=tot("gflop") / tot("dgrad_us") * 1e3,
+                   peak_tf=PEAK)
+    print(summary)
+    os.makedirs(os.path.dirname(opt.out) or ".", exist_ok=True)
+    json.dump(dict(summary=summary, rows=rows), open(opt.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

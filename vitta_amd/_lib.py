@@ -19,6 +19,28 @@ class LayerShape(C.Structure):
     _fields_ = [("outer", C.c_int64), ("C", C.c_int32), ("inner", C.c_int64), ("layout", C.c_int32)]
 
 
+CONV_MAX_TAPS = 9
+CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
+CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU = 16, 32, 64, 128
+
+
+class ConvDesc(C.Structure):
+    """vitta_conv_desc of include/vitta_hip.h (field for field)."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("y", C.c_void_p), ("y_raw", C.c_void_p), ("res", C.c_void_p),
+                ("pro_bn", C.c_void_p * 4), ("epi_bn", C.c_void_p * 4), ("bwd_bn", C.c_void_p * 4),
+                ("pro_eps", C.c_float), ("epi_eps", C.c_float), ("bwd_eps", C.c_float),
+                ("st_shift", C.c_void_p), ("st_s1", C.c_void_p), ("st_s2", C.c_void_p),
+                ("bwd_x", C.c_void_p), ("bwd_mask", C.c_void_p),
+                ("inj_mu", C.c_void_p), ("inj_a", C.c_void_p), ("inj_b", C.c_void_p), ("inj_gscale", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("C", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hg", C.c_int32), ("Wg", C.c_int32), ("Hy", C.c_int32), ("Wy", C.c_int32),
+                ("sstride", C.c_int32), ("ostride", C.c_int32), ("oa", C.c_int32), ("ob", C.c_int32),
+                ("ntaps", C.c_int32),
+                ("dh", C.c_int8 * CONV_MAX_TAPS), ("dw", C.c_int8 * CONV_MAX_TAPS), ("wt", C.c_int8 * CONV_MAX_TAPS),
+                ("flags", C.c_int32), ("tile", C.c_int32)]
+
+
 _p = C.c_void_p
 _i32 = C.c_int32
 _i64 = C.c_int64
@@ -80,8 +102,9 @@ SIGNATURES = {
     "vitta_event_create": (C.c_int, [C.POINTER(_p)]),
     "vitta_event_destroy": (None, [_p]),
     "vitta_event_elapsed_ms": (C.c_int, [_p, _p, C.POINTER(_f32)]),
-    "vitta_conv1x1_bn_act_supported": (C.c_int, [_i32, _i32, _i64]),
-    "vitta_conv1x1_bn_act_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _i32, _p, _i64, _i32, _i32, _i64, _p]),
+    "vitta_conv_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "vitta_conv_num_blocks": (_i64, [C.POINTER(ConvDesc)]),
+    "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_ln_supported": (C.c_int, [_i32]),
     "vitta_ln_num_partials": (_i64, [_i64]),
     "vitta_ln_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _p]),

@@ -1,0 +1,133 @@
+"""Host side of the hand-written convolutions (vitta_amd/csrc/conv.hip, C ABI `vitta_conv_f32`).
+
+Reference call sites: models/tanet_models/temporal_module.py:85-106 (TemporalBottleneck) over torchvision's ResNet-50
+Bottleneck (tanet.py:125-150).  Everything here is geometry and pointer plumbing; the arithmetic is the library's.
+
+Tensors are "channel-major planes" (CM): a [C, N*H*W] fp32 matrix, pixel index p = n*H*W + h*W + w.  `to_cm` /
+`from_cm` convert from / to the reference's [N, C, H, W].
+
+Packed weights (made once per weight version, `pack_fwd` / `pack_bwd`):
+    forward : [kh*kw][C][K]   (w.permute(2, 3, 1, 0))
+    backward: [kh*kw][K][C]   (w.permute(2, 3, 0, 1)); the tap table supplies the flip of the transposed convolution.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (CONV_BWD_BN, CONV_BWD_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_PRO_BN_RELU, CONV_RES, CONV_RES_HALF,
+                   CONV_STATS, ConvDesc, check, lib)
+
+
+def to_cm(x):
+    """[N, C, H, W] -> channel-major planes [C, N*H*W] (a copy)."""
+    n, c, h, w = x.shape
+    return x.permute(1, 0, 2, 3).reshape(c, n * h * w).contiguous()
+
+
+def from_cm(x, n, h, w):
+    """[C, N*H*W] -> [N, C, H, W] (a copy)."""
+    return x.view(x.shape[0], n, h, w).permute(1, 0, 2, 3).contiguous()
+
+
+def pack_fwd(w):
+    k, c, kh, kw = w.shape
+    return w.detach().permute(2, 3, 1, 0).reshape(kh * kw, c, k).contiguous()
+
+
+def pack_bwd(w):
+    k, c, kh, kw = w.shape
+    return w.detach().permute(2, 3, 0, 1).reshape(kh * kw, k, c).contiguous()
+
+
+def out_size(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _bn4(arr, bn):
+    """bn: (gamma, beta, running_mean, running_var) tensors or None."""
+    for i in range(4):
+        arr[i] = bn[i].data_ptr() if bn is not None else None
+
+
+class Geometry:
+    """Tap table + grids of one launch (see the header comment of vitta_conv_desc)."""
+
+    def __init__(self, n, hs, ws, hg, wg, hy, wy, taps, sstride=1, ostride=1, oa=0, ob=0):
+        self.n, self.hs, self.ws, self.hg, self.wg, self.hy, self.wy = n, hs, ws, hg, wg, hy, wy
+        self.taps, self.sstride, self.ostride, self.oa, self.ob = taps, sstride, ostride, oa, ob
+
+    @staticmethod
+    def forward(n, h, w, k=1, stride=1, pad=0):
+        ho, wo = out_size(h, k, stride, pad), out_size(w, k, stride, pad)
+        taps = [(dh - pad, dw - pad, dh * k + dw) for dh in range(k) for dw in range(k)]
+        return Geometry(n, h, w, ho, wo, ho, wo, taps, sstride=stride)
+
+    @staticmethod
+    def dgrad(n, h, w, k=1, stride=1, pad=0):
+        """Launches producing d input [C, N*h*w] from d output [K, N*ho*wo] of conv(k, stride, pad) on h x w planes:
+        one launch for stride 1, one per parity class of the input pixel for stride 2 (k = 3) -- or a single launch on
+        the half-resolution grid for a strided pointwise convolution (its result is added at even positions by the
+        consumer, VITTA_CONV_RES_HALF)."""
+        ho, wo = out_size(h, k, stride, pad), out_size(w, k, stride, pad)
+        if stride == 1:
+            # d in[i] = sum_e d out[i + e - pad'] w[k-1-e], pad' = k - 1 - pad
+            taps = [(eh - (k - 1 - pad), ew - (k - 1 - pad), (k - 1 - eh) * k + (k - 1 - ew)) for eh in range(k)
+                    for ew in range(k)]
+            return [Geometry(n, ho, wo, h, w, h, w, taps)]
+        if stride != 2:
+            raise ValueError("stride 1 or 2")
+        if k == 1:
+            return [Geometry(n, ho, wo, ho, wo, ho, wo, [(0, 0, 0)])]
+        out = []
+        for a in range(2):
+            for b in range(2):
+                taps = []
+                for dh in range(k):
+                    if (a + pad - dh) % 2:
+                        continue
+                    for dw in range(k):
+                        if (b + pad - dw) % 2:
+                            continue
+                        taps.append(((a + pad - dh) // 2, (b + pad - dw) // 2, dh * k + dw))
+                out.append(Geometry(n, ho, wo, (h + 1) // 2, (w + 1) // 2, h, w, taps, ostride=2, oa=a, ob=b))
+        return out
+
+    def fill(self, d):
+        d.N, d.Hs, d.Ws, d.Hg, d.Wg, d.Hy, d.Wy = self.n, self.hs, self.ws, self.hg, self.wg, self.hy, self.wy
+        d.sstride, d.ostride, d.oa, d.ob, d.ntaps = self.sstride, self.ostride, self.oa, self.ob, len(self.taps)
+        for i, (dh, dw, wt) in enumerate(self.taps):
+            d.dh[i], d.dw[i], d.wt[i] = dh, dw, wt
+
+
+def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,
+           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0):
+    """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K], y [K, *].
+    stats = (shift, s1, s2); inj = (mu, a, b, gscale)."""
+    for t in (x, wp, y):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+    d = ConvDesc()
+    d.x, d.w, d.y, d.y_raw, d.res = x.data_ptr(), wp.data_ptr(), y.data_ptr(), _ptr(y_raw), _ptr(res)
+    _bn4(d.pro_bn, pro_bn)
+    _bn4(d.epi_bn, epi_bn)
+    _bn4(d.bwd_bn, bwd_bn)
+    d.pro_eps = d.epi_eps = d.bwd_eps = float(eps)
+    if stats is not None:
+        d.st_shift, d.st_s1, d.st_s2 = (t.data_ptr() for t in stats)
+    d.bwd_x, d.bwd_mask = _ptr(bwd_x), _ptr(bwd_mask)
+    if inj is not None:
+        d.inj_mu, d.inj_a, d.inj_b, d.inj_gscale = (_ptr(t) for t in inj)
+    d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
+    d.C, d.K, d.flags, d.tile = int(c), int(k), int(flags), int(tile)
+    geom.fill(d)
+    check(lib().vitta_conv_f32(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_f32")
+    return y
+
+
+__all__ = ["Geometry", "launch", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
+           "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

@@ -667,27 +667,6 @@ class ResidualDropPath(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-# pointwise convolution + eval BatchNorm (+ residual) (+ ReLU): one MFMA GEMM
-# ------------------------------------------------------------------------------------------------
-def conv1x1_bn_act_supported(x, weight):
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4 and weight.shape[2:] == (1, 1)
-            and bool(lib().vitta_conv1x1_bn_act_supported(x.shape[1], weight.shape[0], x.shape[2] * x.shape[3])))
-
-
-def conv1x1_bn_act_forward(x, weight, bn_w, bn_b, bn_rm, bn_rv, eps, residual, relu):
-    """z = act(bn_eval(conv1x1(x)) (+ residual)); no autograd (see Conv1x1BNAct)."""
-    x = x.contiguous()
-    n, c, h, w = x.shape
-    k = weight.shape[0]
-    z = torch.empty(n, k, h, w, dtype=torch.float32, device=x.device)
-    res = residual.contiguous() if residual is not None else None
-    check(lib().vitta_conv1x1_bn_act_fwd_f32(_p(x), _p(weight), _ptr4(bn_w, bn_b, bn_rm, bn_rv), float(eps), _p(res),
-                                             int(bool(relu)), _p(z), n, c, k, h * w, _stream()),
-          "vitta_conv1x1_bn_act_fwd_f32")
-    return z
-
-
-# ------------------------------------------------------------------------------------------------
 # LayerNorm (+ residual / stochastic depth) (+ ViTTA statistics), channels-last rows
 # ------------------------------------------------------------------------------------------------
 def ln_supported(c):
