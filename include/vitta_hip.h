@@ -410,12 +410,22 @@ typedef struct vitta_conv_desc {
   int32_t ntaps;
   int8_t dh[VITTA_CONV_MAX_TAPS], dw[VITTA_CONV_MAX_TAPS], wt[VITTA_CONV_MAX_TAPS]; /* wt: tap slot in w */
   int32_t flags;
-  int32_t tile; /* 0: library's choice; else (BM << 16) | BN, see vitta_conv_tiles */
+  int32_t tile; /* 0: library's choice; else (BM << 16) | BN */
+  /* Split-K: with few output tiles (the 14x14 / 7x7 stages) several workgroups share a tile, each walking a slice of K;
+   * partial tiles meet in the last-arriving workgroup through `workspace` (arrival counters + slabs).  The workspace
+   * is caller-owned, must be ZERO when first used (its first 64 KiB hold the counters, which return to zero after every
+   * launch; slabs follow), >= 256-byte aligned,
+   * and must not be shared by launches that may run concurrently (one per stream).  NULL / too small: no split. */
+  int32_t ksplit; /* 0: library's choice; 1: never split; n: exactly n slices (VITTA_ERR_WORKSPACE if it does not fit) */
+  void* workspace;
+  int64_t workspace_bytes;
 } vitta_conv_desc;
 
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */
 int vitta_conv_supported(const vitta_conv_desc* h_desc);
 int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream);
+/* Workspace the library's split choice (or h_desc->ksplit) needs for this descriptor; 0 = none. */
+size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
 /* Workgroups the launch of this descriptor would use (for tile selection / tests). */
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
 

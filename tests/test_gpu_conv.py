@@ -54,6 +54,37 @@ def test_forward_matches_fp64_conv(n, c, k, h, ksz, stride, tile):
     _close(CV.from_cm(y, n, geom.hy, geom.wy), ref)
 
 
+@pytest.mark.parametrize("n,c,k,h,ksz,ksplit", [(16, 2048, 512, 7, 1, 0), (16, 512, 512, 7, 3, 0), (8, 1024, 256, 14, 1, 4),
+                                                (8, 256, 256, 14, 3, 7), (4, 512, 128, 14, 1, 16), (16, 256, 256, 14, 3, 2)])
+def test_split_k_matches_fp64_conv_and_leaves_the_workspace_clean(n, c, k, h, ksz, ksplit):
+    """Few output tiles (the 14x14 / 7x7 stages): several workgroups share a tile, each walking a slice of K; the last
+    arriver sums the slabs and runs the epilogue (here with BN + ReLU + moments, which must see the FULL sum exactly
+    once).  Three launches back to back on the same workspace: the arrival counters must return to zero."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(c + k + h + ksplit)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    bn = _bn(k, g)
+    shift = torch.randn(k, generator=g) * 0.1
+    pad = ksz // 2
+    z = _bn_apply(F.conv2d(x.double(), w.double(), padding=pad), bn)
+    ref = torch.relu(z)
+    d = _dev()
+    geom = CV.Geometry.forward(n, h, h, ksz, 1, pad)
+    xc, wp = CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d))
+    for rep in range(3):
+        y = torch.full((k, n * h * h), float("nan"), device=d)
+        s1, s2 = torch.zeros(k, device=d), torch.zeros(k, device=d)
+        CV.launch(geom, xc, wp, y, c, k, flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_STATS, epi_bn=[t.to(d) for t in bn],
+                  stats=(shift.to(d), s1, s2), ksplit=ksplit)
+        _close(CV.from_cm(y, n, h, h), ref, what=f"launch {rep}")
+        dz = z - shift.double().view(1, -1, 1, 1)
+        assert (s1.cpu().double() - dz.sum((0, 2, 3))).abs().max().item() <= 1e-5 * dz.abs().sum((0, 2, 3)).max().item()
+        _close(s2, (dz * dz).sum((0, 2, 3)), tol=1e-5, what="s2")
+    ws = CV.workspace(d)
+    assert int(ws[:65536].view(torch.int32).abs().sum().item()) == 0  # the counter prefix (slabs follow)
+
+
 @pytest.mark.parametrize("n,c,k,h,ksz,stride", [(4, 64, 256, 28, 1, 1), (8, 1024, 256, 14, 1, 1), (4, 64, 64, 28, 3, 1),
                                                 (8, 256, 256, 14, 3, 1), (8, 512, 512, 7, 3, 1), (4, 128, 128, 28, 3, 2),
                                                 (8, 512, 512, 14, 3, 2), (4, 32, 64, 7, 3, 2), (4, 32, 64, 9, 3, 2),

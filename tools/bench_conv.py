@@ -76,7 +76,7 @@ def main():
         row = dict(name=name, C=c, K=k, H=h, k=ksz, stride=s, count=1, gflop=flops / 1e9)
         for tile in tiles:
             tag = "" if tile == 0 else f"_{tile >> 16}x{tile & 0xffff}"
-            if tile and k % (tile & 0xffff):
+            if tile and (k % (tile & 0xffff) or c % (tile & 0xffff)):
                 continue
             t_f = time_it(lambda: CV.launch(gf, x, wf, y, c, k, tile=tile), opt.reps)
             geoms = CV.Geometry.dgrad(n, h, h, ksz, s, pad)

@@ -38,7 +38,8 @@ class ConvDesc(C.Structure):
                 ("sstride", C.c_int32), ("ostride", C.c_int32), ("oa", C.c_int32), ("ob", C.c_int32),
                 ("ntaps", C.c_int32),
                 ("dh", C.c_int8 * CONV_MAX_TAPS), ("dw", C.c_int8 * CONV_MAX_TAPS), ("wt", C.c_int8 * CONV_MAX_TAPS),
-                ("flags", C.c_int32), ("tile", C.c_int32)]
+                ("flags", C.c_int32), ("tile", C.c_int32),
+                ("ksplit", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _p = C.c_void_p
@@ -105,6 +106,7 @@ SIGNATURES = {
     "vitta_conv_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "vitta_conv_num_blocks": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
+    "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "vitta_ln_supported": (C.c_int, [_i32]),
     "vitta_ln_num_partials": (_i64, [_i64]),
     "vitta_ln_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _p]),

@@ -104,8 +104,22 @@ class Geometry:
             d.dh[i], d.dw[i], d.wt[i] = dh, dw, wt
 
 
+WORKSPACE_BYTES = 48 << 20
+_workspaces = {}
+
+
+def workspace(device):
+    """The split-K workspace of the CURRENT stream (zero-filled once; the kernels leave their counters at zero).  One
+    per stream: launches on different streams may overlap and must not share slabs."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = _workspaces[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,
-           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0):
+           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0):
     """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K], y [K, *].
     stats = (shift, s1, s2); inj = (mu, a, b, gscale)."""
     for t in (x, wp, y):
@@ -123,8 +137,11 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if inj is not None:
         d.inj_mu, d.inj_a, d.inj_b, d.inj_gscale = (_ptr(t) for t in inj)
     d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
-    d.C, d.K, d.flags, d.tile = int(c), int(k), int(flags), int(tile)
+    d.C, d.K, d.flags, d.tile, d.ksplit = int(c), int(k), int(flags), int(tile), int(ksplit)
     geom.fill(d)
+    if ksplit != 1:
+        ws = workspace(x.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     check(lib().vitta_conv_f32(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_f32")
     return y
 

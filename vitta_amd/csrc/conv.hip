@@ -22,6 +22,7 @@ using namespace vitta;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRO_MAX = 2048;  // input channels whose prologue BatchNorm constants are held in LDS
 
@@ -31,6 +32,11 @@ struct ConvK {
   int Mtot;            // N * Hg * Wg
   int nMt, nNt;        // tiles
   int contig;          // 1: output pixel index == M index (float4 epilogue)
+  int tap[VITTA_CONV_MAX_TAPS];  // (dh & 0xff) | (dw & 0xff) << 8 | weight slot << 16
+  int ksplit;          // workgroups sharing one output tile (each walks 1 / ksplit of the K slabs)
+  unsigned* cnt;       // [nMt * nNt] arrival counters (zero at rest)
+  float* slabs;        // [nMt * nNt][ksplit][BM * BN] partial accumulators
+  size_t ws_need;      // host only
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -39,7 +45,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GATHER>
+template <int BM, int BN, int BK, int WM, int WN, bool GATHER, bool PRO>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) {
   constexpr int NTH = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN, MT = TM / 32, NT = TN / 32;
@@ -51,19 +57,20 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
   static_assert((BK * BM / 4) % NTH == 0 && (BK * BN / 4) % NTH == 0, "slab must split evenly over the threads");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* As = lds;                   // [2][BK][BM]
-  float* Bs = lds + 2 * BK * BM;     // [2][BK][BN]
-  float* cst = Bs + 2 * BK * BN;     // per-output-channel epilogue constants [9][BN]
+  float* As = lds;                   // [3][BK][BM]  ring of slabs
+  float* Bs = lds + 3 * BK * BM;     // [3][BK][BN]
+  float* cst = Bs + 3 * BK * BN;     // per-output-channel epilogue constants [9][BN]
   float* pro = cst + 9 * BN;         // prologue BN scale / shift [2][C] (only with PRO_BN_RELU)
 
   const vitta_conv_desc& d = a.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lk = lane >> 5;
-  const int L = xcd_remap(blockIdx.x, a.nMt * a.nNt);
+  // logical id -> (tile, K slice): the slices of a tile and the N-tiles of an M-tile are neighbours, i.e. on one XCD
+  const int Lz = xcd_remap(blockIdx.x, a.nMt * a.nNt * a.ksplit);
+  const int L = Lz / a.ksplit, kz = Lz - L * a.ksplit;
   const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
   const int flags = d.flags;
-  const bool PRO = flags & VITTA_CONV_PRO_BN_RELU;
   const int C = d.C, K = d.K;
 
   // ---- per-channel constants ------------------------------------------------------------------------------
@@ -107,6 +114,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
   }
 
   // ---- staging geometry -----------------------------------------------------------------------------------
+  // Every thread keeps the same pixel(s) and the same weight columns for the whole K walk; what changes per slab is the
+  // channel row base (c0) and the tap.  Invalid elements (tile tail, padding taps) are loaded from a clamped address and
+  // zeroed by a select: no branch around a load, all loads of a slab are in flight together.
   const int HWs = d.Hs * d.Ws;
   int g_n = 0, g_i = 0, g_j = 0;
   bool g_valid = false;
@@ -120,76 +130,120 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
     g_i = r / d.Wg;
     g_j = r - g_i * d.Wg;
   }
-
-  float4 ra4[GATHER ? 1 : A4];
-  float ra1[GATHER ? A1 : 1];
-  float4 rb[B4];
-  bool ra_valid = false;
-
-  auto load_slab = [&](int q) {
-    const int cc = q / d.ntaps, t = q - cc * d.ntaps;
-    const int c0 = cc * BK;
-    if (GATHER) {
-      const int sh = g_i * d.sstride + d.dh[t], sw = g_j * d.sstride + d.dw[t];
-      ra_valid = g_valid && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws;
-      const int64_t off = (int64_t)g_n * HWs + sh * d.Ws + sw;
-      const float* src = d.x + (int64_t)(c0 + tid / BM) * a.xP + off;
+  // per-thread element offsets (32-bit, in floats) from the uniform slab base: constant for the whole K walk
+  unsigned a_off[GATHER ? 1 : A4];
+  if (!GATHER) {
 #pragma unroll
-      for (int u = 0; u < A1; ++u) ra1[u] = ra_valid ? src[(int64_t)u * RSTEP * a.xP] : 0.f;
-    } else {
-#pragma unroll
-      for (int u = 0; u < A4; ++u) {
-        const int idx = tid + u * NTH;
-        const int kk = idx / (BM / 4), i4 = (idx % (BM / 4)) * 4;
-        const int m = m0 + i4;
-        ra4[u] = (m < a.Mtot) ? *reinterpret_cast<const float4*>(d.x + (int64_t)(c0 + kk) * a.xP + m)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    const float* wsrc = d.w + ((int64_t)d.wt[t] * C + c0) * K + k0;
-#pragma unroll
-    for (int u = 0; u < B4; ++u) {
+    for (int u = 0; u < A4; ++u) {
       const int idx = tid + u * NTH;
-      const int kk = idx / (BN / 4), j4 = (idx % (BN / 4)) * 4;
-      rb[u] = *reinterpret_cast<const float4*>(wsrc + (int64_t)kk * K + j4);
+      const int kk = idx / (BM / 4), i4 = (idx % (BM / 4)) * 4;
+      const int m = min(m0 + i4, a.Mtot - 4);
+      a_off[u] = (unsigned)(kk * a.xP + m);
     }
-  };
-  auto store_slab = [&](int q, int buf) {
-    const int cc = q / d.ntaps;
-    const int c0 = cc * BK;
-    float* as = As + buf * BK * BM;
-    float* bs = Bs + buf * BK * BN;
-    if (GATHER) {
+  }
+  unsigned b_off[B4];
 #pragma unroll
-      for (int u = 0; u < A1; ++u) {
-        const int kk = tid / BM + u * RSTEP;
-        float v = ra1[u];
-        if (PRO) v = ra_valid ? fmaxf(fmaf(v, pro[c0 + kk], pro[C + c0 + kk]), 0.f) : 0.f;
-        as[kk * BM + (tid % BM)] = v;
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < A4; ++u) {
-        const int idx = tid + u * NTH;
-        const int kk = idx / (BM / 4), i4 = (idx % (BM / 4)) * 4;
-        float4 v = ra4[u];
-        if (PRO) {
-          const float s = pro[c0 + kk], t = pro[C + c0 + kk];
-          v.x = fmaxf(fmaf(v.x, s, t), 0.f);
-          v.y = fmaxf(fmaf(v.y, s, t), 0.f);
-          v.z = fmaxf(fmaf(v.z, s, t), 0.f);
-          v.w = fmaxf(fmaf(v.w, s, t), 0.f);
-        }
-        *reinterpret_cast<float4*>(as + kk * BM + i4) = v;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < B4; ++u) {
-      const int idx = tid + u * NTH;
-      const int kk = idx / (BN / 4), j4 = (idx % (BN / 4)) * 4;
-      *reinterpret_cast<float4*>(bs + kk * BN + j4) = rb[u];
-    }
-  };
+  for (int u = 0; u < B4; ++u) {
+    const int idx = tid + u * NTH;
+    b_off[u] = (unsigned)((idx / (BN / 4)) * K + (idx % (BN / 4)) * 4);
+  }
+
+  // two staging register sets: both are in flight in the prologue (slabs 0 and 1), the steady state uses set 0
+  constexpr int NA = GATHER ? A1 : A4;  // A-side staging items (one load / one LDS store each)
+  constexpr int NI = NA + B4;           // staging items per slab
+  f32x4 ra4[2][GATHER ? 1 : A4];
+  float ra1[2][GATHER ? A1 : 1];
+  f32x4 rb[2][B4];
+  bool ra_valid[2] = {false, false};
+  float ps[2][PRO ? NA : 1], pt[2][PRO ? NA : 1];  // prologue BN scale / shift of the rows held in each staging set
+  int st_c0[2] = {0, 0};    // first channel of the slab held in each staging set
+  const int nslab_all = (C / BK) * d.ntaps;
+  const int q_first = (int)(((int64_t)nslab_all * kz) / a.ksplit), q_end = (int)(((int64_t)nslab_all * (kz + 1)) / a.ksplit);
+  int ld_t = q_first % d.ntaps, ld_c0 = (q_first / d.ntaps) * BK;  // tap / first channel of the next slab to load (uniform)
+  const float* ld_x = d.x;  // slab bases of the loads in flight
+  const float* ld_w = d.w;
+
+  // slab setup (uniform address arithmetic + the tap's validity), then one staging item per call
+#define LOAD_BEGIN(S_)                                                                                           \
+  do {                                                                                                           \
+    const int tp = a.tap[ld_t];                                                                                  \
+    if (GATHER) {                                                                                                \
+      const int sh = g_i * d.sstride + (int)(int8_t)(tp & 0xff), sw = g_j * d.sstride + (int)(int8_t)((tp >> 8) & 0xff); \
+      ra_valid[S_] = g_valid && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws;                   \
+      const int64_t off = ra_valid[S_] ? ((int64_t)g_n * HWs + sh * d.Ws + sw) : 0;                               \
+      ld_x = d.x + (int64_t)(ld_c0 + tid / BM) * a.xP + off;                                                      \
+    } else {                                                                                                     \
+      ld_x = d.x + (int64_t)ld_c0 * a.xP;                                                                        \
+    }                                                                                                            \
+    ld_w = d.w + ((int64_t)(tp >> 16) * C + ld_c0) * K + k0;                                                     \
+    st_c0[S_] = ld_c0;                                                                                           \
+    if (++ld_t == d.ntaps) {                                                                                     \
+      ld_t = 0;                                                                                                  \
+      ld_c0 += BK;                                                                                               \
+    }                                                                                                            \
+  } while (0)
+
+#define LOAD_ITEM(S_, u)                                                                                         \
+  do {                                                                                                           \
+    if ((u) < NA) {                                                                                              \
+      const int ua = (u) < NA ? (u) : 0;                                                                         \
+      if (GATHER) ra1[S_][ua] = ld_x[(int64_t)ua * RSTEP * a.xP];                                                \
+      else ra4[S_][ua] = *reinterpret_cast<const f32x4*>(ld_x + a_off[ua]);                                      \
+      if (PRO) {                                                                                                 \
+        const int kk = GATHER ? (tid / BM + ua * RSTEP) : ((tid + ua * NTH) / (BM / 4));                         \
+        ps[S_][PRO ? ua : 0] = pro[st_c0[S_] + kk];                                                              \
+        pt[S_][PRO ? ua : 0] = pro[C + st_c0[S_] + kk];                                                          \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      rb[S_][(u) >= NA ? (u) - NA : 0] = *reinterpret_cast<const f32x4*>(ld_w + b_off[(u) >= NA ? (u) - NA : 0]); \
+    }                                                                                                            \
+  } while (0)
+
+#define STORE_ITEM(S_, buf, u)                                                                                   \
+  do {                                                                                                           \
+    float* as_ = As + (buf) * BK * BM;                                                                           \
+    float* bs_ = Bs + (buf) * BK * BN;                                                                           \
+    if ((u) < NA) {                                                                                              \
+      constexpr int ua = (u) < NA ? (u) : 0;                                                                     \
+      if (GATHER) {                                                                                              \
+        const int kk = tid / BM + ua * RSTEP;                                                                    \
+        float v = ra1[S_][ua];                                                                                   \
+        if (PRO) v = fmaxf(fmaf(v, ps[S_][PRO ? ua : 0], pt[S_][PRO ? ua : 0]), 0.f);                             \
+        as_[kk * BM + (tid % BM)] = ra_valid[S_] ? v : 0.f;                                                      \
+      } else {                                                                                                   \
+        const int idx = tid + ua * NTH;                                                                          \
+        const int kk = idx / (BM / 4), i4 = (idx % (BM / 4)) * 4;                                                \
+        f32x4 v = ra4[S_][ua];                                                                                   \
+        if (PRO) {                                                                                               \
+          const float s_ = ps[S_][PRO ? ua : 0], t_ = pt[S_][PRO ? ua : 0];                                      \
+          v.x = fmaxf(fmaf(v.x, s_, t_), 0.f);                                                                   \
+          v.y = fmaxf(fmaf(v.y, s_, t_), 0.f);                                                                   \
+          v.z = fmaxf(fmaf(v.z, s_, t_), 0.f);                                                                   \
+          v.w = fmaxf(fmaf(v.w, s_, t_), 0.f);                                                                   \
+        }                                                                                                        \
+        *reinterpret_cast<f32x4*>(as_ + kk * BM + i4) = v;                                                       \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      constexpr int ub = (u) >= NA ? (u) - NA : 0;                                                               \
+      const int idx = tid + ub * NTH;                                                                            \
+      *reinterpret_cast<f32x4*>(bs_ + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = rb[S_][ub];                 \
+    }                                                                                                            \
+  } while (0)
+
+  // MFMA operand registers: a ring of PD + 1 k-steps (k-step s + PD is being read from LDS while k-step s multiplies)
+  constexpr int KS = BK / 2;
+  constexpr int PD = 3;
+  constexpr int KSB = ((2 * KS) / 3 < KS - PD - 1) ? (2 * KS) / 3 : KS - PD - 1;  // k-step of the slab barrier
+  static_assert(KS % (PD + 1) == 0 && KSB + PD < KS && KSB >= 1, "operand ring");
+  float af[PD + 1][MT], bf[PD + 1][NT];
+
+#define READ_OPS(buf, ks, slot)                                                                                  \
+  do {                                                                                                           \
+    const float* as_ = As + (buf) * BK * BM + (2 * (ks) + lk) * BM + wm * TM + li;                               \
+    const float* bs_ = Bs + (buf) * BK * BN + (2 * (ks) + lk) * BN + wn * TN + li;                               \
+    _Pragma("unroll") for (int x = 0; x < MT; ++x) af[slot][x] = as_[32 * x];                                     \
+    _Pragma("unroll") for (int y = 0; y < NT; ++y) bf[slot][y] = bs_[32 * y];                                     \
+  } while (0)
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -199,30 +253,169 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
 
-  const int nslab = (C / BK) * d.ntaps;
-  load_slab(0);
-  __syncthreads();  // prologue constants visible before the first store_slab reads them
-  store_slab(0, 0);
+  // Pipeline (3 LDS slabs, ONE barrier per slab, placed INSIDE the MFMA stream):
+  //   iteration q:  k-steps [0, KSB): MFMAs on slab q, the global loads of slab q+2 issued ONE PER K-STEP between them
+  //                 barrier
+  //                 k-steps [KSB, KS): MFMAs on slab q, the LDS stores of slab q+2 spread over them the same way
+  // * the barrier of iteration q orders (WAR) every wave's reads of slab q-1 before the stores into its ring slot and
+  //   (RAW) the stores of slab q+1 (made in iteration q-1) before any read of it: the last k-steps of iteration q already
+  //   prefetch the first operands of slab q+1, so the MFMA stream runs across the slab boundary without a bubble;
+  // * a wave reaches the barrier with operands for the next k-steps in registers and MFMAs queued: the skew between the
+  //   four waves is covered;
+  // * a vector-memory or LDS-store instruction holds the wave's issue for tens of cycles (1 KB per wave-instruction):
+  //   bunched at the top of the slab they starve the matrix pipe (measured: 144 TF without them, 107 TF with), one
+  //   per 64-cycle MFMA they disappear.
+  const int nslab = q_end - q_first;
+  if (PRO) __syncthreads();  // prologue constants visible before the first loads pick them up
+  LOAD_BEGIN(0);
+#pragma unroll
+  for (int u = 0; u < NI; ++u) LOAD_ITEM(0, u);
+  if (nslab > 1) {
+    LOAD_BEGIN(1);
+#pragma unroll
+    for (int u = 0; u < NI; ++u) LOAD_ITEM(1, u);
+  }
+  __syncthreads();  // prologue constants visible before the first stores read them
+#define STORE_ALL(S_, buf, u) STORE_ITEM(S_, buf, u)
+  {
+    // (constant item indices: the macro needs them at compile time)
+#define ST8(S_, B_, o)                                                                     \
+  do {                                                                                     \
+    if ((o) + 0 < NI) STORE_ITEM(S_, B_, ((o) + 0 < NI ? (o) + 0 : 0));                     \
+    if ((o) + 1 < NI) STORE_ITEM(S_, B_, ((o) + 1 < NI ? (o) + 1 : 0));                     \
+    if ((o) + 2 < NI) STORE_ITEM(S_, B_, ((o) + 2 < NI ? (o) + 2 : 0));                     \
+    if ((o) + 3 < NI) STORE_ITEM(S_, B_, ((o) + 3 < NI ? (o) + 3 : 0));                     \
+    if ((o) + 4 < NI) STORE_ITEM(S_, B_, ((o) + 4 < NI ? (o) + 4 : 0));                     \
+    if ((o) + 5 < NI) STORE_ITEM(S_, B_, ((o) + 5 < NI ? (o) + 5 : 0));                     \
+    if ((o) + 6 < NI) STORE_ITEM(S_, B_, ((o) + 6 < NI ? (o) + 6 : 0));                     \
+    if ((o) + 7 < NI) STORE_ITEM(S_, B_, ((o) + 7 < NI ? (o) + 7 : 0));                     \
+  } while (0)
+    static_assert(NI <= 24, "staging items");
+    ST8(0, 0, 0);
+    ST8(0, 0, 8);
+    ST8(0, 0, 16);
+    if (nslab > 1) {
+      ST8(1, 1, 0);
+      ST8(1, 1, 8);
+      ST8(1, 1, 16);
+    }
+  }
   __syncthreads();
-  for (int q = 0; q < nslab; ++q) {
-    const int buf = q & 1;
-    if (q + 1 < nslab) load_slab(q + 1);
-    const float* as = As + buf * BK * BM + wm * TM + li;
-    const float* bs = Bs + buf * BK * BN + wn * TN + li;
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float af[MT], bf[NT];
+  for (int s = 0; s < PD; ++s) READ_OPS(0, s, s);
+  int r0 = 0, r1 = 1, r2 = 2;  // ring slots of slabs q, q + 1, q + 2
+  int q = 0;
+    // k-step ks: [operand reads of k-step ks + PD] [barrier at KSB] [staging items of this k-step] [MFMAs]
+#define KSTEP(more, ks)                                                                                                \
+  do {                                                                                                           \
+    if ((ks) + PD < KS) READ_OPS(r0, ((ks) + PD < KS ? (ks) + PD : 0), ((ks) + PD) % (PD + 1));                   \
+    else READ_OPS(r1, ((ks) + PD >= KS ? (ks) + PD - KS : 0), ((ks) + PD) % (PD + 1));                            \
+    if ((ks) == KSB) __syncthreads();                                                                            \
+    if (more) {                                                                                                  \
+      if ((ks) < KSB) {                                                                                          \
+        constexpr int lo = ((ks) * NI) / KSB, hi = (((ks) + 1) * NI) / KSB;                                      \
+        if (lo + 0 < hi) LOAD_ITEM(0, (lo + 0 < NI ? lo + 0 : 0));                                               \
+        if (lo + 1 < hi) LOAD_ITEM(0, (lo + 1 < NI ? lo + 1 : 0));                                               \
+        if (lo + 2 < hi) LOAD_ITEM(0, (lo + 2 < NI ? lo + 2 : 0));                                               \
+        if (lo + 3 < hi) LOAD_ITEM(0, (lo + 3 < NI ? lo + 3 : 0));                                               \
+        if (lo + 4 < hi) LOAD_ITEM(0, (lo + 4 < NI ? lo + 4 : 0));                                               \
+        if (lo + 5 < hi) LOAD_ITEM(0, (lo + 5 < NI ? lo + 5 : 0));                                               \
+        static_assert(hi - lo <= 6, "loads per k-step");                                                         \
+      } else {                                                                                                   \
+        constexpr int lo = (((ks) - KSB) * NI) / (KS - KSB), hi = (((ks) - KSB + 1) * NI) / (KS - KSB);          \
+        if (lo + 0 < hi) STORE_ITEM(0, r2, (lo + 0 < NI ? lo + 0 : 0));                                          \
+        if (lo + 1 < hi) STORE_ITEM(0, r2, (lo + 1 < NI ? lo + 1 : 0));                                          \
+        if (lo + 2 < hi) STORE_ITEM(0, r2, (lo + 2 < NI ? lo + 2 : 0));                                          \
+        if (lo + 3 < hi) STORE_ITEM(0, r2, (lo + 3 < NI ? lo + 3 : 0));                                          \
+        if (lo + 4 < hi) STORE_ITEM(0, r2, (lo + 4 < NI ? lo + 4 : 0));                                          \
+        if (lo + 5 < hi) STORE_ITEM(0, r2, (lo + 5 < NI ? lo + 5 : 0));                                          \
+        static_assert(hi - lo <= 6, "stores per k-step");                                                        \
+      }                                                                                                          \
+    }                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int x = 0; x < MT; ++x)                                                                \
+      _Pragma("unroll") for (int y = 0; y < NT; ++y)                                                              \
+        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[(ks) % (PD + 1)][x], bf[(ks) % (PD + 1)][y], acc[x][y], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+  } while (0)
+#define SLAB(more)                                                                                      \
+  do {                                                                                                  \
+    if (more) LOAD_BEGIN(0);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    KSTEP(more, 0); KSTEP(more, 1); KSTEP(more, 2); KSTEP(more, 3);                                     \
+    KSTEP(more, 4); KSTEP(more, 5); KSTEP(more, 6); KSTEP(more, 7);                                     \
+    if constexpr (KS == 16) {                                                                           \
+      KSTEP(more, 8); KSTEP(more, 9); KSTEP(more, 10); KSTEP(more, 11);                                 \
+      KSTEP(more, 12); KSTEP(more, 13); KSTEP(more, 14); KSTEP(more, 15);                               \
+    }                                                                                                   \
+    const int t_ = r0;                                                                                  \
+    r0 = r1;                                                                                            \
+    r1 = r2;                                                                                            \
+    r2 = t_;                                                                                            \
+  } while (0)
+  for (; q + 2 < nslab; ++q) SLAB(true);   // steady state: slab q + 2 is staged while slab q multiplies
+  for (; q < nslab; ++q) SLAB(false);      // the last two slabs
+#undef SLAB
+#undef KSTEP
+#undef LOAD_BEGIN
+#undef LOAD_ITEM
+#undef STORE_ITEM
+#undef STORE_ALL
+#undef ST8
+#undef READ_OPS
+
+  // ---- split-K: partial tiles meet in the last-arriving workgroup ---------------------------------------------------
+  // Each slice stores its accumulators as a slab (16 bytes per lane, the register order IS the slab order, so the reducer
+  // reads exactly its own registers' values), publishes it with one agent-scope release + a ticket, and the workgroup that
+  // draws the last ticket acquires, sums the slabs in slice order (deterministic) and runs the epilogue.  The counter is
+  // back at zero when the launch ends.
+  if (a.ksplit > 1) {
+    float* slab = a.slabs + ((int64_t)L * a.ksplit + kz) * (BM * BN);
 #pragma unroll
-      for (int x = 0; x < MT; ++x) af[x] = as[(2 * ks + lk) * BM + 32 * x];
+    for (int x = 0; x < MT; ++x)
 #pragma unroll
-      for (int y = 0; y < NT; ++y) bf[y] = bs[(2 * ks + lk) * BN + 32 * y];
+      for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          *reinterpret_cast<f32x4*>(slab + (((x * NT + y) * 4 + qd) * NTH + tid) * 4) =
+              f32x4{acc[x][y][4 * qd], acc[x][y][4 * qd + 1], acc[x][y][4 * qd + 2], acc[x][y][4 * qd + 3]};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned ticket = __hip_atomic_fetch_add(a.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool last = ticket == (unsigned)(a.ksplit - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      As[0] = last ? 1.f : 0.f;  // the slab ring is idle now
+    }
+    __syncthreads();
+    if (As[0] == 0.f) return;
+#pragma unroll
+    for (int x = 0; x < MT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
+    const float* s0 = a.slabs + (int64_t)L * a.ksplit * (BM * BN);
+    for (int z = 0; z < a.ksplit; ++z) {
+      const float* sz = s0 + (int64_t)z * (BM * BN);
 #pragma unroll
       for (int x = 0; x < MT; ++x)
 #pragma unroll
-        for (int y = 0; y < NT; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x], bf[y], acc[x][y], 0, 0, 0);
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 p = *reinterpret_cast<const f32x4*>(sz + (((x * NT + y) * 4 + qd) * NTH + tid) * 4);
+            acc[x][y][4 * qd] += p.x;
+            acc[x][y][4 * qd + 1] += p.y;
+            acc[x][y][4 * qd + 2] += p.z;
+            acc[x][y][4 * qd + 3] += p.w;
+          }
     }
-    if (q + 1 < nslab) store_slab(q + 1, buf ^ 1);
-    __syncthreads();
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
@@ -348,22 +541,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
 
 template <int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvK& a, bool gather, hipStream_t st) {
-  const size_t lds = sizeof(float) * (2 * BK * BM + 2 * BK * BN + 9 * BN +
+  const size_t lds = sizeof(float) * (3 * BK * BM + 3 * BK * BN + 9 * BN +
                                       ((a.d.flags & VITTA_CONV_PRO_BN_RELU) ? 2 * a.d.C : 0));
-  const dim3 grid((unsigned)(a.nMt * a.nNt)), block(WM * WN * 64);
+  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit)), block(WM * WN * 64);
   if (lds > 160 * 1024) return VITTA_ERR_UNSUPPORTED;
+  const bool pro = a.d.flags & VITTA_CONV_PRO_BN_RELU;
+  const int v = (gather ? 2 : 0) | (pro ? 1 : 0);
+  const void* fns[4] = {reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, false, false>),
+                        reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, false, true>),
+                        reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, true, false>),
+                        reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, true, true>)};
   if (lds > 48 * 1024) {  // raise the dynamic-LDS ceiling of this instantiation once (not a stream operation)
-    static size_t raised[2] = {0, 0};
-    if (lds > raised[gather]) {
-      const void* fn = gather ? reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, true>)
-                              : reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, BK, WM, WN, false>);
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    static bool raised[4] = {false, false, false, false};
+    if (!raised[v]) {
+      if (hipFuncSetAttribute(fns[v], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
         return VITTA_ERR_LAUNCH;
-      raised[gather] = 160 * 1024;
+      raised[v] = true;
     }
   }
-  if (gather) VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, true>), grid, block, lds, st, a);
-  else VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, false>), grid, block, lds, st, a);
+  switch (v) {
+    case 0: VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, false, false>), grid, block, lds, st, a); break;
+    case 1: VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, false, true>), grid, block, lds, st, a); break;
+    case 2: VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, true, false>), grid, block, lds, st, a); break;
+    default: VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, true, true>), grid, block, lds, st, a); break;
+  }
   return VITTA_OK;
 }
 
@@ -374,20 +575,22 @@ bool is_vector_geometry(const vitta_conv_desc& d) {
 
 // Tile choice: the largest tile that still gives the launch about two workgroups per CU; small problems fall through to
 // 64 x 64 / 64 x 32 (more, shorter workgroups).  BN must divide K.
+// The counters sit in a FIXED prefix of the workspace: launches with different tile counts share one workspace, and a
+// slab of one must never land on a counter of another (counters are zero at rest, slabs are not).
+constexpr int MAX_SPLIT_TILES = 16384;
+size_t counter_bytes(int) { return (size_t)MAX_SPLIT_TILES * sizeof(unsigned); }
+
 void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
   if (d.tile) {
     bm = d.tile >> 16;
     bn = d.tile & 0xffff;
     return;
   }
-  const int cand[][2] = {{128, 128}, {128, 64}, {64, 64}, {64, 32}};
-  for (auto& c : cand) {
-    if (d.K % c[1]) continue;
-    const int64_t blocks = ((M + c[0] - 1) / c[0]) * (d.K / c[1]);
-    bm = c[0];
-    bn = c[1];
-    if (blocks >= 448) return;
-  }
+  // measured on the TANet shapes (tools/bench_conv.py --tiles): 64 x 64 with 3-4 workgroups per CU beats the larger
+  // tiles everywhere below ~3000 workgroups; K % 64 != 0 falls to 64 x 32
+  (void)M;
+  bm = 64;
+  bn = (d.K % 64 == 0) ? 64 : 32;
 }
 
 int fill(const vitta_conv_desc* h, ConvK& a) {
@@ -424,6 +627,27 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   a.nMt = (int)((M + bm - 1) / bm);
   a.nNt = d.K / bn;
   a.d.tile = (bm << 16) | bn;
+  // split K over workgroups when the tiles alone leave CUs idle: aim at >= ~3 workgroups per CU, >= 4 slabs per slice
+  const int bk_ = (d.C % 32 == 0) ? 32 : 16;
+  const int nslab = (d.C / bk_) * d.ntaps, tiles = a.nMt * a.nNt;
+  int ks = 1;
+  if (tiles > MAX_SPLIT_TILES) ks = 1;
+  else if (d.ksplit > 0) ks = d.ksplit;
+  else if (d.ksplit == 0) {
+    while (tiles * ks < 640 && nslab / (ks * 2) >= 4 && ks < 16) ks *= 2;
+  }
+  if (ks > nslab) ks = nslab;
+  const size_t need = ks > 1 ? counter_bytes(tiles) + (size_t)tiles * ks * bm * bn * sizeof(float) : 0;
+  if (ks > 1 && (!d.workspace || (size_t)d.workspace_bytes < need)) {
+    if (d.ksplit > 0) return VITTA_ERR_WORKSPACE;
+    ks = 1;  // no (or too small a) workspace: one workgroup per tile
+  }
+  a.ksplit = ks;
+  a.ws_need = need;
+  a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
+  a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
+  for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t)
+    a.tap[t] = t < d.ntaps ? ((d.dh[t] & 0xff) | ((d.dw[t] & 0xff) << 8) | ((int)d.wt[t] << 16)) : 0;
   return VITTA_OK;
 }
 
@@ -440,6 +664,17 @@ int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc) {
   ConvK a;
   if (fill(h_desc, a) != VITTA_OK) return -1;
   return (int64_t)a.nMt * a.nNt;
+}
+
+size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc) {
+  if (!h_desc) return 0;
+  vitta_conv_desc d = *h_desc;
+  static char probe;  // any non-null pointer: only sizes matter here
+  d.workspace = &probe;
+  d.workspace_bytes = INT64_MAX;
+  ConvK a;
+  if (fill(&d, a) != VITTA_OK) return 0;
+  return a.ws_need;
 }
 
 int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream) {
