@@ -23,6 +23,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRO_MAX = 2048;  // input channels whose prologue BatchNorm constants are held in LDS
 
@@ -366,30 +367,35 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
 
   // ---- split-K: partial tiles meet in the last-arriving workgroup ---------------------------------------------------
   // Each slice stores its accumulators as a slab (16 bytes per lane, the register order IS the slab order, so the reducer
-  // reads exactly its own registers' values), publishes it with one agent-scope release + a ticket, and the workgroup that
-  // draws the last ticket acquires, sums the slabs in slice order (deterministic) and runs the epilogue.  The counter is
-  // back at zero when the launch ends.
+  // reads exactly its own registers' values), then draws a ticket; the workgroup that draws the last one sums the slabs in
+  // slice order (deterministic) and runs the epilogue.  The counter is back at zero when the launch ends.
   if (a.ksplit > 1) {
-    float* slab = a.slabs + ((int64_t)L * a.ksplit + kz) * (BM * BN);
+    // Slabs travel with WRITE-THROUGH (sc1) stores and are read back with sc1 loads: no agent-scope release / acquire
+    // (a release writes back every dirty line of the XCD's L2 -- with dozens of workgroups finishing per XCD each of
+    // them paid for everybody's fresh slabs: 20 us per launch).  Order: slab stores -> vmcnt(0) in every wave -> barrier ->
+    // ticket (relaxed, agent scope).  The ticket cannot overtake the slab: both leave through the same write-through path
+    // after the wait.
+    // one buffer descriptor over this tile's slabs (buffer instructions carry the sc1 bit as `aux`; the compiler counts
+    // them like any other load / store)
+    const int tile_bytes = BM * BN * 4;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)L * a.ksplit * (BM * BN), 0,
+                                                                  a.ksplit * tile_bytes, 0x00020000);
 #pragma unroll
     for (int x = 0; x < MT; ++x)
 #pragma unroll
       for (int y = 0; y < NT; ++y)
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd)
-          *reinterpret_cast<f32x4*>(slab + (((x * NT + y) * 4 + qd) * NTH + tid) * 4) =
-              f32x4{acc[x][y][4 * qd], acc[x][y][4 * qd + 1], acc[x][y][4 * qd + 2], acc[x][y][4 * qd + 3]};
+        for (int qd = 0; qd < 4; ++qd) {
+          const f32x4 v = {acc[x][y][4 * qd], acc[x][y][4 * qd + 1], acc[x][y][4 * qd + 2], acc[x][y][4 * qd + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                 (((x * NT + y) * 4 + qd) * NTH + tid) * 16, kz * tile_bytes, 16);
+        }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned ticket = __hip_atomic_fetch_add(a.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(a.ksplit - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (last) __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       As[0] = last ? 1.f : 0.f;  // the slab ring is idle now
     }
     __syncthreads();
@@ -400,21 +406,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
       for (int y = 0; y < NT; ++y)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[x][y][v] = 0.f;
-    const float* s0 = a.slabs + (int64_t)L * a.ksplit * (BM * BN);
     for (int z = 0; z < a.ksplit; ++z) {
-      const float* sz = s0 + (int64_t)z * (BM * BN);
 #pragma unroll
-      for (int x = 0; x < MT; ++x)
-#pragma unroll
-        for (int y = 0; y < NT; ++y)
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            const f32x4 p = *reinterpret_cast<const f32x4*>(sz + (((x * NT + y) * 4 + qd) * NTH + tid) * 4);
-            acc[x][y][4 * qd] += p.x;
-            acc[x][y][4 * qd + 1] += p.y;
-            acc[x][y][4 * qd + 2] += p.z;
-            acc[x][y][4 * qd + 3] += p.w;
-          }
+      for (int i = 0; i < MT * NT * 4; ++i) {
+        const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTH + tid) * 16, z * tile_bytes, 16));
+        const int xy = i / 4, qd = i % 4;
+        acc[xy / NT][xy % NT][4 * qd] += pv.x;
+        acc[xy / NT][xy % NT][4 * qd + 1] += pv.y;
+        acc[xy / NT][xy % NT][4 * qd + 2] += pv.z;
+        acc[xy / NT][xy % NT][4 * qd + 3] += pv.w;
+      }
     }
   }
 
