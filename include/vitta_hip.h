@@ -430,6 +430,34 @@ size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
 
 /* --------------------------------------------------------------------------
+ * A8 / A9 on channel-major planes (the layout of vitta_conv_f32: tensor[c][f * HW + hw], f = n * T + t).
+ * TemporalBottleneck (temporal_module.py:85-106) with conv1 writing its RAW output x1: the TAM kernels apply
+ * a = relu(bn1(x1)) while loading (h_bn = {gamma, beta, running_mean, running_var} device pointers [C]):
+ *   vitta_tam_pool_cm     d_pool [N, C, T] = mean_hw a                                   (temporal_module.py:47-52)
+ *   vitta_tam_agg_fwd_cm  d_out[c][n,t,:] = sum_j K[n,c,j] gate[n,c,t+j-1] a[c][n,t+j-1,:]   (:56-63)
+ *   vitta_tam_agg_bwd_cm  d_ga = d a (without the pooling path), d_ggate [N,C,T] (+ N*C*T*3 floats of scratch behind it),
+ *                         d_gkern [N*C, 3]
+ * vitta_bn_bwd_cm: backward of y = [relu](bn_eval(x)) in this layout, the element-wise piece between two data-gradient
+ * convolutions:  g = d_g (+ d_g2) (+ rowadd_scale * d_rowadd[n, c, t], the TAM pooling gradient with scale 1 / HW);
+ *   m = relu ? (d_mask ? d_mask > 0 : z > 0) : 1 ;  dz = g m + gscale (a_c + b_c (z - mu_c)) (statistics-loss gradient, A6);
+ *   d_dgamma[c] += sum dz x_hat ; d_dbeta[c] += sum dz (atomics) ; d_dx = dz s_c ; d_gm (optional) = g m.
+ * vitta_avgpool_cm(_bwd): the trunk's AdaptiveAvgPool2d(1) (tanet.py:147) from planes [C][F*HW] to features [F, C].
+ * -------------------------------------------------------------------------- */
+int vitta_tam_pool_cm_f32(const float* d_x, const float* const* h_bn, float eps, int32_t C, int32_t N, int32_t T, int32_t HW,
+                          float* d_pool, void* stream);
+int vitta_tam_agg_fwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
+                             int32_t C, int32_t N, int32_t T, int32_t HW, float* d_out, void* stream);
+int vitta_tam_agg_bwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
+                             const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga, float* d_ggate,
+                             float* d_gkern, void* stream);
+int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, const float* d_rowadd,
+                        float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
+                        const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
+                        float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream);
+int vitta_avgpool_cm_f32(const float* d_x, int32_t C, int32_t F, int32_t HW, float* d_feat, void* stream);
+int vitta_avgpool_cm_bwd_f32(const float* d_gfeat, int32_t C, int32_t F, int32_t HW, float* d_gx, void* stream);
+
+/* --------------------------------------------------------------------------
  * A2 / A10 -- LayerNorm over the channel axis of channels-last rows [rows, C], fused with its surroundings in a Video
  * Swin block (swin_transformer.py:245-275) and with the ViTTA statistics of a hooked LayerNorm
  * (utils/norm_stats_utils.py:222-230).  C in {128, 256, 512, 1024, 2048}.

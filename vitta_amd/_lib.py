@@ -107,6 +107,13 @@ SIGNATURES = {
     "vitta_conv_num_blocks": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "vitta_tam_pool_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitta_tam_agg_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "vitta_tam_agg_bwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "vitta_bn_bwd_cm_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, C.POINTER(_p), _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p,
+                                      _i32, _i32, _i32, _i32, _p]),
+    "vitta_avgpool_cm_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
+    "vitta_avgpool_cm_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "vitta_ln_supported": (C.c_int, [_i32]),
     "vitta_ln_num_partials": (_i64, [_i64]),
     "vitta_ln_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _p]),

@@ -271,6 +271,32 @@ class StatAlignEngine:
             self.plan = fused
         return FusedSite(self, index)
 
+    def begin_direct(self, shapes, device):
+        """Every hooked layer of this step deposits its additive statistics straight into [s1 | s2]: the convolution
+        that produces the layer adds the shifted sums of its tile in the epilogue (vitta_conv_f32, VITTA_CONV_STATS).
+        `shapes`: (frames, C, H*W, NCHW) per hooked layer in hook order.  Returns the plan whose buffers take part."""
+        if self._feats or self._fused_seen:
+            raise RuntimeError("a step must be either all-fused or all-recorded")
+        if not self._built:
+            self._build(device)
+        shapes = tuple(tuple(int(v) for v in s) for s in shapes)
+        if len(shapes) != len(self.hooks):
+            raise RuntimeError("one shape per hooked layer expected")
+        for (_, c, _, _), (sm, _) in zip(shapes, self._src):
+            if c != sm.numel():
+                raise RuntimeError(f"source statistics have {sm.numel()} channels, feature has {c}")
+        plan = self._plans.get(shapes)
+        if plan is None:
+            plan = self._plans[shapes] = self.backend.make_plan(shapes, self.device)
+        if getattr(plan, "_direct_cnt", None) is None:
+            plan._direct_cnt = torch.tensor([float(o * i) for o, _, i, _ in shapes], dtype=torch.float32, device=self.device)
+        self.plan = plan
+        plan.stats.zero_()
+        plan.cnt.copy_(plan._direct_cnt)
+        self._fused_seen = set(range(len(self.hooks)))
+        self._fused_direct = True
+        return plan
+
     def fused_ln_site(self, index, x):
         """A FusedLNSite if this step can take the fused LayerNorm path for hooked layer `index`: a plan for exactly
         these shapes exists and EVERY hooked layer of the plan is a channels-last LayerNorm the kernel covers (a step is

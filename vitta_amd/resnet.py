@@ -93,6 +93,12 @@ class ResNet(nn.Module):
                 (3, 2, 1, 1, False) and y.shape[0] * y.shape[1] <= 65535)
 
     def forward(self, x):
+        # the hand-written trunk (vitta_amd/trunk.py: every convolution is vitta_conv_f32) whenever the configuration
+        # allows it; otherwise module by module (library convolutions + the fused BN passes)
+        from . import trunk
+        feat = trunk.run(self, x)
+        if feat is not None:
+            return self.fc(feat)
         y = self.conv1(x)
         if self._stem_fusable(y):
             from . import ops

@@ -1,0 +1,474 @@
+"""The TANet trunk (ResNet-50 + TAM, models/tanet_models/tanet.py:125-150, temporal_module.py:12-140) on the hand-written
+convolutions: every activation lives as channel-major planes [C, N*H*W] from the stem's max-pool to the global average
+pooling, every convolution is `vitta_conv_f32` (vitta_amd/csrc/conv.hip), and BatchNorm / residual / ReLU / the hooked
+layers' moments ride in the convolutions' epilogues and prologues.
+
+One bottleneck (temporal_module.py:85-106), forward:
+    conv1 (1x1)            -> x1 RAW                          [+ moments of bn1(x1) when hooked]
+    TAM                    reads x1, applies relu(bn1(.)) on load -> a1                         (tam_cm.hip)
+    conv2 (3x3, stride s)  -> x2 RAW                          [+ moments of bn2(x2)]
+    downsample (block 0)   -> xd RAW, zd = bn_d(xd)           [+ moments of zd]
+    conv3 (1x1)            reads x2 with relu(bn2(.)) on load -> x3 RAW, out = relu(bn3(x3) + identity)   [+ moments of bn3(x3)]
+backward (G = gradient w.r.t. out, all consumers summed):
+    bn_bwd  : dz3 = G [out > 0] + inj3 -> dx3, g_id = G [out > 0], d gamma3 / d beta3
+    dgrad conv3, epilogue = BatchNorm(+ReLU) backward of bn2 -> dx2, d gamma2 / d beta2
+    dgrad conv2 -> d a1 ; TAM backward ; bn_bwd of bn1 (+ the pooling gradient) -> dx1
+    (block 0) bn_bwd of bn_d on g_id -> dxd ; dgrad downsample (half resolution when strided) -> gd
+    dgrad conv1, epilogue adds g_id (or gd at the even positions) -> G of the previous block
+`inj` = the statistics-loss gradient gscale (a_c + b_c (z - mu_c)) of a hooked layer.
+
+The whole trunk is ONE autograd node (TrunkFunction): parameter gradients go straight into their `.grad` storage
+(ops._grad_sink), nothing in between is visible to autograd.  Eligibility (`TrunkRunner.eligible`): CUDA fp32 input, every
+block a TemporalBottleneck, every BatchNorm in eval mode, FROZEN convolution weights (requires_grad False: the packed
+copies are cached, and an optimizer that updates weights in place through its own kernel would leave them stale), and no
+forward hook other than the engine-bound statistics hooks -- anything else takes the module-by-module path of resnet.py /
+tanet.py.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, conv as CV
+from ._lib import check, lib
+
+ENABLED = True
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _bn_ptrs(bn):
+    arr = (C.c_void_p * 4)()
+    for i, t in enumerate((bn.weight, bn.bias, bn.running_mean, bn.running_var)):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def _bn_t(bn):
+    return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+def _engine_hook(bn):
+    """(ok, hook): the engine-bound statistics hook of a BatchNorm2d, or None; ok False if the module carries any other
+    forward hook (those need the module-by-module path)."""
+    hook = None
+    for fn in bn._forward_hooks.values():
+        owner = getattr(fn, "__self__", None)
+        if (owner is not None and getattr(owner, "engine", None) is not None and hasattr(owner, "index")
+                and getattr(owner, "kind", None) == "bn2d" and not owner.before_norm and hook is None):
+            hook = owner
+        else:
+            return False, None
+    return not bn._forward_pre_hooks, hook
+
+
+def _noop_hooks_only(module):
+    for fn in module._forward_hooks.values():
+        owner = getattr(fn, "__self__", None)
+        if owner is None or getattr(owner, "kind", None) != "bn1d":
+            return False
+    return not module._forward_pre_hooks
+
+
+class Site:
+    """A hooked BatchNorm2d of this step: where the convolution epilogue deposits the additive statistics and which
+    coefficient slices its backward injects."""
+
+    def __init__(self, engine, plan, index):
+        sl = plan.channel_slice(index)
+        self.stats = (engine.src_mean[sl], plan.s1[sl], plan.s2[sl])
+        self.inj = (plan.mu[sl], plan.coef_a[sl], plan.coef_b[sl], engine.gscale)
+
+
+class TrunkRunner:
+    def __init__(self, resnet):
+        self.net = resnet
+        self._packed = {}
+        self._geo = {}
+
+    # -- structure ---------------------------------------------------------------------------------------------
+    def blocks(self):
+        out = []
+        for name in ("layer1", "layer2", "layer3", "layer4"):
+            out.extend(getattr(self.net, name).children())
+        return out
+
+    def bn2d_modules(self):
+        """Every BatchNorm2d of the trunk the runner evaluates, stem first."""
+        mods = [self.net.bn1]
+        for b in self.blocks():
+            mods += [b.net.bn1, b.net.bn2, b.net.bn3]
+            if b.net.downsample is not None:
+                mods.append(b.net.downsample[1])
+        return mods
+
+    def eligible(self, x):
+        from . import fused_bn, ops
+        from .tanet import TemporalBottleneck
+        net = self.net
+        if not (ENABLED and fused_bn.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            return False
+        grad = torch.is_grad_enabled()
+        mp, c1 = net.maxpool, net.conv1
+        if net._forward_hooks or net._forward_pre_hooks or not isinstance(mp, nn.MaxPool2d) or mp._forward_hooks \
+                or (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) != (3, 2, 1, 1, False) \
+                or net.relu._forward_hooks or c1._forward_hooks or c1.weight.requires_grad \
+                or not isinstance(net.bn1, nn.BatchNorm2d) or net.bn1.training or not net.bn1.affine \
+                or x.shape[0] * 64 > 65535:
+            return False
+        blocks = self.blocks()
+        if not blocks:
+            return False
+        t = blocks[0].n_segment if isinstance(blocks[0], TemporalBottleneck) else 0
+        if t <= 0 or x.shape[0] % t:
+            return False
+        engines = set()
+        for b in blocks:
+            if not isinstance(b, TemporalBottleneck) or b.n_segment != t or b._forward_hooks or b.net._forward_hooks or b.tam._forward_hooks:
+                return False
+            n = b.net
+            convs = [n.conv1, n.conv2, n.conv3]
+            bns = [n.bn1, n.bn2, n.bn3]
+            if n.downsample is not None:
+                ds = n.downsample
+                if not (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d)
+                        and isinstance(ds[1], nn.BatchNorm2d) and not ds._forward_hooks):
+                    return False
+                convs.append(ds[0])
+                bns.append(ds[1])
+            for cv in convs:
+                if cv.bias is not None or cv._forward_hooks or cv._forward_pre_hooks or cv.weight.requires_grad \
+                        or cv.groups != 1 or cv.dilation != (1, 1):
+                    return False
+            if (n.conv1.kernel_size, n.conv1.stride) != ((1, 1), (1, 1)) or (n.conv3.kernel_size, n.conv3.stride) != ((1, 1), (1, 1)) \
+                    or n.conv2.kernel_size != (3, 3) or n.conv2.padding != (1, 1) or n.conv2.stride[0] != n.conv2.stride[1] \
+                    or n.conv2.stride[0] not in (1, 2) or n.relu._forward_hooks:
+                return False
+            for bn in bns:
+                if not isinstance(bn, nn.BatchNorm2d) or bn.training or not bn.affine:
+                    return False
+                ok, hook = _engine_hook(bn)
+                if not ok or (hook is not None and not grad):
+                    return False
+                if hook is not None:
+                    engines.add(id(hook.engine))
+            tam = b.tam
+            bg, bl = tam.G[1], tam.L[1]
+            if bg.training or bl.training or not _noop_hooks_only(bg) or not _noop_hooks_only(bl) \
+                    or not ops.tam_branch_supported(n.conv1.out_channels, t):
+                return False
+            for m in (tam.G[0], tam.G[3], tam.L[0], tam.L[3]):
+                if m._forward_hooks or m.weight.requires_grad:
+                    return False
+        ok, hook = _engine_hook(net.bn1)
+        if not ok or hook is not None:  # a hooked stem BN takes the module path (the shipped configuration hooks layer3/4)
+            return False
+        return len(engines) <= 1
+
+    # -- caches ------------------------------------------------------------------------------------------------
+    def packed(self, conv, kind):
+        w = conv.weight
+        key = (id(w), kind)
+        tag = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
+            self._packed[key] = hit
+        return hit[1]
+
+    def geo(self, kind, n, h, w, k=1, stride=1, pad=0):
+        key = (kind, n, h, w, k, stride, pad)
+        g = self._geo.get(key)
+        if g is None:
+            g = CV.Geometry.forward(n, h, w, k, stride, pad) if kind == "f" else CV.Geometry.dgrad(n, h, w, k, stride, pad)
+            self._geo[key] = g
+        return g
+
+    # -- statistics sites --------------------------------------------------------------------------------------
+    def open_sites(self, x):
+        """{bn module: Site} for this step; the engine is switched to direct deposit (conv epilogues add into [s1 | s2])."""
+        hooked, engine = [], None
+        for bn in self.bn2d_modules():
+            _, hook = _engine_hook(bn)
+            if hook is not None:
+                hooked.append((bn, hook))
+                engine = hook.engine
+        if engine is None:
+            return {}
+        if len(hooked) != len(engine.hooks):
+            raise RuntimeError("statistics hooks outside the trunk share its engine: use the module path")
+        shapes = self.feature_shapes(x)
+        by_index = sorted(hooked, key=lambda p: p[1].index)
+        plan = engine.begin_direct([shapes[id(bn)] for bn, _ in by_index], x.device)
+        return {id(bn): Site(engine, plan, hook.index) for bn, hook in hooked}
+
+    def feature_shapes(self, x):
+        """{id(bn): (frames, C, HW, NCHW)} of every BatchNorm2d output for input x (what a hook would see)."""
+        n = x.shape[0]
+        h, w = CV.out_size(x.shape[2], 7, 2, 3), CV.out_size(x.shape[3], 7, 2, 3)
+        out = {id(self.net.bn1): (n, 64, h * w, _lib.LAYOUT_NCHW)}
+        h, w = CV.out_size(h, 3, 2, 1), CV.out_size(w, 3, 2, 1)
+        for b in self.blocks():
+            net = b.net
+            p, s = net.conv1.out_channels, net.conv2.stride[0]
+            out[id(net.bn1)] = (n, p, h * w, _lib.LAYOUT_NCHW)
+            ho, wo = CV.out_size(h, 3, s, 1), CV.out_size(w, 3, s, 1)
+            out[id(net.bn2)] = (n, p, ho * wo, _lib.LAYOUT_NCHW)
+            out[id(net.bn3)] = (n, 4 * p, ho * wo, _lib.LAYOUT_NCHW)
+            if net.downsample is not None:
+                out[id(net.downsample[1])] = (n, 4 * p, ho * wo, _lib.LAYOUT_NCHW)
+            h, w = ho, wo
+        return out
+
+    # -- forward -----------------------------------------------------------------------------------------------
+    def stem(self, x):
+        """conv1 -> bn1 -> relu -> maxpool: (raw convolution output NCHW, pooled NCHW).  The 7x7 convolution is still the
+        library's; the BN + ReLU + max-pool pass is stem.hip."""
+        from .ops import _ptr4
+        net, bn = self.net, self.net.bn1
+        with torch.no_grad():
+            y = net.conv1(x).contiguous()
+        n, c, h, w = y.shape
+        pooled = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=y.device)
+        check(lib().vitta_stem_bn_relu_pool_fwd_f32(_p(y), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
+                                                    n, c, h, w, _p(pooled), _stream()), "vitta_stem_bn_relu_pool_fwd_f32")
+        return y, pooled
+
+    def stem_backward(self, y, gpool, sink):
+        from .ops import _ptr4
+        bn = self.net.bn1
+        dw, db = sink(bn.weight), sink(bn.bias)
+        if dw is None and db is None:
+            return
+        if dw is None or db is None:  # the kernel writes both
+            dw = dw if dw is not None else torch.zeros_like(bn.weight)
+            db = db if db is not None else torch.zeros_like(bn.bias)
+        n, c, h, w = y.shape
+        check(lib().vitta_stem_bn_relu_pool_bwd_affine_f32(_p(y), _p(gpool.contiguous()),
+                                                           _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
+                                                           n, c, h, w, _p(dw), _p(db), _stream()),
+              "vitta_stem_bn_relu_pool_bwd_affine_f32")
+
+    def block_forward(self, b, xin, n, h, w, keep, sites):
+        net, tam = b.net, b.tam
+        t = b.n_segment
+        nb = n // t
+        cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
+        dev = xin.device
+        f = dict(dtype=torch.float32, device=dev)
+        L = lib()
+        st = _stream()
+        P = n * h * w
+        s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
+        # conv1 -> x1 raw
+        x1 = torch.empty(p, P, **f)
+        CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f"), x1, cin, p, flags=CV.CONV_STATS if s1 else 0,
+                  epi_bn=_bn_t(net.bn1) if s1 else None, eps=net.bn1.eps, stats=s1.stats if s1 else None)
+        # TAM on relu(bn1(x1))
+        bn1p = _bn_ptrs(net.bn1)
+        pooled = torch.empty(nb, p, t, **f)
+        check(L.vitta_tam_pool_cm_f32(_p(x1), bn1p, float(net.bn1.eps), p, nb, t, h * w, _p(pooled), st), "vitta_tam_pool_cm_f32")
+        bg, bl = tam.G[1], tam.L[1]
+        kern, gate, hpre = torch.empty(nb * p, 3, **f), torch.empty(nb, p, t, **f), torch.empty(2, nb, p // 4, t, **f)
+        from .ops import _ptr4
+        check(L.vitta_tam_branch_fwd_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                         _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
+        a1 = torch.empty(p, P, **f)
+        check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
+              "vitta_tam_agg_fwd_cm_f32")
+        # conv2 -> x2 raw
+        g2 = self.geo("f", n, h, w, 3, s, 1)
+        ho, wo = g2.hy, g2.wy
+        Po = n * ho * wo
+        x2 = torch.empty(p, Po, **f)
+        CV.launch(g2, a1, self.packed(net.conv2, "f"), x2, p, p, flags=CV.CONV_STATS if s2 else 0,
+                  epi_bn=_bn_t(net.bn2) if s2 else None, eps=net.bn2.eps, stats=s2.stats if s2 else None)
+        # identity path
+        xd = None
+        if net.downsample is not None:
+            dconv, dbn = net.downsample[0], net.downsample[1]
+            sd = sites.get(id(dbn))
+            ident = torch.empty(4 * p, Po, **f)
+            xd = torch.empty(4 * p, Po, **f) if keep else None
+            CV.launch(self.geo("f", n, h, w, 1, dconv.stride[0], 0), xin, self.packed(dconv, "f"), ident, cin, 4 * p,
+                      flags=CV.CONV_EPI_APPLY | (CV.CONV_STATS if sd else 0), y_raw=xd, epi_bn=_bn_t(dbn), eps=dbn.eps,
+                      stats=sd.stats if sd else None)
+        else:
+            ident = xin
+        # conv3 -> x3 raw, out
+        out = torch.empty(4 * p, Po, **f)
+        x3 = torch.empty(4 * p, Po, **f) if keep else None
+        CV.launch(self.geo("f", n, ho, wo), x2, self.packed(net.conv3, "f"), out, p, 4 * p,
+                  flags=CV.CONV_PRO_BN_RELU | CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if s3 else 0),
+                  y_raw=x3, res=ident, pro_bn=_bn_t(net.bn2), epi_bn=_bn_t(net.bn3), eps=net.bn3.eps,
+                  stats=s3.stats if s3 else None)
+        saved = None
+        if keep:
+            saved = dict(xin=xin, x1=x1, pooled=pooled, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
+                         dims=(n, h, w, ho, wo))
+        return out, ho, wo, saved
+
+    def forward(self, x, keep):
+        """x [N, 3, H, W] -> (features [N, 2048], tape).  keep: save what the backward needs."""
+        sites = self.open_sites(x) if keep else {}
+        y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
+        n, _, h, w = pooled.shape
+        cur = CV.to_cm(pooled)
+        tape = []
+        for b in self.blocks():
+            cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites)
+            tape.append(saved)
+        c = cur.shape[0]
+        feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
+        return feat, dict(tape=tape, sites=sites, stem=y if keep else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
+                          last=(c, n, h, w))
+
+    # -- backward ----------------------------------------------------------------------------------------------
+    def block_backward(self, b, sv, G, sites, sink):
+        """G [4p, Po] = gradient w.r.t. the block output (all consumers) -> gradient w.r.t. the block input."""
+        net, tam = b.net, b.tam
+        t = b.n_segment
+        n, h, w, ho, wo = sv["dims"]
+        nb = n // t
+        cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
+        f = dict(dtype=torch.float32, device=G.device)
+        L = lib()
+        st = _stream()
+        P, Po = n * h * w, n * ho * wo
+        s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
+
+        def bn_bwd(g, x, bn, site, relu, mask=None, gm=None, rowadd=None, c=None, hw=None):
+            dx = torch.empty_like(x)
+            dg, db = sink(bn.weight), sink(bn.bias)
+            inj = site.inj if site else (None, None, None, None)
+            check(L.vitta_bn_bwd_cm_f32(_p(g), None, _p(x), _p(mask), _p(rowadd), (1.0 / hw) if rowadd is not None else 0.0,
+                                        _bn_ptrs(bn), float(bn.eps), _p(inj[0]), _p(inj[1]), _p(inj[2]), _p(inj[3]), int(relu),
+                                        _p(dx), _p(gm), _p(dg), _p(db), c, nb, t, hw, st), "vitta_bn_bwd_cm_f32")
+            return dx
+
+        # bn3 (+ identity add + ReLU) backward
+        g_id = torch.empty_like(G)
+        dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo)
+        # conv3 data gradient, epilogue = bn2 (+ReLU) backward
+        dx2 = torch.empty(p, Po, **f)
+        i2 = s2.inj if s2 else None
+        CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b"), dx2, 4 * p, p,
+                  flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
+                  dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias))
+        del dx3
+        # conv2 data gradient -> d a1
+        ga1 = torch.empty(p, P, **f)
+        for g in self.geo("b", n, h, w, 3, s, 1):
+            CV.launch(g, dx2, self.packed(net.conv2, "b"), ga1, p, p)
+        del dx2
+        # TAM backward
+        bn1p = _bn_ptrs(net.bn1)
+        ga = torch.empty(p, P, **f)
+        ggate = torch.empty(nb * p * t * 4, **f)
+        gkern = torch.empty(nb * p, 3, **f)
+        check(L.vitta_tam_agg_bwd_cm_f32(_p(sv["x1"]), bn1p, float(net.bn1.eps), _p(sv["gate"]), _p(sv["kern"]), _p(ga1), p, nb,
+                                         t, h * w, _p(ga), _p(ggate), _p(gkern), st), "vitta_tam_agg_bwd_cm_f32")
+        del ga1
+        bg, bl = tam.G[1], tam.L[1]
+        from .ops import _ptr4
+        gbuf = torch.empty(nb * p * t + nb * (p // 4) * t, **f)  # d pooled | scratch
+        check(L.vitta_tam_branch_bwd_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                         _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                         _p(ggate), _p(gbuf), _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias)),
+                                         _ptr4(None, None, None, None), st), "vitta_tam_branch_bwd_f32")
+        # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
+        dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w)
+        del ga
+        # identity / downsample path
+        gin = torch.empty(cin, P, **f)
+        if net.downsample is not None:
+            dconv, dbn = net.downsample[0], net.downsample[1]
+            sd = sites.get(id(dbn))
+            dxd = bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo)
+            ds = dconv.stride[0]
+            gd = torch.empty(cin, Po if ds == 2 else P, **f)
+            CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b"), gd, 4 * p, cin)
+            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin,
+                      flags=CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES, res=gd)
+        else:
+            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin, flags=CV.CONV_RES, res=g_id)
+        return gin
+
+    def backward(self, ctxd, gfeat, sink):
+        c, n, h, w = ctxd["last"]
+        G = torch.empty(c, n * h * w, dtype=torch.float32, device=gfeat.device)
+        check(lib().vitta_avgpool_cm_bwd_f32(_p(gfeat.contiguous()), c, n, h * w, _p(G), _stream()), "vitta_avgpool_cm_bwd_f32")
+        blocks = self.blocks()
+        for b, sv in zip(reversed(blocks), reversed(ctxd["tape"])):
+            G = self.block_backward(b, sv, G, ctxd["sites"], sink)
+            sv.clear()
+        # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
+        h0, w0 = ctxd["pooled_hw"]
+        self.stem_backward(ctxd["stem"], CV.from_cm(G, n, h0, w0), sink)
+
+
+class TrunkFunction(torch.autograd.Function):
+    """features = trunk(x) as one autograd node.  Inputs after `runner`: the trainable parameters (so that autograd
+    schedules this node); their gradients are written by the kernels straight into `.grad` storage where it exists."""
+
+    @staticmethod
+    def forward(ctx, x, runner, *params):
+        ctx.set_materialize_grads(False)
+        feat, tape = runner.forward(x, True)
+        ctx.runner, ctx.tape, ctx.params = runner, tape, params
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        from . import ops
+        runner, params = ctx.runner, ctx.params
+        if gfeat is None:
+            return (None, None) + tuple(None for _ in params)
+        bufs = {}
+
+        def sink(param):
+            if not param.requires_grad:
+                return None
+            hit = bufs.get(id(param))
+            if hit is None:
+                buf, ret = ops._grad_sink(param, True, zero=True)
+                hit = bufs[id(param)] = (buf, ret)
+            return hit[0]
+
+        runner.backward(ctx.tape, gfeat, sink)
+        ctx.tape = None
+        grads = []
+        for p in params:
+            hit = bufs.get(id(p))
+            grads.append(hit[1] if hit is not None else None)
+        return (None, None) + tuple(grads)
+
+
+def run(resnet, x):
+    """features [N, 2048] of the trunk on the hand-written path, or None if the configuration needs the module path."""
+    runner = getattr(resnet, "_vitta_trunk", None)
+    if runner is None:
+        runner = TrunkRunner(resnet)
+        object.__setattr__(resnet, "_vitta_trunk", runner)
+    if not runner.eligible(x):
+        return None
+    params = [p for m in runner.bn2d_modules() for p in (m.weight, m.bias)]
+    for b in runner.blocks():
+        params += [b.tam.G[1].weight, b.tam.G[1].bias, b.tam.L[1].weight, b.tam.L[1].bias]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return TrunkFunction.apply(x, runner, *[p for p in params if p.requires_grad])
+    with torch.no_grad():
+        feat, _ = runner.forward(x, False)
+    return feat
