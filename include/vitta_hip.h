@@ -424,6 +424,12 @@ typedef struct vitta_conv_desc {
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */
 int vitta_conv_supported(const vitta_conv_desc* h_desc);
 int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream);
+/* The same launch with two caller-created events (vitta_event_create) attached to the kernel's own dispatch: their elapsed
+ * time is the kernel's duration as rocprofv3 --kernel-trace reports it (bench.py's live roofline figure). */
+int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_start, void* ev_stop);
+/* Multiply-add count x 2 of the launch (algorithmic: N * Hg * Wg output positions x K x C x ntaps; padding taps included,
+ * tile tails excluded). */
+int64_t vitta_conv_flops(const vitta_conv_desc* h_desc);
 /* Workspace the library's split choice (or h_desc->ksplit) needs for this descriptor; 0 = none. */
 size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
 /* Workgroups the launch of this descriptor would use (for tile selection / tests). */
@@ -496,6 +502,26 @@ int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, 
 int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps,
                                            int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
                                            void* stream);
+
+/* --------------------------------------------------------------------------
+ * A8 -- the stem convolution itself: Conv2d(3, 64, kernel 7, stride 2, pad 3, no bias), torchvision ResNet.conv1 under
+ * models/tanet_models/tanet.py:125-150, as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * d_x [N, 3, H, W] (W % 4 == 0); d_wp = the [64, 3, 7, 7] parameter packed [148][64]: row t = (c * 7 + kh) * 7 + kw holds
+ * w[:, c, kh, kw], row 147 is zero; d_y [N, 64, OH, OW] raw convolution output, OH = (H - 1) / 2 + 1 (the NCHW tensor
+ * vitta_stem_bn_relu_pool_* read).
+ * -------------------------------------------------------------------------- */
+int vitta_stem_conv7_f32(const float* d_x, const float* d_wp, int64_t N, int32_t H, int32_t W, float* d_y, void* stream);
+
+/* --------------------------------------------------------------------------
+ * A8 -- classification head: y[m][n] = b[n] + sum_k x[m][k] w[n][k]  (new_fc = nn.Linear(2048, num_class) on the pooled
+ * per-frame features, models/tanet_models/tanet.py:105-123, 243-251).  M = frames (small), K % 4 == 0.
+ * Backward: d_dx [M, K] (overwritten; NULL: skipped); d_dw [N, K] / d_db [N] are ACCUMULATED (may point into .grad /
+ * the flat gradient arena; NULL: skipped, the frozen head of affine-only adaptation).
+ * -------------------------------------------------------------------------- */
+int vitta_linear_fwd_f32(const float* d_x, const float* d_w, const float* d_b, int64_t M, int32_t N, int32_t K, float* d_y,
+                         void* stream);
+int vitta_linear_bwd_f32(const float* d_dy, const float* d_x, const float* d_w, int64_t M, int32_t N, int32_t K, float* d_dx,
+                         float* d_dw, float* d_db, void* stream);
 
 /* --------------------------------------------------------------------------
  * N1 -- decoded RGB frames -> network input, bit-identical to the reference's PIL pipeline

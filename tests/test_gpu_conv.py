@@ -215,3 +215,49 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
         CV.launch(CV.Geometry.forward(4, 6, 6), x, torch.zeros(1, 24, 32, device=d), torch.zeros(32, 4 * 36, device=d), 24, 32)
     with pytest.raises(_lib.VittaHipError):
         CV.launch(CV.Geometry.forward(4, 6, 6), x.cpu(), torch.zeros(1, 24, 32), torch.zeros(32, 4 * 36), 24, 32)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 112, 112), (2, 64, 64), (1, 32, 48), (2, 30, 36), (1, 226, 220)])
+def test_stem_conv7_matches_fp64_conv(n, h, w):
+    """vitta_stem_conv7_f32 (stem_conv.hip): the 7x7 / stride 2 / pad 3 convolution of the ResNet stem, NCHW in and out,
+    tiles of 256 consecutive output pixels (ragged last tile, odd output sizes)."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n * 7 + h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 147 ** -0.5
+    ref = F.conv2d(x.double(), wt.double(), stride=2, padding=3)
+    d = _dev()
+    y = CV.stem_conv(x.to(d), CV.pack_stem(wt.to(d)))
+    assert y.shape == ref.shape
+    _close(y, ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(16, 101, 2048), (8, 101, 2048), (3, 7, 64), (24, 174, 2048), (1, 400, 2048)])
+def test_head_linear_forward_and_gradients(m, n, k):
+    """vitta_linear_{fwd,bwd}_f32 (head.hip) against fp64: y, dx, and ACCUMULATED dw / db."""
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g)
+    wt = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    gy = torch.randn(m, n, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, wt, b))
+    ref = F.linear(xr, wr, br)
+    ref.backward(gy.double())
+    d = _dev()
+    old = ops.DIRECT_PARAM_GRAD
+    ops.DIRECT_PARAM_GRAD = False
+    try:
+        xg, wg, bg = (t.to(d).requires_grad_() for t in (x, wt, b))
+        y = ops.HeadLinear.apply(xg, wg, bg)
+        y.backward(gy.to(d))
+    finally:
+        ops.DIRECT_PARAM_GRAD = old
+    _close(y, ref.detach())
+    _close(xg.grad, xr.grad)
+    _close(wg.grad, wr.grad)
+    _close(bg.grad, br.grad)
+    # frozen head (affine-only adaptation): only the data gradient
+    xg2 = x.to(d).requires_grad_()
+    ops.HeadLinear.apply(xg2, wt.to(d), b.to(d)).backward(gy.to(d))
+    _close(xg2.grad, xr.grad)

@@ -95,13 +95,24 @@ def main():
         seen[key] = row
         rows.append(row)
         print({kk: (round(v, 1) if isinstance(v, float) else v) for kk, v in row.items()}, flush=True)
+    # the stem (stem_conv.hip) beside the library's 7x7 forward
+    xs = torch.randn(n, 3, 224, 224, device=d)
+    ws = torch.randn(64, 3, 7, 7, device=d) * 147 ** -0.5
+    wps = CV.pack_stem(ws)
+    sflops = 2.0 * n * 112 * 112 * 147 * 64
+    t_s = time_it(lambda: CV.stem_conv(xs, wps), opt.reps)
+    stem = dict(name="stem.conv1", gflop=sflops / 1e9, fwd_us=t_s, fwd_tf=sflops / t_s / 1e6)
+    if not opt.no_vendor:
+        t_v = time_it(lambda: F.conv2d(xs, ws, stride=2, padding=3), opt.reps)
+        stem["vendor_fwd_us"], stem["vendor_fwd_tf"] = t_v, sflops / t_v / 1e6
+    print({kk: (round(v, 1) if isinstance(v, float) else v) for kk, v in stem.items()}, flush=True)
     tot = lambda f: sum(r[f] * r["count"] for r in rows if f in r)
     summary = dict(frames=n, fwd_ms=tot("fwd_us") / 1e3, dgrad_ms=tot("dgrad_us") / 1e3, vendor_fwd_ms=tot("vendor_fwd_us") / 1e3,
                    gflop=tot("gflop"), fwd_tf=tot("gflop") / tot("fwd_us") * 1e3, dgrad_tf=tot("gflop") / tot("dgrad_us") * 1e3,
                    peak_tf=PEAK)
     print(summary)
     os.makedirs(os.path.dirname(opt.out) or ".", exist_ok=True)
-    json.dump(dict(summary=summary, rows=rows), open(opt.out, "w"), indent=1)
+    json.dump(dict(summary=summary, stem=stem, rows=rows), open(opt.out, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -107,6 +107,11 @@ SIGNATURES = {
     "vitta_conv_num_blocks": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
+    "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
+    "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
+    "vitta_linear_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
+    "vitta_linear_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
     "vitta_tam_pool_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_bwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),

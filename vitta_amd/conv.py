@@ -142,9 +142,40 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if ksplit != 1:
         ws = workspace(x.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(lib().vitta_conv_f32(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_f32")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if TIMING is not None:  # bench.py: one event pair per launch, attached to the kernel's dispatch
+        ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg))
+        check(lib().vitta_conv_timed_f32(C.byref(d), st, ev.start, ev.stop), "vitta_conv_timed_f32")
+        return y
+    check(lib().vitta_conv_f32(C.byref(d), st), "vitta_conv_f32")
     return y
 
 
-__all__ = ["Geometry", "launch", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
+# callable(flops, shape_key) -> ops.KernelEventPair, or None (the product never sets it)
+TIMING = None
+
+
+def pack_stem(w):
+    """[64, 3, 7, 7] stem parameter -> [148][64]: row (c * 7 + kh) * 7 + kw = w[:, c, kh, kw], row 147 zero."""
+    k, c, kh, kw = w.shape
+    if (k, c, kh, kw) != (64, 3, 7, 7):
+        raise _lib.VittaHipError("the stem kernel is Conv2d(3, 64, 7, stride 2, pad 3)")
+    out = torch.zeros(148, 64, dtype=torch.float32, device=w.device)
+    out[:147] = w.detach().permute(1, 2, 3, 0).reshape(147, 64)
+    return out
+
+
+def stem_conv(x, wp):
+    """Raw output [N, 64, OH, OW] of the 7x7 / stride 2 / pad 3 stem convolution of x [N, 3, H, W] (vitta_stem_conv7_f32)."""
+    for t in (x, wp):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+    n, c, h, w = x.shape
+    y = torch.empty(n, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+    check(lib().vitta_stem_conv7_f32(C.c_void_p(x.data_ptr()), C.c_void_p(wp.data_ptr()), n, h, w, C.c_void_p(y.data_ptr()),
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_stem_conv7_f32")
+    return y
+
+
+__all__ = ["Geometry", "launch", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
            "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

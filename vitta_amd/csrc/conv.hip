@@ -15,6 +15,8 @@
 // each other and hit the L1 / L2; each weight slab is read once.  Global -> LDS goes through registers (double-buffered
 // LDS, the next slab's loads are in flight under the current slab's MFMAs, one barrier per slab).
 // Workgroups are numbered so that the N-tiles of one M-tile run on the same XCD (shared A rows in one L2).
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 using namespace vitta;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
-int launch_cfg(const ConvK& a, bool gather, hipStream_t st) {
+int launch_cfg(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds = sizeof(float) * (3 * BK * BM + 3 * BK * BN + 9 * BN +
                                       ((a.d.flags & VITTA_CONV_PRO_BN_RELU) ? 2 * a.d.C : 0));
   const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit)), block(WM * WN * 64);
@@ -559,6 +561,16 @@ int launch_cfg(const ConvK& a, bool gather, hipStream_t st) {
         return VITTA_ERR_LAUNCH;
       raised[v] = true;
     }
+  }
+  if (e0) {  // events attached to this dispatch (bench.py's live per-kernel timing)
+    (void)hipGetLastError();
+    switch (v) {
+      case 0: hipExtLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN, false, false>), grid, block, lds, st, e0, e1, 0, a); break;
+      case 1: hipExtLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN, false, true>), grid, block, lds, st, e0, e1, 0, a); break;
+      case 2: hipExtLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN, true, false>), grid, block, lds, st, e0, e1, 0, a); break;
+      default: hipExtLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WM, WN, true, true>), grid, block, lds, st, e0, e1, 0, a); break;
+    }
+    return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
   }
   switch (v) {
     case 0: VITTA_LAUNCH((conv_igemm_kernel<BM, BN, BK, WM, WN, false, false>), grid, block, lds, st, a); break;
@@ -678,16 +690,26 @@ size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc) {
   return a.ws_need;
 }
 
-int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream) {
+int64_t vitta_conv_flops(const vitta_conv_desc* h_desc) {
+  ConvK a;
+  if (fill(h_desc, a) != VITTA_OK) return -1;
+  return 2ll * a.Mtot * a.d.K * a.d.C * a.d.ntaps;
+}
+
+int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream) { return vitta_conv_timed_f32(h_desc, stream, nullptr, nullptr); }
+
+int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_start, void* ev_stop) {
   ConvK a;
   const int rc = fill(h_desc, a);
   if (rc != VITTA_OK) return rc;
+  if ((ev_start == nullptr) != (ev_stop == nullptr)) return VITTA_ERR_INVALID_ARG;
+  hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool gather = !is_vector_geometry(a.d);
   const int bm = a.d.tile >> 16, bn = a.d.tile & 0xffff;
   const int bk = (a.d.C % 32 == 0) ? 32 : 16;
 #define CFG(M_, N_, K_, WM_, WN_) \
-  if (bm == M_ && bn == N_ && bk == K_) return launch_cfg<M_, N_, K_, WM_, WN_>(a, gather, st)
+  if (bm == M_ && bn == N_ && bk == K_) return launch_cfg<M_, N_, K_, WM_, WN_>(a, gather, st, e0, e1)
   CFG(128, 128, 32, 2, 2);
   CFG(128, 64, 32, 2, 2);
   CFG(64, 64, 32, 2, 2);

@@ -1,0 +1,152 @@
+// The ResNet stem convolution (7x7, stride 2, pad 3, 3 -> 64 channels; torchvision ResNet.conv1 under
+// models/tanet_models/tanet.py:125-150) as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32).
+//
+//   D[k][q] = sum_t Wp[t][k] * X[c(t)][2 oh(q) + kh(t) - 3][2 ow(q) + kw(t) - 3],   t = (c, kh, kw), 147 taps (+1 zero row)
+//
+// Output CHANNELS sit on the MFMA row axis (A operand = weights), output PIXELS on the column axis (B operand = the input
+// patch): a lane of the 32x32 accumulator owns ONE pixel column and 16 channel rows, so every store instruction writes 32
+// consecutive pixels of a channel plane = one 128-byte line per half-wave, and the result lands in the reference's NCHW
+// layout (what stem.hip's BN + ReLU + max-pool pass reads).
+// A workgroup = 256 consecutive output pixels of one frame (linear index q = oh * OW + ow, so any OW works: 112 -> 49
+// tiles per frame) x all 64 channels; 4 waves = 2 channel halves x 2 pixel halves, 4 accumulator tiles each.
+// LDS: the packed weights [148][64] and the input patch [3][PR][PW] of the rows the tile touches (zero padded, patch
+// column 0 = input column -4 so that the 16-byte staging loads are aligned).  The B operand of pixel q, tap t is
+// patch[off(t) + lane_off(q)]: the lane part is fixed for the whole K walk, the tap part is wave-uniform; the stride-2
+// pixel walk maps 32 lanes onto 32 distinct even banks (the other half-wave reads tap t + 1: odd banks).
+#include "common.h"
+
+using namespace vitta;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KT = 148;    // 3 * 7 * 7 taps + one zero row (the MFMA consumes taps in pairs)
+constexpr int NPIX = 256;  // output pixels per workgroup
+
+struct StemConvArgs {
+  const float* x;   // [N][3][H][W]
+  const float* wp;  // [KT][64]
+  float* y;         // [N][64][OH][OW]
+  int H, W, OH, OW;
+  int PR, PW;       // patch rows, row pitch in floats (PW % 4 == 0)
+  int tiles;        // tiles per frame
+};
+
+__device__ __forceinline__ int tap_off(int t, int prpw, int pw) {
+  t = t < 147 ? t : 146;  // the zero row multiplies a finite in-patch value
+  const int c = t / 49, r = t - c * 49, kh = r / 7, kw = r - kh * 7;
+  return c * prpw + kh * pw + kw;
+}
+
+__global__ __launch_bounds__(256) void stem_conv7_kernel(const StemConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;               // [KT][64]
+  float* patch = lds + KT * 64;  // [3][PR][PW]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 31, kk = lane >> 5;
+  const int wm = wave & 1, wg = wave >> 1;
+  const int n = blockIdx.x / a.tiles, tile = blockIdx.x - n * a.tiles;
+  const int q0 = tile * NPIX, npix = a.OH * a.OW;
+  const int r0 = q0 / a.OW, ih0 = 2 * r0 - 3;
+
+  for (int i = tid; i < KT * 16; i += 256) reinterpret_cast<f32x4*>(wl)[i] = reinterpret_cast<const f32x4*>(a.wp)[i];
+  const int pw4 = a.PW >> 2, rows4 = a.PR * pw4, total4 = 3 * rows4;
+  const float* xn = a.x + (int64_t)n * 3 * a.H * a.W;
+  for (int i = tid; i < total4; i += 256) {
+    const int c = i / rows4, rem = i - c * rows4, pr = rem / pw4, p4 = rem - pr * pw4;
+    const int ih = ih0 + pr, iw = p4 * 4 - 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+      v = *reinterpret_cast<const f32x4*>(xn + ((int64_t)c * a.H + ih) * a.W + iw);
+    reinterpret_cast<f32x4*>(patch)[i] = v;
+  }
+
+  // lane part of the patch offset of this lane's pixel in each of its four 32-pixel groups
+  int loff[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    int q = q0 + 32 * (wg * 4 + g) + li;
+    q = q < npix ? q : npix - 1;
+    const int r = q / a.OW, col = q - r * a.OW;
+    loff[g] = (r - r0) * 2 * a.PW + 2 * col + 1;  // + 1: patch column 0 is input column -4, tap kw = 0 reads 2 col - 3
+  }
+  __syncthreads();
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[g][v] = 0.f;
+
+  const int prpw = a.PR * a.PW;
+  const float* wlane = wl + kk * 64 + wm * 32 + li;
+  float af[2], bf[2][4];
+#define READ_STEP(s, slot)                                                          \
+  do {                                                                              \
+    const int o0 = tap_off(2 * (s), prpw, a.PW), o1 = tap_off(2 * (s) + 1, prpw, a.PW); \
+    const float* pk = patch + (kk ? o1 : o0);                                       \
+    af[slot] = wlane[(s) * 128];                                                    \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) bf[slot][g] = pk[loff[g]];        \
+  } while (0)
+  READ_STEP(0, 0);
+#pragma unroll
+  for (int s = 0; s < KT / 2; ++s) {
+    if (s + 1 < KT / 2) READ_STEP(s + 1, (s + 1) & 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1], bf[s & 1][g], acc[g], 0, 0, 0);
+  }
+#undef READ_STEP
+
+  // register v of group g: channel 32 wm + 8 (v / 4) + 4 kk + (v % 4), pixel q0 + 32 (4 wg + g) + li
+  float* yn = a.y + (int64_t)n * 64 * npix;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int q = q0 + 32 * (wg * 4 + g) + li;
+    if (q >= npix) continue;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int ch = 32 * wm + 8 * (v >> 2) + 4 * kk + (v & 3);
+      yn[(int64_t)ch * npix + q] = acc[g][v];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitta_stem_conv7_f32(const float* d_x, const float* d_wp, int64_t N, int32_t H, int32_t W, float* d_y, void* stream) {
+  if (!d_x || !d_wp || !d_y || N <= 0 || H < 7 || W < 7) return VITTA_ERR_INVALID_ARG;
+  if (W % 4) return VITTA_ERR_UNSUPPORTED;
+  StemConvArgs a;
+  a.x = d_x;
+  a.wp = d_wp;
+  a.y = d_y;
+  a.H = H;
+  a.W = W;
+  a.OH = (H - 1) / 2 + 1;
+  a.OW = (W - 1) / 2 + 1;
+  const int npix = a.OH * a.OW;
+  a.tiles = (npix + NPIX - 1) / NPIX;
+  int rows = (NPIX - 1) / a.OW + 2;  // output rows a tile of NPIX consecutive pixels can touch
+  if (rows > a.OH) rows = a.OH;
+  a.PR = 2 * (rows - 1) + 7;
+  a.PW = ((2 * a.OW + 5 + 4 + 3) / 4) * 4;  // taps reach patch column 2 (OW - 1) + 1 + 6, + the zero row's neighbour
+  const size_t lds = sizeof(float) * ((size_t)KT * 64 + (size_t)3 * a.PR * a.PW);
+  if (lds > 160 * 1024 || N * a.tiles > 0x7fffffffll) return VITTA_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv7_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024) != hipSuccess)
+        return VITTA_ERR_LAUNCH;
+      raised = true;
+    }
+  }
+  VITTA_LAUNCH(stem_conv7_kernel, dim3((unsigned)(N * a.tiles)), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  return VITTA_OK;
+}
+
+}  // extern "C"

@@ -774,3 +774,38 @@ class FusedStemPool(torch.autograd.Function):
                                                                                                running_var), ctx.eps, n, c, h, w,
                                                            _p(dw), _p(db), _stream()), "vitta_stem_bn_relu_pool_bwd_affine_f32")
         return (None, r_w if ctx.needs_input_grad[1] else None, r_b if ctx.needs_input_grad[2] else None, None, None, None)
+
+
+class HeadLinear(torch.autograd.Function):
+    """y = x @ weight.T + bias for the handful of pooled frame features of the classification head (vitta_linear_*_f32,
+    models/tanet_models/tanet.py:243-251).  Parameter gradients go straight into their `.grad` storage (_grad_sink)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_cuda_f32(x, "x")
+        _require_cuda_f32(weight, "weight")
+        x = x.contiguous()
+        m, k = x.shape
+        n = weight.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        check(lib().vitta_linear_fwd_f32(_p(x), _p(weight), _p(bias), m, n, k, _p(y), _stream()), "vitta_linear_fwd_f32")
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias = ctx.saved_tensors
+        m, k = x.shape
+        n = weight.shape[0]
+        gy = gy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw, r_w = _grad_sink(weight, ctx.needs_input_grad[1])
+        db, r_b = _grad_sink(bias, bias is not None and ctx.needs_input_grad[2])
+        check(lib().vitta_linear_bwd_f32(_p(gy), _p(x), _p(weight), m, n, k, _p(dx), _p(dw), _p(db), _stream()),
+              "vitta_linear_bwd_f32")
+        return dx, r_w, r_b
+
+
+def head_linear_supported(x, linear):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[0] <= 4096
+            and linear.weight.dtype == torch.float32 and not linear._forward_hooks and not linear._forward_pre_hooks)

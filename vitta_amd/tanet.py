@@ -192,7 +192,12 @@ class TSN(nn.Module):
             input = input.view((-1, sample_len) + input.size()[-2:])
         base_out = self.base_model(input)
         if self.dropout > 0:
-            base_out = self.new_fc(base_out)
+            from . import fused_bn, ops
+            fc = self.new_fc
+            if fused_bn.ENABLED and ops.head_linear_supported(base_out, fc):
+                base_out = ops.HeadLinear.apply(base_out, fc.weight, fc.bias)  # head.hip
+            else:
+                base_out = fc(base_out)
         base_out = base_out.view((-1, self.num_segments) + base_out.size()[1:])
         return self.consensus(base_out).squeeze(1)
 

@@ -118,7 +118,9 @@ class TrunkRunner:
         mp, c1 = net.maxpool, net.conv1
         if net._forward_hooks or net._forward_pre_hooks or not isinstance(mp, nn.MaxPool2d) or mp._forward_hooks \
                 or (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) != (3, 2, 1, 1, False) \
-                or net.relu._forward_hooks or c1._forward_hooks or c1.weight.requires_grad \
+                or net.relu._forward_hooks or c1._forward_hooks or c1.weight.requires_grad or c1.bias is not None \
+                or (tuple(c1.weight.shape), c1.stride, c1.padding, c1.dilation, c1.groups) != ((64, 3, 7, 7), (2, 2), (3, 3), (1, 1), 1) \
+                or x.shape[3] % 4 \
                 or not isinstance(net.bn1, nn.BatchNorm2d) or net.bn1.training or not net.bn1.affine \
                 or x.shape[0] * 64 > 65535:
             return False
@@ -179,7 +181,7 @@ class TrunkRunner:
         hit = self._packed.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                hit = (tag, CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
+                hit = (tag, CV.pack_stem(w) if kind == "s" else CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
             self._packed[key] = hit
         return hit[1]
 
@@ -229,12 +231,11 @@ class TrunkRunner:
 
     # -- forward -----------------------------------------------------------------------------------------------
     def stem(self, x):
-        """conv1 -> bn1 -> relu -> maxpool: (raw convolution output NCHW, pooled NCHW).  The 7x7 convolution is still the
-        library's; the BN + ReLU + max-pool pass is stem.hip."""
+        """conv1 -> bn1 -> relu -> maxpool: (raw convolution output NCHW, pooled NCHW): stem_conv.hip, then the BN + ReLU +
+        max-pool pass of stem.hip."""
         from .ops import _ptr4
         net, bn = self.net, self.net.bn1
-        with torch.no_grad():
-            y = net.conv1(x).contiguous()
+        y = CV.stem_conv(x.contiguous(), self.packed(net.conv1, "s"))
         n, c, h, w = y.shape
         pooled = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=y.device)
         check(lib().vitta_stem_bn_relu_pool_fwd_f32(_p(y), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
