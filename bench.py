@@ -13,13 +13,20 @@ evaluation forward of the same video (centre view).  `value` = videos of all ran
 wall time of the K timed steps (barrier + synchronize on both sides).
 
 Extra objects on the JSON line:
-  roofline      the north-star kernel, moments_nchw_partial_kernel (one launch over all 29 hooked
-                layers): algorithmic bytes = 4 B x 44 556 288 hooked elements per video,
-                time = a hipEvent pair attached to that kernel's dispatch (hipExtLaunchKernelGGL via
-                vitta_moments_partials_timed_f32) in every timed step: the kernel's own duration, the
-                figure rocprofv3 --kernel-trace reports for the same launches.  The hooked tensors were just written by the BN kernels and fit the 256 MiB
-                Infinity Cache, so `achieved` is an on-die rate; `streaming` repeats the launch on
-                2.85 GB of features (16 videos' worth per layer) that cannot be cache resident.
+  roofline      the dominant kernel of the timed step, conv_igemm_kernel (vitta_conv_f32: every bottleneck
+                convolution of the trunk, forward and data gradient, ~71 % of the step's kernel time), bound
+                "mfma": achieved = algorithmic flops of the step's convolution launches / the sum of their
+                durations, each duration from a hipEvent pair attached to that launch's own dispatch
+                (vitta_conv_timed_f32 -> hipExtLaunchKernelGGL; a kernel inside a replayed hipGraph cannot carry
+                events, so the timed steps are repeated eagerly with the same kernels for this); peak = 157.3
+                TFLOP/s, the fp32 matrix rate (v_mfma_f32_32x32x2_f32, the instruction the kernel issues).
+                roofline.moments: the north-star statistics kernel, moments_nchw_partial_kernel (one launch over all
+                29 hooked layers; in the TANet step its work rides in the convolution epilogues, so it is timed
+                stand-alone): `one_video` = 178 MB (4 B x 44 556 288 hooked elements; fits the Infinity
+                Cache), `streaming` = 2.85 GB that cannot be cache resident, against 8 TB/s.
+  sgd_all       the same iteration under the reference's DEFAULT optimizer (SGD over all parameters,
+                corpus/basics.py:547-560), timed in the same run after the headline configuration.
+  ranks         what every rank saw: torch.distributed world size and its device (for the driver to verify N ranks).
   cpu_baseline  the CPU restatement of the reference path (oracle/: stock PyTorch CPU ops in the
                 reference's op order), same workload, a few steps on the host cores of this box.
 """
@@ -40,6 +47,7 @@ if ROOT not in sys.path:
 
 HOOKED_ELEMENTS_PER_VIDEO = 44556288  # 29 BN2d outputs of layer3/4 at 2x8x224^2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3  # same guide: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4), 155 TF measured
 
 
 _T0 = time.time()
@@ -59,6 +67,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--no-streaming", action="store_true")
+    p.add_argument("--no-sgd-all", action="store_true", help="skip the second (SGD over all parameters) timing")
     p.add_argument("--timed-only", action="store_true",
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
                         "the tail of a rocprofv3 trace is the shipped hipGraph replay and nothing else")
@@ -242,31 +251,59 @@ def run_gpu(opt, rank, world, device):
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps ({'hipGraph replay' if use_graph else 'eager'})")
     eager_elapsed = float("nan")
+    run_gpu.conv = None
     if opt.timed_only:
         run_gpu.mode, run_gpu.eager_ms = ("hipGraph replay" if use_graph else "eager launches"), None
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
         return elapsed, float("nan"), float("nan"), None, adapter
+    conv_events = []
     if use_graph:
-        # A kernel inside a replayed graph cannot be bracketed by events; its duration does not depend
-        # on how it was launched, so the K steps are repeated eagerly (same videos, same kernels) with an
-        # event pair around the moments kernel of every step.
-        # In the shipped step the moments of the hooked layers ride on the fused BN pass (no launch of their
-        # own, no extra traffic); for the roofline line the stand-alone kernel is timed on the same features,
-        # so the repeat runs with the BN fusion off.
-        from vitta_amd import fused_bn, fused_ln
-        fused_bn.ENABLED = fused_ln.ENABLED = False
+        # A kernel inside a replayed graph cannot be bracketed by events; its duration does not depend on how it was
+        # launched, so the K steps are repeated eagerly (same videos, same kernels) with an event pair attached to the
+        # dispatch of every convolution launch (TANet: the dominant kernel) / of the moments kernel (Swin).
+        from vitta_amd import conv as CV, fused_bn, fused_ln
         graph, adapter._graph = adapter._graph, None
         plan_of_graph = adapter.engine.plan  # the captured graphs write this plan's buffers (the eager exchanges read them)
-        adapter.engine.timing_events = new_events
+        if opt.arch == "swin":
+            fused_bn.ENABLED = fused_ln.ENABLED = False  # stand-alone moments kernel on the hooked LayerNorm outputs
+            adapter.engine.timing_events = new_events
+        else:
+            def conv_timing(flops, key):
+                ev = ops.KernelEventPair()
+                conv_events.append((flops, key, ev))
+                return ev
+            CV.TIMING = conv_timing
         barrier()
         te = time.perf_counter()
-        for i in range(opt.steps):
+        n_rep = opt.steps if opt.arch == "swin" else min(opt.steps, 12)
+        for i in range(n_rep):
             one_step(opt.warmup + i)
         barrier()
-        eager_elapsed = time.perf_counter() - te
+        eager_elapsed = (time.perf_counter() - te) * opt.steps / n_rep
+        CV.TIMING = None
         adapter._graph = graph
         adapter.engine.plan = plan_of_graph
         fused_bn.ENABLED = fused_ln.ENABLED = True
-        log(f"eager repeat of the timed steps (kernel events): {eager_elapsed:.3f}s")
+        log(f"eager repeat of {n_rep} timed steps (kernel events): {eager_elapsed:.3f}s per {opt.steps}")
+        run_gpu.conv = None
+        if conv_events:
+            torch.cuda.synchronize()
+            fl = np.array([f for f, _, _ in conv_events], dtype=np.float64)
+            ms = np.array([ev.elapsed_ms() for _, _, ev in conv_events], dtype=np.float64)
+            by_shape = {}
+            for (f, key, _), t in zip(conv_events, ms):
+                r = by_shape.setdefault(key, [0, 0.0, 0.0])
+                r[0] += 1
+                r[1] += f
+                r[2] += t
+            run_gpu.conv = dict(launches=len(fl), steps=n_rep, flops=float(fl.sum()), ms=float(ms.sum()),
+                                by_shape=[dict(C=k[0], K=k[1], taps=k[2], positions=k[3], launches_per_step=v[0] / n_rep,
+                                               avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9)
+                                          for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][2])])
+            conv_events.clear()
     adapter.engine.timing_events = None
     torch.cuda.synchronize()
     kern_ms = float(np.mean([p.elapsed_ms() for p in pairs])) if pairs else float("nan")
@@ -308,8 +345,11 @@ def run_gpu(opt, rank, world, device):
         adapt_only = (time.perf_counter() - t1) / max(4, opt.steps // 3)
 
     streaming = None
+    run_gpu.one_video = None
     if rank == 0 and not opt.no_streaming:
         streaming = streaming_moments(adapter, device)
+        if opt.arch == "tanet":  # the in-step size (one video's hooked features, Infinity-Cache resident)
+            run_gpu.one_video = streaming_moments(adapter, device, copies=1, reps=30, target_blocks=None)
         log("streaming-size moments done")
     run_gpu.mode = ("hipGraph replay" + (" (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph) else "")) \
         if use_graph else "eager launches"
@@ -317,7 +357,7 @@ def run_gpu(opt, rank, world, device):
     return elapsed, kern_ms, adapt_only, streaming, adapter
 
 
-def streaming_moments(adapter, device, copies=16, reps=20):
+def streaming_moments(adapter, device, copies=16, reps=20, target_blocks=4096):
     """The same batched launch on features that cannot be cache resident: every hooked layer with
     `copies` videos' worth of frames (16 x 178 MB = 2.85 GB >> 256 MiB Infinity Cache)."""
     from vitta_amd import ops
@@ -325,7 +365,7 @@ def streaming_moments(adapter, device, copies=16, reps=20):
     shapes = [(outer * copies, c, inner, layout) for outer, c, inner, layout in base]
     # twice the workgroups of the in-step launch (same speed at this size): the two show up as separate lines of a
     # rocprofv3 summary split by launch geometry
-    plan = ops.StatPlan(shapes, device, target_blocks=4096)
+    plan = ops.StatPlan(shapes, device, target_blocks=target_blocks) if target_blocks else ops.StatPlan(shapes, device)
     feats = [torch.randn(outer * c * inner, device=device) for outer, c, inner, _ in shapes]
     nbytes = 4 * sum(f.numel() for f in feats)
     shift = torch.zeros(plan.total_channels, device=device)
@@ -405,13 +445,25 @@ def main():
     # per conv shape); the bench keeps MIOpen's default immediate mode
 
     elapsed, kern_ms, adapt_only, streaming, adapter = run_gpu(opt, rank, world, device)
+    mode, eager_ms, conv, one_video = run_gpu.mode, run_gpu.eager_ms, run_gpu.conv, getattr(run_gpu, "one_video", None)
     videos = opt.steps * world
     value = videos / elapsed
+
+    # what every rank saw (the driver can verify N ranks on N devices)
+    props = torch.cuda.get_device_properties(device)
+    mine = dict(rank=rank, local_rank=local, device_index=device.index, device=props.name,
+                pci_bus_id=getattr(props, "pci_bus_id", None),
+                dist_world_size=torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                dist_backend=torch.distributed.get_backend() if torch.distributed.is_initialized() else None)
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, mine)
+
     if opt.arch == "swin":
         algo_bytes = 4.0 * sum(o * c * i for o, c, i, _ in adapter.engine.plan.shapes)  # 253.7 MB at 2x16x224^2
     else:
         algo_bytes = 4 * HOOKED_ELEMENTS_PER_VIDEO * (opt.size / 224.0) ** 2 * (opt.clip_length / 8.0)
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
 
     # HBM traffic of the moments launch from the PMC passes committed under profiles/ (bench.py itself
     # cannot run rocprofv3 --pmc): corrected read bytes + write bytes of the in-step (1 video) launch
@@ -420,6 +472,46 @@ def main():
     if os.path.exists(pmc_file) and opt.size == 224 and opt.clip_length == 8 and opt.arch == "tanet":
         pmc = json.load(open(pmc_file))["in_step_1_video"]
         traffic = pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]
+
+    if opt.arch == "swin":
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms == kern_ms else None
+        roofline = {"kernel": "moments_nhwc_partial_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                    "algorithmic_bytes": algo_bytes, "avg_ms": kern_ms, "streaming": streaming}
+    else:
+        moments = {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch; stand-alone: in the TANet step the "
+                             "hooked moments ride in the convolution epilogues)",
+                   "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "one_video": one_video, "streaming": streaming,
+                   "traffic_one_video": traffic,
+                   "traffic_source": "profiles/r1_moments_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per "
+                                     "the gfx950 note)"}
+        if conv:
+            tf = conv["flops"] / conv["ms"] / 1e9
+            conv_pmc = None
+            cpf = os.path.join(ROOT, "profiles", "r2_conv_traffic_pmc.json")
+            if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
+                conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
+            roofline = {"kernel": "conv_igemm_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, forward + "
+                                  "data gradient + evaluation forward)",
+                        "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": tf / MFMA_F32_PEAK_TF, "traffic": conv_pmc,
+                        "traffic_source": "profiles/r2_conv_traffic_pmc.json" if conv_pmc else None,
+                        "launches_per_step": conv["launches"] / conv["steps"],
+                        "algorithmic_flops_per_launch": conv["flops"] / conv["launches"],
+                        "avg_launch_us": 1e3 * conv["ms"] / conv["launches"],
+                        "algorithmic_flops_per_step": conv["flops"] / conv["steps"],
+                        "kernel_ms_per_step": conv["ms"] / conv["steps"],
+                        "share_of_step": conv["ms"] / conv["steps"] / (1e3 * elapsed / opt.steps),
+                        "note": "per-launch durations from hipEvent pairs attached to each dispatch in an eager repeat of "
+                                "the timed steps (a replayed hipGraph cannot carry events); flops = 2 x output positions "
+                                "x C x K x taps per launch (vitta_conv_flops); share_of_step > what a serial schedule "
+                                "would allow where the evaluation stream overlaps the adaptation stream",
+                        "by_shape": conv["by_shape"][:12], "moments": moments, "streaming": streaming}
+        else:
+            ov = one_video or {}
+            roofline = {"kernel": moments["kernel"], "bound": "hbm", "achieved": ov.get("achieved"), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ov.get("frac"), "traffic": traffic, "algorithmic_bytes": algo_bytes,
+                        "avg_ms": ov.get("ms"), "streaming": streaming, "moments": moments}
 
     line = {
         "metric": f"videos/sec TTA step (TANet-R50, 2x{opt.clip_length}x{opt.size}^2), whole job", "value": value,
@@ -435,16 +527,8 @@ def main():
                    "schedule": "sequential: adapt(i); eval(i)" if opt.sequential else
                                "overlapped: eval(i-1) on a second stream beside adapt(i), optimizer update after both "
                                "(same weights and results as the sequential order)"},
-        "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "launch_mode": run_gpu.mode, "eager_ms_per_step": run_gpu.eager_ms,
-        "roofline": {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch)", "bound": "hbm",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                     "traffic_source": "profiles/r1_moments_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per the gfx950 note)",
-                     "algorithmic_bytes": algo_bytes, "avg_ms": kern_ms,
-                     "note": "stand-alone batched kernel timed on the step's own hooked features (Infinity-Cache "
-                             "resident: 178 MB just written); in the shipped step these moments ride on the fused "
-                             "BN pass (bn_act_fwd_kernel) at zero extra traffic",
-                     "streaming": streaming},
+        "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "launch_mode": mode, "eager_ms_per_step": eager_ms,
+        "roofline": roofline, "ranks": ranks,
     }
     if opt.arch == "swin":
         n_ln = len(adapter.engine.hooks)
@@ -456,14 +540,24 @@ def main():
             else "SGD all parameters"
         line["config"]["exchanges"] = "moments all-reduce + gradient all-reduce" if world > 1 else "none"
         line["roofline"]["kernel"] = f"moments_nhwc_partial_kernel ({n_ln} layers, 1 launch)"
-        line["roofline"]["traffic_source"] = None
         line["config"]["gemm_selection"] = ("measured table vitta_amd/tuning (hipBLASLt / rocBLAS solution per shape, no search at "
                                             "run time)") if opt.tuned_gemms else "library default"
         line["roofline"]["note"] = ("stand-alone batched kernel timed on the step's own hooked LayerNorm outputs; in the "
                                     "shipped step these moments ride on the fused LayerNorm pass (ln_fwd_kernel)")
-    if rank == 0 and world == 1 and not opt.no_cpu_baseline and opt.arch == "tanet":
-        del adapter
+    del adapter
+    torch.cuda.empty_cache()
+    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_sgd_all and not opt.timed_only:
+        # report both optimizer modes -- the reference's default (SGD over every parameter) in the same run
+        import copy
+        o2 = copy.copy(opt)
+        o2.optimizer, o2.timed_only = "sgd_all", True
+        log("second timing: SGD over all parameters ...")
+        e2 = run_gpu(o2, rank, world, device)[0]
+        line["sgd_all"] = {"value": videos / e2, "unit": "videos/s", "ms_per_step": 1e3 * e2 / opt.steps, "steps": opt.steps,
+                           "optimizer": "SGD all parameters (reference default, corpus/basics.py:547-560)",
+                           "launch_mode": run_gpu.mode}
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not opt.no_cpu_baseline and opt.arch == "tanet":
         log("cpu baseline ...")
         line["cpu_baseline"] = run_cpu_baseline(opt)
         log("cpu baseline done")

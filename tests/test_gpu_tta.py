@@ -225,9 +225,9 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
 
 def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
     """BASELINE config 5 shape in small: Video Swin-B, window (16,7,7), 4 views x 32 frames.  N = 784 tokens per
-    window at the first stages exceeds the fused W-MSA kernel's 400 -> composed GPU ops there, fused kernel at
-    the clamped later stages; LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU
-    with the oracle backend."""
+    window at the first stages: the CHUNKED W-MSA kernels (keys / queries walked in chunks of 400, online softmax)
+    run there -- asserted below by spying on the C-ABI entry --, the single-pass kernels at the clamped later stages;
+    LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU with the oracle backend."""
     import numpy as np
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, scripts, tta
@@ -252,14 +252,27 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
     args.update_only_bn_affine, args.lr = True, 1e-4
     x = data.SyntheticVideoDataset(1, views, T, size, 174, "swin", seed0=40)[0][0].unsqueeze(0)
     res = {}
-    for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
-        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(dev), args, engine_backend=backend)
-        adapter.set_adapt_mode()
-        _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(dev)))
-        named = dict(adapter.model.named_parameters())
-        res[dev.type] = (float(loss_reg), float(loss_consis),
-                         named["module.backbone.layers.2.blocks.4.norm1.weight"].grad.cpu().clone(),
-                         named["module.backbone.norm.bias"].grad.cpu().clone())
+    from vitta_amd import _lib
+    L = _lib.lib()
+    orig, seen = L.vitta_wmsa_rel_fwd_f32, []
+
+    def spy(*a):
+        seen.append(int(a[8]))  # tokens per window of this launch
+        return orig(*a)
+
+    L.vitta_wmsa_rel_fwd_f32 = spy
+    try:
+        for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
+            adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(dev), args, engine_backend=backend)
+            adapter.set_adapt_mode()
+            _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(dev)))
+            named = dict(adapter.model.named_parameters())
+            res[dev.type] = (float(loss_reg), float(loss_consis),
+                             named["module.backbone.layers.2.blocks.4.norm1.weight"].grad.cpu().clone(),
+                             named["module.backbone.norm.bias"].grad.cpu().clone())
+    finally:
+        L.vitta_wmsa_rel_fwd_f32 = orig
+    assert seen.count(784) == 22, sorted(set(seen))  # stages 1-3 (2 + 2 + 18 blocks): N = 784, the chunked kernels
     c, gdev = res["cpu"], res["cuda"]
     assert gdev[0] == pytest.approx(c[0], rel=2e-5) and gdev[1] == pytest.approx(c[1], rel=1e-3, abs=1e-6)
     for a, b in zip(gdev[2:], c[2:]):
