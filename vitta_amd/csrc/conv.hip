@@ -17,36 +17,14 @@
 // Workgroups are numbered so that the N-tiles of one M-tile run on the same XCD (shared A rows in one L2).
 #include <hip/hip_ext.h>
 
-#include "common.h"
+#include <cstdlib>
+
+#include "conv_common.h"
 
 using namespace vitta;
+using namespace vitta_conv;
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PRO_MAX = 2048;  // input channels whose prologue BatchNorm constants are held in LDS
-
-struct ConvK {
-  vitta_conv_desc d;
-  int64_t xP, yP, rP;  // pixels per channel row of x, y, res
-  int Mtot;            // N * Hg * Wg
-  int nMt, nNt;        // tiles
-  int contig;          // 1: output pixel index == M index (float4 epilogue)
-  int tap[VITTA_CONV_MAX_TAPS];  // (dh & 0xff) | (dw & 0xff) << 8 | weight slot << 16
-  int ksplit;          // workgroups sharing one output tile (each walks 1 / ksplit of the K slabs)
-  unsigned* cnt;       // [nMt * nNt] arrival counters (zero at rest)
-  float* slabs;        // [nMt * nNt][ksplit][BM * BN] partial accumulators
-  size_t ws_need;      // host only
-};
-
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {
-  // dispatcher places workgroup b on XCD b % 8: give every XCD a contiguous range of logical ids (bijective for any nwg)
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 template <int BM, int BN, int BK, int WM, int WN, bool GATHER, bool PRO>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) {
@@ -593,6 +571,30 @@ bool is_vector_geometry(const vitta_conv_desc& d) {
 constexpr int MAX_SPLIT_TILES = 16384;
 size_t counter_bytes(int) { return (size_t)MAX_SPLIT_TILES * sizeof(unsigned); }
 
+// workgroups of the 64 x 64 x 32 configuration the chip holds at once: 3 per CU (LDS: 3 x 49 KB)
+int resident_slots() {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0)
+      cus = 256;
+    (void)hipGetLastError();
+    slots = 3 * cus;
+  }
+  return slots;
+}
+
+// VITTA_CONV_STREAM_K=0 keeps the tile-per-workgroup kernels (A/B measurements)
+bool sk_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VITTA_CONV_STREAM_K");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
 void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
   if (d.tile) {
     bm = d.tile >> 16;
@@ -659,6 +661,27 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   a.ws_need = need;
   a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
   a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
+  // Persistent stream-K form (conv_sk.hip) for the 64 x 64 x 32 configuration whenever the caller left tile and split to
+  // the library and lent a workspace: as many workgroups as the chip holds at once (3 per CU), each walking an equal
+  // share of the launch's K-slabs.  Short-K launches (< 4 slabs per tile) and launches with >= 8 tiles per workgroup
+  // keep their ranges on tile boundaries (no partial tiles).
+  a.sk_G = a.sk_aligned = 0;
+  if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && d.workspace && tiles <= MAX_SPLIT_TILES && sk_enabled() &&
+      (int64_t)d.C * a.xP * 4 < (1ll << 31)) {  // buffer addressing: 31-bit byte offsets into x
+    const int64_t units = (int64_t)tiles * nslab;
+    int G = (int)(units < resident_slots() ? units : resident_slots());
+    const int aligned = (nslab < 4 || tiles >= 8 * G) ? 1 : 0;
+    if (aligned && G > tiles) G = tiles;
+    const size_t sk_need = counter_bytes(tiles) + (size_t)G * 2 * 64 * 64 * sizeof(float);
+    if ((size_t)d.workspace_bytes >= sk_need) {
+      a.sk_G = G;
+      a.sk_aligned = aligned;
+      a.ksplit = 1;
+      a.ws_need = sk_need;
+      a.cnt = static_cast<unsigned*>(d.workspace);
+      a.slabs = reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles));
+    }
+  }
   for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t)
     a.tap[t] = t < d.ntaps ? ((d.dh[t] & 0xff) | ((d.dw[t] & 0xff) << 8) | ((int)d.wt[t] << 16)) : 0;
   return VITTA_OK;
@@ -706,6 +729,7 @@ int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_s
   hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool gather = !is_vector_geometry(a.d);
+  if (a.sk_G) return launch_stream_k(a, gather, st, e0, e1);
   const int bm = a.d.tile >> 16, bn = a.d.tile & 0xffff;
   const int bk = (a.d.C % 32 == 0) ? 32 : 16;
 #define CFG(M_, N_, K_, WM_, WN_) \

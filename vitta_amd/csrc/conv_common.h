@@ -1,0 +1,37 @@
+// Shared between conv.hip (tile-per-workgroup kernels) and conv_sk.hip (persistent stream-K kernel).
+#pragma once
+#include "common.h"
+
+namespace vitta_conv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PRO_MAX = 2048;  // input channels whose prologue BatchNorm constants are held in LDS
+
+struct ConvK {
+  vitta_conv_desc d;
+  int64_t xP, yP, rP;  // pixels per channel row of x, y, res
+  int Mtot;            // N * Hg * Wg
+  int nMt, nNt;        // tiles
+  int contig;          // 1: output pixel index == M index (float4 epilogue)
+  int tap[VITTA_CONV_MAX_TAPS];  // (dh & 0xff) | (dw & 0xff) << 8 | weight slot << 16
+  int ksplit;          // workgroups sharing one output tile (each walks 1 / ksplit of the K slabs)
+  unsigned* cnt;       // [nMt * nNt] arrival counters (zero at rest)
+  float* slabs;        // [nMt * nNt][ksplit][BM * BN] partial accumulators (stream-K: [workgroups][2][BM * BN])
+  size_t ws_need;      // host only
+  int sk_G;            // stream-K: persistent workgroups (0: the tile-per-workgroup kernels)
+  int sk_aligned;      // stream-K: unit ranges end on tile boundaries (no partial tiles)
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  // dispatcher places workgroup b on XCD b % 8: give every XCD a contiguous range of logical ids (bijective for any nwg)
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// conv_sk.hip
+int launch_stream_k(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+
+}  // namespace vitta_conv

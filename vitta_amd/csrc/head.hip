@@ -1,6 +1,6 @@
 // The classification head of the TANet path: new_fc = Linear(2048 -> num_class) on the [frames, 2048] pooled features
 // (models/tanet_models/tanet.py:105-123, 243-251).  A [16 x 2048] x [2048 x 101] product is microseconds of HBM / L2
-// traffic and far too small for a matrix-core tile walk; what it costs is latency, so it is a wave-per-output dot product
+// traffic and far too small for a matrix-core tile walk; what it costs is latency, so it is a wave-per-output-element dot product
 // (forward), a thread-per-element walk over the classes (data gradient) and over the frames (weight gradient).
 //   y[m][n] = b[n] + sum_k x[m][k] w[n][k]
 #include "common.h"
@@ -9,31 +9,29 @@ using namespace vitta;
 
 namespace {
 
+// one wave per output element (m, n): M * N waves of K / 256 float4 loads per lane (x and w rows stay in L2)
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ b, float* __restrict__ y, int M, int N, int K) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
+  const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= (int64_t)M * N) return;
+  const int m = (int)(o / N), n = (int)(o - (int64_t)m * N);
   const float4* wr = reinterpret_cast<const float4*>(w + (int64_t)n * K);
-  const float bias = b ? b[n] : 0.f;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)m * K);
   const int k4n = K >> 2;
-  for (int m0 = 0; m0 < M; m0 += 4) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k4 = lane; k4 < k4n; k4 += 64) {
-      const float4 wv = wr[k4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (m0 + u < M) {
-          const float4 xv = reinterpret_cast<const float4*>(x + (int64_t)(m0 + u) * K)[k4];
-          s[u] = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, s[u]))));
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float t = wave_sum(s[u]);
-      if (lane == 0 && m0 + u < M) y[(int64_t)(m0 + u) * N + n] = t + bias;
-    }
+  float s0 = 0.f, s1 = 0.f;
+  int k4 = lane;
+  for (; k4 + 64 < k4n; k4 += 128) {
+    const float4 w0 = wr[k4], x0 = xr[k4], w1 = wr[k4 + 64], x1 = xr[k4 + 64];
+    s0 = fmaf(x0.x, w0.x, fmaf(x0.y, w0.y, fmaf(x0.z, w0.z, fmaf(x0.w, w0.w, s0))));
+    s1 = fmaf(x1.x, w1.x, fmaf(x1.y, w1.y, fmaf(x1.z, w1.z, fmaf(x1.w, w1.w, s1))));
   }
+  for (; k4 < k4n; k4 += 64) {
+    const float4 w0 = wr[k4], x0 = xr[k4];
+    s0 = fmaf(x0.x, w0.x, fmaf(x0.y, w0.y, fmaf(x0.z, w0.z, fmaf(x0.w, w0.w, s0))));
+  }
+  const float t = wave_sum(s0 + s1);
+  if (lane == 0) y[o] = t + (b ? b[n] : 0.f);
 }
 
 // dx[m][k] = sum_n dy[m][n] w[n][k]
@@ -93,7 +91,7 @@ int vitta_linear_fwd_f32(const float* d_x, const float* d_w, const float* d_b, i
                          void* stream) {
   if (!d_x || !d_w || !d_y || M <= 0 || N <= 0 || K <= 0) return VITTA_ERR_INVALID_ARG;
   if (K % 4 || M > (1 << 20)) return VITTA_ERR_UNSUPPORTED;
-  VITTA_LAUNCH(linear_fwd_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x, d_w, d_b,
+  VITTA_LAUNCH(linear_fwd_kernel, dim3((unsigned)((M * N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x, d_w, d_b,
                d_y, (int)M, N, K);
   return VITTA_OK;
 }
