@@ -262,6 +262,21 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
                              const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                              float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* stream);
+/* The same two passes with their two launches each fused into ONE (F1 -> F2, B1 -> B2): the workgroups of a clip meet on a
+ * device-scope counter inside the launch (the second half's staging -- and in the backward the whole G branch -- runs while
+ * the first half's tiles finish).  d_sync: >= 2 * N uint32, ZERO when first used (the kernels leave it zero), not shared by
+ * launches that may run concurrently (one per stream).  Results are bit-identical to the unfused entry points.
+ * VITTA_ERR_UNSUPPORTED when the launch could not be resident at once (N * tiles > 512 or LDS > 160 KiB). */
+int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                                   const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
+                                   float* d_hpre, void* d_sync, void* stream);
+int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                                   const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
+                                   const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
+                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, void* stream);
+
 
 /* --------------------------------------------------------------------------
  * A8 glue -- eval-mode BatchNorm2d fused with its neighbours and with the ViTTA statistics.
@@ -434,6 +449,40 @@ int64_t vitta_conv_flops(const vitta_conv_desc* h_desc);
 size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
 /* Workgroups the launch of this descriptor would use (for tile selection / tests). */
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
+
+/* --------------------------------------------------------------------------
+ * A8 -- weight gradients of the same convolutions (the reference's default optimizer trains every parameter,
+ * corpus/basics.py:547-560):   grad_w[k][c][wt[t]] += sum_p A[c][src(p, t)] * dy[k][p]
+ * over the N * Hg * Wg output positions p of the forward convolution; A = x, or relu(bn(x)) with VITTA_CONV_PRO_BN_RELU
+ * (pro_bn as in vitta_conv_desc).  x [C][N * Hs * Ws] and dy [K][N * Hg * Wg] are channel-major planes; grad_w is the
+ * parameter's own [K][C][wtaps] layout (wtaps = kh * kw) and is ACCUMULATED with atomics (may point into .grad).
+ * Tap t reads source pixel (i * sstride + dh[t], j * sstride + dw[t]) of output position (i, j).  Unless the convolution
+ * is pointwise with stride 1, the caller supplies two per-position tables (device, int32 [N * Hg * Wg]):
+ *   src_off[p]  = n * Hs * Ws + (i * sstride) * Ws + j * sstride        (source pixel of tap (0, 0))
+ *   src_mask[p] = bit t set when tap t's source pixel lies inside the plane.
+ * C % 64 == 0, K % 64 == 0, pixel counts % 4 == 0.
+ * -------------------------------------------------------------------------- */
+typedef struct vitta_wgrad_desc {
+  const float* x;
+  const float* dy;
+  float* grad_w;
+  const float* pro_bn[4];
+  float pro_eps;
+  const int32_t* src_off;
+  const int32_t* src_mask;
+  int32_t C, K, N;
+  int32_t Hs, Ws, Hg, Wg;
+  int32_t sstride;
+  int32_t ntaps, wtaps;
+  int8_t dh[VITTA_CONV_MAX_TAPS], dw[VITTA_CONV_MAX_TAPS], wt[VITTA_CONV_MAX_TAPS];
+  int32_t flags; /* VITTA_CONV_PRO_BN_RELU or 0 */
+  /* optional scratch (>= 768 x 32 KiB = 24 MiB on an MI355X; no initial content required, one per stream): the workgroups'
+   * partial tiles meet there and a second launch adds them to grad_w in a fixed order; without it every partial tile is
+   * added to grad_w with atomics (thousands of adds per weight on the small early layers) */
+  void* workspace;
+  int64_t workspace_bytes;
+} vitta_wgrad_desc;
+int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
 
 /* --------------------------------------------------------------------------
  * A8 / A9 on channel-major planes (the layout of vitta_conv_f32: tensor[c][f * HW + hw], f = n * T + t).

@@ -261,3 +261,29 @@ def test_head_linear_forward_and_gradients(m, n, k):
     xg2 = x.to(d).requires_grad_()
     ops.HeadLinear.apply(xg2, wt.to(d), b.to(d)).backward(gy.to(d))
     _close(xg2.grad, xr.grad)
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz,stride,pro", [
+    (4, 64, 64, 56, 1, 1, False), (16, 256, 64, 14, 1, 1, False), (2, 64, 256, 28, 1, 1, True), (8, 512, 128, 7, 1, 1, True),
+    (4, 64, 64, 28, 3, 1, False), (16, 256, 256, 14, 3, 1, False), (8, 128, 128, 28, 3, 2, False), (16, 512, 512, 7, 3, 1, False),
+    (4, 256, 512, 28, 1, 2, False), (3, 64, 128, 10, 3, 1, False), (4, 64, 64, 9, 3, 2, False), (1, 128, 64, 6, 1, 1, False)])
+def test_weight_gradient_matches_fp64_autograd(n, c, k, h, ksz, stride, pro):
+    """vitta_conv_wgrad_f32 (conv_wgrad.hip) against the fp64 autograd weight gradient, ACCUMULATED onto a non-zero buffer;
+    `pro`: the forward applied relu(bn(x)) on load, so does the gradient."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n + c + k + h + ksz)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    pad = ksz // 2
+    bn = _bn(c, g) if pro else None
+    wr = w.double().requires_grad_()
+    a = torch.relu(_bn_apply(x.double(), bn)) if pro else x.double()
+    y = F.conv2d(a, wr, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    d = _dev()
+    geom = CV.Geometry.forward(n, h, h, ksz, stride, pad)
+    base = torch.randn(k, c, ksz, ksz, generator=g) * 0.1
+    gw = base.clone().to(d)
+    CV.wgrad(geom, CV.to_cm(x.to(d)), CV.to_cm(dy.to(d)), gw, c, k, pro_bn=[t.to(d) for t in bn] if pro else None)
+    _close(gw, wr.grad + base.double(), tol=5e-5)

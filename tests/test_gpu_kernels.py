@@ -677,3 +677,52 @@ def test_fused_stem_pool_matches_torch(shape):
     torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-5, atol=1e-5)
     assert (wg.grad.cpu().double() - 0.5 - wd.grad).abs().max().item() <= 1e-4 * wd.grad.abs().max().item() + 1e-5
     assert (bg.grad.cpu().double() + 0.25 - bd.grad).abs().max().item() <= 1e-4 * bd.grad.abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("c,t,n", [(64, 8, 2), (128, 8, 1), (256, 8, 2), (512, 8, 2), (512, 8, 3), (256, 16, 1)])
+def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
+    """vitta_tam_branch_{fwd,bwd}_fused_f32 (F1 -> F2 / B1 -> B2 inside one launch, the clip's workgroups meeting on a
+    device-scope counter) against the two-launch entry points: identical outputs (the arithmetic is the same code; only
+    the atomically accumulated parameter gradients may differ in summation order), the counters back at zero, and the
+    same again on a second and third launch."""
+    import ctypes as C
+    from vitta_amd import _lib
+    from vitta_amd.ops import _p, _ptr4, _stream
+    L = _lib.lib()
+    d = _dev()
+    g = torch.Generator().manual_seed(c + t + n)
+    o = c // 4
+    r = lambda *s: torch.randn(*s, generator=g).to(d)
+    pooled = r(n, c, t)
+    wg1, wg3, w0, w3 = r(2 * t, t) * 0.3, r(3, 2 * t) * 0.3, r(o, c, 3) * (3 * c) ** -0.5, r(c, o) * o ** -0.5
+    bng = [torch.rand(2 * t, generator=g).to(d) + 0.5, r(2 * t) * 0.1, r(2 * t) * 0.1, torch.rand(2 * t, generator=g).to(d) + 0.5]
+    bnl = [torch.rand(o, generator=g).to(d) + 0.5, r(o) * 0.1, r(o) * 0.1, torch.rand(o, generator=g).to(d) + 0.5]
+    gkern, ggate = r(n * c, 3), r(n, c, t)
+    sync = torch.zeros(256, dtype=torch.int32, device=d)
+
+    def run(fused):
+        kern, gate, hpre = torch.empty(n * c, 3, device=d), torch.empty(n, c, t, device=d), torch.empty(2, n, o, t, device=d)
+        args = (_p(pooled), _p(wg1), _ptr4(*bng), 1e-5, _p(wg3), _p(w0), _ptr4(*bnl), 1e-5, _p(w3), n, c, t)
+        if fused:
+            _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), _stream()), "fwd fused")
+        else:
+            _lib.check(L.vitta_tam_branch_fwd_f32(*args, _p(kern), _p(gate), _p(hpre), _stream()), "fwd")
+        gbuf = torch.empty(n * c * t + n * o * t, device=d)
+        dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
+        dw = [torch.zeros_like(wg1), torch.zeros_like(wg3), torch.zeros_like(w0), torch.zeros_like(w3)]
+        bargs = args + (_p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
+        if fused:
+            _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), _stream()), "bwd fused")
+        else:
+            _lib.check(L.vitta_tam_branch_bwd_f32(*bargs, _stream()), "bwd")
+        torch.cuda.synchronize()
+        return kern, gate, hpre, gbuf[:n * c * t].clone(), dbn, dw
+
+    ref = run(False)
+    for rep in range(3):
+        got = run(True)
+        assert int(sync.abs().sum()) == 0, "meeting counters must be zero at rest"
+        for a, b in zip(got[:4], ref[:4]):
+            assert torch.equal(a, b), rep
+        for a, b in zip(got[4] + got[5], ref[4] + ref[5]):
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7

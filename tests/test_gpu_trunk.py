@@ -101,11 +101,37 @@ def test_adapt_step_equals_module_path(tmp_path, size, over):
     assert (a[3] - b[3]).abs().max().item() <= max(2e-3 * b[3].abs().max().item(), 4.0 * floor), (floor, b[3].abs().max().item())
 
 
-def test_sgd_all_mode_takes_the_module_path(tmp_path):
-    """Trainable convolution weights (the reference's default optimizer) are outside the hand-written trunk until its
-    weight-gradient kernels exist: the runner must decline, not silently freeze them."""
+def test_sgd_all_step_equals_module_path(tmp_path):
+    """The reference's default optimizer (SGD over ALL parameters, corpus/basics.py:547-560) on the hand-written trunk:
+    convolution weight gradients from vitta_conv_wgrad_f32, TAM / head weights from their own kernels, the stem as torch
+    modules in front of the node -- against the module path (library convolutions + autograd): losses, the direction of
+    the whole gradient, sampled convolution-weight gradients, and the evaluation logits after the update."""
     from vitta_amd import trunk
-    adapter, T = _adapter(tmp_path, 64, True, mode="sgd")
-    x = H.seeded_randn((2 * T, 3, 64, 64), 1).to(_dev())
-    adapter.set_adapt_mode()
-    assert trunk.run(adapter.model.module.base_model, x) is None
+    res = {}
+    try:
+        for fast in (True, False):
+            (tmp_path / str(fast)).mkdir()
+            adapter, T = _adapter(tmp_path / str(fast), 64, fast, mode="sgd", reg_type="mse_loss")
+            x = H.seeded_randn((1, 2 * T * 3, 64, 64), 7).to(_dev())
+            adapter.set_adapt_mode()
+            if fast:
+                xin = adapter.shape_tta_input(x).view(-1, 3, 64, 64)
+                assert trunk.TrunkRunner(adapter.model.module.base_model).eligible(xin)
+            _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+            grads = {k: v.grad.detach().clone() for k, v in adapter.model.named_parameters() if v.requires_grad and v.grad is not None}
+            adapter.close_hooks()
+            ev = adapter.evaluate(adapter.shape_eval_input(H.seeded_randn((1, T * 3, 64, 64), 8).to(_dev()))).clone()
+            res[fast] = (float(loss_reg), float(loss_consis), grads, ev)
+    finally:
+        trunk.ENABLED = True
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) <= 2e-5 * abs(b[0]) + 1e-7 and abs(a[1] - b[1]) <= 1e-4 * abs(b[1]) + 1e-6
+    assert sorted(a[2]) == sorted(b[2])
+    va = torch.cat([a[2][k].flatten() for k in b[2]])
+    vb = torch.cat([b[2][k].flatten() for k in b[2]])
+    assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.9995
+    for k in ("module.base_model.layer1.0.net.conv2.weight", "module.base_model.layer2.0.net.downsample.0.weight",
+              "module.base_model.layer3.2.net.conv3.weight", "module.base_model.layer4.1.net.conv1.weight",
+              "module.base_model.conv1.weight", "module.base_model.layer2.1.tam.L.0.weight", "module.new_fc.weight"):
+        assert (a[2][k] - b[2][k]).norm().item() <= 2e-2 * b[2][k].norm().item() + 1e-9, k
+    assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()

@@ -20,6 +20,17 @@ class LayerShape(C.Structure):
 
 
 CONV_MAX_TAPS = 9
+
+
+class WgradDesc(C.Structure):
+    """vitta_wgrad_desc of include/vitta_hip.h (field for field)."""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("grad_w", C.c_void_p), ("pro_bn", C.c_void_p * 4),
+                ("pro_eps", C.c_float), ("src_off", C.c_void_p), ("src_mask", C.c_void_p),
+                ("C", C.c_int32), ("K", C.c_int32), ("N", C.c_int32),
+                ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hg", C.c_int32), ("Wg", C.c_int32), ("sstride", C.c_int32),
+                ("ntaps", C.c_int32), ("wtaps", C.c_int32),
+                ("dh", C.c_int8 * 9), ("dw", C.c_int8 * 9), ("wt", C.c_int8 * 9), ("flags", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
 CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU = 16, 32, 64, 128
 
@@ -86,6 +97,10 @@ SIGNATURES = {
                                            _p, _p, _p, _p]),
     "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                            _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p]),
+    "vitta_tam_branch_fwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
+                                                 _p, _p, _p, _p, _p]),
+    "vitta_tam_branch_bwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
+                                                 _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_bn_act_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i64, _i32, _i32, _p, _p]),
     "vitta_bn_act_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _i32, _i64, _i32,
@@ -107,6 +122,7 @@ SIGNATURES = {
     "vitta_conv_num_blocks": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
     "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
     "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

@@ -97,6 +97,26 @@ class Geometry:
                 out.append(Geometry(n, ho, wo, (h + 1) // 2, (w + 1) // 2, h, w, taps, ostride=2, oa=a, ob=b))
         return out
 
+    def wgrad_tables(self, device):
+        """(src_off, src_mask) int32 [N * Hg * Wg] of vitta_wgrad_desc for this (forward) geometry, built once."""
+        key = str(device)
+        hit = getattr(self, "_wg_tables", {}).get(key)
+        if hit is None:
+            n = torch.arange(self.n, device=device).view(-1, 1, 1)
+            i = torch.arange(self.hg, device=device).view(1, -1, 1)
+            j = torch.arange(self.wg, device=device).view(1, 1, -1)
+            si, sj = i * self.sstride, j * self.sstride
+            off = (n * (self.hs * self.ws) + si * self.ws + sj).reshape(-1).to(torch.int32)
+            mask = torch.zeros(self.n, self.hg, self.wg, dtype=torch.int32, device=device)
+            for t, (dh, dw, _) in enumerate(self.taps):
+                ok = ((si + dh >= 0) & (si + dh < self.hs) & (sj + dw >= 0) & (sj + dw < self.ws)).expand(self.n, -1, -1)
+                mask |= ok.to(torch.int32) << t
+            hit = (off.contiguous(), mask.reshape(-1).contiguous())
+            if not hasattr(self, "_wg_tables"):
+                self._wg_tables = {}
+            self._wg_tables[key] = hit
+        return hit
+
     def fill(self, d):
         d.N, d.Hs, d.Ws, d.Hg, d.Wg, d.Hy, d.Wy = self.n, self.hs, self.ws, self.hg, self.wg, self.hy, self.wy
         d.sstride, d.ostride, d.oa, d.ob, d.ntaps = self.sstride, self.ostride, self.oa, self.ob, len(self.taps)
@@ -151,6 +171,34 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     return y
 
 
+def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5):
+    """grad_w [K, C, kh, kw] += weight gradient of the convolution with FORWARD geometry `geom` (Geometry.forward):
+    x [C, *] its input planes (raw, with pro_bn = the BatchNorm whose relu(bn(.)) the forward applied on load),
+    dy [K, *] the gradient of its raw output (`vitta_conv_wgrad_f32`)."""
+    for t in (x, dy, grad_w):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+    d = _lib.WgradDesc()
+    d.x, d.dy, d.grad_w = x.data_ptr(), dy.data_ptr(), grad_w.data_ptr()
+    _bn4(d.pro_bn, pro_bn)
+    d.pro_eps = float(eps)
+    d.flags = CONV_PRO_BN_RELU if pro_bn is not None else 0
+    d.C, d.K, d.N = int(c), int(k), geom.n
+    d.Hs, d.Ws, d.Hg, d.Wg, d.sstride = geom.hs, geom.ws, geom.hg, geom.wg, geom.sstride
+    d.ntaps, d.wtaps = len(geom.taps), grad_w.shape[2] * grad_w.shape[3]
+    for i, (dh, dw, wt) in enumerate(geom.taps):
+        d.dh[i], d.dw[i], d.wt[i] = dh, dw, wt
+    pointwise = len(geom.taps) == 1 and geom.sstride == 1 and geom.taps[0][:2] == (0, 0) and (geom.hg, geom.wg) == (geom.hs, geom.ws)
+    if not pointwise:
+        off, mask = geom.wgrad_tables(x.device)
+        d.src_off, d.src_mask = off.data_ptr(), mask.data_ptr()
+    ws = workspace(x.device)
+    # the partial tiles use the slab region of the split-K workspace (its first 64 KiB are the convolutions' counters)
+    d.workspace, d.workspace_bytes = ws.data_ptr() + 65536, ws.numel() - 65536
+    check(lib().vitta_conv_wgrad_f32(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_wgrad_f32")
+    return grad_w
+
+
 # callable(flops, shape_key) -> ops.KernelEventPair, or None (the product never sets it)
 TIMING = None
 
@@ -177,5 +225,5 @@ def stem_conv(x, wp):
     return y
 
 
-__all__ = ["Geometry", "launch", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
+__all__ = ["Geometry", "launch", "wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
            "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

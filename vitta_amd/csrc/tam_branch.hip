@@ -202,10 +202,38 @@ __device__ __forceinline__ void g_forward(const GLds& p, int T, int sub, bool ac
   k3[0] = e0 * inv; k3[1] = e1 * inv; k3[2] = e2 * inv;
 }
 
-__global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, float* __restrict__ kern,
-                                                            float* __restrict__ h_pre, float* __restrict__ h_act) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, tile = blockIdx.y, ntiles = gridDim.y;
+// write-through store / coherent load of a tensor another workgroup of the SAME launch consumes (fused kernels below)
+__device__ __forceinline__ void store_wt(float* base, int64_t idx, float v) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)(idx * 4), 0, 16);
+}
+__device__ __forceinline__ float load_wt(const float* base, int64_t idx) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(idx * 4), 0, 16));
+}
+
+// All workgroups of clip n meet (fused kernels): arrive on cnt[0], leave on cnt[1]; the last one to leave zeroes both, so
+// the pair is at rest (zero) when the launch ends.  Data handed across the meeting point travels with write-through stores
+// and coherent loads (store_wt / load_wt): no agent-scope release, which would write back every dirty line of the XCD's
+// L2 (the convolution outputs of the step).  Every workgroup of the launch is resident (<= 2 x 128 workgroups).
+__device__ __forceinline__ void clip_meet(unsigned* cnt, unsigned nwg) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nwg) __builtin_amdgcn_s_sleep(2);
+    const unsigned left = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == nwg - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+
+template <bool WT>
+__device__ __forceinline__ void f1_body(const TamBranchArgs& a, float* __restrict__ kern, float* __restrict__ h_pre,
+                                        float* __restrict__ h_act, int n, int tile, int ntiles, float* smem) {
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2;
   float* wl = smem;                      // [OBF][C*3] conv1 weights of this tile
   float* pl = wl + OBF * C * 3;           // [C][T+2]
@@ -255,19 +283,32 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
     const float sc = bw * rsqrtf(brv + a.bnl.eps);
     const int64_t idx = ((int64_t)n * O + o) * T + t;
     h_pre[idx] = pre;
-    h_act[idx] = fmaxf(fmaf(pre - brm, sc, bb), 0.f);
+    const float hv = fmaxf(fmaf(pre - brm, sc, bb), 0.f);
+    if (WT) store_wt(h_act, idx, hv);
+    else h_act[idx] = hv;
   }
 }
 
-__global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, const float* __restrict__ h_act,
-                                                            float* __restrict__ gate) {
+__global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, float* __restrict__ kern,
+                                                            float* __restrict__ h_pre, float* __restrict__ h_act) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, c0 = blockIdx.y * CB;
+  f1_body<false>(a, kern, h_pre, h_act, blockIdx.x, blockIdx.y, gridDim.y, smem);
+}
+
+// PHASE 0: whole body; 1: everything that does not need h_act (weight staging); 2: the rest
+template <int PHASE>
+__device__ __forceinline__ void f2_body(const TamBranchArgs& a, const float* __restrict__ h_act, float* __restrict__ gate,
+                                        int n, int c0, float* smem) {
   const int C = a.C, T = a.T, O = C / 4;
   float* wl = smem;            // [CB][O] conv2 weights of this tile
   float* hl = wl + CB * O;     // [O][T]
-  stage_linear(wl, a.w3 + (int64_t)c0 * O, min(CB, C - c0) * O);
-  stage_linear(hl, h_act + (int64_t)n * O * T, O * T);
+  if (PHASE != 2) stage_linear(wl, a.w3 + (int64_t)c0 * O, min(CB, C - c0) * O);
+  if (PHASE == 1) return;
+  if (PHASE == 2) {
+    for (int i = threadIdx.x; i < O * T; i += TBW) hl[i] = load_wt(h_act, (int64_t)n * O * T + i);
+  } else {
+    stage_linear(hl, h_act + (int64_t)n * O * T, O * T);
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
     const int c = c0 + i / T, t = i % T;
@@ -277,6 +318,25 @@ __global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, con
     for (int o = 0; o < O; ++o) acc = fmaf(w[o], hl[o * T + t], acc);
     gate[((int64_t)n * C + c) * T + t] = sigmoidf(acc);
   }
+}
+
+__global__ __launch_bounds__(TBW) void tam_branch_f2_kernel(TamBranchArgs a, const float* __restrict__ h_act,
+                                                            float* __restrict__ gate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f2_body<0>(a, h_act, gate, blockIdx.x, blockIdx.y * CB, smem);
+}
+
+// F1 and F2 in ONE launch: grid (N, max(tiles of F1, tiles of F2)); F2's weights are staged while the clip's F1 tiles finish
+__global__ __launch_bounds__(TBW) void tam_branch_fwd_fused_kernel(TamBranchArgs a, float* __restrict__ kern,
+                                                                   float* __restrict__ h_pre, float* __restrict__ h_act,
+                                                                   float* __restrict__ gate, unsigned* sync, int nt1, int nt2,
+                                                                   int lds1_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tile = blockIdx.y;
+  if (tile < nt1) f1_body<true>(a, kern, h_pre, h_act, n, tile, nt1, smem);
+  if (tile < nt2) f2_body<1>(a, h_act, gate, n, tile * CB, smem + lds1_floats);
+  clip_meet(sync + 2 * n, gridDim.y);
+  if (tile < nt2) f2_body<2>(a, h_act, gate, n, tile * CB, smem + lds1_floats);
 }
 
 struct TamBranchGrads {
@@ -289,13 +349,10 @@ struct TamBranchGrads {
 };
 
 // B1: d(conv1 output) for OBB channels
-__global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, const float* __restrict__ gate,
-                                                            const float* __restrict__ h_pre,
-                                                            const float* __restrict__ h_act,
-                                                            const float* __restrict__ ggate, float* __restrict__ dpre_g,
-                                                            TamBranchGrads g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, tile = blockIdx.y;
+template <bool WT>
+__device__ __forceinline__ void b1_body(const TamBranchArgs& a, const float* __restrict__ gate, const float* __restrict__ h_pre,
+                                        const float* __restrict__ h_act, const float* __restrict__ ggate,
+                                        float* __restrict__ dpre_g, const TamBranchGrads& g, int n, int tile, float* smem) {
   const int C = a.C, T = a.T, O = C / 4;
   float* dz = smem;            // [C][T]   (staged as gate, then overwritten by d(pre-sigmoid))
   float* gg = dz + C * T;      // [C][T]   upstream gradient of the gate
@@ -339,7 +396,8 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
     const int64_t idx = ((int64_t)n * O + o) * T + t;
     const float is = rsqrtf(brv + a.bnl.eps);
     const float gy = hact > 0.f ? dh : 0.f;
-    dpre_g[idx] = gy * bw * is;
+    if (WT) store_wt(dpre_g, idx, gy * bw * is);
+    else dpre_g[idx] = gy * bw * is;
     atomicAdd(g.dbnl_w + o, gy * (hpre - brm) * is);
     atomicAdd(g.dbnl_b + o, gy);
   }
@@ -354,12 +412,20 @@ __global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, con
   }
 }
 
-// B2: d pooled for CBB channels (+ G branch)
-__global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, const float* __restrict__ kern,
-                                                            const float* __restrict__ gkern,
-                                                            const float* __restrict__ dpre_g, TamBranchGrads g) {
+__global__ __launch_bounds__(TBW) void tam_branch_b1_kernel(TamBranchArgs a, const float* __restrict__ gate,
+                                                            const float* __restrict__ h_pre,
+                                                            const float* __restrict__ h_act,
+                                                            const float* __restrict__ ggate, float* __restrict__ dpre_g,
+                                                            TamBranchGrads g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = blockIdx.x, c0 = blockIdx.y * CBB;
+  b1_body<false>(a, gate, h_pre, h_act, ggate, dpre_g, g, blockIdx.x, blockIdx.y, smem);
+}
+
+// B2: d pooled for CBB channels (+ G branch).  PHASE 0: whole body; 1: everything that does not need d(conv1 output)
+// (staging, the G branch); 2: the L branch and the results
+template <int PHASE>
+__device__ __forceinline__ void b2_body(const TamBranchArgs& a, const float* __restrict__ kern, const float* __restrict__ gkern,
+                                        const float* __restrict__ dpre_g, const TamBranchGrads& g, int n, int c0, float* smem) {
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2, M = 2 * T;
   float* wl = smem;                  // [O][CBB*3] conv1 weights W0[o, c0 .. c0+CBB, :]
   float* dpre = wl + O * CBB * 3;     // [O][T+2], zero padded in t
@@ -367,6 +433,8 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
   float* gp = pl + CBB * TP;          // [CBB][T] result staging
   float* gacc = gp + CBB * T;         // [5M + M*T] block accumulators of the G-branch parameter gradients
   float* gl = gacc + 5 * M + M * T;  // G parameters
+  GLds p;
+  if (PHASE != 2) {
   if (c0 + CBB <= C) {
     stage_rows(wl, a.w0 + (int64_t)c0 * 3, O, CBB * 3, (int64_t)C * 3);
   } else {
@@ -376,16 +444,25 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
       wl[i] = r < cw ? a.w0[((int64_t)o * C + c0) * 3 + r] : 0.f;
     }
   }
-  {  // d(conv1 output) [O][T] of the clip -> [O][T+2]: the same padded staging as the pooled rows
+  load_pooled_t(a, n, c0, CBB, pl);
+  for (int i = threadIdx.x; i < 5 * M + M * T; i += TBW) gacc[i] = 0.f;
+  for (int i = threadIdx.x; i < CBB * T; i += TBW) gp[i] = 0.f;
+  p = stage_g(a, gl);
+  }
+  if (PHASE == 0) {  // d(conv1 output) [O][T] of the clip -> [O][T+2]: the same padded staging as the pooled rows
     TamBranchArgs tmp = a;
     tmp.pooled = dpre_g;
     tmp.C = O;
     load_pooled_t(tmp, n, 0, O, dpre);
   }
-  load_pooled_t(a, n, c0, CBB, pl);
-  for (int i = threadIdx.x; i < 5 * M + M * T; i += TBW) gacc[i] = 0.f;
-  const GLds p = stage_g(a, gl);
+  if (PHASE == 2) {  // written by the B1 tiles of this launch: coherent loads
+    for (int i = threadIdx.x; i < O * TP; i += TBW) {
+      const int t = i % TP - 1;
+      dpre[i] = (t >= 0 && t < T) ? load_wt(dpre_g, ((int64_t)n * O + i / TP) * T + t) : 0.f;
+    }
+  }
   __syncthreads();
+  if (PHASE != 1) {
   // L: transposed conv, item (c, t); the lanes of a pair split the o reduction (even / odd o)
   for (int i0 = 0; i0 < CBB * T; i0 += TBW / 2) {
     const int i = i0 + threadIdx.x / 2, half = threadIdx.x & 1;
@@ -401,7 +478,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
       }
     }
     acc += __shfl_xor(acc, 1, VITTA_WAVE);
-    if (half == 0 && i < CBB * T) gp[i] = acc;
+    if (half == 0 && i < CBB * T) gp[i] += acc;
   }
   if (g.dw0) {  // dW0[o, c, j] += sum_t dpre[o,t] pooled[c, t+j-1] for this tile's c
     for (int i = threadIdx.x; i < O * CBB * 3; i += TBW) {
@@ -412,9 +489,10 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
       atomicAdd(g.dw0 + ((int64_t)o * C + c0 + cl) * 3 + j, s);
     }
   }
-  __syncthreads();
+  }
+  if (PHASE == 0) __syncthreads();
   // G: GL lanes per channel of the tile (all 256 lanes busy), hidden unit m on lane m % GL
-  {
+  if (PHASE != 2) {
     const int cl = threadIdx.x / GL, sub = threadIdx.x % GL, c = c0 + cl;
     const bool active = c < C;
     const float* prow = pl + cl * TP + 1;
@@ -473,6 +551,7 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     }
   }
   __syncthreads();
+  if (PHASE == 1) return;
   for (int i = threadIdx.x; i < CBB * T; i += TBW) {
     const int c = c0 + i / T;
     if (c < C) g.gpooled[((int64_t)n * C + c) * T + i % T] = gp[i];
@@ -485,6 +564,30 @@ __global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, con
     for (int i = threadIdx.x; i < 3 * M; i += TBW) atomicAdd(g.dwg3 + i, gacc[2 * M + i]);
   if (g.dwg1)
     for (int i = threadIdx.x; i < M * T; i += TBW) atomicAdd(g.dwg1 + i, gacc[5 * M + i]);
+}
+
+__global__ __launch_bounds__(TBW) void tam_branch_b2_kernel(TamBranchArgs a, const float* __restrict__ kern,
+                                                            const float* __restrict__ gkern,
+                                                            const float* __restrict__ dpre_g, TamBranchGrads g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  b2_body<0>(a, kern, gkern, dpre_g, g, blockIdx.x, blockIdx.y * CBB, smem);
+}
+
+// B1 and B2 in ONE launch: grid (N, max(tiles)); B2's staging and its whole G branch run while the clip's B1 tiles finish
+__global__ __launch_bounds__(TBW) void tam_branch_bwd_fused_kernel(TamBranchArgs a, const float* __restrict__ kern,
+                                                                   const float* __restrict__ gate,
+                                                                   const float* __restrict__ h_pre,
+                                                                   const float* __restrict__ h_act,
+                                                                   const float* __restrict__ gkern,
+                                                                   const float* __restrict__ ggate, float* __restrict__ dpre_g,
+                                                                   TamBranchGrads g, unsigned* sync, int nt1, int nt2,
+                                                                   int lds1_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tile = blockIdx.y;
+  if (tile < nt1) b1_body<true>(a, gate, h_pre, h_act, ggate, dpre_g, g, n, tile, smem);
+  if (tile < nt2) b2_body<1>(a, kern, gkern, dpre_g, g, n, tile * CBB, smem + lds1_floats);
+  clip_meet(sync + 2 * n, gridDim.y);
+  if (tile < nt2) b2_body<2>(a, kern, gkern, dpre_g, g, n, tile * CBB, smem + lds1_floats);
 }
 
 inline size_t g_floats(int T) { return (size_t)2 * T * T + 3 * 2 * T + 5 * 2 * T; }
@@ -534,6 +637,49 @@ int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const fl
   if (!set_lds(tam_branch_f1_kernel, f1_lds(C, T)) || !set_lds(tam_branch_f2_kernel, f2_lds(C, T))) return VITTA_ERR_LAUNCH;
   VITTA_LAUNCH(tam_branch_f1_kernel, dim3(N, (O + OBF - 1) / OBF), dim3(TBW), f1_lds(C, T), st, a, d_kern, d_hpre, d_hact);
   VITTA_LAUNCH(tam_branch_f2_kernel, dim3(N, (C + CB - 1) / CB), dim3(TBW), f2_lds(C, T), st, a, d_hact, d_gate);
+  return VITTA_OK;
+}
+
+int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                                   const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
+                                   float* d_hpre, void* d_sync, void* stream) {
+  if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_sync) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_tam_branch_supported(C, T) || N > 32) return VITTA_ERR_UNSUPPORTED;
+  TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+  if (tb_bad(a)) return VITTA_ERR_INVALID_ARG;
+  const int O = C / 4, nt1 = (O + OBF - 1) / OBF, nt2 = (C + CB - 1) / CB;
+  const size_t l1 = (f1_lds(C, T) + 15) / 16 * 16, lds = l1 + f2_lds(C, T);
+  if (lds > 160 * 1024 || (int64_t)N * (nt1 > nt2 ? nt1 : nt2) > 512) return VITTA_ERR_UNSUPPORTED;  // every workgroup resident
+  if (!set_lds(tam_branch_fwd_fused_kernel, lds)) return VITTA_ERR_LAUNCH;
+  float* d_hact = d_hpre + (int64_t)N * O * T;
+  VITTA_LAUNCH(tam_branch_fwd_fused_kernel, dim3(N, nt1 > nt2 ? nt1 : nt2), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern,
+               d_hpre, d_hact, d_gate, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4));
+  return VITTA_OK;
+}
+
+int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
+                                   const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
+                                   const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
+                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, void* stream) {
+  if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn || !d_sync)
+    return VITTA_ERR_INVALID_ARG;
+  if (!vitta_tam_branch_supported(C, T) || N > 32) return VITTA_ERR_UNSUPPORTED;
+  TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+  if (tb_bad(a) || !h_dbn[0] || !h_dbn[1] || !h_dbn[2] || !h_dbn[3]) return VITTA_ERR_INVALID_ARG;
+  TamBranchGrads g{d_gpooled, h_dbn[0], h_dbn[1], h_dbn[2], h_dbn[3], h_dw ? h_dw[0] : nullptr, h_dw ? h_dw[1] : nullptr,
+                   h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};
+  const int O = C / 4, nt1 = (O + OBB - 1) / OBB, nt2 = (C + CBB - 1) / CBB;
+  const size_t l1 = (b1_lds(C, T) + 15) / 16 * 16, lds = l1 + b2_lds(C, T);
+  if (lds > 160 * 1024 || (int64_t)N * (nt1 > nt2 ? nt1 : nt2) > 512) return VITTA_ERR_UNSUPPORTED;
+  if (!set_lds(tam_branch_bwd_fused_kernel, lds)) return VITTA_ERR_LAUNCH;
+  const float* d_hact = d_hpre + (int64_t)N * O * T;
+  float* d_dpre = d_gpooled + (int64_t)N * C * T;
+  VITTA_LAUNCH(tam_branch_bwd_fused_kernel, dim3(N, nt1 > nt2 ? nt1 : nt2), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern,
+               d_gate, d_hpre, d_hact, d_gkern, d_ggate, d_dpre, g, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4));
   return VITTA_OK;
 }
 

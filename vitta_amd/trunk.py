@@ -19,10 +19,13 @@ backward (G = gradient w.r.t. out, all consumers summed):
 
 The whole trunk is ONE autograd node (TrunkFunction): parameter gradients go straight into their `.grad` storage
 (ops._grad_sink), nothing in between is visible to autograd.  Eligibility (`TrunkRunner.eligible`): CUDA fp32 input, every
-block a TemporalBottleneck, every BatchNorm in eval mode, FROZEN convolution weights (requires_grad False: the packed
-copies are cached, and an optimizer that updates weights in place through its own kernel would leave them stale), and no
-forward hook other than the engine-bound statistics hooks -- anything else takes the module-by-module path of resnet.py /
-tanet.py.
+block a TemporalBottleneck, every BatchNorm in eval mode, and no forward hook other than the engine-bound statistics hooks
+-- anything else takes the module-by-module path of resnet.py / tanet.py.  Convolution weights may be frozen (the packed
+copies are cached per weight version) or TRAINABLE (SGD over all parameters, the reference's default optimizer,
+corpus/basics.py:547-560): then they are re-packed in every forward (an optimizer that updates weights through its own
+kernel does not bump tensor versions), the backward adds their gradients with `vitta_conv_wgrad_f32`, and the stem
+(7x7 convolution + BN + ReLU + max-pool), whose weight gradient has no kernel here yet, runs as torch modules in front of
+the node.
 """
 import ctypes as C
 
@@ -41,6 +44,19 @@ def _stream():
 
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_sync_bufs = {}
+
+
+def _sync(device):
+    """Meeting counters of the fused TAM branch launches on the CURRENT stream (zero at rest; one buffer per stream: launches
+    on different streams may overlap)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _sync_bufs.get(key)
+    if buf is None:
+        buf = _sync_bufs[key] = torch.zeros(256, dtype=torch.int32, device=device)
+    return buf
 
 
 def _bn_ptrs(bn):
@@ -90,6 +106,7 @@ class TrunkRunner:
     def __init__(self, resnet):
         self.net = resnet
         self._packed = {}
+        self._step_packs = {}
         self._geo = {}
 
     # -- structure ---------------------------------------------------------------------------------------------
@@ -118,7 +135,7 @@ class TrunkRunner:
         mp, c1 = net.maxpool, net.conv1
         if net._forward_hooks or net._forward_pre_hooks or not isinstance(mp, nn.MaxPool2d) or mp._forward_hooks \
                 or (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) != (3, 2, 1, 1, False) \
-                or net.relu._forward_hooks or c1._forward_hooks or c1.weight.requires_grad or c1.bias is not None \
+                or net.relu._forward_hooks or c1._forward_hooks or c1.bias is not None \
                 or (tuple(c1.weight.shape), c1.stride, c1.padding, c1.dilation, c1.groups) != ((64, 3, 7, 7), (2, 2), (3, 3), (1, 1), 1) \
                 or x.shape[3] % 4 \
                 or not isinstance(net.bn1, nn.BatchNorm2d) or net.bn1.training or not net.bn1.affine \
@@ -145,7 +162,7 @@ class TrunkRunner:
                 convs.append(ds[0])
                 bns.append(ds[1])
             for cv in convs:
-                if cv.bias is not None or cv._forward_hooks or cv._forward_pre_hooks or cv.weight.requires_grad \
+                if cv.bias is not None or cv._forward_hooks or cv._forward_pre_hooks \
                         or cv.groups != 1 or cv.dilation != (1, 1):
                     return False
             if (n.conv1.kernel_size, n.conv1.stride) != ((1, 1), (1, 1)) or (n.conv3.kernel_size, n.conv3.stride) != ((1, 1), (1, 1)) \
@@ -163,10 +180,11 @@ class TrunkRunner:
             tam = b.tam
             bg, bl = tam.G[1], tam.L[1]
             if bg.training or bl.training or not _noop_hooks_only(bg) or not _noop_hooks_only(bl) \
-                    or not ops.tam_branch_supported(n.conv1.out_channels, t):
+                    or not ops.tam_branch_supported(n.conv1.out_channels, t) \
+                    or (x.shape[0] // t) * max(n.conv1.out_channels // 8, n.conv1.out_channels // 16, 1) > 512:
                 return False
             for m in (tam.G[0], tam.G[3], tam.L[0], tam.L[3]):
-                if m._forward_hooks or m.weight.requires_grad:
+                if m._forward_hooks:
                     return False
         ok, hook = _engine_hook(net.bn1)
         if not ok or hook is not None:  # a hooked stem BN takes the module path (the shipped configuration hooks layer3/4)
@@ -176,6 +194,13 @@ class TrunkRunner:
     # -- caches ------------------------------------------------------------------------------------------------
     def packed(self, conv, kind):
         w = conv.weight
+        if w.requires_grad:  # trainable: re-packed per forward (self._step_packs lives for one forward + backward)
+            key = (id(w), kind, torch.cuda.current_stream(w.device).cuda_stream)  # per stream: evaluation runs beside adaptation
+            hit = self._step_packs.get(key)
+            if hit is None:
+                with torch.no_grad():
+                    hit = self._step_packs[key] = CV.pack_stem(w) if kind == "s" else CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w)
+            return hit
         key = (id(w), kind)
         tag = (w.data_ptr(), w._version, tuple(w.shape))
         hit = self._packed.get(key)
@@ -279,10 +304,11 @@ class TrunkRunner:
         bg, bl = tam.G[1], tam.L[1]
         kern, gate, hpre = torch.empty(nb * p, 3, **f), torch.empty(nb, p, t, **f), torch.empty(2, nb, p // 4, t, **f)
         from .ops import _ptr4
-        check(L.vitta_tam_branch_fwd_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                         _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
+        check(L.vitta_tam_branch_fwd_fused_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                               float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                               _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                               _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), st),
+              "vitta_tam_branch_fwd_fused_f32")  # (eligible() admits only shapes the fused launch holds resident)
         a1 = torch.empty(p, P, **f)
         check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
               "vitta_tam_agg_fwd_cm_f32")
@@ -315,13 +341,19 @@ class TrunkRunner:
         saved = None
         if keep:
             saved = dict(xin=xin, x1=x1, pooled=pooled, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
-                         dims=(n, h, w, ho, wo))
+                         a1=a1 if net.conv2.weight.requires_grad else None, dims=(n, h, w, ho, wo))
         return out, ho, wo, saved
 
-    def forward(self, x, keep):
-        """x [N, 3, H, W] -> (features [N, 2048], tape).  keep: save what the backward needs."""
+    def forward(self, x, keep, pooled_in=None):
+        """x [N, 3, H, W] -> (features [N, 2048], tape).  keep: save what the backward needs.  pooled_in: the stem's output
+        [N, 64, h, w] computed outside (trainable stem convolution); the tape then ends at it."""
+        cur_stream = torch.cuda.current_stream(x.device).cuda_stream
+        self._step_packs = {k: v for k, v in self._step_packs.items() if k[2] != cur_stream}  # this stream's packs are stale
         sites = self.open_sites(x) if keep else {}
-        y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
+        if pooled_in is None:
+            y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
+        else:
+            y, pooled = None, pooled_in.contiguous()
         n, _, h, w = pooled.shape
         cur = CV.to_cm(pooled)
         tape = []
@@ -331,7 +363,7 @@ class TrunkRunner:
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
-        return feat, dict(tape=tape, sites=sites, stem=y if keep else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
+        return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
                           last=(c, n, h, w))
 
     # -- backward ----------------------------------------------------------------------------------------------
@@ -366,7 +398,11 @@ class TrunkRunner:
         CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b"), dx2, 4 * p, p,
                   flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
                   dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias))
+        if net.conv3.weight.requires_grad:
+            CV.wgrad(self.geo("f", n, ho, wo), sv["x2"], dx3, sink(net.conv3.weight), p, 4 * p, pro_bn=_bn_t(net.bn2), eps=net.bn2.eps)
         del dx3
+        if net.conv2.weight.requires_grad:
+            CV.wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p)
         # conv2 data gradient -> d a1
         ga1 = torch.empty(p, P, **f)
         for g in self.geo("b", n, h, w, 3, s, 1):
@@ -383,15 +419,19 @@ class TrunkRunner:
         bg, bl = tam.G[1], tam.L[1]
         from .ops import _ptr4
         gbuf = torch.empty(nb * p * t + nb * (p // 4) * t, **f)  # d pooled | scratch
-        check(L.vitta_tam_branch_bwd_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                         _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
-                                         _p(ggate), _p(gbuf), _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias)),
-                                         _ptr4(None, None, None, None), st), "vitta_tam_branch_bwd_f32")
+        check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                               float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                               _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                               _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                               _p(ggate), _p(gbuf), _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias)),
+                                               _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), sink(tam.L[0].weight),
+                                                     sink(tam.L[3].weight)), _p(_sync(G.device)), st),
+              "vitta_tam_branch_bwd_fused_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
         dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w)
         del ga
+        if net.conv1.weight.requires_grad:
+            CV.wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p)
         # identity / downsample path
         gin = torch.empty(cin, P, **f)
         if net.downsample is not None:
@@ -399,6 +439,8 @@ class TrunkRunner:
             sd = sites.get(id(dbn))
             dxd = bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo)
             ds = dconv.stride[0]
+            if dconv.weight.requires_grad:
+                CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
             gd = torch.empty(cin, Po if ds == 2 else P, **f)
             CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b"), gd, 4 * p, cin)
             CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin,
@@ -415,9 +457,12 @@ class TrunkRunner:
         for b, sv in zip(reversed(blocks), reversed(ctxd["tape"])):
             G = self.block_backward(b, sv, G, ctxd["sites"], sink)
             sv.clear()
-        # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
         h0, w0 = ctxd["pooled_hw"]
+        if ctxd["stem"] is None:  # the stem ran outside (trainable 7x7 convolution): hand its output gradient back
+            return CV.from_cm(G, n, h0, w0)
+        # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
         self.stem_backward(ctxd["stem"], CV.from_cm(G, n, h0, w0), sink)
+        return None
 
 
 class TrunkFunction(torch.autograd.Function):
@@ -425,9 +470,9 @@ class TrunkFunction(torch.autograd.Function):
     schedules this node); their gradients are written by the kernels straight into `.grad` storage where it exists."""
 
     @staticmethod
-    def forward(ctx, x, runner, *params):
+    def forward(ctx, x, runner, pooled, *params):
         ctx.set_materialize_grads(False)
-        feat, tape = runner.forward(x, True)
+        feat, tape = runner.forward(x, True, pooled_in=pooled)
         ctx.runner, ctx.tape, ctx.params = runner, tape, params
         return feat
 
@@ -436,7 +481,7 @@ class TrunkFunction(torch.autograd.Function):
         from . import ops
         runner, params = ctx.runner, ctx.params
         if gfeat is None:
-            return (None, None) + tuple(None for _ in params)
+            return (None, None, None) + tuple(None for _ in params)
         bufs = {}
 
         def sink(param):
@@ -448,13 +493,13 @@ class TrunkFunction(torch.autograd.Function):
                 hit = bufs[id(param)] = (buf, ret)
             return hit[0]
 
-        runner.backward(ctx.tape, gfeat, sink)
+        gpooled = runner.backward(ctx.tape, gfeat, sink)
         ctx.tape = None
         grads = []
         for p in params:
             hit = bufs.get(id(p))
             grads.append(hit[1] if hit is not None else None)
-        return (None, None) + tuple(grads)
+        return (None, None, gpooled) + tuple(grads)
 
 
 def run(resnet, x):
@@ -467,9 +512,19 @@ def run(resnet, x):
         return None
     params = [p for m in runner.bn2d_modules() for p in (m.weight, m.bias)]
     for b in runner.blocks():
-        params += [b.tam.G[1].weight, b.tam.G[1].bias, b.tam.L[1].weight, b.tam.L[1].bias]
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        return TrunkFunction.apply(x, runner, *[p for p in params if p.requires_grad])
+        params += [b.tam.G[1].weight, b.tam.G[1].bias, b.tam.L[1].weight, b.tam.L[1].bias,
+                   b.tam.G[0].weight, b.tam.G[3].weight, b.tam.L[0].weight, b.tam.L[3].weight,
+                   b.net.conv1.weight, b.net.conv2.weight, b.net.conv3.weight]
+        if b.net.downsample is not None:
+            params.append(b.net.downsample[0].weight)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params + [resnet.conv1.weight]):
+        pooled = None
+        if resnet.conv1.weight.requires_grad:  # trainable stem: torch modules (autograd) in front of the node
+            from .fused_bn import bn_act
+            pooled = resnet.maxpool(bn_act(resnet.bn1, resnet.conv1(x), relu=True, act=resnet.relu))
+            stem_params = {id(resnet.bn1.weight), id(resnet.bn1.bias)}
+            params = [p for p in params if id(p) not in stem_params]
+        return TrunkFunction.apply(x, runner, pooled, *[p for p in params if p.requires_grad])
     with torch.no_grad():
         feat, _ = runner.forward(x, False)
     return feat
