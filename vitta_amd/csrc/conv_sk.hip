@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvK a) {
   float* As = lds;                 // [3][BK][BM]
   float* Bs = lds + 3 * BK * BM;   // [3][BK][BN]
   int* flag = reinterpret_cast<int*>(Bs + 3 * BK * BN);  // [4] ticket result
-  float* pro = Bs + 3 * BK * BN + 4;                     // [2][C] prologue BN scale / shift
+  float* red = Bs + 3 * BK * BN + 4;                     // [2][32][2] per-channel sums of the upper pixel half of a tile
+  float* pro = red + 128;                                // [2][C] prologue BN scale / shift
 
   const vitta_conv_desc& d = a.d;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -353,9 +354,19 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvK a) {
       }
     }
     if (STATS || BWD) {
+      // per-channel sums: lanes of a wave, then the two waves that share the channels (pixel halves wm = 0 / 1) through
+      // LDS, then ONE atomic per (tile, channel) -- same-address atomics serialise at ~8 ns each, and a 64-channel layer
+      // has 784 tiles adding into the same 64 + 64 words
       r1 += __shfl_xor(r1, 32, 64);
       r2 += __shfl_xor(r2, 32, 64);
-      if (lk == 0) {
+      if (wm == 1 && lk == 0) {
+        red[(wn * 32 + li) * 2] = r1;
+        red[(wn * 32 + li) * 2 + 1] = r2;
+      }
+      __syncthreads();
+      if (wm == 0 && lk == 0) {
+        r1 += red[(wn * 32 + li) * 2];
+        r2 += red[(wn * 32 + li) * 2 + 1];
         if (BWD) {
           if (d.dgamma) atomicAdd(d.dgamma + k, r1);
           if (d.dbeta) atomicAdd(d.dbeta + k, r2);
@@ -364,6 +375,7 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvK a) {
           atomicAdd(d.st_s2 + k, r2);
         }
       }
+      __syncthreads();  // `red` is free again before the next tile's epilogue
     }
   };
 
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(256) void conv_sk_kernel(const ConvK a) {
 
 template <bool GATHER, bool PRO>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  const size_t lds = sizeof(float) * (3 * 32 * 64 * 2 + 4 + (PRO ? 2 * a.d.C : 0));
+  const size_t lds = sizeof(float) * (3 * 32 * 64 * 2 + 4 + 128 + (PRO ? 2 * a.d.C : 0));
   if (lds > 160 * 1024) return VITTA_ERR_UNSUPPORTED;
   static bool raised = false;
   if (lds > 48 * 1024 && !raised) {

@@ -6,9 +6,9 @@ layers' moments ride in the convolutions' epilogues and prologues.
 One bottleneck (temporal_module.py:85-106), forward:
     conv1 (1x1)            -> x1 RAW                          [+ moments of bn1(x1) when hooked]
     TAM                    reads x1, applies relu(bn1(.)) on load -> a1                         (tam_cm.hip)
-    conv2 (3x3, stride s)  -> x2 RAW                          [+ moments of bn2(x2)]
+    conv2 (3x3, stride s)  -> x2 RAW, a2 = relu(bn2(x2))      [+ moments of bn2(x2)]
     downsample (block 0)   -> xd RAW, zd = bn_d(xd)           [+ moments of zd]
-    conv3 (1x1)            reads x2 with relu(bn2(.)) on load -> x3 RAW, out = relu(bn3(x3) + identity)   [+ moments of bn3(x3)]
+    conv3 (1x1)            reads a2 -> x3 RAW, out = relu(bn3(x3) + identity)   [+ moments of bn3(x3)]
 backward (G = gradient w.r.t. out, all consumers summed):
     bn_bwd  : dz3 = G [out > 0] + inj3 -> dx3, g_id = G [out > 0], d gamma3 / d beta3
     dgrad conv3, epilogue = BatchNorm(+ReLU) backward of bn2 -> dx2, d gamma2 / d beta2
@@ -312,13 +312,17 @@ class TrunkRunner:
         a1 = torch.empty(p, P, **f)
         check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
               "vitta_tam_agg_fwd_cm_f32")
-        # conv2 -> x2 raw
+        # conv2 -> a2 = relu(bn2(x2)) (+ x2 raw for the backward): the activation is applied ONCE in this epilogue -- as a
+        # prologue of conv3 it sits in the slab loop (two VALU instructions per staged element beside the MFMAs: the
+        # 1024 -> 256 pointwise launch 43 us against 26 us plain, tools/debug/conv_epilogue_probe.py)
         g2 = self.geo("f", n, h, w, 3, s, 1)
         ho, wo = g2.hy, g2.wy
         Po = n * ho * wo
-        x2 = torch.empty(p, Po, **f)
-        CV.launch(g2, a1, self.packed(net.conv2, "f"), x2, p, p, flags=CV.CONV_STATS if s2 else 0,
-                  epi_bn=_bn_t(net.bn2) if s2 else None, eps=net.bn2.eps, stats=s2.stats if s2 else None)
+        a2 = torch.empty(p, Po, **f)
+        x2 = torch.empty(p, Po, **f) if keep else None
+        CV.launch(g2, a1, self.packed(net.conv2, "f"), a2, p, p,
+                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | (CV.CONV_STATS if s2 else 0), y_raw=x2,
+                  epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None)
         # identity path
         xd = None
         if net.downsample is not None:
@@ -334,14 +338,14 @@ class TrunkRunner:
         # conv3 -> x3 raw, out
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
-        CV.launch(self.geo("f", n, ho, wo), x2, self.packed(net.conv3, "f"), out, p, 4 * p,
-                  flags=CV.CONV_PRO_BN_RELU | CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if s3 else 0),
-                  y_raw=x3, res=ident, pro_bn=_bn_t(net.bn2), epi_bn=_bn_t(net.bn3), eps=net.bn3.eps,
-                  stats=s3.stats if s3 else None)
+        CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f"), out, p, 4 * p,
+                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if s3 else 0),
+                  y_raw=x3, res=ident, epi_bn=_bn_t(net.bn3), eps=net.bn3.eps, stats=s3.stats if s3 else None)
         saved = None
         if keep:
             saved = dict(xin=xin, x1=x1, pooled=pooled, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
-                         a1=a1 if net.conv2.weight.requires_grad else None, dims=(n, h, w, ho, wo))
+                         a1=a1 if net.conv2.weight.requires_grad else None,
+                         a2=a2 if net.conv3.weight.requires_grad else None, dims=(n, h, w, ho, wo))
         return out, ho, wo, saved
 
     def forward(self, x, keep, pooled_in=None):
@@ -368,13 +372,17 @@ class TrunkRunner:
 
     # -- backward ----------------------------------------------------------------------------------------------
     def block_backward(self, b, sv, G, sites, sink):
-        """G [4p, Po] = gradient w.r.t. the block output (all consumers) -> gradient w.r.t. the block input."""
+        """G [4p, Po] = gradient w.r.t. the block output (all consumers) -> gradient w.r.t. the block input.
+        (Differentiating the previous block's bn3 + add + ReLU in the epilogue of this block's last launch was measured:
+        the three extra streams of a 4p-channel tensor cost the convolution epilogue more than the stand-alone pass they
+        replace, 79.8 vs 57.7 us on the layer1 launches -- kept as its own kernel.)"""
         net, tam = b.net, b.tam
         t = b.n_segment
         n, h, w, ho, wo = sv["dims"]
         nb = n // t
         cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
-        f = dict(dtype=torch.float32, device=G.device)
+        dev = G.device
+        f = dict(dtype=torch.float32, device=dev)
         L = lib()
         st = _stream()
         P, Po = n * h * w, n * ho * wo
@@ -399,7 +407,7 @@ class TrunkRunner:
                   flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
                   dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias))
         if net.conv3.weight.requires_grad:
-            CV.wgrad(self.geo("f", n, ho, wo), sv["x2"], dx3, sink(net.conv3.weight), p, 4 * p, pro_bn=_bn_t(net.bn2), eps=net.bn2.eps)
+            CV.wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p)
         del dx3
         if net.conv2.weight.requires_grad:
             CV.wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p)
@@ -425,7 +433,7 @@ class TrunkRunner:
                                                _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
                                                _p(ggate), _p(gbuf), _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias)),
                                                _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), sink(tam.L[0].weight),
-                                                     sink(tam.L[3].weight)), _p(_sync(G.device)), st),
+                                                     sink(tam.L[3].weight)), _p(_sync(dev)), st),
               "vitta_tam_branch_bwd_fused_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
         dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w)
@@ -443,10 +451,10 @@ class TrunkRunner:
                 CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
             gd = torch.empty(cin, Po if ds == 2 else P, **f)
             CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b"), gd, 4 * p, cin)
-            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin,
-                      flags=CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES, res=gd)
+            res, rflag = gd, (CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES)
         else:
-            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin, flags=CV.CONV_RES, res=g_id)
+            res, rflag = g_id, CV.CONV_RES
+        CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin, flags=rflag, res=res)
         return gin
 
     def backward(self, ctxd, gfeat, sink):
