@@ -13,7 +13,7 @@ evaluation forward of the same video (centre view).  `value` = videos of all ran
 wall time of the K timed steps (barrier + synchronize on both sides).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed step, conv_igemm_kernel (vitta_conv_f32: every bottleneck
+  roofline      the dominant kernel of the timed step, conv_sk_kernel (vitta_conv_f32: every bottleneck
                 convolution of the trunk, forward and data gradient, ~71 % of the step's kernel time), bound
                 "mfma": achieved = algorithmic flops of the step's convolution launches / the sum of their
                 durations, each duration from a hipEvent pair attached to that launch's own dispatch
@@ -491,7 +491,7 @@ def main():
             cpf = os.path.join(ROOT, "profiles", "r2_conv_traffic_pmc.json")
             if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
                 conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
-            roofline = {"kernel": "conv_igemm_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, forward + "
+            roofline = {"kernel": "conv_sk_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, forward + "
                                   "data gradient + evaluation forward)",
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": tf / MFMA_F32_PEAK_TF, "traffic": conv_pmc,

@@ -1,29 +1,34 @@
+# Every judged artefact of the round in one gpurun call: bash tools/run/round_artifacts.sh [tag]
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-timeout 300 python bench.py > $O/r1p_bench.json 2> $O/r1p_bench.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_r1p -o r1p -- python bench.py > $O/r1p_bench_profiled_run.json 2> $O/r1p_prof.err
-DB=$(ls $O/prof_r1p/*.db $O/prof_r1p/*/*.db 2>/dev/null | head -1)
-test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/r1p_bench_kernel_stats.csv > /dev/null
-rm -rf $O/prof_r1p
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_r1pg -o g -- python bench.py --timed-only --steps 128 > $O/r1p_timed_only.json 2>> $O/r1p_prof.err
-DB=$(ls $O/prof_r1pg/*.db $O/prof_r1pg/*/*.db 2>/dev/null | head -1)
-test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/r1p_graph_replay_kernel_stats.csv 250 > /dev/null
-rm -rf $O/prof_r1pg
-timeout 300 python bench.py --sequential > $O/r1p_bench_sequential.json 2> /dev/null
-timeout 300 python bench.py --optimizer sgd_all > $O/r1p_bench_sgd_all.json 2> /dev/null
-timeout 400 python bench.py --arch swin > $O/r1p_bench_swin.json 2> /dev/null
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_r1pf -o f -- python tools/bench_frames.py --iters 5 > $O/r1p_frames.json 2>> $O/r1p_prof.err
-DB=$(ls $O/prof_r1pf/*.db $O/prof_r1pf/*/*.db 2>/dev/null | head -1)
-test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/r1p_frames_kernel_stats.csv --split-all > /dev/null
-rm -rf $O/prof_r1pf
-timeout 300 python tools/bench_frames.py --clips 16 --chain 10 --iters 10 > $O/r1p_frames_16clips.json 2>/dev/null
-for f in r1p_bench r1p_bench_profiled_run r1p_bench_sequential r1p_bench_sgd_all r1p_bench_swin; do python - <<PY
+T=${1:-r2f}
+timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
+timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- python bench.py --no-sgd-all > $O/${T}_bench_profiled_run.json 2> $O/${T}_prof.err
+DB=$(ls $O/prof_$T/*.db $O/prof_$T/*/*.db 2>/dev/null | head -1)
+test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/${T}_bench_kernel_stats.csv > /dev/null
+rm -rf $O/prof_$T
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_${T}g -o g -- python bench.py --timed-only --steps 128 --no-cpu-baseline > $O/${T}_timed_only.json 2>> $O/${T}_prof.err
+DB=$(ls $O/prof_${T}g/*.db $O/prof_${T}g/*/*.db 2>/dev/null | head -1)
+test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/${T}_graph_replay_kernel_stats.csv 250 > /dev/null
+rm -rf $O/prof_${T}g
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_${T}s -o g -- python bench.py --timed-only --steps 128 --no-cpu-baseline --sequential > $O/${T}_timed_only_seq.json 2>> $O/${T}_prof.err
+DB=$(ls $O/prof_${T}s/*.db $O/prof_${T}s/*/*.db 2>/dev/null | head -1)
+test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/${T}_sequential_graph_replay_kernel_stats.csv 250 > /dev/null
+rm -rf $O/prof_${T}s
+timeout 300 python bench.py --sequential --no-cpu-baseline --no-sgd-all > $O/${T}_bench_sequential.json 2> /dev/null
+timeout 300 python bench.py --optimizer sgd_all --no-cpu-baseline > $O/${T}_bench_sgd_all.json 2> /dev/null
+timeout 300 python bench.py --force-exchanges --no-cpu-baseline --no-sgd-all > $O/${T}_bench_rccl_one_rank.json 2> /dev/null
+timeout 400 python bench.py --arch swin --no-cpu-baseline > $O/${T}_bench_swin.json 2> /dev/null
+timeout 200 python tools/bench_conv.py --frames 16 --out $O/${T}_conv_bench_16frames.json > /dev/null 2>&1
+timeout 200 python tools/bench_conv.py --frames 8 --no-vendor --out $O/${T}_conv_bench_8frames.json > /dev/null 2>&1
+timeout 200 python tools/debug/wgrad_probe.py > $O/${T}_wgrad_bench_16frames.txt 2>&1
+for f in bench bench_profiled_run bench_sequential bench_sgd_all bench_rccl_one_rank bench_swin; do python - <<PY
 import json
 try:
-    d=json.loads(open("$O/$f.json").read().strip().splitlines()[-1]); print("$f", round(d["value"],2), round(d["ms_per_step"],3), d.get("adapt_only_ms"), round(d["roofline"]["frac"],3), round(d["roofline"]["avg_ms"]*1e3,1))
+    d=json.loads(open("$O/${T}_$f.json").read().strip().splitlines()[-1]); r=d["roofline"]
+    print("$f", round(d["value"],2), round(d["ms_per_step"],3), d.get("adapt_only_ms"), r["kernel"][:24], round(r["frac"],3), (d.get("sgd_all") or {}).get("value"))
 except Exception as e: print("$f", "ERR", e)
 PY
 done
-grep -i "moments_nchw" $O/r1p_bench_kernel_stats.csv | head -3
-grep -i "frames" $O/r1p_frames_kernel_stats.csv | head -3
+grep -i "conv_sk\|stem_conv" $O/${T}_bench_kernel_stats.csv | head -5
