@@ -81,6 +81,8 @@ def parse():
     p.add_argument("--tuned-gemms", action="store_true",
                    help="--arch swin: the measured GEMM selection table (vitta_amd/tuning) instead of the library default; "
                         "off by default (see vitta_amd/tuning/__init__.py)")
+    p.add_argument("--graph-collectives", action="store_true",
+                   help="data-parallel step as ONE hipGraph with the two RCCL all-reduces captured inside it")
     p.add_argument("--force-exchanges", action="store_true",
                    help="single process: form a ONE-rank RCCL group and run the data-parallel step (segmented graphs, both "
                         "all-reduces) anyway -- exercises the RCCL calls on a one-GPU box")
@@ -236,7 +238,8 @@ def run_gpu(opt, rank, world, device):
         x, _ = tta_set[0]
         ev, _ = eval_set[0]
         adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
-                               segmented=opt.segmented_graph, overlap_eval=not opt.sequential)
+                               segmented=opt.segmented_graph and not opt.graph_collectives, overlap_eval=not opt.sequential,
+                               collectives_in_graph=opt.graph_collectives)
         one_step(opt.warmup)  # first replay outside the timed region
         torch.cuda.synchronize()
         log("hipGraphs captured")
@@ -351,7 +354,8 @@ def run_gpu(opt, rank, world, device):
         if opt.arch == "tanet":  # the in-step size (one video's hooked features, Infinity-Cache resident)
             run_gpu.one_video = streaming_moments(adapter, device, copies=1, reps=30, target_blocks=None)
         log("streaming-size moments done")
-    run_gpu.mode = ("hipGraph replay" + (" (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph) else "")) \
+    run_gpu.mode = ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if opt.graph_collectives else
+                                         " (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph) else "")) \
         if use_graph else "eager launches"
     run_gpu.eager_ms = (1e3 * eager_elapsed / opt.steps) if use_graph else None
     return elapsed, kern_ms, adapt_only, streaming, adapter

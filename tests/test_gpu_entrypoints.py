@@ -230,10 +230,28 @@ def test_rccl_exchanges_between_graph_segments_with_a_one_rank_group():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "8", "--warmup", "4",
-           "--no-cpu-baseline", "--no-streaming", "--size", "112"]
+           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--size", "112"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.strip().splitlines()
     assert len(lines) == 1, lines  # RCCL's version banner (C stdio, flushed at exit) must not follow the JSON line
     rec = json.loads(lines[0])
     assert "3 segments" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0
+
+
+def test_rccl_exchanges_captured_inside_one_graph_with_a_one_rank_group():
+    """bench.py --force-exchanges --graph-collectives: the same data-parallel step with both RCCL all-reduces CAPTURED in
+    the step's single hipGraph (no host round trip between segments); opt-in until a multi-GPU node has run it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--graph-collectives", "--steps", "8", "--warmup", "4",
+           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--size", "112"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert "one graph" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0

@@ -555,7 +555,7 @@ class ViTTAAdapter:
             self.optimizer.step()
         g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
 
-    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False):
+    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False, collectives_in_graph=False):
         """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
         evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
         the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
@@ -572,7 +572,10 @@ class ViTTAAdapter:
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
         self.set_adapt_mode()
-        if self.world > 1 or segmented or self.bucket is not None:
+        # collectives_in_graph (opt-in, bench.py --graph-collectives): the two RCCL all-reduces are captured like any other
+        # launch and the data-parallel step is ONE graph (no host round trip between segments); the default keeps the
+        # collectives outside captures
+        if (self.world > 1 or segmented or self.bucket is not None) and not collectives_in_graph:
             self._capture_segments(g, overlap_eval)
             if overlap_eval:
                 g["step"] = None  # step() replays the three segments
