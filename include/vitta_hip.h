@@ -484,6 +484,19 @@ typedef struct vitta_wgrad_desc {
 } vitta_wgrad_desc;
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
 
+/* Packed copies of MANY convolution weights in one launch (trainable weights are re-packed every step).  d_table: device
+ * array of entries; `first` = number of weight elements of all entries before this one (entries ordered by it);
+ * dst_fwd [taps][C][K], dst_bwd [taps][K][C] or NULL (a 1x1 weight is its own backward pack); src the [K][C][taps]
+ * parameter.  total_elements = sum of K * C * taps. */
+typedef struct vitta_repack_entry {
+  const float* src;
+  float* dst_fwd;
+  float* dst_bwd;
+  int64_t first;
+  int32_t K, C, taps, pad;
+} vitta_repack_entry;
+int vitta_conv_repack_f32(const vitta_repack_entry* d_table, int32_t n_entries, int64_t total_elements, void* stream);
+
 /* --------------------------------------------------------------------------
  * A8 / A9 on channel-major planes (the layout of vitta_conv_f32: tensor[c][f * HW + hw], f = n * T + t).
  * TemporalBottleneck (temporal_module.py:85-106) with conv1 writing its RAW output x1: the TAM kernels apply

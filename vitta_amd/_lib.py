@@ -123,6 +123,7 @@ SIGNATURES = {
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
+    "vitta_conv_repack_f32": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
     "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),

@@ -107,6 +107,7 @@ class TrunkRunner:
         self.net = resnet
         self._packed = {}
         self._step_packs = {}
+        self._repack = {}
         self._geo = {}
 
     # -- structure ---------------------------------------------------------------------------------------------
@@ -194,7 +195,11 @@ class TrunkRunner:
     # -- caches ------------------------------------------------------------------------------------------------
     def packed(self, conv, kind):
         w = conv.weight
-        if w.requires_grad:  # trainable: re-packed per forward (self._step_packs lives for one forward + backward)
+        if w.requires_grad and kind in ("f", "b"):  # trainable: this pass's copies, rebuilt by ONE launch per forward
+            st = self._repack.get(torch.is_grad_enabled())
+            if st is not None and (id(w), kind) in st["packs"]:
+                return st["packs"][(id(w), kind)]
+        if w.requires_grad:  # (stem, or outside a refreshed forward): re-packed on demand
             key = (id(w), kind, torch.cuda.current_stream(w.device).cuda_stream)  # per stream: evaluation runs beside adaptation
             hit = self._step_packs.get(key)
             if hit is None:
@@ -209,6 +214,38 @@ class TrunkRunner:
                 hit = (tag, CV.pack_stem(w) if kind == "s" else CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
             self._packed[key] = hit
         return hit[1]
+
+    def refresh_packs(self, device):
+        """Trainable convolution weights: rebuild the packed copies (`vitta_conv_repack_f32`, one launch over all of them).
+        Two sets, created once (before any graph capture: the table is a host -> device copy): one for passes under
+        autograd (adaptation), one for no_grad passes (the evaluation, which may run beside it on a second stream)."""
+        convs = []
+        for b in self.blocks():
+            convs += [b.net.conv1, b.net.conv2, b.net.conv3] + ([b.net.downsample[0]] if b.net.downsample is not None else [])
+        convs = [c for c in convs if c.weight.requires_grad]
+        if not convs:
+            return
+        key = torch.is_grad_enabled()
+        st = self._repack.get(key)
+        sig = tuple((c.weight.data_ptr(), tuple(c.weight.shape)) for c in convs)
+        if st is None or st["sig"] != sig:
+            import numpy as np
+            dt = np.dtype([("src", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"), ("first", "<i8"), ("K", "<i4"), ("C", "<i4"), ("taps", "<i4"),
+                           ("pad", "<i4")])
+            tab = np.zeros(len(convs), dtype=dt)
+            packs, first = {}, 0
+            for i, c in enumerate(convs):
+                w = c.weight
+                k, ci, kh, kw = w.shape
+                taps = kh * kw
+                pf = torch.empty(taps, ci, k, dtype=torch.float32, device=device)
+                pb = torch.empty(taps, k, ci, dtype=torch.float32, device=device) if taps > 1 else w.detach().view(1, k, ci)
+                packs[(id(w), "f")], packs[(id(w), "b")] = pf, pb
+                tab[i] = (w.data_ptr(), pf.data_ptr(), pb.data_ptr() if taps > 1 else 0, first, k, ci, taps, 0)
+                first += k * ci * taps
+            dtab = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
+            st = self._repack[key] = dict(sig=sig, packs=packs, table=dtab, n=len(convs), total=first)
+        check(lib().vitta_conv_repack_f32(_p(st["table"]), st["n"], st["total"], _stream()), "vitta_conv_repack_f32")
 
     def geo(self, kind, n, h, w, k=1, stride=1, pad=0):
         key = (kind, n, h, w, k, stride, pad)
@@ -353,6 +390,7 @@ class TrunkRunner:
         [N, 64, h, w] computed outside (trainable stem convolution); the tape then ends at it."""
         cur_stream = torch.cuda.current_stream(x.device).cuda_stream
         self._step_packs = {k: v for k, v in self._step_packs.items() if k[2] != cur_stream}  # this stream's packs are stale
+        self.refresh_packs(x.device)
         sites = self.open_sites(x) if keep else {}
         if pooled_in is None:
             y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
