@@ -564,6 +564,17 @@ int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, 
 int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps,
                                            int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
                                            void* stream);
+/* The same backward that ALSO produces d_dy [N, C, H, W], the gradient w.r.t. the convolution output (trainable stem
+ * convolution): ADDED into d_dy, which the caller zeroes (max-pool windows overlap).  d_dy NULL = the affine-only form.
+ * W % 4 == 0, W <= 256. */
+int vitta_stem_bn_relu_pool_bwd_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps, int64_t N,
+                                    int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta, float* d_dy, void* stream);
+/* Weight gradient of the stem convolution: d_dw [64, 3, 7, 7] += sum over frames and output pixels of d_dy [N, 64, OH, OW]
+ * times the 7x7 / stride 2 / pad 3 patches of d_x [N, 3, H, W] (v_mfma_f32_32x32x2_f32; per-workgroup partial sums meet in
+ * d_ws, >= vitta_stem_conv7_wgrad_workspace_bytes() bytes, no initial content required).  W % 4 == 0. */
+size_t vitta_stem_conv7_wgrad_workspace_bytes(void);
+int vitta_stem_conv7_wgrad_f32(const float* d_x, const float* d_dy, int64_t N, int32_t H, int32_t W, float* d_dw, void* d_ws,
+                               size_t ws_bytes, void* stream);
 
 /* --------------------------------------------------------------------------
  * A8 -- the stem convolution itself: Conv2d(3, 64, kernel 7, stride 2, pad 3, no bias), torchvision ResNet.conv1 under

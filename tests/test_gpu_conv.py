@@ -287,3 +287,35 @@ def test_weight_gradient_matches_fp64_autograd(n, c, k, h, ksz, stride, pro):
     gw = base.clone().to(d)
     CV.wgrad(geom, CV.to_cm(x.to(d)), CV.to_cm(dy.to(d)), gw, c, k, pro_bn=[t.to(d) for t in bn] if pro else None)
     _close(gw, wr.grad + base.double(), tol=5e-5)
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 224, 224), (2, 112, 112), (2, 64, 64), (1, 40, 56)])
+def test_stem_backward_and_weight_gradient_match_fp64_autograd(n, h, w):
+    """bn1 -> relu -> maxpool backward WITH the gradient w.r.t. the convolution output (vitta_stem_bn_relu_pool_bwd_f32)
+    and the stem weight gradient (vitta_stem_conv7_wgrad_f32), accumulated onto a non-zero buffer, against fp64 autograd of
+    BatchNorm(eval) -> ReLU -> MaxPool2d(3, 2, 1) on the kernel's own convolution output, resp. of the convolution.  An
+    arg-max decided inside fp32 round-off of a tie moves one whole gradient entry: a handful of such windows are allowed."""
+    from vitta_amd import _lib, conv as CV
+    from vitta_amd.ops import _p, _ptr4, _stream
+    g = torch.Generator().manual_seed(n + h + w)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 7, 7, generator=g) * 147 ** -0.5
+    bn = _bn(64, g)
+    d = _dev()
+    yd = CV.stem_conv(x.to(d), CV.pack_stem(wt.to(d)))
+    y = yd.cpu().double().requires_grad_()
+    pooled = F.max_pool2d(torch.relu(_bn_apply(y, bn)), 3, 2, 1)
+    gp = torch.randn(pooled.shape, generator=g)
+    pooled.backward(gp.double())
+    dy, dg, db = torch.zeros_like(yd), torch.zeros(64, device=d), torch.zeros(64, device=d)
+    bnd = [t.to(d) for t in bn]
+    _lib.check(_lib.lib().vitta_stem_bn_relu_pool_bwd_f32(_p(yd), _p(gp.to(d)), _ptr4(*bnd), 1e-5, n, 64, yd.shape[2], yd.shape[3],
+                                                          _p(dg), _p(db), _p(dy), _stream()), "stem bwd")
+    bad = ((dy.cpu().double() - y.grad).abs() > 1e-5 * y.grad.abs().max()).sum().item()
+    assert bad <= 8, bad
+    wr = wt.double().requires_grad_()
+    F.conv2d(x.double(), wr, stride=2, padding=3).backward(dy.cpu().double())
+    base = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    gw = base.clone().to(d)
+    CV.stem_wgrad(x.to(d), dy, gw)
+    _close(gw, wr.grad + base.double(), tol=5e-5, what="dw")

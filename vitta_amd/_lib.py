@@ -127,6 +127,9 @@ SIGNATURES = {
     "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
     "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
     "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
+    "vitta_stem_conv7_wgrad_workspace_bytes": (_sz, []),
+    "vitta_stem_conv7_wgrad_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),
+    "vitta_stem_bn_relu_pool_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p, _p]),
     "vitta_linear_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "vitta_linear_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
     "vitta_tam_pool_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -199,6 +199,21 @@ def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5):
     return grad_w
 
 
+def stem_wgrad(x, dy, grad_w):
+    """grad_w [64, 3, 7, 7] += weight gradient of the stem convolution: x [N, 3, H, W] its input, dy [N, 64, OH, OW] the
+    gradient of its raw output (`vitta_stem_conv7_wgrad_f32`)."""
+    for t in (x, dy, grad_w):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
+    n, _, h, w = x.shape
+    ws = workspace(x.device)
+    need = int(lib().vitta_stem_conv7_wgrad_workspace_bytes())
+    check(lib().vitta_stem_conv7_wgrad_f32(C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), n, h, w, C.c_void_p(grad_w.data_ptr()),
+                                           C.c_void_p(ws.data_ptr() + 65536), min(ws.numel() - 65536, max(need, 0) + (1 << 20)),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_stem_conv7_wgrad_f32")
+    return grad_w
+
+
 # callable(flops, shape_key) -> ops.KernelEventPair, or None (the product never sets it)
 TIMING = None
 
@@ -225,5 +240,5 @@ def stem_conv(x, wp):
     return y
 
 
-__all__ = ["Geometry", "launch", "wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
+__all__ = ["Geometry", "launch", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
            "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

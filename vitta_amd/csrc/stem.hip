@@ -108,7 +108,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void stem_tiled_kernel(const float* __
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  const float* __restrict__ rmean, const float* __restrict__ rvar,
                                                                  float eps, StemGeom g, float* __restrict__ out,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dy) {
   __shared__ __attribute__((aligned(16))) float tile[(2 * SR + 1) * SW_MAX];
   __shared__ float red[2][VITTA_BLOCK / VITTA_WAVE];
   const int64_t nc = blockIdx.y;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void stem_tiled_kernel(const float* __
     const int pr = i / g.PW, pw = i % g.PW;
     const int w0 = 2 * pw - 1;
     float best = 0.f, bx = 0.f;
+    int bpos = 0;
     bool found = false;
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void stem_tiled_kernel(const float* __
         if (w < 0 || w >= g.W) continue;
         const float xv = row[w];
         const float y = BWD ? fmaxf(fmaf(xv, sc, sh), 0.f) : xv;
-        if (!found || y > best) { best = y; bx = xv; found = true; }
+        if (!found || y > best) { best = y; bx = xv; bpos = h * g.W + w; found = true; }
       }
     }
     const int64_t o = nc * (int64_t)g.PH * g.PW + (int64_t)(ph0 + pr) * g.PW + pw;
@@ -166,6 +168,9 @@ __global__ __launch_bounds__(VITTA_BLOCK) void stem_tiled_kernel(const float* __
       const float gy = best > 0.f ? gpool[o] : 0.f;
       a = fmaf(gy, (bx - rm) * is, a);
       b += gy;
+      // gradient w.r.t. the convolution output: max-pool routes it to the window's (first) arg-max, ReLU passes it where
+      // the activation is positive, BatchNorm scales it; windows overlap, hence the atomic (dy is zeroed by the caller)
+      if (dy && gy != 0.f) atomicAdd(dy + nc * (int64_t)g.H * g.W + bpos, gy * sc);
     }
   }
   }  // strips
@@ -210,7 +215,7 @@ int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, 
   if (tiled_ok(g, d_x)) {
     VITTA_LAUNCH(stem_tiled_kernel<false>, dim3((g.PH + SR - 1) / SR, (unsigned)(N * C)), dim3(VITTA_BLOCK), 0,
                  static_cast<hipStream_t>(stream), d_x, nullptr, h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps, g, d_out, nullptr,
-                 nullptr);
+                 nullptr, nullptr);
     return VITTA_OK;
   }
   const int64_t po = (int64_t)g.PH * g.PW;
@@ -223,6 +228,11 @@ int vitta_stem_bn_relu_pool_fwd_f32(const float* d_x, const float* const* h_bn, 
 int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps,
                                            int64_t N, int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta,
                                            void* stream) {
+  return vitta_stem_bn_relu_pool_bwd_f32(d_x, d_gpool, h_bn, eps, N, C, H, W, d_dgamma, d_dbeta, nullptr, stream);
+}
+
+int vitta_stem_bn_relu_pool_bwd_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps, int64_t N,
+                                    int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta, float* d_dy, void* stream) {
   StemGeom g;
   if (!d_x || !d_gpool || !h_bn || !h_bn[0] || !h_bn[1] || !h_bn[2] || !h_bn[3] || !d_dgamma || !d_dbeta)
     return VITTA_ERR_INVALID_ARG;
@@ -232,9 +242,10 @@ int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpoo
   if (tiled_ok(g, d_x)) {
     VITTA_LAUNCH(stem_tiled_kernel<true>, dim3(1, (unsigned)(N * C)), dim3(VITTA_BLOCK), 0,
                  static_cast<hipStream_t>(stream), d_x, d_gpool, h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps, g, nullptr, d_dgamma,
-                 d_dbeta);
+                 d_dbeta, d_dy);
     return VITTA_OK;
   }
+  if (d_dy) return VITTA_ERR_UNSUPPORTED;  // the convolution-output gradient exists on the tiled path only
   // one workgroup per (n, c) plane, or two for large planes: every workgroup ends in two atomics on its channel, and
   // 13 312 workgroups on 128 addresses measured 88 us for this 64 MB pass
   const int64_t po = (int64_t)g.PH * g.PW;

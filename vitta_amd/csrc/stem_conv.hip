@@ -113,9 +113,135 @@ __global__ __launch_bounds__(256) void stem_conv7_kernel(const StemConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient (SGD over all parameters): dW[k][t] = sum over frames and output pixels q of dY[k][q] * patch[t][q],
+// t = (c, kh, kw).  Taps on the MFMA row axis (5 row tiles of 32 = 160 >= 147: one wave each), output channels on the
+// column axis (2 tiles per wave), the reduction runs over chunks of 128 consecutive output pixels of one frame: the input
+// patch of the chunk and the dY tile [64][129] sit in LDS.  Persistent workgroups (2 per CU) accumulate over their chunks
+// in registers and leave ONE partial [160][64] each; a second launch adds the partials to dW.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int WQ = 128;      // output pixels per chunk
+constexpr int WTH = 320;     // 5 waves
+constexpr int WDP = 129;     // LDS pitch of the dY tile
+constexpr int WG_MAX = 512;  // persistent workgroups
+
+struct StemWgradArgs {
+  const float* x;   // [N][3][H][W]
+  const float* dy;  // [N][64][OH][OW]
+  float* partial;   // [G][160][64]
+  float* dw;        // [64][147]
+  int H, W, OH, OW, PR, PW, tiles, chunks, G;
+};
+
+__global__ __launch_bounds__(WTH) void stem_wgrad_kernel(const StemWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* patch = lds;                                  // [3][PR][PW]
+  float* dyl = lds + 3 * a.PR * a.PW;                  // [64][WDP]
+  int* pixoff = reinterpret_cast<int*>(dyl + 64 * WDP);  // [WQ]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lk = lane >> 5;
+  const int npix = a.OH * a.OW, prpw = a.PR * a.PW;
+  const int toff = tap_off(32 * wave + li, prpw, a.PW);  // rows >= 147 repeat tap 146 and are never written out
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc0[v] = acc1[v] = 0.f;
+  const int pw4 = a.PW >> 2, rows4 = a.PR * pw4, total4 = 3 * rows4;
+  for (int chunk = blockIdx.x; chunk < a.chunks; chunk += gridDim.x) {
+    const int n = chunk / a.tiles, tile = chunk - n * a.tiles;
+    const int q0 = tile * WQ, r0 = q0 / a.OW, ih0 = 2 * r0 - 3;
+    __syncthreads();  // the previous chunk's operand reads are done
+    const float* xn = a.x + (int64_t)n * 3 * a.H * a.W;
+    for (int i = tid; i < total4; i += WTH) {
+      const int c = i / rows4, rem = i - c * rows4, pr = rem / pw4, p4 = rem - pr * pw4;
+      const int ih = ih0 + pr, iw = p4 * 4 - 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)
+        v = *reinterpret_cast<const f32x4*>(xn + ((int64_t)c * a.H + ih) * a.W + iw);
+      reinterpret_cast<f32x4*>(patch)[i] = v;
+    }
+    const float* dyn = a.dy + (int64_t)n * 64 * npix;
+    for (int i = tid; i < 64 * WQ; i += WTH) {
+      const int k = i / WQ, j = i - k * WQ, q = q0 + j;
+      dyl[k * WDP + j] = q < npix ? dyn[(int64_t)k * npix + q] : 0.f;
+    }
+    for (int j = tid; j < WQ; j += WTH) {
+      int q = q0 + j;
+      q = q < npix ? q : npix - 1;
+      const int r = q / a.OW, col = q - r * a.OW;
+      pixoff[j] = (r - r0) * 2 * a.PW + 2 * col + 1;
+    }
+    __syncthreads();
+    const float* pa = patch + toff;
+    const float* pb0 = dyl + li * WDP + lk;
+    const float* pb1 = dyl + (32 + li) * WDP + lk;
+#pragma unroll 4
+    for (int s = 0; s < WQ / 2; ++s) {
+      const float av = pa[pixoff[2 * s + lk]];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pb0[2 * s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, pb1[2 * s], acc1, 0, 0, 0);
+    }
+  }
+  // register v: tap row 32 wave + 8 (v / 4) + 4 lk + (v % 4), channel column li (acc0) / 32 + li (acc1)
+  float* pp = a.partial + (int64_t)blockIdx.x * 160 * 64;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int row = 32 * wave + 8 * (v >> 2) + 4 * lk + (v & 3);
+    pp[row * 64 + li] = acc0[v];
+    pp[row * 64 + 32 + li] = acc1[v];
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const StemWgradArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // (t, k)
+  if (i >= 147 * 64) return;
+  const int t = i >> 6, k = i & 63;
+  float s = 0.f;
+  for (int g = 0; g < a.G; ++g) s += a.partial[((int64_t)g * 160 + t) * 64 + k];
+  a.dw[k * 147 + t] += s;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t vitta_stem_conv7_wgrad_workspace_bytes(void) { return (size_t)WG_MAX * 160 * 64 * sizeof(float); }
+
+int vitta_stem_conv7_wgrad_f32(const float* d_x, const float* d_dy, int64_t N, int32_t H, int32_t W, float* d_dw, void* d_ws,
+                               size_t ws_bytes, void* stream) {
+  if (!d_x || !d_dy || !d_dw || !d_ws || N <= 0 || H < 7 || W < 7) return VITTA_ERR_INVALID_ARG;
+  if (W % 4) return VITTA_ERR_UNSUPPORTED;
+  if (ws_bytes < vitta_stem_conv7_wgrad_workspace_bytes()) return VITTA_ERR_WORKSPACE;
+  StemWgradArgs a;
+  a.x = d_x;
+  a.dy = d_dy;
+  a.partial = static_cast<float*>(d_ws);
+  a.dw = d_dw;
+  a.H = H;
+  a.W = W;
+  a.OH = (H - 1) / 2 + 1;
+  a.OW = (W - 1) / 2 + 1;
+  const int npix = a.OH * a.OW;
+  a.tiles = (npix + WQ - 1) / WQ;
+  if (N * a.tiles > 0x7fffffffll) return VITTA_ERR_UNSUPPORTED;
+  a.chunks = (int)(N * a.tiles);
+  int rows = (WQ - 1) / a.OW + 2;
+  if (rows > a.OH) rows = a.OH;
+  a.PR = 2 * (rows - 1) + 7;
+  a.PW = ((2 * a.OW + 5 + 4 + 3) / 4) * 4;
+  a.G = a.chunks < WG_MAX ? a.chunks : WG_MAX;
+  const size_t lds = sizeof(float) * ((size_t)3 * a.PR * a.PW + 64 * WDP + WQ);
+  if (lds > 160 * 1024) return VITTA_ERR_UNSUPPORTED;
+  static bool raised = false;
+  if (lds > 48 * 1024 && !raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return VITTA_ERR_LAUNCH;
+    raised = true;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  VITTA_LAUNCH(stem_wgrad_kernel, dim3((unsigned)a.G), dim3(WTH), lds, st, a);
+  VITTA_LAUNCH(stem_wgrad_reduce_kernel, dim3((147 * 64 + 255) / 256), dim3(256), 0, st, a);
+  return VITTA_OK;
+}
 
 int vitta_stem_conv7_f32(const float* d_x, const float* d_wp, int64_t N, int32_t H, int32_t W, float* d_y, void* stream) {
   if (!d_x || !d_wp || !d_y || N <= 0 || H < 7 || W < 7) return VITTA_ERR_INVALID_ARG;

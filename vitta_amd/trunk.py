@@ -23,9 +23,9 @@ block a TemporalBottleneck, every BatchNorm in eval mode, and no forward hook ot
 -- anything else takes the module-by-module path of resnet.py / tanet.py.  Convolution weights may be frozen (the packed
 copies are cached per weight version) or TRAINABLE (SGD over all parameters, the reference's default optimizer,
 corpus/basics.py:547-560): then they are re-packed in every forward (an optimizer that updates weights through its own
-kernel does not bump tensor versions), the backward adds their gradients with `vitta_conv_wgrad_f32`, and the stem
-(7x7 convolution + BN + ReLU + max-pool), whose weight gradient has no kernel here yet, runs as torch modules in front of
-the node.
+kernel does not bump tensor versions), the backward adds their gradients with `vitta_conv_wgrad_f32` /
+`vitta_stem_conv7_wgrad_f32` (the stem falls back to torch modules in front of the node only for output widths the tiled
+stem pass does not cover).
 """
 import ctypes as C
 
@@ -304,10 +304,23 @@ class TrunkRunner:
                                                     n, c, h, w, _p(pooled), _stream()), "vitta_stem_bn_relu_pool_fwd_f32")
         return y, pooled
 
-    def stem_backward(self, y, gpool, sink):
+    def stem_backward(self, y, gpool, sink, x=None):
         from .ops import _ptr4
         bn = self.net.bn1
         dw, db = sink(bn.weight), sink(bn.bias)
+        conv_w = self.net.conv1.weight
+        if conv_w.requires_grad and x is not None:
+            # trainable stem convolution: the same pass also scatters the gradient w.r.t. the convolution output, then
+            # vitta_stem_conv7_wgrad_f32 turns it into the weight gradient (the clip itself needs no gradient)
+            dw = dw if dw is not None else torch.zeros_like(bn.weight)
+            db = db if db is not None else torch.zeros_like(bn.bias)
+            n, c, h, w = y.shape
+            dy = torch.zeros_like(y)
+            check(lib().vitta_stem_bn_relu_pool_bwd_f32(_p(y), _p(gpool.contiguous()), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                                                        float(bn.eps), n, c, h, w, _p(dw), _p(db), _p(dy), _stream()),
+                  "vitta_stem_bn_relu_pool_bwd_f32")
+            CV.stem_wgrad(x, dy, sink(conv_w))
+            return
         if dw is None and db is None:
             return
         if dw is None or db is None:  # the kernel writes both
@@ -405,7 +418,8 @@ class TrunkRunner:
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
-        return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
+        return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None,
+                          x=x if (keep and pooled_in is None and self.net.conv1.weight.requires_grad) else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
                           last=(c, n, h, w))
 
     # -- backward ----------------------------------------------------------------------------------------------
@@ -507,7 +521,7 @@ class TrunkRunner:
         if ctxd["stem"] is None:  # the stem ran outside (trainable 7x7 convolution): hand its output gradient back
             return CV.from_cm(G, n, h0, w0)
         # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
-        self.stem_backward(ctxd["stem"], CV.from_cm(G, n, h0, w0), sink)
+        self.stem_backward(ctxd["stem"], CV.from_cm(G, n, h0, w0), sink, x=ctxd.get("x"))
         return None
 
 
@@ -565,11 +579,14 @@ def run(resnet, x):
             params.append(b.net.downsample[0].weight)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params + [resnet.conv1.weight]):
         pooled = None
-        if resnet.conv1.weight.requires_grad:  # trainable stem: torch modules (autograd) in front of the node
+        y_w = (x.shape[3] - 1) // 2 + 1
+        if resnet.conv1.weight.requires_grad and (y_w % 4 or y_w > 256):  # stem gradient kernels: tiled path only
             from .fused_bn import bn_act
             pooled = resnet.maxpool(bn_act(resnet.bn1, resnet.conv1(x), relu=True, act=resnet.relu))
             stem_params = {id(resnet.bn1.weight), id(resnet.bn1.bias)}
             params = [p for p in params if id(p) not in stem_params]
+        if pooled is None and resnet.conv1.weight.requires_grad:
+            params = params + [resnet.conv1.weight]
         return TrunkFunction.apply(x, runner, pooled, *[p for p in params if p.requires_grad])
     with torch.no_grad():
         feat, _ = runner.forward(x, False)
