@@ -9,10 +9,10 @@ from test_host_cpu import BASE, assert_logits_close, check_tta_records, run_prod
 
 pytestmark = pytest.mark.gpu
 
-# On the GPU the convolutions run in MIOpen / rocBLAS kernels with their own reduction orders, so the
-# first-step bounds are a little wider than on the CPU; later steps are bounded by the reference's own
-# noise floor exactly as in tests/test_host_cpu.py.
-BASE_GPU = dict(loss_rel=5e-5, logit_frac=5e-3, grad_frac=2e-2, param_lr_mult=0.1)
+# First-step bounds on the GPU = the CPU suite's (tests/test_host_cpu.py::BASE) for the gradients and logits now that every
+# TANet convolution is our own fp32-MFMA kernel (round 1 ran them in MIOpen / rocBLAS with their own reduction orders and
+# needed grad_frac 2e-2); later steps are bounded by the reference's own noise floor exactly as on the CPU.
+BASE_GPU = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.1)
 
 
 def _dev():
