@@ -25,7 +25,7 @@ Extra objects on the JSON line:
                 stand-alone): `one_video` = 178 MB (4 B x 44 556 288 hooked elements; fits the Infinity
                 Cache), `streaming` = 2.85 GB that cannot be cache resident, against 8 TB/s.
   sgd_all       the same iteration under the reference's DEFAULT optimizer (SGD over all parameters,
-                corpus/basics.py:547-560), timed in the same run after the headline configuration.
+                corpus/basics.py:547-560), timed in the same run after the headline configuration (single-GPU runs).
   ranks         what every rank saw: torch.distributed world size and its device (for the driver to verify N ranks).
   cpu_baseline  the CPU restatement of the reference path (oracle/: stock PyTorch CPU ops in the
                 reference's op order), same workload, a few steps on the host cores of this box.
@@ -461,8 +461,12 @@ def main():
                 dist_backend=torch.distributed.get_backend() if torch.distributed.is_initialized() else None)
     ranks = [mine]
     if world > 1:
-        ranks = [None] * world
-        torch.distributed.all_gather_object(ranks, mine)
+        try:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, mine)
+            ranks = gathered
+        except Exception as e:  # noqa: BLE001  (the report must never cost the benchmark line)
+            log(f"rank report not gathered: {e!r}")
 
     if opt.arch == "swin":
         algo_bytes = 4.0 * sum(o * c * i for o, c, i, _ in adapter.engine.plan.shapes)  # 253.7 MB at 2x16x224^2
@@ -550,7 +554,7 @@ def main():
                                     "shipped step these moments ride on the fused LayerNorm pass (ln_fwd_kernel)")
     del adapter
     torch.cuda.empty_cache()
-    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_sgd_all and not opt.timed_only:
+    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_sgd_all and not opt.timed_only and world == 1:
         # report both optimizer modes -- the reference's default (SGD over every parameter) in the same run
         import copy
         o2 = copy.copy(opt)
