@@ -333,6 +333,23 @@ int vitta_wmsa_rel_bwd_f32(const float* d_qkv, const float* d_table, int32_t T, 
                            int64_t tokens_per_sample, const float* d_out, const float* d_dout, const float* d_lse,
                            float* d_delta, float* d_dqkv, float* d_dtable, void* stream);
 
+/* bfloat16-OPERAND form of the two entry points above (BASELINE config 5: window (16,7,7) = 784 tokens): q, k, v, dO are
+ * rounded to bf16 while they are staged, both GEMMs of every direction run on v_mfma_f32_16x16x16_bf16 with fp32
+ * accumulation; softmax, bias / mask terms, lse, delta and all outputs are fp32.  Windows up to 800 tokens in one pass (K
+ * and V fit LDS together at 2 bytes per element).  The bias table is an input only (no d_dtable: train it with the fp32
+ * entry points).  vitta_wmsa_bf16_supported: head_dim == 32, N <= 800, table_rows <= 8192 and the three kernels' LDS
+ * carves within 160 KiB. */
+int vitta_wmsa_bf16_supported(int32_t N, int32_t head_dim, int32_t table_rows);
+int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                            float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                            float* d_out, float* d_lse, void* stream);
+int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                            float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                            const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
+                            void* stream);
+
 /* --------------------------------------------------------------------------
  * A7 -- optimizer update on the flat parameter arena, one launch.
  * Replaces optimizer.step() of corpus/basics.py:671 for the optimizers built at corpus/basics.py:547-560 (torch.optim.Adam over the affine tensors /

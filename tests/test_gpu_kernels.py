@@ -349,6 +349,70 @@ def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
     assert (td.grad.cpu().double() - tr.grad).abs().max().item() <= 5e-4 * tr.grad.abs().max().item() + 1e-6
 
 
+@pytest.mark.parametrize("ws,clamp,B,nh,shift,rowmap", [((8, 7, 7), (8, 7, 7), 1, 4, False, False), ((8, 7, 7), (8, 7, 7), 2, 4, True, False),
+                                                        ((16, 7, 7), (16, 7, 7), 1, 4, True, False), ((16, 7, 7), (16, 7, 7), 1, 8, True, True),
+                                                        ((16, 7, 7), (9, 7, 7), 1, 4, True, False), ((8, 7, 7), (4, 7, 7), 1, 8, False, True)])
+def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap):
+    """vitta_wmsa_rel_{fwd,bwd}_bf16 (BASELINE config 5: bf16 MFMA W-MSA, window (16,7,7) = 784 tokens in ONE pass) against the
+    fp64 composed reference evaluated on bf16-ROUNDED q (x scale), k, v.  Tolerances (bf16 operands, fp32 accumulation: the
+    probabilities and dS are rounded to 8 bits of mantissa before their GEMMs): output 1e-2, gradients 3e-2 of the tensor's
+    maximum; the fp32 kernels on the same inputs are held to 1e-4."""
+    from vitta_amd import ops, swin
+    g = torch.Generator().manual_seed(29)
+    N = clamp[0] * clamp[1] * clamp[2]
+    C = nh * 32
+    T = (2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    table = torch.randn(T, nh, generator=g) * 0.5
+    index = swin.relative_position_index(ws)[:N, :N]
+    code, off = swin.relative_position_code(ws)
+    nW = 4
+    region = torch.randint(0, 4, (nW, N), generator=g, dtype=torch.int32) if shift else None
+    mask = torch.where(region.unsqueeze(1) != region.unsqueeze(2), torch.tensor(-100.0), torch.tensor(0.0)) if shift else None
+    B_ = B * nW
+    scale = 32 ** -0.5
+    qkv = torch.randn(B_, N, 3 * C, generator=g)
+    gout = torch.randn(B_, N, C, generator=g)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    # reference on the values the kernel multiplies: q is scaled in fp32 and then rounded
+    q, k, v = qkv.view(B_, N, 3, C).unbind(2)
+    qkv_r = torch.stack([rb(q * scale) / scale, rb(k), rb(v)], 2).reshape(B_, N, 3 * C)
+    qr = qkv_r.double().requires_grad_(True)
+    bias = table.double()[index.reshape(-1)].view(N, N, nh).permute(2, 0, 1)
+    ref = _wmsa_reference(qr, bias, mask.double() if mask is not None else None, scale, nh)
+    ref.backward(rb(gout).double())
+    d = _dev()
+    rm = None
+    qd_in, gd_in = qkv, gout
+    if rowmap:  # natural token order: window w of a sample gathers its rows through the map
+        perm = torch.stack([torch.randperm(nW * N, generator=g) for _ in range(1)])[0].view(nW, N).to(torch.int32)
+        rm = perm.to(d)
+        nat = torch.empty(B, nW * N, 3 * C)
+        gnat = torch.empty(B, nW * N, C)
+        for bb in range(B):
+            for w in range(nW):
+                nat[bb, perm[w].long()] = qkv[bb * nW + w]
+                gnat[bb, perm[w].long()] = gout[bb * nW + w]
+        qd_in, gd_in = nat, gnat
+    old = ops.WMSA_BF16
+    ops.WMSA_BF16 = True
+    try:
+        qd = qd_in.to(d).requires_grad_(True)
+        out = ops.WindowAttentionRel.apply(qd, table.to(d), code[:N].to(d), off, region.to(d) if shift else None, scale, nh, rm)
+        out.backward(gd_in.to(d))
+    finally:
+        ops.WMSA_BF16 = old
+    o, gq = out.detach().cpu(), qd.grad.cpu()
+    if rowmap:
+        o = torch.stack([o[bb, perm[w].long()] for bb in range(B) for w in range(nW)])
+        gq = torch.stack([gq[bb, perm[w].long()] for bb in range(B) for w in range(nW)])
+    assert (o.double() - ref.detach()).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    gr = qr.grad.view(B_, N, 3, C)
+    gk = gq.double().view(B_, N, 3, C)
+    for sel, name in enumerate(("dq", "dk", "dv")):
+        err = (gk[:, :, sel] - gr[:, :, sel]).abs().max().item()
+        assert err <= 3e-2 * gr[:, :, sel].abs().max().item(), (name, err, gr[:, :, sel].abs().max().item())
+
+
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("shape", [(16, 64, 14, 14), (16, 512, 7, 7), (8, 24, 5, 4)])
 def test_fused_bn_act_matches_torch(shape, relu, res):

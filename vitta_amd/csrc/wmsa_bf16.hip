@@ -1,0 +1,495 @@
+// bfloat16-operand form of the fused 3-D shifted-window attention of wmsa.hip (BASELINE config 5: Video Swin-B on SSv2-C,
+// 32 frames x 4 views, window (16,7,7) = 784 tokens; reference models/videoswintransformer_models/swin_transformer.py:
+// 138-169, recipe recognizer3d.py:36-40).  q, k, v, dO are converted to bf16 while they are staged (round to nearest even),
+// the two GEMMs of every direction run on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, the softmax, the relative-
+// position bias / shift mask (generated on chip from the code table exactly as in wmsa.hip), lse, delta and every output
+// stay fp32.  At 2 bytes per element K and V of a 784-token window fit LDS together (115 KB), so windows up to 800 tokens
+// need no chunking (the fp32 kernels re-stage keys / queries in chunks of 400 there).
+//
+// MFMA operand layouts (16x16x16: lane (i = lane & 15, g = lane >> 4) supplies 4 consecutive k of row / column i):
+//   * contraction over the head dim (S = K Q^T, dP = V dO^T): d = 8 g + 4 s + e, s = 0, 1 -> one 16-byte read of a
+//     row-major [token][d] bf16 row per lane and tile;
+//   * contraction over keys (O = P V, dQ = dS K) / over queries (dV = P^T dO, dK = dS^T Q): the A operand IS the C layout
+//     of the score tile (rows 4 g + r of column i), packed to bf16; the B operand needs 4 consecutive tokens of one d:
+//     the forward stages V TRANSPOSED ([d][token], one 8-byte read), the backward kernels gather the four 2-byte values
+//     from the row-major copy they hold anyway (a transposed second copy would not fit LDS at 784 tokens).
+// Relative-position form only; the bias table is an input (its gradient -- SGD over all parameters -- stays on the fp32 kernels).
+#include "common.h"
+
+using namespace vitta;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HD = 32;
+constexpr int RP = 40;        // row pitch of a [token][32] bf16 tile in elements (80 bytes: conflict-free 16-byte reads)
+constexpr int NTB = 50;       // 16-token tiles per window: N <= 800
+constexpr int TH = 256;       // threads (4 waves, one per SIMD: up to 512 VGPRs each)
+constexpr int WV = TH / 64;
+constexpr int T_MAX = 8192;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+  bf16x4 r;
+  r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
+  return r;
+}
+__device__ __forceinline__ f32x4 mfma(bf16x4 a, bf16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+struct RowMap {
+  const int* map;
+  int nWm;
+  int64_t L;
+};
+
+struct Args {
+  const float* qkv; const float* table; const int* code; const int* region;
+  int T, off, nW; int64_t B_; int N, nH; float scale;
+  RowMap rm;
+};
+
+__device__ __forceinline__ int pk_code(int p) { return p & 0xffff; }
+__device__ __forceinline__ int pk_region(int p) { return p >> 16; }
+
+// pitch of the transposed [32][tokens] bf16 tile: (pitch / 2) % 16 == 2 spreads the 16 rows a half-wave reads over the banks
+__host__ __device__ inline int tpitch(int nt) { return 16 * nt + ((nt & 1) ? 20 : 4); }
+
+struct Carve {
+  unsigned short* a0;  // [16 nt][RP]
+  unsigned short* a1;  // [16 nt][RP] or [32][tpitch]
+  float* extra; float* tab; int* cr; int* rows;
+};
+__device__ __forceinline__ Carve carve(unsigned char* smem, int nt, size_t a1_elems, int extra_floats, int T) {
+  Carve c;
+  c.a0 = reinterpret_cast<unsigned short*>(smem);
+  c.a1 = c.a0 + 16 * nt * RP;
+  c.extra = reinterpret_cast<float*>(c.a1 + ((a1_elems + 7) & ~(size_t)7));
+  c.tab = c.extra + extra_floats;
+  c.cr = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
+  c.rows = c.cr + 16 * nt;
+  return c;
+}
+inline size_t lds_bytes(int nt, size_t a1_elems, int extra_floats, int T) {
+  return 2 * ((size_t)16 * nt * RP + ((a1_elems + 7) & ~(size_t)7)) + 4 * ((size_t)extra_floats + ((T + 3) & ~3) + 2 * 16 * nt);
+}
+
+__device__ __forceinline__ void fill_rows(int* rows, const RowMap& rm, int64_t b, int N, int nt) {
+  for (int i = threadIdx.x; i < 16 * nt; i += TH) {
+    const int n = i < N ? i : N - 1;
+    rows[i] = rm.map ? (int)((b / rm.nWm) * rm.L + rm.map[(b % rm.nWm) * (int64_t)N + n]) : (int)(b * N + n);
+  }
+  __syncthreads();
+}
+
+// table column of head h + packed code | region of the window's tokens
+__device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h, int64_t b, int nt) {
+  for (int i0 = threadIdx.x; i0 < a.T; i0 += 8 * TH) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a.table[(int64_t)min(i0 + u * TH, a.T - 1) * a.nH + h];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * TH < a.T) c.tab[i0 + u * TH] = v[u];
+  }
+  for (int i = threadIdx.x; i < 16 * nt; i += TH) {
+    const int n = i < a.N ? i : a.N - 1;
+    const int reg = a.region ? a.region[(b % a.nW) * (int64_t)a.N + n] : 0;
+    c.cr[i] = a.code[n] | (reg << 16);
+  }
+}
+
+// rows [0, N) of a [rows, row_stride] fp32 slice (32 floats per row) -> bf16 [16 nt][RP] (x mul); rows >= N are zero
+__device__ __forceinline__ void stage_rows(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
+                                           const int* rows, float mul) {
+  const int total = 16 * nt * 8;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TH, row = i >> 3, c4 = i & 7;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)rows[row] * row_stride + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TH;
+      if (i < total)
+        *reinterpret_cast<bf16x4*>(dst + (i >> 3) * RP + 4 * (i & 7)) = pack4(v[u].x * mul, v[u].y * mul, v[u].z * mul, v[u].w * mul);
+    }
+  }
+}
+
+// the same rows transposed: bf16 [32][TP], columns >= N zero
+__device__ __forceinline__ void stage_rows_t(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
+                                             const int* rows, int TP) {
+  const int total = 16 * nt * 8;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TH, row = i >> 3, c4 = i & 7;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)rows[row] * row_stride + 4 * c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TH;
+      if (i < total) {
+        const int row = i >> 3, d0 = 4 * (i & 7);
+        dst[(d0 + 0) * TP + row] = f2bf(v[u].x);
+        dst[(d0 + 1) * TP + row] = f2bf(v[u].y);
+        dst[(d0 + 2) * TP + row] = f2bf(v[u].z);
+        dst[(d0 + 3) * TP + row] = f2bf(v[u].w);
+      }
+    }
+  }
+}
+
+// 8 contiguous floats of a global row -> two bf16x4 (d = 8 g .. 8 g + 3 | 8 g + 4 .. 8 g + 7), scaled
+__device__ __forceinline__ void load_frag(const float* p, float mul, bf16x4& lo, bf16x4& hi) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  lo = pack4(a.x * mul, a.y * mul, a.z * mul, a.w * mul);
+  hi = pack4(b.x * mul, b.y * mul, b.z * mul, b.w * mul);
+}
+
+// additive terms of the S^T tile t (rows = keys 16 t + 4 g + r, column = query q): bias + shift mask, -inf past N
+__device__ __forceinline__ void add_terms_t(f32x4& acc, const float* tab, const int* cr, int off, int t, int g, int pq, int N) {
+  const int key0 = 16 * t + 4 * g;
+  const int4 ck = *reinterpret_cast<const int4*>(cr + key0);
+  const int cq = pk_code(pq) + off, rq = pk_region(pq);
+  const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
+  float tv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tv[r] = tab[cq - pk_code(kc[r])];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = pk_region(kc[r]) != rq ? tv[r] - 100.f : tv[r];
+    acc[r] = key0 + r < N ? acc[r] + v : -INFINITY;
+  }
+}
+
+// B operand of a contraction over tokens from a ROW-major tile: the four tokens 16 t + 4 g + e of column d
+__device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int g, int d) {
+  const unsigned short* p = tile + (16 * t + 4 * g) * RP + d;
+  bf16x4 r;
+  r[0] = (short)p[0]; r[1] = (short)p[RP]; r[2] = (short)p[2 * RP]; r[3] = (short)p[3 * RP];
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: K row-major, V transposed; a wave keeps all score tiles of its 16 queries in registers
+// ------------------------------------------------------------------------------------------------
+template <int NTM>
+__global__ __launch_bounds__(TH) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a.N, nH = a.nH, nt = (N + 15) / 16, TP = tpitch(nt);
+  const Carve cv = carve(smem, nt, (size_t)32 * TP, 0, a.T);
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  fill_rows(cv.rows, a.rm, b, N, nt);
+  stage_rows(cv.a0, a.qkv + (int64_t)(nH + h) * HD, rs, N, nt, cv.rows, 1.f);
+  stage_rows_t(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, TP);
+  setup_terms(cv, a, h, b, nt);
+  __syncthreads();
+  const unsigned short* krow = cv.a0;
+  const unsigned short* vt = cv.a1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int C = nH * HD;
+  const float* q_base = a.qkv + (int64_t)h * HD;
+  for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
+    const int q = min(16 * rt + i, N - 1);
+    bf16x4 qa, qb;
+    load_frag(q_base + (int64_t)cv.rows[q] * rs + 8 * g, a.scale, qa, qb);
+    const int pq = cv.cr[q];
+    f32x4 acc[NTM];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+      if (t < nt) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * t + i) * RP + 8 * g);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
+        s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
+        add_terms_t(s, cv.tab, cv.cr, a.off, t, g, pq, N);
+        acc[t] = s;
+        m = fmaxf(m, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTM; ++t) {
+      if (t < nt) {
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __expf(acc[t][r] - m);
+          l += p[r];
+        }
+        const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]);
+        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vt + i * TP + 16 * t + 4 * g);
+        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vt + (16 + i) * TP + 16 * t + 4 * g);
+        o0 = mfma(pa, v0, o0);
+        o1 = mfma(pa, v1, o1);
+      }
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv_l = 1.f / l;
+    // C layout: row = query 4 g + r, column = d = i; the row's 1 / l lives in lane 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * g + r;
+      const float il = __shfl(inv_l, 4 * g + r, 64);
+      if (qrow < N) {
+        float* o = out + (int64_t)cv.rows[qrow] * C + h * HD;
+        o[i] = o0[r] * il;
+        o[16 + i] = o1[r] * il;
+      }
+    }
+    if (g == 0 && 16 * rt + i < N) lse[(b * nH + h) * N + 16 * rt + i] = m + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 1: dQ (query-tile major; K and V row-major); also writes delta[q] = sum_d dO O
+//   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dq_kernel(const Args a, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
+  const Carve cv = carve(smem, nt, (size_t)16 * nt * RP, 0, a.T);
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  fill_rows(cv.rows, a.rm, b, N, nt);
+  stage_rows(cv.a0, a.qkv + (int64_t)(nH + h) * HD, rs, N, nt, cv.rows, 1.f);
+  stage_rows(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, 1.f);
+  setup_terms(cv, a, h, b, nt);
+  __syncthreads();
+  const unsigned short* krow = cv.a0;
+  const unsigned short* vrow = cv.a1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int C = nH * HD;
+  const float* q_base = a.qkv + (int64_t)h * HD;
+  for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
+    const bool qvalid = 16 * rt + i < N;
+    const int q = min(16 * rt + i, N - 1);
+    bf16x4 qa, qb, ga, gb;
+    load_frag(q_base + (int64_t)cv.rows[q] * rs + 8 * g, a.scale, qa, qb);
+    const float* gp = dout + (int64_t)cv.rows[q] * C + h * HD + 8 * g;
+    const float* op = out + (int64_t)cv.rows[q] * C + h * HD + 8 * g;
+    load_frag(gp, 1.f, ga, gb);
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dl = fmaf(gp[s], op[s], dl);
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    const float L = lse[(b * nH + h) * N + q];
+    if (g == 0 && qvalid) delta[(b * nH + h) * N + q] = dl;
+    const int pq = cv.cr[q];
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * t + i) * RP + 8 * g);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + (16 * t + i) * RP + 8 * g);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
+      s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
+      dp = mfma(__builtin_shufflevector(vf, vf, 0, 1, 2, 3), ga, dp);
+      dp = mfma(__builtin_shufflevector(vf, vf, 4, 5, 6, 7), gb, dp);
+      add_terms_t(s, cv.tab, cv.cr, a.off, t, g, pq, N);
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[r] = __expf(s[r] - L) * (dp[r] - dl);  // exp(-inf) = 0 for padded keys
+      const bf16x4 da = pack4(ds[0], ds[1], ds[2], ds[3]);
+      dq0 = mfma(da, gather4(krow, t, g, i), dq0);
+      dq1 = mfma(da, gather4(krow, t, g, 16 + i), dq1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qrow = 16 * rt + 4 * g + r;
+      if (qrow < N) {
+        float* o = dqkv + (int64_t)cv.rows[qrow] * rs + (int64_t)h * HD;
+        o[i] = dq0[r] * a.scale;
+        o[16 + i] = dq1[r] * a.scale;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward 2: dK, dV (key-tile major; Q (pre-scaled) and dO row-major, lse / delta in LDS)
+//   dV = P^T dO ; dK = dS^T (scale Q)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dkv_kernel(const Args a, const float* __restrict__ dout,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               float* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
+  const Carve cv = carve(smem, nt, (size_t)16 * nt * RP, 2 * 16 * nt, a.T);
+  float* l_lds = cv.extra;
+  float* d_lds = l_lds + 16 * nt;
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  fill_rows(cv.rows, a.rm, b, N, nt);
+  stage_rows(cv.a0, a.qkv + (int64_t)h * HD, rs, N, nt, cv.rows, a.scale);
+  stage_rows(cv.a1, dout + h * HD, C, N, nt, cv.rows, 1.f);
+  setup_terms(cv, a, h, b, nt);
+  for (int r = threadIdx.x; r < 16 * nt; r += TH) {
+    l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
+    d_lds[r] = r < N ? delta[(b * nH + h) * N + r] : 0.f;
+  }
+  __syncthreads();
+  const unsigned short* qrow_l = cv.a0;
+  const unsigned short* grow_l = cv.a1;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  for (int kt = blockIdx.x * WV + wave; kt < nt; kt += gridDim.x * WV) {
+    const int key = min(16 * kt + i, N - 1);
+    const bool kvalid = 16 * kt + i < N;
+    bf16x4 ka, kb, va, vb;
+    load_frag(a.qkv + (int64_t)cv.rows[key] * rs + (int64_t)(nH + h) * HD + 8 * g, 1.f, ka, kb);
+    load_frag(a.qkv + (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, 1.f, va, vb);
+    const int pkey = cv.cr[key];
+    const int ckey = pk_code(pkey), rkey = pk_region(pkey);
+    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < nt; ++qt) {
+      // S tile [query][key]: A = Q rows (LDS), B = K (registers); C layout: column = key i, row = query 4 g + r
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qrow_l + (16 * qt + i) * RP + 8 * g);
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(grow_l + (16 * qt + i) * RP + 8 * g);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = mfma(__builtin_shufflevector(qf, qf, 0, 1, 2, 3), ka, s);
+      s = mfma(__builtin_shufflevector(qf, qf, 4, 5, 6, 7), kb, s);
+      dp = mfma(__builtin_shufflevector(gf, gf, 0, 1, 2, 3), va, dp);
+      dp = mfma(__builtin_shufflevector(gf, gf, 4, 5, 6, 7), vb, dp);
+      const int q0 = 16 * qt + 4 * g;
+      const int4 cq = *reinterpret_cast<const int4*>(cv.cr + q0);
+      const float4 lq = *reinterpret_cast<const float4*>(l_lds + q0);
+      const float4 dq = *reinterpret_cast<const float4*>(d_lds + q0);
+      const int qc[4] = {cq.x, cq.y, cq.z, cq.w};
+      const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
+      float p[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float term = cv.tab[pk_code(qc[r]) - ckey + a.off];
+        if (pk_region(qc[r]) != rkey) term -= 100.f;
+        const float sv = (q0 + r < N && kvalid) ? s[r] + term : -INFINITY;
+        p[r] = __expf(sv - lv[r]);
+        ds[r] = p[r] * (dp[r] - dv[r]);
+      }
+      const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
+      dv0 = mfma(pa, gather4(grow_l, qt, g, i), dv0);
+      dv1 = mfma(pa, gather4(grow_l, qt, g, 16 + i), dv1);
+      dk0 = mfma(da, gather4(qrow_l, qt, g, i), dk0);
+      dk1 = mfma(da, gather4(qrow_l, qt, g, 16 + i), dk1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = 16 * kt + 4 * g + r;
+      if (krow < N) {
+        float* ok = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(nH + h) * HD;
+        float* ov = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
+        ok[i] = dk0[r];
+        ok[16 + i] = dk1[r];
+        ov[i] = dv0[r];
+        ov[16 + i] = dv1[r];
+      }
+    }
+  }
+}
+
+inline int pick_split(int64_t pairs, int nt) {
+  int qs = 1;  // one workgroup per CU (LDS): split the tiles of a (window, head) pair only while CUs would sit idle
+  while (pairs * qs < 256 && (nt + qs * WV - 1) / (qs * WV) >= 2 && qs < 8) qs *= 2;
+  return qs;
+}
+
+template <typename K>
+inline bool set_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+inline bool misaligned(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) | reinterpret_cast<uintptr_t>(d)) & 15u) != 0;
+}
+
+inline int check(const Args& a, int head_dim, const int32_t* rowmap, int map_windows, int64_t tokens) {
+  if (!a.qkv || !a.table || !a.code || a.B_ <= 0 || a.nH <= 0 || a.T <= 0) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_wmsa_bf16_supported(a.N, head_dim, a.T)) return VITTA_ERR_UNSUPPORTED;
+  if (a.region && (a.nW <= 0 || a.B_ % a.nW)) return VITTA_ERR_INVALID_ARG;
+  if (rowmap && (map_windows <= 0 || a.B_ % map_windows || tokens != (int64_t)map_windows * a.N)) return VITTA_ERR_INVALID_ARG;
+  return VITTA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vitta_wmsa_bf16_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
+  if (head_dim != HD || N < 1 || N > 16 * NTB || table_rows < 1 || table_rows > T_MAX) return 0;
+  const int nt = (N + 15) / 16;
+  const size_t f = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, table_rows), b1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows),
+               b2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, table_rows);
+  return (f <= 160 * 1024 && b1 <= 160 * 1024 && b2 <= 160 * 1024) ? 1 : 0;
+}
+
+int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                            float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                            float* d_out, float* d_lse, void* stream) {
+  const Args a{d_qkv, d_table, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
+               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+  if (!d_out || !d_lse) return VITTA_ERR_INVALID_ARG;
+  const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
+  if (rc != VITTA_OK) return rc;
+  if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
+  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt);
+  const size_t lds = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, T);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nt <= 25) {
+    if (!set_lds(wmsa_bf16_fwd_kernel<25>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH(wmsa_bf16_fwd_kernel<25>, dim3(qs, nH, (unsigned)B_), dim3(TH), lds, st, a, d_out, d_lse);
+  } else {
+    if (!set_lds(wmsa_bf16_fwd_kernel<NTB>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH(wmsa_bf16_fwd_kernel<NTB>, dim3(qs, nH, (unsigned)B_), dim3(TH), lds, st, a, d_out, d_lse);
+  }
+  return VITTA_OK;
+}
+
+int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                            const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                            float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                            const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
+                            void* stream) {
+  const Args a{d_qkv, d_table, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
+               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+  if (!d_out || !d_dout || !d_lse || !d_delta || !d_dqkv) return VITTA_ERR_INVALID_ARG;
+  const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
+  if (rc != VITTA_OK) return rc;
+  if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
+  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt);
+  const size_t l1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, T), l2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, T);
+  if (!set_lds(wmsa_bf16_bwd_dq_kernel, l1) || !set_lds(wmsa_bf16_bwd_dkv_kernel, l2)) return VITTA_ERR_LAUNCH;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  VITTA_LAUNCH(wmsa_bf16_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH), l1, st, a, d_out, d_dout, d_lse, d_delta, d_dqkv);
+  VITTA_LAUNCH(wmsa_bf16_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH), l2, st, a, d_dout, d_lse, d_delta, d_dqkv);
+  return VITTA_OK;
+}
+
+}  // extern "C"

@@ -431,6 +431,11 @@ class WindowAttention(torch.autograd.Function):
         return dqkv, dbias, None, None, None
 
 
+# bfloat16-operand window attention (vitta_wmsa_rel_{fwd,bwd}_bf16; BASELINE config 5's recipe): opt-in, and only where the
+# relative-position table is frozen (its gradient lives on the fp32 kernels)
+WMSA_BF16 = False
+
+
 class WindowAttentionRel(torch.autograd.Function):
     """WindowAttention with the relative-position bias looked up from the [T, nH] table and the shift
     mask derived from region ids inside the kernel (nothing of size N x N in memory).
@@ -459,20 +464,27 @@ class WindowAttentionRel(torch.autograd.Function):
             out = torch.empty(bsz, tokens, c, dtype=torch.float32, device=qkv.device)
         lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
         nw = region.shape[0] if region is not None else 1
-        check(lib().vitta_wmsa_rel_fwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
-                                           b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
-                                           _stream()), "vitta_wmsa_rel_fwd_f32")
+        bf16 = bool(WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0]))
+        fwd = lib().vitta_wmsa_rel_fwd_bf16 if bf16 else lib().vitta_wmsa_rel_fwd_f32
+        check(fwd(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
+                  b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
+                  _stream()), "vitta_wmsa_rel_fwd_bf16" if bf16 else "vitta_wmsa_rel_fwd_f32")
         ctx.save_for_backward(qkv, table, code, region, rowmap, out, lse)
-        ctx.meta = (int(code_off), float(scale), num_heads, hd, nw, b_, n, nwm, tokens)
+        ctx.meta = (int(code_off), float(scale), num_heads, hd, nw, b_, n, nwm, tokens, bf16)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, table, code, region, rowmap, out, lse = ctx.saved_tensors
-        off, scale, nh, hd, nw, b_, n, nwm, tokens = ctx.meta
+        off, scale, nh, hd, nw, b_, n, nwm, tokens, bf16 = ctx.meta
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
+        if bf16:
+            check(lib().vitta_wmsa_rel_bwd_bf16(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
+                                                hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
+                                                _p(dqkv), _stream()), "vitta_wmsa_rel_bwd_bf16")
+            return dqkv, None, None, None, None, None, None, None
         dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         check(lib().vitta_wmsa_rel_bwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                            hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
