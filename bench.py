@@ -81,6 +81,8 @@ def parse():
     p.add_argument("--tuned-gemms", action="store_true",
                    help="--arch swin: the measured GEMM selection table (vitta_amd/tuning) instead of the library default; "
                         "off by default (see vitta_amd/tuning/__init__.py)")
+    p.add_argument("--wmsa-bf16", action="store_true",
+                   help="--arch swin: window attention with bf16 MFMA operands (BASELINE config 5's recipe); dtype is reported")
     p.add_argument("--graph-collectives", action="store_true",
                    help="data-parallel step as ONE hipGraph with the two RCCL all-reduces captured inside it")
     p.add_argument("--force-exchanges", action="store_true",
@@ -443,6 +445,9 @@ def main():
     if opt.arch == "swin" and want_tuned and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
         from vitta_amd import tuning
         opt.tuned_gemms = tuning.enable_tuned_gemms()
+    if opt.wmsa_bf16:
+        from vitta_amd import ops as _ops
+        _ops.WMSA_BF16 = True
     if opt.miopen_find:
         torch.backends.cudnn.benchmark = True
     # corpus/main_eval.py:77 sets cudnn.benchmark (an exhaustive MIOpen find on ROCm: minutes of search
@@ -548,6 +553,9 @@ def main():
             else "SGD all parameters"
         line["config"]["exchanges"] = "moments all-reduce + gradient all-reduce" if world > 1 else "none"
         line["roofline"]["kernel"] = f"moments_nhwc_partial_kernel ({n_ln} layers, 1 launch)"
+        line["config"]["window_attention"] = "bf16 operands, fp32 softmax / accumulation" if opt.wmsa_bf16 else "fp32"
+        if opt.wmsa_bf16:
+            line["dtype"] = "f32 (window attention: bf16 MFMA operands)"
         line["config"]["gemm_selection"] = ("measured table vitta_amd/tuning (hipBLASLt / rocBLAS solution per shape, no search at "
                                             "run time)") if opt.tuned_gemms else "library default"
         line["roofline"]["note"] = ("stand-alone batched kernel timed on the step's own hooked LayerNorm outputs; in the "

@@ -223,11 +223,15 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
         assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
 
 
-def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
+@pytest.mark.parametrize("bf16", [False, True])
+def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     """BASELINE config 5 shape in small: Video Swin-B, window (16,7,7), 4 views x 32 frames.  N = 784 tokens per
     window at the first stages: the CHUNKED W-MSA kernels (keys / queries walked in chunks of 400, online softmax)
     run there -- asserted below by spying on the C-ABI entry --, the single-pass kernels at the clamped later stages;
-    LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU with the oracle backend."""
+    LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU with the oracle backend.
+    bf16: the bf16-OPERAND attention kernels (ops.WMSA_BF16, BASELINE config 5's "bf16 MFMA W-MSA"; 784 tokens in one
+    pass) against the same fp32 CPU path at the tolerance 8-bit operand mantissas allow through 24 blocks: statistics loss
+    rel 2e-3, consistency loss rel 5e-2, sampled gradients 1e-1 of their maximum."""
     import numpy as np
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, scripts, tta
@@ -252,15 +256,17 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
     args.update_only_bn_affine, args.lr = True, 1e-4
     x = data.SyntheticVideoDataset(1, views, T, size, 174, "swin", seed0=40)[0][0].unsqueeze(0)
     res = {}
-    from vitta_amd import _lib
+    from vitta_amd import _lib, ops
     L = _lib.lib()
-    orig, seen = L.vitta_wmsa_rel_fwd_f32, []
+    entry = "vitta_wmsa_rel_fwd_bf16" if bf16 else "vitta_wmsa_rel_fwd_f32"
+    orig, seen = getattr(L, entry), []
 
     def spy(*a):
         seen.append(int(a[8]))  # tokens per window of this launch
         return orig(*a)
 
-    L.vitta_wmsa_rel_fwd_f32 = spy
+    setattr(L, entry, spy)
+    old_flag, ops.WMSA_BF16 = ops.WMSA_BF16, bf16
     try:
         for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
             adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(dev), args, engine_backend=backend)
@@ -271,12 +277,14 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path):
                              named["module.backbone.layers.2.blocks.4.norm1.weight"].grad.cpu().clone(),
                              named["module.backbone.norm.bias"].grad.cpu().clone())
     finally:
-        L.vitta_wmsa_rel_fwd_f32 = orig
-    assert seen.count(784) == 22, sorted(set(seen))  # stages 1-3 (2 + 2 + 18 blocks): N = 784, the chunked kernels
+        setattr(L, entry, orig)
+        ops.WMSA_BF16 = old_flag
+    assert seen.count(784) == 22, sorted(set(seen))  # stages 1-3 (2 + 2 + 18 blocks): N = 784 (fp32: the chunked kernels)
     c, gdev = res["cpu"], res["cuda"]
-    assert gdev[0] == pytest.approx(c[0], rel=2e-5) and gdev[1] == pytest.approx(c[1], rel=1e-3, abs=1e-6)
+    r0, r1, rg = (2e-3, 5e-2, 1e-1) if bf16 else (2e-5, 1e-3, 2e-2)
+    assert gdev[0] == pytest.approx(c[0], rel=r0) and gdev[1] == pytest.approx(c[1], rel=r1, abs=1e-6)
     for a, b in zip(gdev[2:], c[2:]):
-        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-9
+        assert (a - b).abs().max().item() <= rg * b.abs().max().item() + 1e-9
 
 
 @pytest.mark.gpu

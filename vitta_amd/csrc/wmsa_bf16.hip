@@ -27,8 +27,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int HD = 32;
 constexpr int RP = 40;        // row pitch of a [token][32] bf16 tile in elements (80 bytes: conflict-free 16-byte reads)
 constexpr int NTB = 50;       // 16-token tiles per window: N <= 800
-constexpr int TH = 256;       // threads (4 waves, one per SIMD: up to 512 VGPRs each)
-constexpr int WV = TH / 64;
+constexpr int TH_FWD = 256;   // forward, 401..800 tokens: 4 waves (all 50 score tiles of 16 queries live in registers: 256 VGPRs)
+constexpr int TH_FWD_S = 512; // forward, <= 400 tokens: 8 waves (25 tiles: 176 VGPRs)
+constexpr int TH_BWD = 1024;  // backward: 16 waves (the tile loops are rolled: ~56 registers per lane)
 constexpr int T_MAX = 8192;
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -83,7 +84,7 @@ inline size_t lds_bytes(int nt, size_t a1_elems, int extra_floats, int T) {
 }
 
 __device__ __forceinline__ void fill_rows(int* rows, const RowMap& rm, int64_t b, int N, int nt) {
-  for (int i = threadIdx.x; i < 16 * nt; i += TH) {
+  for (int i = threadIdx.x; i < 16 * nt; i += blockDim.x) {
     const int n = i < N ? i : N - 1;
     rows[i] = rm.map ? (int)((b / rm.nWm) * rm.L + rm.map[(b % rm.nWm) * (int64_t)N + n]) : (int)(b * N + n);
   }
@@ -92,6 +93,7 @@ __device__ __forceinline__ void fill_rows(int* rows, const RowMap& rm, int64_t b
 
 // table column of head h + packed code | region of the window's tokens
 __device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h, int64_t b, int nt) {
+  const int TH = blockDim.x;
   for (int i0 = threadIdx.x; i0 < a.T; i0 += 8 * TH) {
     float v[8];
 #pragma unroll
@@ -110,6 +112,7 @@ __device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h
 // rows [0, N) of a [rows, row_stride] fp32 slice (32 floats per row) -> bf16 [16 nt][RP] (x mul); rows >= N are zero
 __device__ __forceinline__ void stage_rows(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
                                            const int* rows, float mul) {
+  const int TH = blockDim.x;
   const int total = 16 * nt * 8;
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
     float4 v[4];
@@ -131,6 +134,7 @@ __device__ __forceinline__ void stage_rows(unsigned short* dst, const float* src
 // the same rows transposed: bf16 [32][TP], columns >= N zero
 __device__ __forceinline__ void stage_rows_t(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
                                              const int* rows, int TP) {
+  const int TH = blockDim.x;
   const int total = 16 * nt * 8;
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
     float4 v[4];
@@ -189,8 +193,8 @@ __device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int
 // ------------------------------------------------------------------------------------------------
 // forward: K row-major, V transposed; a wave keeps all score tiles of its 16 queries in registers
 // ------------------------------------------------------------------------------------------------
-template <int NTM>
-__global__ __launch_bounds__(TH) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
+template <int NTM, int THREADS>
+__global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16, TP = tpitch(nt);
   const Carve cv = carve(smem, nt, (size_t)32 * TP, 0, a.T);
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_fwd_kernel(const Args a, float* 
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vt = cv.a1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   const float* q_base = a.qkv + (int64_t)h * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_fwd_kernel(const Args a, float* 
 // backward 1: dQ (query-tile major; K and V row-major); also writes delta[q] = sum_d dO O
 //   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dq_kernel(const Args a, const float* __restrict__ out,
+__global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dq_kernel(const Args a, cons
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   const float* q_base = a.qkv + (int64_t)h * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dq_kernel(const Args a, cons
 // backward 2: dK, dV (key-tile major; Q (pre-scaled) and dO row-major, lse / delta in LDS)
 //   dV = P^T dO ; dK = dS^T (scale Q)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dkv_kernel(const Args a, const float* __restrict__ dout,
+__global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -352,14 +356,14 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dkv_kernel(const Args a, con
   stage_rows(cv.a0, a.qkv + (int64_t)h * HD, rs, N, nt, cv.rows, a.scale);
   stage_rows(cv.a1, dout + h * HD, C, N, nt, cv.rows, 1.f);
   setup_terms(cv, a, h, b, nt);
-  for (int r = threadIdx.x; r < 16 * nt; r += TH) {
+  for (int r = threadIdx.x; r < 16 * nt; r += blockDim.x) {
     l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
     d_lds[r] = r < N ? delta[(b * nH + h) * N + r] : 0.f;
   }
   __syncthreads();
   const unsigned short* qrow_l = cv.a0;
   const unsigned short* grow_l = cv.a1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   for (int kt = blockIdx.x * WV + wave; kt < nt; kt += gridDim.x * WV) {
     const int key = min(16 * kt + i, N - 1);
     const bool kvalid = 16 * kt + i < N;
@@ -414,9 +418,9 @@ __global__ __launch_bounds__(TH) void wmsa_bf16_bwd_dkv_kernel(const Args a, con
   }
 }
 
-inline int pick_split(int64_t pairs, int nt) {
+inline int pick_split(int64_t pairs, int nt, int waves) {
   int qs = 1;  // one workgroup per CU (LDS): split the tiles of a (window, head) pair only while CUs would sit idle
-  while (pairs * qs < 256 && (nt + qs * WV - 1) / (qs * WV) >= 2 && qs < 8) qs *= 2;
+  while (pairs * qs < 256 && (nt + qs * waves - 1) / (qs * waves) >= 2 && qs < 8) qs *= 2;
   return qs;
 }
 
@@ -459,15 +463,15 @@ int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
   const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
   if (rc != VITTA_OK) return rc;
   if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
-  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt);
+  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, (nt <= 25 ? TH_FWD_S : TH_FWD) / 64);
   const size_t lds = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nt <= 25) {
-    if (!set_lds(wmsa_bf16_fwd_kernel<25>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH(wmsa_bf16_fwd_kernel<25>, dim3(qs, nH, (unsigned)B_), dim3(TH), lds, st, a, d_out, d_lse);
+    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
   } else {
-    if (!set_lds(wmsa_bf16_fwd_kernel<NTB>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH(wmsa_bf16_fwd_kernel<NTB>, dim3(qs, nH, (unsigned)B_), dim3(TH), lds, st, a, d_out, d_lse);
+    if (!set_lds(wmsa_bf16_fwd_kernel<NTB, TH_FWD>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<NTB, TH_FWD>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD), lds, st, a, d_out, d_lse);
   }
   return VITTA_OK;
 }
@@ -483,12 +487,12 @@ int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
   const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
   if (rc != VITTA_OK) return rc;
   if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
-  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt);
+  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, TH_BWD / 64);
   const size_t l1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, T), l2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, T);
   if (!set_lds(wmsa_bf16_bwd_dq_kernel, l1) || !set_lds(wmsa_bf16_bwd_dkv_kernel, l2)) return VITTA_ERR_LAUNCH;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  VITTA_LAUNCH(wmsa_bf16_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH), l1, st, a, d_out, d_dout, d_lse, d_delta, d_dqkv);
-  VITTA_LAUNCH(wmsa_bf16_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH), l2, st, a, d_dout, d_lse, d_delta, d_dqkv);
+  VITTA_LAUNCH(wmsa_bf16_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l1, st, a, d_out, d_dout, d_lse, d_delta, d_dqkv);
+  VITTA_LAUNCH(wmsa_bf16_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l2, st, a, d_dout, d_lse, d_delta, d_dqkv);
   return VITTA_OK;
 }
 

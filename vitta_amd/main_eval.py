@@ -83,6 +83,9 @@ def eval(args=None, model=None):
                 logger.debug(f"{arg} {getattr(args, arg)}")
     args.num_classes = num_classes = NUM_CLASSES[args.dataset]
     if device.type == "cuda":
+        if args.arch == "videoswintransformer":
+            from . import ops
+            ops.WMSA_BF16 = bool(getattr(args, "wmsa_bf16", False))
         if getattr(args, "tuned_gemms", False) and args.arch == "videoswintransformer":
             from . import tuning
             logger.debug(f"tuned GEMM table loaded: {tuning.enable_tuned_gemms()}")

@@ -8,6 +8,8 @@
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 * `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
 * `--tuned_gemms` (extension, default False) loads the measured GEMM-solution table for the Video Swin-B step.
+* `--wmsa_bf16` (extension, default False) runs Video Swin's window attention on the bf16-operand kernels (fp32 softmax and
+  accumulation; BASELINE config 5's recipe), vitta_amd/csrc/wmsa_bf16.hip.
 * `--device_preprocess` (extension, default False) uploads the decoded uint8 frames and runs crop / resize / normalise
   of the TANet pipeline in one HIP launch (bit-identical to the PIL path, vitta_amd/frames.py).
 """
@@ -104,6 +106,9 @@ _FLAGS = [
     (("--device_preprocess",), dict(type=_bool, default=False,
                                     help="(extension) TANet real-video pipeline: crop + PIL-BILINEAR resize + normalise on "
                                          "the GPU from the uploaded uint8 frames (bit-identical to the host PIL path)")),
+    (("--wmsa_bf16",), dict(type=_bool, default=False,
+                            help="(extension) Video Swin-B: window attention with bf16 MFMA operands, fp32 softmax / accumulation "
+                                 "(windows up to 800 tokens in one pass; the relative-position table must be frozen)")),
     (("--tuned_gemms",), dict(type=_bool, default=False,
                               help="(extension) Video Swin-B: take the measured hipBLASLt / rocBLAS solution per GEMM shape "
                                    "(vitta_amd/tuning) instead of the library's default heuristic")),
