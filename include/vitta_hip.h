@@ -632,6 +632,18 @@ int vitta_frames_resample_norm_f32(const uint8_t* d_frames, int32_t n_frames, in
                                    int32_t ky, const float* d_lut, float* d_out, int32_t out_h, int32_t out_w,
                                    int32_t tile_rows, int32_t lds_rows, void* stream);
 
+/* N1, Video Swin pipeline: cv2.resize(INTER_LINEAR) on uint8 frames as mmcv.imresize runs it
+ * (models/videoswintransformer_models/transforms_backup.py:193-349 Resize; RandomResizedCrop / CenterCrop; Normalize;
+ * FormatShape NCTHW), restated from OpenCV's resize.cpp -- cv2 is absent from this image, parity with cv2 itself is
+ * UNPINNED.  d_frames [n_frames][in_h][in_w][3]; mode 0: copy of the out_h x out_w crop at (x0, y0); 1: the exact-2x area
+ * shortcut on the 2 out_h x 2 out_w crop; 2: fixed-point bilinear, d_tables int32 [x0 | x1 | a0 | a1] (out_w each) then
+ * [y0 | y1 | b0 | b1] (out_h each): absolute source indices and 11-bit weights (vitta_amd/frames.py::cv2_linear_axis).
+ * Exactly one output: d_out_u8 [n_frames][out_h][out_w][3], or d_out_f32 [n_frames / clip_len][3][clip_len][out_h][out_w]
+ * = (value - d_mean[c]) * d_stdinv[c]. */
+int vitta_frames_cv2_resize(const uint8_t* d_frames, int32_t n_frames, int32_t in_h, int32_t in_w, int32_t x0, int32_t y0,
+                            int32_t mode, const int32_t* d_tables, int32_t out_h, int32_t out_w, uint8_t* d_out_u8,
+                            float* d_out_f32, int32_t clip_len, const float* d_mean, const float* d_stdinv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

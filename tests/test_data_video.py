@@ -105,3 +105,29 @@ def test_tanet_dataset_host_pipeline_with_a_stand_in_decoder(tmp_path, monkeypat
     assert e.shape == (8 * 3, 224, 224) and y == 7
     idx = tta.frame_indices(40)
     assert len(idx) == 16 and idx.max() == 40  # 1-based; the dataset clamps to the decoder's last frame (video_dataset.py:328)
+
+
+def test_swin_dataset_host_pipeline_equals_oracle(tmp_path, monkeypatch):
+    """VideoSwinDataset end to end on the host (index sampling -> decode (stand-in) -> Resize((-1, scale)) -> CenterCrop /
+    RandomResizedCrop + Resize -> Normalize -> NCTHW; video_dataset.py:60-101) against the oracle restatement of the same
+    chain (cv2 arithmetic: unpinned, see oracle/frames_oracle.py)."""
+    import numpy as np
+    from oracle import frames_oracle as FO
+    fake = H.FakeDecord(n_frames=37, w=96, h=72)
+    monkeypatch.setattr(DV, "_decord", lambda: fake)
+    lst = tmp_path / "list.txt"
+    lst.write_text("clipA 37 3\nclipB 37 7\n")
+    cfg = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375])
+    fixed = (6, 4, 6 + 50, 4 + 44)
+    monkeypatch.setattr(DV, "random_resized_crop_box", lambda nh, nw, **kw: fixed)
+    for views in (None, 2):
+        extra = dict(tta_views=views, tta_styles=["uniform_equidist"]) if views else {}
+        ds = DV.VideoSwinDataset(str(lst), 4, str(tmp_path), vid_format=".mp4", scale_size=64, input_size=48, img_norm_cfg=cfg, **extra)
+        x, y = ds[1]
+        n = views or 1
+        assert y == 7 and tuple(x.shape) == (n, 3, 4, 48, 48)
+        reader = fake.VideoReader(str(tmp_path / "clipB.mp4"))
+        idx, _ = ds.frame_indices(len(reader))
+        frames = reader.get_batch(np.minimum(idx, len(reader) - 1)).asnumpy()
+        ref = FO.swin_clip(frames, n, 4, 64, 48, (lambda nh, nw: fixed) if views else None, cfg["mean"], cfg["std"])
+        np.testing.assert_array_equal(x.numpy(), ref)

@@ -106,3 +106,49 @@ def test_frame_plan_tiles_fit_lds_and_refuse_host_tensors():
         FR.resample_normalise(torch.zeros(2, 1080, 1920, 3, dtype=torch.uint8), plan, 1)
     with pytest.raises(ValueError):
         FR.FramePlan([FR.ViewSpec((0, 0, 100, 100), (200, 200), (10, 10))], (224, 224), "cpu", MEAN, STD)
+
+
+# ---- Video Swin pipeline: cv2.resize(INTER_LINEAR) restated (UNPINNED: no cv2 in this image) ---------------------------------
+@pytest.mark.parametrize("h,w,dh,dw", [(240, 320, 256, 341), (256, 341, 224, 224), (97, 131, 224, 224), (60, 80, 30, 40),
+                                       (50, 70, 50, 70), (33, 47, 11, 200), (120, 90, 7, 5)])
+def test_cv2_linear_host_path_equals_the_oracle_restatement(h, w, dh, dw):
+    """The product's vectorised host resize (vitta_amd/frames.py::cv2_resize_linear) against the scalar-loop restatement of
+    OpenCV's 8-bit INTER_LINEAR in oracle/frames_oracle.py, bit for bit (up- and down-scaling, the same-size copy, the exact-2x
+    area shortcut, full-range bytes).  Neither is pinned against cv2 itself -- DESIGN.md section 5."""
+    from oracle import frames_oracle as FO
+    from vitta_amd import frames as F
+    rng = np.random.RandomState(h * 7 + w + dh + dw)
+    img = rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(F.cv2_resize_linear(img, dw, dh), FO.cv2_resize_linear(img, dw, dh))
+
+
+def test_cv2_linear_restatement_properties():
+    """What any correct bilinear byte resampler satisfies: constants stay constant, a resize is within one byte (plus the
+    fixed-point rounding) of the float bilinear interpolation with half-pixel centres, weights sum to 2048 away from the rows'
+    borders."""
+    import torch
+    from vitta_amd import frames as F
+    c = np.full((40, 60, 3), 201, np.uint8)
+    assert np.unique(F.cv2_resize_linear(c, 224, 224)).tolist() == [201]
+    rng = np.random.RandomState(3)
+    base = rng.randint(0, 256, size=(12, 16, 3)).astype(np.uint8)
+    img = np.repeat(np.repeat(base, 8, axis=0), 8, axis=1)  # piecewise constant: no aliasing in the comparison
+    got = F.cv2_resize_linear(img, 150, 120).astype(np.float32)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].float(), size=(120, 150), mode="bilinear",
+                                          align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(got - ref).max() <= 1.5
+    i0, i1, w0, w1 = F.cv2_linear_axis(97, 224, False)
+    assert ((w0 + w1) == 2048).all() and (i1 - i0 <= 1).all() and i0.min() == 0 and i1.max() == 96
+
+
+def test_swin_clip_host_pipeline_equals_oracle():
+    from oracle import frames_oracle as FO
+    from vitta_amd import frames as F
+    rng = np.random.RandomState(5)
+    frames = rng.randint(0, 256, size=(4, 48, 64, 3)).astype(np.uint8)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    box = lambda nh, nw: (5, 3, 5 + 40, 3 + 37)
+    for bx in (None, box):
+        got = F.swin_clip_host(frames, 2, 2, 56, 32, bx, mean, std).numpy()
+        ref = FO.swin_clip(frames, 2, 2, 56, 32, bx, mean, std)
+        np.testing.assert_array_equal(got, ref)

@@ -132,3 +132,20 @@ def test_dataset_with_device_preprocess_equals_the_host_dataset(tmp_path, monkey
     assert loader.num_workers == 0
     xb, yb = next(iter(loader))
     assert xb.is_cuda and xb.shape == (2, 24, 224, 224) and yb.tolist() == [3, 7]
+
+
+@pytest.mark.parametrize("h,w,scale,size,box", [(240, 320, 256, 224, None), (240, 320, 224, 224, (17, 9, 17 + 180, 9 + 150)),
+                                                (128, 96, 64, 32, None), (100, 100, 200, 64, (0, 0, 100, 100)),
+                                                (64, 48, 32, 16, (2, 4, 2 + 8, 4 + 8))])
+def test_swin_cv2_pipeline_on_device_equals_host(h, w, scale, size, box):
+    """vitta_frames_cv2_resize (two launches: short-edge rescale to uint8, crop + resize + normalise + NCTHW) against the host
+    numpy path of the same restated cv2 arithmetic, bit for bit; the box cases include the exact-2x shortcut and a copy."""
+    from vitta_amd import frames as F
+    rng = np.random.RandomState(h + w + size)
+    frames = rng.randint(0, 256, size=(6, h, w, 3)).astype(np.uint8)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    bx = (lambda nh, nw: box) if box is not None else None
+    ref = F.swin_clip_host(frames, 2, 3, scale, size, bx, mean, std)
+    got = F.swin_clip_on_device(frames, torch.device("cuda:0"), 2, 3, scale, size, bx, mean, std)
+    assert got.shape == ref.shape == (2, 3, 3, size, size)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy())

@@ -232,3 +232,77 @@ int vitta_frames_resample_norm_f32(const uint8_t* d_frames, int32_t n_frames, in
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Video Swin pipeline (N1, second half): cv2.resize(INTER_LINEAR) of uint8 frames as mmcv.imresize runs it
+// (models/videoswintransformer_models/transforms_backup.py:193-349 Resize, RandomResizedCrop + Resize, CenterCrop), restated
+// from OpenCV's resize.cpp (cv2 is not in this image: unpinned, see vitta_amd/frames.py).  One thread per destination pixel;
+// mode 0 = copy of the crop, 1 = the exact-2x area shortcut, 2 = the fixed-point bilinear with host-built tables
+// [x0 | x1 | a0 | a1 | y0 | y1 | b0 | b1] (absolute source indices, 11-bit weights).  Output: uint8 frames (the intermediate
+// of the two-resize TTA chain) or the normalised fp32 clip in NCTHW (mmcv.imnormalize + FormatShape).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Cv2Args {
+  const uint8_t* src; int F, sh, sw, x0, y0, mode; const int* tab; int dh, dw;
+  uint8_t* out_u8; float* out_f32; int clip_len; const float* mean; const float* stdinv;
+};
+
+__global__ __launch_bounds__(256) void frames_cv2_resize_kernel(const Cv2Args a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)a.dh * a.dw;
+  if (i >= per * a.F) return;
+  const int f = (int)(i / per), r = (int)(i - f * per), y = r / a.dw, x = r - y * a.dw;
+  const uint8_t* s = a.src + (int64_t)f * a.sh * a.sw * 3;
+  int v[3];
+  if (a.mode == 0) {
+    const uint8_t* p = s + ((int64_t)(a.y0 + y) * a.sw + a.x0 + x) * 3;
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+  } else if (a.mode == 1) {
+    const uint8_t* p = s + ((int64_t)(a.y0 + 2 * y) * a.sw + a.x0 + 2 * x) * 3;
+    const uint8_t* q = p + (int64_t)a.sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = (p[c] + p[3 + c] + q[c] + q[3 + c] + 2) >> 2;
+  } else {
+    const int* t = a.tab;
+    const int xa = t[x], xb = t[a.dw + x], wa = t[2 * a.dw + x], wb = t[3 * a.dw + x];
+    const int* ty = t + 4 * a.dw;
+    const int ya = ty[y], yb = ty[a.dh + y], ba = ty[2 * a.dh + y], bb = ty[3 * a.dh + y];
+    const uint8_t* r0 = s + (int64_t)ya * a.sw * 3;
+    const uint8_t* r1 = s + (int64_t)yb * a.sw * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int h0 = r0[xa * 3 + c] * wa + r0[xb * 3 + c] * wb;
+      const int h1 = r1[xa * 3 + c] * wa + r1[xb * 3 + c] * wb;
+      int o = (((ba * (h0 >> 4)) >> 16) + ((bb * (h1 >> 4)) >> 16) + 2) >> 2;
+      v[c] = o < 0 ? 0 : (o > 255 ? 255 : o);
+    }
+  }
+  if (a.out_u8) {
+    uint8_t* o = a.out_u8 + i * 3;
+    o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2];
+  } else {
+    const int view = f / a.clip_len, tt = f - view * a.clip_len;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      a.out_f32[(((int64_t)view * 3 + c) * a.clip_len + tt) * per + r] = ((float)v[c] - a.mean[c]) * a.stdinv[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int vitta_frames_cv2_resize(const uint8_t* d_frames, int32_t n_frames, int32_t in_h, int32_t in_w, int32_t x0, int32_t y0,
+                                       int32_t mode, const int32_t* d_tables, int32_t out_h, int32_t out_w, uint8_t* d_out_u8,
+                                       float* d_out_f32, int32_t clip_len, const float* d_mean, const float* d_stdinv, void* stream) {
+  if (!d_frames || n_frames <= 0 || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0 || mode < 0 || mode > 2 || x0 < 0 || y0 < 0)
+    return VITTA_ERR_INVALID_ARG;
+  if ((d_out_u8 == nullptr) == (d_out_f32 == nullptr)) return VITTA_ERR_INVALID_ARG;
+  if (mode == 2 && !d_tables) return VITTA_ERR_INVALID_ARG;
+  if (d_out_f32 && (clip_len <= 0 || n_frames % clip_len || !d_mean || !d_stdinv)) return VITTA_ERR_INVALID_ARG;
+  const int sx = mode == 1 ? 2 : 1;
+  if (mode != 2 && (x0 + sx * out_w > in_w || y0 + sx * out_h > in_h)) return VITTA_ERR_INVALID_ARG;
+  const Cv2Args a{d_frames, n_frames, in_h, in_w, x0, y0, mode, d_tables, out_h, out_w, d_out_u8, d_out_f32, clip_len, d_mean, d_stdinv};
+  const int64_t n = (int64_t)n_frames * out_h * out_w;
+  VITTA_LAUNCH(frames_cv2_resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return VITTA_OK;
+}

@@ -19,8 +19,10 @@ Video Swin (models/videoswintransformer_models/video_dataset.py:59-107 + transfo
     sampling for 'eval' (get_seq_frames :549-568), clamped to n_frames-1 (:700); decode; Resize(short edge
     scale_size) -> RandomResizedCrop (area .08-1, ratio 3/4-4/3, ONE crop for all views) or CenterCrop -> Resize
     to input_size -> Normalize(mean/std on 0-255) -> [V, 3, T, H, W].
-  The reference resizes with mmcv.imresize (cv2, not installed here): the Swin image ops below use torch bilinear
-  interpolation on the host and are therefore NOT bit-pinned (index sampler and crop-box arithmetic are).
+  The reference resizes with mmcv.imresize (cv2, not installed here): the Swin image ops restate cv2's 8-bit INTER_LINEAR
+  resampler (vitta_amd/frames.py::cv2_resize_linear on the host, vitta_frames_cv2_resize with --device_preprocess; the two
+  are bit-identical to each other and to oracle/frames_oracle.py, NOT pinned against cv2 itself; index sampler and
+  crop-box arithmetic are pinned).
 
 decord is imported lazily: constructing a dataset without it raises with a clear message.
 """
@@ -32,6 +34,7 @@ import numpy as np
 import torch
 
 from . import data
+from . import frames as F
 
 
 def _decord():
@@ -249,7 +252,7 @@ def random_resized_crop_box(img_h, img_w, area_range=(0.08, 1.0), aspect_ratio_r
 class VideoSwinDataset(torch.utils.data.Dataset):
     def __init__(self, list_file, clip_len, video_data_dir, vid_format="", frame_interval=2, num_clips=1,
                  frame_uniform=True, scale_size=224, input_size=224, img_norm_cfg=None, tta_views=None, tta_styles=None,
-                 debug=False):
+                 debug=False, device_preprocess=None):
         self.records = data.parse_video_list(list_file, remove_missing=False, debug=debug)
         self.T, self.dir, self.fmt = clip_len, video_data_dir, vid_format
         self.frame_interval, self.num_clips, self.frame_uniform = frame_interval, num_clips, frame_uniform
@@ -258,6 +261,9 @@ class VideoSwinDataset(torch.utils.data.Dataset):
         self.mean = torch.tensor(cfg["mean"], dtype=torch.float32).view(3, 1, 1, 1)
         self.std = torch.tensor(cfg["std"], dtype=torch.float32).view(3, 1, 1, 1)
         self.tta_views, self.tta_styles = tta_views, tta_styles
+        # device_preprocess = a torch device: the uint8 frames are uploaded and resized / normalised there (two launches of
+        # vitta_frames_cv2_resize, bit-identical to the host path below); None: the host numpy path
+        self.device = torch.device(device_preprocess) if device_preprocess is not None else None
         self._decord = _decord()
 
     def __len__(self):
@@ -278,21 +284,19 @@ class VideoSwinDataset(torch.utils.data.Dataset):
         reader = self._decord.VideoReader(osp.join(self.dir, f"{rec.path}{self.fmt}"))
         idx, views = self.frame_indices(len(reader))
         idx = np.minimum(idx, len(reader) - 1).astype(np.int64)
-        x = torch.from_numpy(reader.get_batch(idx).asnumpy()).permute(0, 3, 1, 2).float()  # F, 3, H, W
-        h, w = x.shape[-2:]
-        short = self.scale_size
-        nh, nw = (short, int(w * short / h + 0.5)) if h < w else (int(h * short / w + 0.5), short)
-        x = torch.nn.functional.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False)
-        if self.tta_views:
-            l, t, r, b = random_resized_crop_box(nh, nw)
+        fr = reader.get_batch(idx).asnumpy()  # F, H, W, 3 uint8
+        box = None
+        if self.tta_views:  # ONE RandomResizedCrop box for all frames of the sample, drawn on the rescaled size
+            h, w = fr.shape[1:3]
+            nh, nw = F.swin_scaled_size(h, w, self.scale_size)
+            fixed = random_resized_crop_box(nh, nw)
+            box = lambda _nh, _nw: fixed
+        mean, std = self.mean.flatten().tolist(), self.std.flatten().tolist()
+        if self.device is not None:
+            x = F.swin_clip_on_device(fr, self.device, views, self.T, self.scale_size, self.input_size, box, mean, std)
         else:
-            s = self.input_size
-            l, t = (nw - s) // 2, (nh - s) // 2
-            r, b = l + s, t + s
-        x = torch.nn.functional.interpolate(x[:, :, t:b, l:r], size=(self.input_size, self.input_size), mode="bilinear",
-                                            align_corners=False)
-        x = x.view(views, self.T, 3, self.input_size, self.input_size).permute(0, 2, 1, 3, 4)  # V, 3, T, H, W
-        return (x - self.mean) / self.std, rec.label
+            x = F.swin_clip_host(fr, views, self.T, self.scale_size, self.input_size, box, mean, std)
+        return x, rec.label
 
 
 def swin_video_dataset(args, dataset_type):
@@ -301,4 +305,5 @@ def swin_video_dataset(args, dataset_type):
                             frame_interval=args.frame_interval, num_clips=args.num_clips,
                             frame_uniform=args.frame_uniform, scale_size=args.scale_size, input_size=args.input_size,
                             img_norm_cfg=args.img_norm_cfg, tta_views=args.n_augmented_views if tta else None,
-                            tta_styles=args.tta_view_sample_style_list if tta else None, debug=args.debug)
+                            tta_styles=args.tta_view_sample_style_list if tta else None, debug=args.debug,
+                            device_preprocess=_preprocess_device(args))

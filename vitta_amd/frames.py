@@ -156,3 +156,123 @@ def eval_view(frame_size, scale_size, input_size):
         rw, rh = int(scale_size * w / h), scale_size
     top, left = int(round((rh - input_size) / 2.0)), int(round((rw - input_size) / 2.0))
     return ViewSpec((0, 0, w, h), (rw, rh), (left, top))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Video Swin pipeline (models/videoswintransformer_models/video_dataset.py:60-101 over transforms_backup.py Resize :193-349,
+# RandomResizedCrop / CenterCrop, Normalize, FormatShape NCTHW): every resize is mmcv.imresize = cv2.resize(...,
+# INTER_LINEAR) on uint8 frames.  cv2 is not installed in this image: the arithmetic below restates OpenCV's published 8-bit
+# bilinear resampler (modules/imgproc/src/resize.cpp: 11-bit fixed-point weights, integer horizontal pass, the
+# (b0 (S0 >> 4) >> 16) + (b1 (S1 >> 4) >> 16) + 2 >> 2 vertical pass, the exact-2x area shortcut) and is NOT pinned against
+# cv2 itself.  Host path: numpy; device path: vitta_frames_cv2_resize_* (bit-identical to the host path).
+# ------------------------------------------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=256)
+def cv2_linear_axis(src, dst, vertical):
+    """(first index, second index, w0, w1) int32 [dst] of cv2.resize(INTER_LINEAR) along one axis of `src` -> `dst` samples."""
+    scale = 1.0 / (float(dst) / float(src))
+    d = np.arange(dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int32)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    if vertical:  # rows are clipped, the weights keep the unclamped fraction
+        i0, i1 = np.clip(s, 0, src - 1), np.clip(s + 1, 0, src - 1)
+    else:         # columns: fraction forced to 0 at both borders
+        lo, hi = s < 0, s >= src - 1
+        f = np.where(lo | hi, np.float32(0), f).astype(np.float32)
+        s = np.where(lo, 0, np.where(hi, src - 1, s))
+        i0, i1 = s, np.minimum(s + 1, src - 1)
+    w1 = np.rint(f * np.float32(2048)).astype(np.int32)
+    w0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int32)
+    return i0.astype(np.int32), i1.astype(np.int32), w0, w1
+
+
+def cv2_resize_linear(img, dw, dh):
+    """uint8 [..., H, W, C] -> [..., dh, dw, C] as cv2.resize(img, (dw, dh), interpolation=cv2.INTER_LINEAR) (host path)."""
+    h, w = img.shape[-3], img.shape[-2]
+    if (h, w) == (dh, dw):
+        return img.copy()
+    if h == 2 * dh and w == 2 * dw:  # INTER_LINEAR at exactly 2x down takes cv2's INTER_AREA fast path
+        v = img.astype(np.int32)
+        return ((v[..., 0::2, 0::2, :] + v[..., 0::2, 1::2, :] + v[..., 1::2, 0::2, :] + v[..., 1::2, 1::2, :] + 2) >> 2).astype(np.uint8)
+    x0, x1, a0, a1 = cv2_linear_axis(w, dw, False)
+    y0, y1, b0, b1 = cv2_linear_axis(h, dh, True)
+    v = img.astype(np.int32)
+    hb = v[..., :, x0, :] * a0[:, None] + v[..., :, x1, :] * a1[:, None]          # [..., H, dw, C]
+    s0, s1 = hb[..., y0, :, :], hb[..., y1, :, :]
+    out = (((b0[:, None, None] * (s0 >> 4)) >> 16) + ((b1[:, None, None] * (s1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def swin_norm_constants(mean, std):
+    """mmcv.imnormalize: float32 (x - mean) * (1 / std), mean and 1 / std rounded to float32."""
+    m = np.asarray(mean, dtype=np.float64).astype(np.float32)
+    s = (1.0 / np.asarray(std, dtype=np.float64)).astype(np.float32)
+    return m, s
+
+
+def swin_clip_host(frames, views, clip_len, scale_size, input_size, crop_box, mean, std):
+    """frames uint8 [F, H, W, 3] (F = views * clip_len) -> float32 [views, 3, clip_len, S, S]: short edge -> scale_size,
+    crop_box(nh, nw) -> (l, t, r, b) (None: centre crop of input_size), resize to S x S, normalise, NCTHW."""
+    f, h, w, _ = frames.shape
+    nh, nw = swin_scaled_size(h, w, scale_size)
+    x = cv2_resize_linear(frames, nw, nh)
+    l, t, r, b = crop_box(nh, nw) if crop_box is not None else centre_box(nh, nw, input_size)
+    x = cv2_resize_linear(np.ascontiguousarray(x[:, t:b, l:r]), input_size, input_size)
+    m, s = swin_norm_constants(mean, std)
+    y = (x.astype(np.float32) - m) * s
+    return torch.from_numpy(np.ascontiguousarray(y.reshape(views, clip_len, input_size, input_size, 3).transpose(0, 4, 1, 2, 3)))
+
+
+def swin_scaled_size(h, w, short):
+    """mmcv.rescale_size((w, h), (inf, short)): the short edge becomes `short`, the other int(x * factor + 0.5)."""
+    factor = short / min(h, w)
+    return int(h * float(factor) + 0.5), int(w * float(factor) + 0.5)
+
+
+def centre_box(nh, nw, s):
+    l, t = (nw - s) // 2, (nh - s) // 2
+    return l, t, l + s, t + s
+
+
+class Cv2ResizePlan:
+    """Device tables of one cv2-style resize (source size, crop box inside it, destination size)."""
+
+    def __init__(self, src_hw, box, dst_hw, device):
+        (sh, sw), (l, t, r, b), (dh, dw) = src_hw, box, dst_hw
+        ch, cw = b - t, r - l
+        self.src_hw, self.box, self.dst_hw = (sh, sw), (l, t, r, b), (dh, dw)
+        self.mode = 0 if (ch, cw) == (dh, dw) else (1 if (ch == 2 * dh and cw == 2 * dw) else 2)
+        x0, x1, a0, a1 = cv2_linear_axis(cw, dw, False) if self.mode == 2 else (np.zeros(dw, np.int32),) * 4
+        y0, y1, b0, b1 = cv2_linear_axis(ch, dh, True) if self.mode == 2 else (np.zeros(dh, np.int32),) * 4
+        tab = np.concatenate([x0 + l, x1 + l, a0, a1, y0 + t, y1 + t, b0, b1]).astype(np.int32)
+        self.table = torch.from_numpy(tab).to(device)
+
+
+def cv2_resize_device(frames, plan, out_u8=None, out_f32=None, clip_len=0, mean=None, stdinv=None):
+    """frames uint8 [F, sh, sw, 3] on the GPU -> uint8 [F, dh, dw, 3] (out_u8) or normalised float32 [V, 3, T, dh, dw]
+    (out_f32, V = F / clip_len) through `vitta_frames_cv2_resize`."""
+    if not frames.is_cuda or frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise _lib.VittaHipError("frames must be a contiguous uint8 tensor on the GPU (no CPU fallback)")
+    f, sh, sw, _ = frames.shape
+    dh, dw = plan.dst_hw
+    l, t, _, _ = plan.box
+    ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+    check(lib().vitta_frames_cv2_resize(ptr(frames), f, sh, sw, l, t, plan.mode, ptr(plan.table), dh, dw, ptr(out_u8), ptr(out_f32),
+                                        int(clip_len), ptr(mean), ptr(stdinv), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "vitta_frames_cv2_resize")
+    return out_u8 if out_u8 is not None else out_f32
+
+
+def swin_clip_on_device(frames_u8, device, views, clip_len, scale_size, input_size, crop_box, mean, std):
+    """The same pipeline as swin_clip_host in two launches on the uploaded uint8 frames (bit-identical to it)."""
+    fr = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(device) if not torch.is_tensor(frames_u8) else frames_u8.to(device)
+    f, h, w, _ = fr.shape
+    nh, nw = swin_scaled_size(h, w, scale_size)
+    mid = torch.empty(f, nh, nw, 3, dtype=torch.uint8, device=device)
+    cv2_resize_device(fr, Cv2ResizePlan((h, w), (0, 0, w, h), (nh, nw), device), out_u8=mid)
+    box = crop_box(nh, nw) if crop_box is not None else centre_box(nh, nw, input_size)
+    m, s = swin_norm_constants(mean, std)
+    out = torch.empty(views, 3, clip_len, input_size, input_size, dtype=torch.float32, device=device)
+    cv2_resize_device(mid, Cv2ResizePlan((nh, nw), box, (input_size, input_size), device), out_f32=out, clip_len=clip_len,
+                      mean=torch.from_numpy(m).to(device), stdinv=torch.from_numpy(s).to(device))
+    return out
