@@ -614,6 +614,22 @@ int vitta_linear_bwd_f32(const float* d_dy, const float* d_x, const float* d_w, 
                          float* d_dw, float* d_db, void* stream);
 
 /* --------------------------------------------------------------------------
+ * A10 -- dense layers of Video Swin-B: d_y[m][n] = epi(sum_k d_a[m][k] d_b[n][k]), all row-major fp32, K % 32 == 0
+ * (the qkv / proj Linear of WindowAttention3D, models/videoswintransformer_models/swin_transformer.py:144, 165;
+ * Mlp.fc1 + GELU + fc2, :30-35; PatchMerging.reduction, :304-311; replaces torch.nn.functional.linear / nn.GELU
+ * there).  d_b is nn.Linear's own [out][in] weight; a data gradient is the same product with d_a = dy and d_b = the
+ * transposed weight [in][out].  Exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), fp32 accumulation.
+ *   mode 0: y = acc (+ d_bias[n], NULL: none)
+ *   mode 1: h = acc + d_bias[n]; d_pre[m][n] = h (NULL: not kept); y = 0.5 h (1 + erf(h / sqrt 2))      (nn.GELU)
+ *   mode 2: y = acc * gelu'(d_aux[m][n])                 (fc2's data gradient arriving at fc1's output, d_aux = h)
+ * tile: 0 = library's choice, 1 = 128 x 128 output tiles, 2 = 64 x 128, 3 = 64 x 64.  VITTA_ERR_UNSUPPORTED: K % 32 != 0 or an
+ * operand of 2 GiB or more (vitta_gemm_nt_supported).
+ * -------------------------------------------------------------------------- */
+int vitta_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
+int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y, float* d_pre,
+                      int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream);
+
+/* --------------------------------------------------------------------------
  * N1 -- decoded RGB frames -> network input, bit-identical to the reference's PIL pipeline
  * (models/tanet_models/transforms.py:277-384 per-view multi-scale crop + Image.resize(BILINEAR); :46-54, :170-184
  * short-edge scale + centre crop; :637-678 stack + ToTorchFormatTensor(div 255); :140-152 GroupNormalize).

@@ -1,0 +1,96 @@
+"""Dense layers of Video Swin-B on the hand-written GEMM (csrc/gemm.hip, through the C ABI) -- GPU box only.
+
+Reference arithmetic: torch.nn.functional.linear / nn.GELU as models/videoswintransformer_models/swin_transformer.py:30-35,
+144, 165, 304-311 call them, evaluated in fp64 on the CPU.  Tolerance (fp32 products, fp32 accumulation over K <= 4096):
+|err| <= 2e-5 * max|y| + 1e-6."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, rel=2e-5):
+    ref = ref.to(torch.float64)
+    err = (got.detach().cpu().to(torch.float64) - ref).abs().max().item()
+    assert err <= rel * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+
+
+# (M, N, K): Swin-B stage shapes (tokens x out x in) incl. ragged token counts (784 = 12.25 x 64, 392) and N = 3 C
+SHAPES = [(3136, 1536, 512), (784, 1024, 4096), (392, 3072, 1024), (12544, 256, 256), (50176 // 4, 384, 128), (200, 128, 32),
+          (1, 256, 64), (3136, 512, 2048)]
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("m,n,k", SHAPES)
+def test_gemm_modes_vs_fp64(m, n, k, tile):
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    aux = torch.randn(m, n, generator=g) * 1.5
+    ad, wd, bd, auxd = (t.to(_dev()) for t in (a, w, b, aux))
+    ops.GEMM_TILE = tile
+    try:
+        y0 = ops.gemm_nt(ad, wd, bd)
+        y0n = ops.gemm_nt(ad, wd)
+        pre = torch.empty(m, n, device=_dev())
+        y1 = ops.gemm_nt(ad, wd, bd, mode=1, pre=pre)
+        y2 = ops.gemm_nt(ad, wd, mode=2, aux=auxd)
+    finally:
+        ops.GEMM_TILE = 0
+    a64, w64, b64, x64 = a.double(), w.double(), b.double(), aux.double()
+    lin = a64 @ w64.t()
+    _close(y0, lin + b64)
+    _close(y0n, lin)
+    _close(pre, lin + b64)
+    _close(y1, F.gelu(lin + b64))
+    x = x64.clone().requires_grad_(True)
+    (dg,) = torch.autograd.grad(F.gelu(x).sum(), x)
+    _close(y2, lin * dg, rel=4e-5)
+
+
+def test_gemm_rejects_unsupported_and_host_tensors():
+    from vitta_amd import _lib, ops
+    assert not ops.gemm_nt_supported(64, 64, 48)
+    with pytest.raises(_lib.VittaHipError):
+        ops.gemm_nt(torch.randn(8, 32), torch.randn(8, 32))
+    with pytest.raises(_lib.VittaHipError):
+        ops.gemm_nt(torch.randn(8, 48, device=_dev()), torch.randn(8, 48, device=_dev()))
+
+
+@pytest.mark.parametrize("train_weights", [False, True])
+def test_mlp_and_linear_autograd_match_module_path(train_weights):
+    """Mlp / Linear modules on the hand-written path vs the same modules on torch's own kernels: outputs, input gradient,
+    and (SGD over all parameters) weight / bias gradients."""
+    from vitta_amd import ops, swin
+    torch.manual_seed(3)
+    mlp = swin.Mlp(256, 1024).to(_dev())
+    lin = torch.nn.Linear(256, 768).to(_dev())
+    for p in list(mlp.parameters()) + list(lin.parameters()):
+        p.requires_grad_(train_weights)
+    x = torch.randn(2, 196, 256, device=_dev())
+    gy = torch.randn(2, 196, 256, device=_dev())
+    gq = torch.randn(2, 196, 768, device=_dev())
+    res = {}
+    old = ops.DIRECT_PARAM_GRAD
+    ops.DIRECT_PARAM_GRAD = False
+    try:
+        for fused in (True, False):
+            swin.FUSED_DENSE = fused
+            xi = x.clone().requires_grad_(True)
+            params = [p for p in list(mlp.parameters()) + list(lin.parameters()) if p.requires_grad]
+            y, q = mlp(xi), swin.linear(lin, xi)
+            grads = torch.autograd.grad([y, q], [xi] + params, [gy, gq])
+            res[fused] = [y, q] + list(grads)
+    finally:
+        swin.FUSED_DENSE = True
+        ops.DIRECT_PARAM_GRAD = old
+    assert len(res[True]) == len(res[False]) == (3 + (6 if train_weights else 0))
+    for got, ref in zip(res[True], res[False]):
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6

@@ -1,0 +1,70 @@
+"""Per-shape timing of the hand-written dense kernel (csrc/gemm.hip) against torch's library GEMM (rocBLAS / hipBLASLt)
+on the Video Swin-B shapes of BASELINE config 3 (2 views x 16 frames x 224^2): python tools/bench_gemm.py [--out f.json]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.nn.functional as F
+
+from vitta_amd import ops
+
+p = argparse.ArgumentParser()
+p.add_argument("--out", default=None)
+p.add_argument("--reps", type=int, default=20)
+p.add_argument("--views", type=int, default=2)
+opt = p.parse_args()
+dev = torch.device("cuda:0")
+PEAK = 157.3
+
+
+def timed(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3  # us
+
+
+rows = []
+tok0 = opt.views * 8 * 56 * 56
+for stage, (c, blocks) in enumerate([(128, 2), (256, 2), (512, 18), (1024, 2)]):
+    m = tok0 >> (2 * stage)
+    for name, n, k, mode in [("qkv", 3 * c, c, 0), ("proj", c, c, 0), ("fc1+gelu", 4 * c, c, 1), ("fc2", c, 4 * c, 0),
+                             ("fc2.dgrad*gelu'", 4 * c, c, 2)]:
+        a = torch.randn(m, k, device=dev)
+        w = torch.randn(n, k, device=dev) * k ** -0.5
+        b = torch.randn(n, device=dev)
+        aux = torch.randn(m, n, device=dev) if mode == 2 else None
+        pre = torch.empty(m, n, device=dev) if mode == 1 else None
+        y = torch.empty(m, n, device=dev)
+        gf = 2.0 * m * n * k / 1e9
+        row = dict(stage=stage, layer=name, M=m, N=n, K=k, gflop=gf, blocks=blocks)
+        for tile in (1, 2, 3, 0):
+            ops.GEMM_TILE = tile
+            us = timed(lambda: ops.gemm_nt(a, w, b if mode != 2 else None, mode=mode, aux=aux, pre=pre, out=y), opt.reps)
+            row[f"tile{tile}_us"] = us
+            row[f"tile{tile}_tf"] = gf / us * 1e3
+        ops.GEMM_TILE = 0
+        if mode == 0:
+            lib_fn = lambda: F.linear(a, w, b)
+        elif mode == 1:
+            lib_fn = lambda: F.gelu(F.linear(a, w, b))
+        else:
+            lib_fn = lambda: torch.mm(a, w.t()) * aux
+        row["library_us"] = timed(lib_fn, opt.reps)
+        row["library_tf"] = gf / row["library_us"] * 1e3
+        rows.append(row)
+        print(f"s{stage} {name:16s} M={m:6d} N={n:5d} K={k:5d} {gf:7.2f} GF | 128x128 {row['tile1_us']:7.1f} us {row['tile1_tf']:6.1f} TF"
+              f" | 64x128 {row['tile2_us']:7.1f} us {row['tile2_tf']:6.1f} TF | 64x64 {row['tile3_us']:7.1f} us {row['tile3_tf']:6.1f} TF | auto {row['tile0_us']:7.1f} us {row['tile0_tf']:6.1f} TF | library"
+              f" {row['library_us']:7.1f} us {row['library_tf']:6.1f} TF", flush=True)
+tot = lambda key: sum(r[key] * r["blocks"] for r in rows)
+summary = dict(ours_auto_ms=tot("tile0_us") / 1e3, library_ms=tot("library_us") / 1e3, gflop=tot("gflop"), peak_tf=PEAK,
+               ours_tf=tot("gflop") / tot("tile0_us") * 1e3, library_tf=tot("gflop") / tot("library_us") * 1e3)
+print(json.dumps(summary))
+if opt.out:
+    json.dump(dict(summary=summary, rows=rows), open(opt.out, "w"), indent=1)

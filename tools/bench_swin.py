@@ -24,6 +24,7 @@ p.add_argument("--window-depth", type=int, default=8, help="temporal window (16 
 p.add_argument("--tuned-gemms", action="store_true", help="measured GEMM selection table (vitta_amd/tuning); off by default")
 p.add_argument("--blas", default=None, choices=["hipblaslt", "hipblas", "default"], help="torch.backends.cuda.preferred_blas_library")
 p.add_argument("--wmsa-bf16", action="store_true", help="bf16-operand window attention (vitta_wmsa_rel_*_bf16, BASELINE config 5)")
+p.add_argument("--library-dense", action="store_true", help="qkv / proj / MLP on torch's library GEMMs + ATen GELU instead of csrc/gemm.hip")
 p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
 if opt.blas:
@@ -33,6 +34,9 @@ if opt.tuned_gemms and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     from vitta_amd import tuning
     tuned = tuning.enable_tuned_gemms()
 dev = torch.device("cuda:0")
+if opt.library_dense:
+    from vitta_amd import swin as _swin
+    _swin.FUSED_DENSE = False
 if opt.wmsa_bf16:
     from vitta_amd import ops as _ops
     _ops.WMSA_BF16 = True
@@ -89,5 +93,5 @@ for i in range(opt.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
 print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph, tuned_gemms=tuned,
-                      frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine", wmsa="bf16 operands" if opt.wmsa_bf16 else "fp32",
+                      frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine", wmsa="bf16 operands" if opt.wmsa_bf16 else "fp32", dense="library" if opt.library_dense else "gemm.hip",
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

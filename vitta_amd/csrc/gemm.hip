@@ -1,0 +1,247 @@
+// Dense layers of Video Swin-B: y[m][n] = epi(sum_k a[m][k] b[n][k]) -- the qkv / proj Linear of
+// WindowAttention3D (models/videoswintransformer_models/swin_transformer.py:144, 165), Mlp.fc1 + GELU + fc2 (:30-35),
+// PatchMerging.reduction (:304-311) and their data gradients (the same product against the transposed weight).
+//
+// Both operands are row-major with the REDUCTION axis contiguous (tokens x channels, nn.Linear's [out][in] weight), so
+// a slab tile sits in LDS exactly as it sits in memory: [row][32 k + 4 pad].  A lane of the 32x32x2 fp32 MFMA needs
+// (row = lane % 32, k = lane / 32) per k-step; since both operands may walk k in ANY common order, a lane takes the four
+// k = 8 j + 4 (lane / 32) + {0..3} of its row with ONE 16-byte LDS read and feeds four k-steps from it.  Row stride 36
+// floats: 9 (odd) sixteen-byte units, so the 16 lanes a ds_read_b128 services per cycle start in 16 different bank quads,
+// and a global 16-byte load lands as one conflict-free ds_write_b128.
+//
+// Workgroup = 256 lanes = 2 x 2 waves over a BM x 128 output tile (BM = 128: every wave owns 2 x 2 accumulator blocks of
+// 32 x 32, i.e. 16 MFMAs per pair of 16-byte reads -- the matrix pipe, not LDS or issue, is what is busy; BM = 64 for
+// launches that would otherwise leave CUs idle; 64 x 64: one block per wave).  K is walked in slabs of 32 through two LDS stages; the global loads of
+// slab s + 2 are in flight in registers while slab s is multiplied: one barrier per slab (4096 matrix-pipe cycles at
+// BM = 128).  Tiles are numbered n-fastest and handed to XCDs in contiguous ranges (a token tile's rows are re-read by
+// the n-tiles of one L2).
+//
+// Epilogues (lane = output column, so every store instruction writes two full 128-byte lines):
+//   mode 0  y = acc (+ bias[n])
+//   mode 1  h = acc + bias[n];  (pre = h);  y = gelu(h)                 fc1 + nn.GELU (exact erf form)
+//   mode 2  y = acc * gelu'(aux[m][n])                                   fc2's data gradient lands on fc1's output
+#include <hip/hip_runtime.h>
+
+#include "conv_common.h"
+
+using vitta_conv::f32x16;
+using vitta_conv::f32x4;
+using vitta_conv::xcd_remap;
+
+namespace {
+
+constexpr int BK = 32, LS = 36, NTH = 256;
+
+struct GemmArgs {
+  const float* a;      // [M][K]
+  const float* b;      // [N][K]
+  const float* bias;   // [N] or null
+  const float* aux;    // [M][N] (mode 2)
+  float* y;            // [M][N]
+  float* pre;          // [M][N] or null (mode 1)
+  int M, N, K, mode;
+  int nMt, nNt;
+};
+
+__device__ __forceinline__ float gelu_f(float h) { return 0.5f * h * (1.f + erff(h * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float h) {
+  return 0.5f * (1.f + erff(h * 0.70710678118654752f)) + h * 0.3989422804014327f * expf(-0.5f * h * h);
+}
+
+template <int BM, int BN, bool AUX>
+__global__ __launch_bounds__(NTH) void gemm_nt_kernel(const GemmArgs g) {
+  constexpr int MI = BM / 64, NI = BN / 64;                       // 32 x 32 blocks per wave (waves 2 x 2)
+  constexpr int A4 = BM * BK / 4 / NTH, B4 = BN * BK / 4 / NTH;   // 16-byte staging loads per lane and slab
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const As = lds;                    // [2][BM][LS]
+  float* const Bs = lds + 2 * BM * LS;      // [2][BN][LS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / g.nNt) * BM, n0 = (t % g.nNt) * BN;
+  const int K = g.K;
+
+  // rows past M / N read zeros: the buffer's extent is the operand's true size
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a), 0, (int)((int64_t)g.M * K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, (int)((int64_t)g.N * K * 4), 0x00020000);
+  constexpr int OOB = (int)0x80000000u;
+  int voff_a[A4], voff_b[B4];
+#pragma unroll
+  for (int u = 0; u < A4; ++u) {
+    const int r = m0 + (tid >> 3) + u * 32;
+    voff_a[u] = r < g.M ? (r * K + (tid & 7) * 4) * 4 : OOB;
+  }
+#pragma unroll
+  for (int u = 0; u < B4; ++u) {
+    const int r = n0 + (tid >> 3) + u * 32;
+    voff_b[u] = r < g.N ? (r * K + (tid & 7) * 4) * 4 : OOB;
+  }
+  f32x4 ra[A4], rb[B4];
+  auto load_global = [&](int s) __attribute__((always_inline)) {
+    const int so = s * BK * 4;
+#pragma unroll
+    for (int u = 0; u < A4; ++u) ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff_a[u], so, 0));
+#pragma unroll
+    for (int u = 0; u < B4; ++u) rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b[u], so, 0));
+  };
+  float* const st_a = As + (tid >> 3) * LS + (tid & 7) * 4;
+  float* const st_b = Bs + (tid >> 3) * LS + (tid & 7) * 4;
+  auto store_lds = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A4; ++u) *reinterpret_cast<f32x4*>(st_a + buf * BM * LS + u * 32 * LS) = ra[u];
+#pragma unroll
+    for (int u = 0; u < B4; ++u) *reinterpret_cast<f32x4*>(st_b + buf * BN * LS + u * 32 * LS) = rb[u];
+  };
+
+  const float* const rd_a = As + (wm * (BM / 2) + li) * LS + 4 * lk;
+  const float* const rd_b = Bs + (wn * (BN / 2) + li) * LS + 4 * lk;
+  f32x4 fa[2][MI], fb[2][NI];
+  auto read_frag = [&](int buf, int j, int set) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(rd_a + buf * BM * LS + i * 32 * LS + 8 * j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fb[set][i] = *reinterpret_cast<const f32x4*>(rd_b + buf * BN * LS + i * 32 * LS + 8 * j);
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // mode 2: the gelu' operand of this lane's outputs is requested BEFORE the K walk (its latency hides under the MFMAs;
+  // a load -> multiply -> store chain at the end of a short-K launch ran the epilogue at 1 TB/s)
+  float auxv[AUX ? MI : 1][AUX ? NI : 1][16];
+  if constexpr (AUX) {
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int col = n0 + wn * (BN / 2) + n * 32 + li;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = rbase + 8 * (v >> 2) + (v & 3);
+          auxv[i][n][v] = (row < g.M && col < g.N) ? g.aux[(int64_t)row * g.N + col] : 0.f;
+        }
+      }
+    }
+  }
+
+  const int ns = K / BK;
+  load_global(0);
+  store_lds(0);
+  if (ns > 1) load_global(1);
+  __syncthreads();
+
+  auto slab = [&](int s, int buf) __attribute__((always_inline)) {
+    read_frag(buf, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < 3) read_frag(buf, j + 1, (j + 1) & 1);
+      if (j == 1 && s + 1 < ns) store_lds(buf ^ 1);   // slab s + 1: its stage was last read before the previous barrier
+      if (j == 2 && s + 2 < ns) load_global(s + 2);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int n = 0; n < NI; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][i][kk], fb[j & 1][n][kk], acc[i][n], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < ns; s += 2) {
+    slab(s, 0);
+    if (s + 1 < ns) slab(s + 1, 1);
+  }
+
+  // ---- epilogue: register v of block (i, n): row 8 (v / 4) + 4 lk + v % 4, column li ------------------------------
+  const int mode = AUX ? 2 : g.mode;
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int col = n0 + wn * (BN / 2) + n * 32 + li;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = rbase + 8 * (v >> 2) + (v & 3);
+        if (row >= g.M) continue;
+        const int64_t o = (int64_t)row * g.N + col;
+        float h = acc[i][n][v] + bv;
+        if (mode == 1) {
+          if (g.pre) g.pre[o] = h;
+          h = gelu_f(h);
+        } else if constexpr (AUX) {
+          h *= dgelu_f(auxv[i][n][v]);
+        }
+        g.y[o] = h;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool AUX>
+int launch_one(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  g.nMt = (g.M + BM - 1) / BM;
+  g.nNt = (g.N + BN - 1) / BN;
+  const size_t lds = sizeof(float) * 2 * (BM + BN) * LS;
+  static bool raised = false;
+  if (lds > 48 * 1024 && !raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return VITTA_ERR_LAUNCH;
+    raised = true;
+  }
+  VITTA_LAUNCH((gemm_nt_kernel<BM, BN, AUX>), dim3((unsigned)(g.nMt * g.nNt)), dim3(NTH), lds, st, g);
+  return VITTA_OK;
+}
+
+template <int BM, int BN>
+int launch(const GemmArgs& g, hipStream_t st) {
+  return g.mode == 2 ? launch_one<BM, BN, true>(g, st) : launch_one<BM, BN, false>(g, st);
+}
+
+// Tile choice: the launch lasts as long as its busiest CU -- ceil(tiles / 256) tiles of MI x NI accumulator blocks each
+// (workgroups sharing a CU share its matrix pipes) -- so the finest tile wins the quantisation and the coarsest the LDS /
+// L2 traffic per flop; `pen` = measured relative cost of a block's work in each tile shape (profiles/r2h_gemm_bench.json: on
+// every Swin-B shape the 64 x 64 tile -- four workgroups per CU hiding each other's staging -- is the fastest, 82-100 TF).
+int choose_tile(int64_t M, int N, int mode) {
+  const struct { int bm, bn; double pen; } cfg[3] = {{128, 128, 1.25}, {64, 128, 1.20}, {64, 64, 1.00}};
+  int best = 1;
+  double best_cost = 0;
+  const int first = mode == 2 ? 1 : 0;  // the gelu' operand held in registers leaves the 128 x 128 tile one wave per SIMD
+  for (int c = first; c < 3; ++c) {
+    const int64_t tiles = ((M + cfg[c].bm - 1) / cfg[c].bm) * ((N + cfg[c].bn - 1) / cfg[c].bn);
+    const double cost = (double)((tiles + 255) / 256) * (cfg[c].bm / 32) * (cfg[c].bn / 32) * cfg[c].pen;
+    if (c == first || cost < best_cost) best = c + 1, best_cost = cost;
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" int vitta_gemm_nt_supported(int64_t M, int32_t N, int32_t K) {
+  return M > 0 && N > 0 && K >= BK && K % BK == 0 && M * (int64_t)K * 4 < (int64_t)1 << 31 && (int64_t)N * K * 4 < (int64_t)1 << 31 &&
+         M * (int64_t)N < (int64_t)1 << 40;
+}
+
+extern "C" int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y,
+                                 float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream) {
+  if (!d_a || !d_b || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux)) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_gemm_nt_supported(M, N, K)) return VITTA_ERR_UNSUPPORTED;
+  GemmArgs g{d_a, d_b, d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tile == 0) tile = choose_tile(M, N, mode);
+  if (tile == 1) return launch<128, 128>(g, st);
+  if (tile == 2) return launch<64, 128>(g, st);
+  if (tile == 3) return launch<64, 64>(g, st);
+  return VITTA_ERR_INVALID_ARG;
+}

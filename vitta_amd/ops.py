@@ -821,3 +821,131 @@ class HeadLinear(torch.autograd.Function):
 def head_linear_supported(x, linear):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[0] <= 4096
             and linear.weight.dtype == torch.float32 and not linear._forward_hooks and not linear._forward_pre_hooks)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense layers of Video Swin-B (csrc/gemm.hip): qkv / proj / Mlp / PatchMerging.reduction
+# ------------------------------------------------------------------------------------------------
+GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128)
+_WT_CACHE = {}      # id(weight) -> (weakref, version, transposed copy): frozen weights are transposed once
+
+
+def gemm_nt_supported(m, n, k):
+    return bool(lib().vitta_gemm_nt_supported(m, n, k))
+
+
+def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
+    """y[m][n] = epi(sum_k a[m][k] b[n][k]) (vitta_gemm_nt_f32; mode 0: + bias, 1: bias + GELU (pre-activation kept in
+    `pre`), 2: times gelu'(aux))."""
+    _require_cuda_f32(a, "a")
+    _require_cuda_f32(b, "b")
+    m, k = a.shape
+    n = b.shape[0]
+    assert a.is_contiguous() and b.is_contiguous() and b.shape[1] == k
+    y = out if out is not None else torch.empty(m, n, dtype=torch.float32, device=a.device)
+    check(lib().vitta_gemm_nt_f32(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()),
+          "vitta_gemm_nt_f32")
+    return y
+
+
+def _transposed(weight):
+    """[in][out] copy of an nn.Linear weight for the data gradient.  A frozen weight (LN-affine adaptation) is transposed
+    once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
+    `_version`, and a captured graph must hold the copy launch)."""
+    if weight.requires_grad:
+        return weight.detach().t().contiguous()
+    import weakref
+    ent = _WT_CACHE.get(id(weight))
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2].device == weight.device:
+        return ent[2]
+    wt = weight.detach().t().contiguous()
+    _WT_CACHE[id(weight)] = (weakref.ref(weight), weight._version, wt)
+    return wt
+
+
+def _param_grad(param, needed, value_fn):
+    """Hand a parameter gradient to its sink (accumulated in place when `.grad` is a live arena view)."""
+    if not needed:
+        return None
+    sink, ret = _grad_sink(param, True, zero=False)
+    val = value_fn()
+    if ret is None:
+        sink.add_(val.view_as(sink))
+        return None
+    return val.view_as(param)
+
+
+class DenseLinear(torch.autograd.Function):
+    """F.linear(x, weight, bias) on the hand-written GEMM: forward y = x W^T + b, backward dx = dy W (the same kernel
+    against the transposed weight); weight / bias gradients (SGD over all parameters only) as library products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = gemm_nt(x2, weight, bias)
+        ctx.save_for_backward(x2 if weight.requires_grad else None, weight, bias)
+        ctx.xshape = shape
+        return y.view(shape[:-1] + (weight.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, weight, bias = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        dx = gemm_nt(g2, _transposed(weight)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = _param_grad(weight, ctx.needs_input_grad[1], lambda: g2.t() @ x2)
+        db = _param_grad(bias, bias is not None and ctx.needs_input_grad[2], lambda: g2.sum(0))
+        return dx, dw, db
+
+
+class FusedMlp(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) (swin_transformer.py:30-35 with drop = 0): bias + GELU in fc1's epilogue (the pre-activation h is
+    kept for the backward), gelu'(h) in the epilogue of fc2's data gradient -- no stand-alone activation pass in either
+    direction."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = any(ctx.needs_input_grad)
+        h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
+        a = gemm_nt(x2, w1, b1, mode=1, pre=h)
+        y = gemm_nt(a, w2, b2)
+        train_w = w1.requires_grad or w2.requires_grad
+        ctx.save_for_backward(x2 if train_w else None, h, a if train_w else None, w1, b1, w2, b2)
+        ctx.xshape = shape
+        return y.view(shape[:-1] + (w2.shape[0],))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, h, a, w1, b1, w2, b2 = ctx.saved_tensors
+        g2 = gy.reshape(-1, gy.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        gh = gemm_nt(g2, _transposed(w2), mode=2, aux=h)
+        dx = gemm_nt(gh, _transposed(w1)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1 = _param_grad(w1, ctx.needs_input_grad[1], lambda: gh.t() @ x2)
+        db1 = _param_grad(b1, b1 is not None and ctx.needs_input_grad[2], lambda: gh.sum(0))
+        dw2 = _param_grad(w2, ctx.needs_input_grad[3], lambda: g2.t() @ a)
+        db2 = _param_grad(b2, b2 is not None and ctx.needs_input_grad[4], lambda: g2.sum(0))
+        return dx, dw1, db1, dw2, db2
+
+
+def dense_supported(x, *linears):
+    """The hand-written dense path takes fp32 device activations through hook-free nn.Linear modules with K % 32 == 0."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+        return False
+    m = x.numel() // x.shape[-1]
+    k = x.shape[-1]
+    for lin in linears:
+        if (lin.weight.dtype != torch.float32 or lin._forward_hooks or lin._forward_pre_hooks or lin.weight.shape[1] != k
+                or not gemm_nt_supported(m, lin.weight.shape[0], k)):
+            return False
+        k = lin.weight.shape[0]
+    return True

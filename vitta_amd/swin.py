@@ -90,6 +90,15 @@ def residual(x, branch, drop_path):
     return x + drop_path(branch)
 
 
+def linear(mod, x):
+    """nn.Linear on the hand-written GEMM (csrc/gemm.hip) for fp32 device activations; the module itself elsewhere."""
+    if FUSED_DENSE and x.is_cuda:
+        from . import ops
+        if ops.dense_supported(x, mod):
+            return ops.DenseLinear.apply(x, mod.weight, mod.bias)
+    return mod(x)
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
@@ -101,6 +110,12 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if (FUSED_DENSE and x.is_cuda and (self.drop.p == 0.0 or not self.training) and isinstance(self.act, nn.GELU)
+                and getattr(self.act, "approximate", "none") == "none"):
+            from . import ops
+            if ops.dense_supported(x, self.fc1, self.fc2):
+                # bias + GELU in fc1's epilogue, gelu' in the epilogue of fc2's data gradient
+                return ops.FusedMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -189,6 +204,7 @@ def relative_position_index(window_size):
     return (rel[..., 0] * (2 * wh - 1) + rel[..., 1]) * (2 * ww - 1) + rel[..., 2]
 
 
+FUSED_DENSE = True      # qkv / proj / Mlp / PatchMerging.reduction on csrc/gemm.hip instead of rocBLAS + ATen GELU
 FUSED_ATTENTION = True  # tests flip this to compare the fused kernel with the composed ops on the GPU
 FUSED_RESIDUAL = True   # x + DropPath(branch) as one pass
 FUSED_PARTITION = True  # ... and this to compare the row-mapped kernel with roll + window_partition copies
@@ -241,14 +257,14 @@ class WindowAttention3D(nn.Module):
         if x.is_cuda and FUSED_ATTENTION and (mask is None or region is not None):
             from . import ops
             if ops.wmsa_rel_supported(N, C // self.num_heads, self.relative_position_bias_table.shape[0]):
-                out = ops.WindowAttentionRel.apply(self.qkv(x), self.relative_position_bias_table,
+                out = ops.WindowAttentionRel.apply(linear(self.qkv, x), self.relative_position_bias_table,
                                                    self.relative_position_code[:N], self.code_offset, region, self.scale,
                                                    self.num_heads)
-                return self.proj_drop(self.proj(out))
+                return self.proj_drop(linear(self.proj, out))
         idx = self.relative_position_index[:N, :N].reshape(-1)
         bias = self.relative_position_bias_table[idx].view(N, N, self.num_heads).permute(2, 0, 1).contiguous()
-        out = window_attention(self.qkv(x), bias, mask, self.scale, self.num_heads)
-        return self.proj_drop(self.proj(out))
+        out = window_attention(linear(self.qkv, x), bias, mask, self.scale, self.num_heads)
+        return self.proj_drop(linear(self.proj, out))
 
 
 class SwinTransformerBlock3D(nn.Module):
@@ -282,10 +298,10 @@ class SwinTransformerBlock3D(nn.Module):
             if ops.wmsa_rel_supported(n_tok, C // attn.num_heads, attn.relative_position_bias_table.shape[0]):
                 # shift + partition + reverse + inverse shift as address arithmetic inside the attention kernel
                 rowmap = compute_rowmap(D, H, W, ws, ss, x.device)
-                out = ops.WindowAttentionRel.apply(attn.qkv(x.view(B, D * H * W, C)), attn.relative_position_bias_table,
+                out = ops.WindowAttentionRel.apply(linear(attn.qkv, x.view(B, D * H * W, C)), attn.relative_position_bias_table,
                                                    attn.relative_position_code[:n_tok], attn.code_offset,
                                                    region if shifted else None, attn.scale, attn.num_heads, rowmap)
-                return attn.proj_drop(attn.proj(out)).view(B, D, H, W, C)
+                return attn.proj_drop(linear(attn.proj, out)).view(B, D, H, W, C)
         if shifted:
             x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
         windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None,
@@ -323,7 +339,7 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
         from .fused_ln import ln
-        return self.reduction(ln(self.norm, x))
+        return linear(self.reduction, ln(self.norm, x))
 
 
 class BasicLayer(nn.Module):
