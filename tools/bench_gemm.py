@@ -12,6 +12,7 @@ p = argparse.ArgumentParser()
 p.add_argument("--out", default=None)
 p.add_argument("--reps", type=int, default=20)
 p.add_argument("--views", type=int, default=2)
+p.add_argument("--tanet", action="store_true", help="the pointwise-convolution shapes of the TANet trunk at 16 frames, as GEMMs")
 opt = p.parse_args()
 dev = torch.device("cuda:0")
 PEAK = 157.3
@@ -30,6 +31,20 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e3  # us
 
 
+if opt.tanet:
+    for (m, n, k) in [(50176, 256, 64), (50176, 64, 256), (12544, 512, 128), (12544, 128, 512), (3136, 1024, 256), (3136, 256, 1024),
+                      (784, 2048, 512), (784, 512, 2048), (50176, 128, 256), (12544, 256, 512), (3136, 512, 1024)]:
+        a = torch.randn(m, k, device=dev)
+        w = torch.randn(n, k, device=dev)
+        y = torch.empty(m, n, device=dev)
+        gf = 2.0 * m * n * k / 1e9
+        line = f"M={m:6d} N={n:5d} K={k:5d} {gf:5.2f} GF"
+        for tile in (2, 3):
+            ops.GEMM_TILE = tile
+            us = timed(lambda: ops.gemm_nt(a, w, out=y), opt.reps)
+            line += f" | tile{tile} {us:6.1f} us {gf / us * 1e3:6.1f} TF"
+        print(line, flush=True)
+    sys.exit(0)
 rows = []
 tok0 = opt.views * 8 * 56 * 56
 for stage, (c, blocks) in enumerate([(128, 2), (256, 2), (512, 18), (1024, 2)]):

@@ -595,6 +595,16 @@ bool sk_enabled() {
   return on == 1;
 }
 
+// VITTA_CONV_PW=0 keeps the pointwise launches on the stream-K kernel (A/B measurements)
+bool pw_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("VITTA_CONV_PW");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
 void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
   if (d.tile) {
     bm = d.tile >> 16;
@@ -665,7 +675,18 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // the library and lent a workspace: as many workgroups as the chip holds at once (3 per CU), each walking an equal
   // share of the launch's K-slabs.  Short-K launches (< 4 slabs per tile) and launches with >= 8 tiles per workgroup
   // keep their ranges on tile boundaries (no partial tiles).
-  a.sk_G = a.sk_aligned = 0;
+  a.sk_G = a.sk_aligned = a.pw = 0;
+  // Pointwise launches whose tiles fit the chip in one round of four workgroups per CU, with K short enough that a tile
+  // is not the whole launch's critical path: conv_pw.hip (VITTA_CONV_PW=0 keeps them on the stream-K kernel)
+  if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && pw_enabled() && is_vector_geometry(d) && a.contig &&
+      !(d.flags & VITTA_CONV_PRO_BN_RELU) && tiles >= 192 && tiles <= MAX_SPLIT_TILES && nslab <= 32 &&
+      (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
+    a.pw = 1;
+    a.ksplit = 1;
+    a.ws_need = 0;
+    a.cnt = nullptr;
+    a.slabs = nullptr;
+  } else
   if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && d.workspace && tiles <= MAX_SPLIT_TILES && sk_enabled() &&
       (int64_t)d.C * a.xP * 4 < (1ll << 31)) {  // buffer addressing: 31-bit byte offsets into x
     const int64_t units = (int64_t)tiles * nslab;
@@ -729,6 +750,7 @@ int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_s
   hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool gather = !is_vector_geometry(a.d);
+  if (a.pw) return launch_pointwise(a, st, e0, e1);
   if (a.sk_G) return launch_stream_k(a, gather, st, e0, e1);
   const int bm = a.d.tile >> 16, bn = a.d.tile & 0xffff;
   const int bk = (a.d.C % 32 == 0) ? 32 : 16;

@@ -23,6 +23,7 @@ struct ConvK {
   size_t ws_need;      // host only
   int sk_G;            // stream-K: persistent workgroups (0: the tile-per-workgroup kernels)
   int sk_aligned;      // stream-K: unit ranges end on tile boundaries (no partial tiles)
+  int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -30,6 +31,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// conv_pw.hip
+int launch_pointwise(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
 // conv_sk.hip
 int launch_stream_k(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

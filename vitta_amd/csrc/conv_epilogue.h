@@ -1,0 +1,178 @@
+// Epilogue of one finished 64 x 64 output tile of the implicit-GEMM convolution, shared by the persistent stream-K kernel
+// (conv_sk.hip) and the tile-per-workgroup pointwise kernel (conv_pw.hip).  Accumulator layout of a wave (2 x 2 waves per
+// tile): register v = pixel row 8 (v / 4) + 4 lk + (v % 4), channel column li.  Eval-mode BatchNorm (+ residual) (+ ReLU)
+// (+ hooked moments) (+ raw copy), or the BatchNorm (+ ReLU mask) backward with the statistics-loss injection and
+// d gamma / d beta (models/tanet_models/temporal_module.py:85-106; utils/norm_stats_utils.py:238-253).
+#pragma once
+#include "conv_common.h"
+
+namespace vitta_conv {
+
+struct TileEpilogue {
+  const ConvK& a;
+  const vitta_conv_desc& d;
+  float* red;  // LDS [2][32][2]: per-channel sums of the upper pixel half of a tile
+  int wm, wn, li, lk;
+  bool BWD;
+  static constexpr int BM = 64, BN = 64;
+  // constants of the current tile's channel of this lane: loaded at the tile's start, used at its end
+  float c_gam = 1.f, c_bet = 0.f, c_mean = 0.f, c_var = 1.f, c_sh = 0.f, c_a = 0.f, c_b = 0.f, c_mu = 0.f, c_gs = 0.f;
+
+  __device__ __forceinline__ TileEpilogue(const ConvK& a_, float* red_, int wm_, int wn_, int li_, int lk_)
+      : a(a_), d(a_.d), red(red_), wm(wm_), wn(wn_), li(li_), lk(lk_), BWD(a_.d.flags & VITTA_CONV_BWD_BN) {}
+
+  __device__ __forceinline__ void load_consts(int L) {
+    const int k = (L % a.nNt) * BN + wn * 32 + li;
+    if (BWD) {
+      c_gam = d.bwd_bn[0][k];
+      c_bet = d.bwd_bn[1][k];
+      c_mean = d.bwd_bn[2][k];
+      c_var = d.bwd_bn[3][k];
+      if (d.inj_mu) {
+        c_gs = d.inj_gscale ? d.inj_gscale[0] : 1.f;
+        c_a = d.inj_a[k];
+        c_b = d.inj_b[k];
+        c_mu = d.inj_mu[k];
+      }
+    } else {
+      if (d.epi_bn[0]) {
+        c_gam = d.epi_bn[0][k];
+        c_bet = d.epi_bn[1][k];
+        c_mean = d.epi_bn[2][k];
+        c_var = d.epi_bn[3][k];
+      }
+      if (d.st_shift) c_sh = d.st_shift[k];
+    }
+  }
+
+  // ---- epilogue of one finished tile (register v: pixel row 8 (v / 4) + 4 lk + (v % 4), channel column li) ------------
+  __device__ __forceinline__ void run(int L, const f32x16& acc) {
+    const int flags = d.flags;
+    const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
+    const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
+    const bool APPLY = flags & VITTA_CONV_EPI_APPLY;
+    const bool RELU = flags & VITTA_CONV_EPI_RELU;
+    const bool RES = (flags & VITTA_CONV_RES) && d.res;
+    const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
+    const bool BRELU = flags & VITTA_CONV_BWD_RELU;
+    const int HWy = d.Hy * d.Wy;
+    const int k = k0 + wn * 32 + li;
+    float es = 1.f, et = 0.f, sh = c_sh, bsc = 0.f, bt = 0.f, brm = 0.f, brs = 0.f, ia = 0.f, ib = 0.f;
+    if (BWD) {
+      brs = rsqrtf(c_var + d.bwd_eps);
+      bsc = c_gam * brs;
+      bt = c_bet - c_mean * bsc;
+      brm = c_mean;
+      ia = c_gs * c_a;
+      ib = c_gs * c_b;
+      sh = c_mu;
+    } else if (d.epi_bn[0]) {
+      es = c_gam * rsqrtf(c_var + d.epi_eps);
+      et = c_bet - c_mean * es;
+    }
+    float r1 = 0.f, r2 = 0.f;
+    const int64_t yrow = (int64_t)k * a.yP;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int m = m0 + wm * 32 + 8 * qd + 4 * lk;
+      if (m >= a.Mtot) continue;
+      float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
+      if (a.contig) {
+        float* yp = d.y + yrow + m;
+        if (RES && BWD) {
+          const float4 r = *reinterpret_cast<const float4*>(d.res + (int64_t)k * a.rP + m);
+          v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+        }
+        if (RESH) {
+          const int Hh = (d.Hy + 1) >> 1, Wh = (d.Wy + 1) >> 1;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int p = m + e;
+            const int n = p / HWy, r = p - n * HWy, h = r / d.Wy, w = r - h * d.Wy;
+            if (!((h | w) & 1)) v[e] += d.res[(int64_t)k * a.rP + (int64_t)n * Hh * Wh + (h >> 1) * Wh + (w >> 1)];
+          }
+        }
+        if (BWD) {
+          const float4 xr = *reinterpret_cast<const float4*>(d.bwd_x + yrow + m);
+          const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
+          float mk[4] = {1.f, 1.f, 1.f, 1.f};
+          if (BRELU && d.bwd_mask) {
+            const float4 mr = *reinterpret_cast<const float4*>(d.bwd_mask + yrow + m);
+            mk[0] = mr.x > 0.f; mk[1] = mr.y > 0.f; mk[2] = mr.z > 0.f; mk[3] = mr.w > 0.f;
+          }
+          float o[4], gm[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(xv[e], bsc, bt);
+            const float mm = (BRELU && !d.bwd_mask) ? (z > 0.f ? 1.f : 0.f) : mk[e];
+            gm[e] = v[e] * mm;
+            const float dz = gm[e] + fmaf(ib, z - sh, ia);
+            r1 += dz * (xv[e] - brm) * brs;
+            r2 += dz;
+            o[e] = dz * bsc;
+          }
+          *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+          if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(gm[0], gm[1], gm[2], gm[3]);
+        } else {
+          if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(v[e], es, et);
+            if (STATS) {
+              const float dd = z - sh;
+              r1 += dd;
+              r2 = fmaf(dd, dd, r2);
+            }
+            o[e] = APPLY ? z : v[e];
+          }
+          if (RES) {
+            const float4 r = *reinterpret_cast<const float4*>(d.res + (int64_t)k * a.rP + m);
+            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+          }
+          if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+          }
+          *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      } else {
+        // scattered destination (data gradient of a stride-2 convolution, one parity class per launch): plain values
+        const int hwg = d.Hg * d.Wg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int p = m + e;
+          const int n = p / hwg, r = p - n * hwg, gi = r / d.Wg, gj = r - gi * d.Wg;
+          const int h = gi * d.ostride + d.oa, w = gj * d.ostride + d.ob;
+          if (h < d.Hy && w < d.Wy) d.y[yrow + (int64_t)n * HWy + h * d.Wy + w] = v[e];
+        }
+      }
+    }
+    if (STATS || BWD) {
+      // per-channel sums: lanes of a wave, then the two waves that share the channels (pixel halves wm = 0 / 1) through
+      // LDS, then ONE atomic per (tile, channel) -- same-address atomics serialise at ~8 ns each, and a 64-channel layer
+      // has 784 tiles adding into the same 64 + 64 words
+      r1 += __shfl_xor(r1, 32, 64);
+      r2 += __shfl_xor(r2, 32, 64);
+      if (wm == 1 && lk == 0) {
+        red[(wn * 32 + li) * 2] = r1;
+        red[(wn * 32 + li) * 2 + 1] = r2;
+      }
+      __syncthreads();
+      if (wm == 0 && lk == 0) {
+        r1 += red[(wn * 32 + li) * 2];
+        r2 += red[(wn * 32 + li) * 2 + 1];
+        if (BWD) {
+          if (d.dgamma) atomicAdd(d.dgamma + k, r1);
+          if (d.dbeta) atomicAdd(d.dbeta + k, r2);
+        } else {
+          atomicAdd(d.st_s1 + k, r1);
+          atomicAdd(d.st_s2 + k, r2);
+        }
+      }
+      __syncthreads();  // `red` is free again before the next tile's epilogue
+    }
+  }
+};
+
+}  // namespace vitta_conv
