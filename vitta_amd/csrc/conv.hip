@@ -605,6 +605,22 @@ bool pw_enabled() {
   return on == 1;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+// smallest tile count / longest K walk (slabs per tile) conv_pw.hip takes.  Measured with bench.py: 96-192 tiles and 32-64
+// slabs are within noise of each other (148.9-150.3 videos/s); a gathered (3x3) variant of the kernel was measured and
+// dropped (64-channel layer 46.8 vs 47.6 us, 128-channel layer 49.2 vs 47.4 us: the stream-K kernel keeps those).
+int pw_min_tiles() {
+  static int v = env_int("VITTA_CONV_PW_MIN_TILES", 192);
+  return v;
+}
+int pw_max_slabs() {
+  static int v = env_int("VITTA_CONV_PW_MAX_SLABS", 32);
+  return v;
+}
+
 void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
   if (d.tile) {
     bm = d.tile >> 16;
@@ -679,7 +695,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // Pointwise launches whose tiles fit the chip in one round of four workgroups per CU, with K short enough that a tile
   // is not the whole launch's critical path: conv_pw.hip (VITTA_CONV_PW=0 keeps them on the stream-K kernel)
   if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && pw_enabled() && is_vector_geometry(d) && a.contig &&
-      !(d.flags & VITTA_CONV_PRO_BN_RELU) && tiles >= 192 && tiles <= MAX_SPLIT_TILES && nslab <= 32 &&
+      !(d.flags & VITTA_CONV_PRO_BN_RELU) && tiles >= pw_min_tiles() && tiles <= MAX_SPLIT_TILES && nslab <= pw_max_slabs() &&
       (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
     a.pw = 1;
     a.ksplit = 1;
