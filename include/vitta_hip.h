@@ -628,6 +628,12 @@ int vitta_linear_bwd_f32(const float* d_dy, const float* d_x, const float* d_w, 
 int vitta_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
 int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y, float* d_pre,
                       int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream);
+/* The same product on bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogues; an extension beside
+ * BASELINE config 5's bf16 window attention, opt-in because the reference computes in fp32): d_a stays fp32 in memory and
+ * is rounded to bf16 (nearest even) while it is staged, d_b_bf16 is the caller's bfloat16 copy of the weight [N][K].
+ * K % 64 == 0. */
+int vitta_gemm_nt_bf16w_f32(const float* d_a, const uint16_t* d_b_bf16, const float* d_bias, const float* d_aux, float* d_y,
+                            float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream);
 
 /* --------------------------------------------------------------------------
  * N1 -- decoded RGB frames -> network input, bit-identical to the reference's PIL pipeline

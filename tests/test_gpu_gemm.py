@@ -94,3 +94,56 @@ def test_mlp_and_linear_autograd_match_module_path(train_weights):
     assert len(res[True]) == len(res[False]) == (3 + (6 if train_weights else 0))
     for got, ref in zip(res[True], res[False]):
         assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("m,n,k", [(3136, 1536, 512), (784, 1024, 4096), (392, 3072, 1024), (12544, 256, 256), (200, 128, 64),
+                                   (1, 256, 64)])
+def test_gemm_bf16_operands_vs_fp64_on_rounded_operands(m, n, k, tile):
+    """bf16-operand variant: the products of bf16-rounded operands are exact in fp32, so against fp64 on the ROUNDED
+    operands only the fp32 accumulation order is left: same tolerance as the fp32 kernel (x2)."""
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(m + n + k + 1)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    aux = torch.randn(m, n, generator=g) * 1.5
+    ad, bd, auxd = (t.to(_dev()) for t in (a, b, aux))
+    wb = w.to(_dev()).to(torch.bfloat16)
+    ops.GEMM_TILE = tile
+    try:
+        y0 = ops.gemm_nt(ad, wb, bd)
+        pre = torch.empty(m, n, device=_dev())
+        y1 = ops.gemm_nt(ad, wb, bd, mode=1, pre=pre)
+        y2 = ops.gemm_nt(ad, wb, mode=2, aux=auxd)
+    finally:
+        ops.GEMM_TILE = 0
+    a64, w64 = a.to(torch.bfloat16).double(), w.to(torch.bfloat16).double()
+    lin = a64 @ w64.t()
+    _close(y0, lin + b.double(), rel=4e-5)
+    _close(pre, lin + b.double(), rel=4e-5)
+    _close(y1, F.gelu(lin + b.double()), rel=4e-5)
+    x = aux.double().clone().requires_grad_(True)
+    (dg,) = torch.autograd.grad(F.gelu(x).sum(), x)
+    _close(y2, lin * dg, rel=8e-5)
+
+
+def test_dense_bf16_flag_switches_module_path_and_stays_close_to_fp32():
+    from vitta_amd import ops, swin
+    torch.manual_seed(5)
+    mlp = swin.Mlp(256, 1024).to(_dev())
+    for p in mlp.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(2, 196, 256, device=_dev(), requires_grad=True)
+    out = {}
+    try:
+        for flag in (False, True):
+            ops.DENSE_BF16 = flag
+            y = mlp(x)
+            (gx,) = torch.autograd.grad(y, x, torch.ones_like(y))
+            out[flag] = (y.detach(), gx)
+    finally:
+        ops.DENSE_BF16 = False
+    for got, ref in zip(out[True], out[False]):
+        err = (got - ref).abs().max().item()
+        assert 0 < err <= 2e-2 * ref.abs().max().item()   # bf16 operand rounding: visible, and bounded

@@ -64,7 +64,13 @@ for stage, (c, blocks) in enumerate([(128, 2), (256, 2), (512, 18), (1024, 2)]):
             us = timed(lambda: ops.gemm_nt(a, w, b if mode != 2 else None, mode=mode, aux=aux, pre=pre, out=y), opt.reps)
             row[f"tile{tile}_us"] = us
             row[f"tile{tile}_tf"] = gf / us * 1e3
+        wb = w.to(torch.bfloat16)
+        for tile in (1, 2, 3):
+            ops.GEMM_TILE = tile
+            us = timed(lambda: ops.gemm_nt(a, wb, b if mode != 2 else None, mode=mode, aux=aux, pre=pre, out=y), opt.reps)
+            row[f"bf16_tile{tile}_us"] = us
         ops.GEMM_TILE = 0
+        row["bf16_auto_us"] = timed(lambda: ops.gemm_nt(a, wb, b if mode != 2 else None, mode=mode, aux=aux, pre=pre, out=y), opt.reps)
         if mode == 0:
             lib_fn = lambda: F.linear(a, w, b)
         elif mode == 1:
@@ -76,9 +82,10 @@ for stage, (c, blocks) in enumerate([(128, 2), (256, 2), (512, 18), (1024, 2)]):
         rows.append(row)
         print(f"s{stage} {name:16s} M={m:6d} N={n:5d} K={k:5d} {gf:7.2f} GF | 128x128 {row['tile1_us']:7.1f} us {row['tile1_tf']:6.1f} TF"
               f" | 64x128 {row['tile2_us']:7.1f} us {row['tile2_tf']:6.1f} TF | 64x64 {row['tile3_us']:7.1f} us {row['tile3_tf']:6.1f} TF | auto {row['tile0_us']:7.1f} us {row['tile0_tf']:6.1f} TF | library"
-              f" {row['library_us']:7.1f} us {row['library_tf']:6.1f} TF", flush=True)
+              f" {row['library_us']:7.1f} us {row['library_tf']:6.1f} TF | bf16 operands 128x128 {row['bf16_tile1_us']:6.1f} 64x128"
+              f" {row['bf16_tile2_us']:6.1f} 64x64 {row['bf16_tile3_us']:6.1f} auto {row['bf16_auto_us']:6.1f} us", flush=True)
 tot = lambda key: sum(r[key] * r["blocks"] for r in rows)
-summary = dict(ours_auto_ms=tot("tile0_us") / 1e3, library_ms=tot("library_us") / 1e3, gflop=tot("gflop"), peak_tf=PEAK,
+summary = dict(bf16_auto_ms=tot("bf16_auto_us") / 1e3, ours_auto_ms=tot("tile0_us") / 1e3, library_ms=tot("library_us") / 1e3, gflop=tot("gflop"), peak_tf=PEAK,
                ours_tf=tot("gflop") / tot("tile0_us") * 1e3, library_tf=tot("gflop") / tot("library_us") * 1e3)
 print(json.dumps(summary))
 if opt.out:

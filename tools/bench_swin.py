@@ -25,6 +25,7 @@ p.add_argument("--tuned-gemms", action="store_true", help="measured GEMM selecti
 p.add_argument("--blas", default=None, choices=["hipblaslt", "hipblas", "default"], help="torch.backends.cuda.preferred_blas_library")
 p.add_argument("--wmsa-bf16", action="store_true", help="bf16-operand window attention (vitta_wmsa_rel_*_bf16, BASELINE config 5)")
 p.add_argument("--library-dense", action="store_true", help="qkv / proj / MLP on torch's library GEMMs + ATen GELU instead of csrc/gemm.hip")
+p.add_argument("--dense-bf16", action="store_true", help="bf16-operand dense layers (vitta_gemm_nt_bf16w_f32)")
 p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
 if opt.blas:
@@ -40,6 +41,9 @@ if opt.library_dense:
 if opt.wmsa_bf16:
     from vitta_amd import ops as _ops
     _ops.WMSA_BF16 = True
+if opt.dense_bf16:
+    from vitta_amd import ops as _ops
+    _ops.DENSE_BF16 = True
 tmp = tempfile.mkdtemp()
 model = S.build_swin(101, 0, window_size=(opt.window_depth, 7, 7)).to(dev)
 lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
@@ -93,5 +97,5 @@ for i in range(opt.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
 print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph, tuned_gemms=tuned,
-                      frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine", wmsa="bf16 operands" if opt.wmsa_bf16 else "fp32", dense="library" if opt.library_dense else "gemm.hip",
+                      frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine", wmsa="bf16 operands" if opt.wmsa_bf16 else "fp32", dense="library" if opt.library_dense else ("gemm.hip bf16 operands" if opt.dense_bf16 else "gemm.hip fp32"),
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

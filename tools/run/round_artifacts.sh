@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-T=${1:-r2f}
+T=${1:-r2h}
 timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- python bench.py --no-sgd-all > $O/${T}_bench_profiled_run.json 2> $O/${T}_prof.err
 DB=$(ls $O/prof_$T/*.db $O/prof_$T/*/*.db 2>/dev/null | head -1)
@@ -20,6 +20,10 @@ timeout 300 python bench.py --sequential --no-cpu-baseline --no-sgd-all > $O/${T
 timeout 300 python bench.py --optimizer sgd_all --no-cpu-baseline > $O/${T}_bench_sgd_all.json 2> /dev/null
 timeout 300 python bench.py --force-exchanges --no-cpu-baseline --no-sgd-all > $O/${T}_bench_rccl_one_rank.json 2> /dev/null
 timeout 400 python bench.py --arch swin --no-cpu-baseline > $O/${T}_bench_swin.json 2> /dev/null
+timeout 300 python tools/bench_swin.py --library-dense > $O/${T}_swin_library_dense.json 2> /dev/null
+timeout 300 python tools/bench_swin.py > $O/${T}_swin.json 2> /dev/null
+timeout 300 python tools/bench_swin.py --wmsa-bf16 > $O/${T}_swin_bf16_wmsa.json 2> /dev/null
+timeout 300 python tools/bench_gemm.py --out $O/${T}_gemm_bench.json > /dev/null 2>&1
 timeout 200 python tools/bench_conv.py --frames 16 --out $O/${T}_conv_bench_16frames.json > /dev/null 2>&1
 timeout 200 python tools/bench_conv.py --frames 8 --no-vendor --out $O/${T}_conv_bench_8frames.json > /dev/null 2>&1
 timeout 200 python tools/debug/wgrad_probe.py > $O/${T}_wgrad_bench_16frames.txt 2>&1

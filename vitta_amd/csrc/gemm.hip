@@ -26,6 +26,7 @@
 
 using vitta_conv::f32x16;
 using vitta_conv::f32x4;
+using vitta_conv::u32x4;
 using vitta_conv::xcd_remap;
 
 namespace {
@@ -46,6 +47,61 @@ struct GemmArgs {
 __device__ __forceinline__ float gelu_f(float h) { return 0.5f * h * (1.f + erff(h * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float h) {
   return 0.5f * (1.f + erff(h * 0.70710678118654752f)) + h * 0.3989422804014327f * expf(-0.5f * h * h);
+}
+
+// mode 2: the gelu' operand of this lane's outputs is requested BEFORE the K walk (its latency hides under the MFMAs; a
+// load -> multiply -> store chain at the end of a short-K launch ran the epilogue at 1 TB/s)
+template <int BM, int BN, bool AUX>
+__device__ __forceinline__ void prefetch_aux(const GemmArgs& g, float (&auxv)[AUX ? BM / 64 : 1][AUX ? BN / 64 : 1][16], int m0, int n0,
+                                             int wm, int wn, int li, int lk) {
+  if constexpr (AUX) {
+#pragma unroll
+    for (int n = 0; n < BN / 64; ++n) {
+      const int col = n0 + wn * (BN / 2) + n * 32 + li;
+#pragma unroll
+      for (int i = 0; i < BM / 64; ++i) {
+        const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int row = rbase + 8 * (v >> 2) + (v & 3);
+          auxv[i][n][v] = (row < g.M && col < g.N) ? g.aux[(int64_t)row * g.N + col] : 0.f;
+        }
+      }
+    }
+  }
+}
+
+// register v of block (i, n): row 8 (v / 4) + 4 lk + v % 4, column li
+template <int BM, int BN, bool AUX>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[BM / 64][BN / 64],
+                                         const float (&auxv)[AUX ? BM / 64 : 1][AUX ? BN / 64 : 1][16], int m0, int n0, int wm, int wn,
+                                         int li, int lk) {
+  constexpr int MI = BM / 64, NI = BN / 64;
+  const int mode = AUX ? 2 : g.mode;
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int col = n0 + wn * (BN / 2) + n * 32 + li;
+    if (col >= g.N) continue;
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = rbase + 8 * (v >> 2) + (v & 3);
+        if (row >= g.M) continue;
+        const int64_t o = (int64_t)row * g.N + col;
+        float h = acc[i][n][v] + bv;
+        if (mode == 1) {
+          if (g.pre) g.pre[o] = h;
+          h = gelu_f(h);
+        } else if constexpr (AUX) {
+          h *= dgelu_f(auxv[i][n][v]);
+        }
+        g.y[o] = h;
+      }
+    }
+  }
 }
 
 template <int BM, int BN, bool AUX>
@@ -112,24 +168,8 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(const GemmArgs g) {
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-  // mode 2: the gelu' operand of this lane's outputs is requested BEFORE the K walk (its latency hides under the MFMAs;
-  // a load -> multiply -> store chain at the end of a short-K launch ran the epilogue at 1 TB/s)
   float auxv[AUX ? MI : 1][AUX ? NI : 1][16];
-  if constexpr (AUX) {
-#pragma unroll
-    for (int n = 0; n < NI; ++n) {
-      const int col = n0 + wn * (BN / 2) + n * 32 + li;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const int row = rbase + 8 * (v >> 2) + (v & 3);
-          auxv[i][n][v] = (row < g.M && col < g.N) ? g.aux[(int64_t)row * g.N + col] : 0.f;
-        }
-      }
-    }
-  }
+  prefetch_aux<BM, BN, AUX>(g, auxv, m0, n0, wm, wn, li, lk);
 
   const int ns = K / BK;
   load_global(0);
@@ -159,32 +199,108 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(const GemmArgs g) {
     if (s + 1 < ns) slab(s + 1, 1);
   }
 
-  // ---- epilogue: register v of block (i, n): row 8 (v / 4) + 4 lk + v % 4, column li ------------------------------
-  const int mode = AUX ? 2 : g.mode;
+  epilogue<BM, BN, AUX>(g, acc, auxv, m0, n0, wm, wn, li, lk);
+}
+
+// ---- bf16-operand variant (opt-in, BASELINE config 5's arithmetic: bf16 MFMA operands, fp32 accumulation) ----------------
+// a stays fp32 in memory and is rounded to bf16 (nearest even) while it is staged; b is a bf16 copy of the weight the caller
+// keeps (2 bytes / element: [N][K]).  v_mfma_f32_32x32x16_bf16: a lane supplies 8 consecutive k of its row = one 16-byte LDS
+// read per operand block and k-step of 16.  Slabs of 64 k; rows of 64 bf16 + 8 pad = 144 bytes (the same odd multiple of 16
+// bytes as the fp32 layout).  The epilogues are the fp32 kernel's.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKH = 64, LSH = 72;  // slab depth / row pitch in bf16 elements
+
+template <int BM, int BN, bool AUX>
+__global__ __launch_bounds__(NTH) void gemm_nt_bf16_kernel(const GemmArgs g) {
+  constexpr int MI = BM / 64, NI = BN / 64;
+  constexpr int A4 = BM * BKH / 4 / NTH;   // fp32 16-byte loads per lane and slab (4 floats -> 4 bf16)
+  constexpr int B8 = BN * BKH / 8 / NTH;   // bf16 16-byte loads per lane and slab
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __bf16* const As = reinterpret_cast<__bf16*>(lds);   // [2][BM][LSH]
+  __bf16* const Bs = As + 2 * BM * LSH;                 // [2][BN][LSH]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (t / g.nNt) * BM, n0 = (t % g.nNt) * BN;
+  const int K = g.K;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a), 0, (int)((int64_t)g.M * K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, (int)((int64_t)g.N * K * 2), 0x00020000);
+  constexpr int OOB = (int)0x80000000u;
+  int voff_a[A4], voff_b[B8];
 #pragma unroll
-  for (int n = 0; n < NI; ++n) {
-    const int col = n0 + wn * (BN / 2) + n * 32 + li;
-    if (col >= g.N) continue;
-    const float bv = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int rbase = m0 + wm * (BM / 2) + i * 32 + 4 * lk;
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int row = rbase + 8 * (v >> 2) + (v & 3);
-        if (row >= g.M) continue;
-        const int64_t o = (int64_t)row * g.N + col;
-        float h = acc[i][n][v] + bv;
-        if (mode == 1) {
-          if (g.pre) g.pre[o] = h;
-          h = gelu_f(h);
-        } else if constexpr (AUX) {
-          h *= dgelu_f(auxv[i][n][v]);
-        }
-        g.y[o] = h;
-      }
-    }
+  for (int u = 0; u < A4; ++u) {   // 16 lanes per row of 64 floats
+    const int r = m0 + (tid >> 4) + u * 16;
+    voff_a[u] = r < g.M ? (r * K + (tid & 15) * 4) * 4 : OOB;
   }
+#pragma unroll
+  for (int u = 0; u < B8; ++u) {   // 8 lanes per row of 64 bf16
+    const int r = n0 + (tid >> 3) + u * 32;
+    voff_b[u] = r < g.N ? (r * K + (tid & 7) * 8) * 2 : OOB;
+  }
+  f32x4 ra[A4];
+  u32x4 rb[B8];
+  auto load_global = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A4; ++u) ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff_a[u], s * BKH * 4, 0));
+#pragma unroll
+    for (int u = 0; u < B8; ++u) rb[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b[u], s * BKH * 2, 0);
+  };
+  __bf16* const st_a = As + (tid >> 4) * LSH + (tid & 15) * 4;
+  __bf16* const st_b = Bs + (tid >> 3) * LSH + (tid & 7) * 8;
+  auto store_lds = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < A4; ++u) *reinterpret_cast<bf16x4*>(st_a + buf * BM * LSH + u * 16 * LSH) = __builtin_convertvector(ra[u], bf16x4);
+#pragma unroll
+    for (int u = 0; u < B8; ++u) *reinterpret_cast<u32x4*>(st_b + buf * BN * LSH + u * 32 * LSH) = rb[u];
+  };
+
+  const __bf16* const rd_a = As + (wm * (BM / 2) + li) * LSH + 8 * lk;
+  const __bf16* const rd_b = Bs + (wn * (BN / 2) + li) * LSH + 8 * lk;
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  float auxv[AUX ? MI : 1][AUX ? NI : 1][16];
+  prefetch_aux<BM, BN, AUX>(g, auxv, m0, n0, wm, wn, li, lk);
+
+  const int ns = K / BKH;
+  load_global(0);
+  store_lds(0);
+  if (ns > 1) load_global(1);
+  __syncthreads();
+
+  auto slab = [&](int s, int buf) __attribute__((always_inline)) {
+    bf16x8 fa[4][MI], fb[4][NI];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[j][i] = *reinterpret_cast<const bf16x8*>(rd_a + buf * BM * LSH + i * 32 * LSH + 16 * j);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) fb[j][i] = *reinterpret_cast<const bf16x8*>(rd_b + buf * BN * LSH + i * 32 * LSH + 16 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j == 1 && s + 1 < ns) store_lds(buf ^ 1);
+      if (j == 2 && s + 2 < ns) load_global(s + 2);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int n = 0; n < NI; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[j][i], fb[j][n], acc[i][n], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int s = 0; s < ns; s += 2) {
+    slab(s, 0);
+    if (s + 1 < ns) slab(s + 1, 1);
+  }
+  epilogue<BM, BN, AUX>(g, acc, auxv, m0, n0, wm, wn, li, lk);
 }
 
 template <int BM, int BN, bool AUX>
@@ -209,6 +325,28 @@ int launch(const GemmArgs& g, hipStream_t st) {
   return g.mode == 2 ? launch_one<BM, BN, true>(g, st) : launch_one<BM, BN, false>(g, st);
 }
 
+template <int BM, int BN, bool AUX>
+int launch_one_bf16(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  g.nMt = (g.M + BM - 1) / BM;
+  g.nNt = (g.N + BN - 1) / BN;
+  const size_t lds = 2 * 2 * (BM + BN) * LSH;
+  static bool raised = false;
+  if (lds > 48 * 1024 && !raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_bf16_kernel<BM, BN, AUX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return VITTA_ERR_LAUNCH;
+    raised = true;
+  }
+  VITTA_LAUNCH((gemm_nt_bf16_kernel<BM, BN, AUX>), dim3((unsigned)(g.nMt * g.nNt)), dim3(NTH), lds, st, g);
+  return VITTA_OK;
+}
+
+template <int BM, int BN>
+int launch_bf16(const GemmArgs& g, hipStream_t st) {
+  return g.mode == 2 ? launch_one_bf16<BM, BN, true>(g, st) : launch_one_bf16<BM, BN, false>(g, st);
+}
+
 // Tile choice: the launch lasts as long as its busiest CU -- ceil(tiles / 256) tiles of MI x NI accumulator blocks each
 // (workgroups sharing a CU share its matrix pipes) -- so the finest tile wins the quantisation and the coarsest the LDS /
 // L2 traffic per flop; `pen` = measured relative cost of a block's work in each tile shape (profiles/r2h_gemm_bench.json: on
@@ -224,6 +362,14 @@ int choose_tile(int64_t M, int N, int mode) {
     if (c == first || cost < best_cost) best = c + 1, best_cost = cost;
   }
   return best;
+}
+
+// bf16 operands: the matrix work of a tile is 1 / 16 of the fp32 kernel's and the launch is bound by what it moves and by
+// how many workgroups hide each other's latencies: measured (profiles/r2i_gemm_bench.json) the 64 x 64 tile wins on 17 of
+// the 20 Swin-B shapes, 64 x 128 on the short, wide ones (784 tokens x >= 2048 outputs) by 4-7 %
+int choose_tile_bf16(int64_t M, int N, int mode) {
+  (void)mode;
+  return (M <= 1024 && N >= 2048) ? 2 : 3;
 }
 
 }  // namespace
@@ -243,5 +389,18 @@ extern "C" int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float
   if (tile == 1) return launch<128, 128>(g, st);
   if (tile == 2) return launch<64, 128>(g, st);
   if (tile == 3) return launch<64, 64>(g, st);
+  return VITTA_ERR_INVALID_ARG;
+}
+
+extern "C" int vitta_gemm_nt_bf16w_f32(const float* d_a, const uint16_t* d_b_bf16, const float* d_bias, const float* d_aux, float* d_y,
+                                       float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream) {
+  if (!d_a || !d_b_bf16 || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux)) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_gemm_nt_supported(M, N, K) || K % BKH) return VITTA_ERR_UNSUPPORTED;
+  GemmArgs g{d_a, reinterpret_cast<const float*>(d_b_bf16), d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (tile == 0) tile = choose_tile_bf16(M, N, mode);
+  if (tile == 1) return launch_bf16<128, 128>(g, st);
+  if (tile == 2) return launch_bf16<64, 128>(g, st);
+  if (tile == 3) return launch_bf16<64, 64>(g, st);
   return VITTA_ERR_INVALID_ARG;
 }

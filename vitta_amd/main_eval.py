@@ -86,6 +86,7 @@ def eval(args=None, model=None):
         if args.arch == "videoswintransformer":
             from . import ops
             ops.WMSA_BF16 = bool(getattr(args, "wmsa_bf16", False))
+            ops.DENSE_BF16 = bool(getattr(args, "dense_bf16", False))
         if getattr(args, "tuned_gemms", False) and args.arch == "videoswintransformer":
             from . import tuning
             logger.debug(f"tuned GEMM table loaded: {tuning.enable_tuned_gemms()}")

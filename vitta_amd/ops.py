@@ -826,8 +826,9 @@ def head_linear_supported(x, linear):
 # ------------------------------------------------------------------------------------------------
 # dense layers of Video Swin-B (csrc/gemm.hip): qkv / proj / Mlp / PatchMerging.reduction
 # ------------------------------------------------------------------------------------------------
-GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128)
-_WT_CACHE = {}      # id(weight) -> (weakref, version, transposed copy): frozen weights are transposed once
+GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128) / 3 (64 x 64)
+DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
+_W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, operand copy): frozen weights are prepared once
 
 
 def gemm_nt_supported(m, n, k):
@@ -835,32 +836,46 @@ def gemm_nt_supported(m, n, k):
 
 
 def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
-    """y[m][n] = epi(sum_k a[m][k] b[n][k]) (vitta_gemm_nt_f32; mode 0: + bias, 1: bias + GELU (pre-activation kept in
-    `pre`), 2: times gelu'(aux))."""
+    """y[m][n] = epi(sum_k a[m][k] b[n][k]) (mode 0: + bias, 1: bias + GELU (pre-activation kept in `pre`), 2: times
+    gelu'(aux)).  b float32: vitta_gemm_nt_f32 (exact fp32 MFMA); b bfloat16: vitta_gemm_nt_bf16w_f32 (a is rounded to
+    bf16 while staged)."""
     _require_cuda_f32(a, "a")
-    _require_cuda_f32(b, "b")
+    if not b.is_cuda or b.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.VittaHipError(f"b must be a float32 or bfloat16 device tensor (got {b.dtype} on {b.device})")
     m, k = a.shape
     n = b.shape[0]
     assert a.is_contiguous() and b.is_contiguous() and b.shape[1] == k
     y = out if out is not None else torch.empty(m, n, dtype=torch.float32, device=a.device)
-    check(lib().vitta_gemm_nt_f32(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()),
-          "vitta_gemm_nt_f32")
+    fn, name = (lib().vitta_gemm_nt_f32, "vitta_gemm_nt_f32") if b.dtype == torch.float32 else \
+        (lib().vitta_gemm_nt_bf16w_f32, "vitta_gemm_nt_bf16w_f32")
+    check(fn(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()), name)
     return y
 
 
-def _transposed(weight):
-    """[in][out] copy of an nn.Linear weight for the data gradient.  A frozen weight (LN-affine adaptation) is transposed
-    once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
+def _operand(weight, transposed):
+    """The B operand of a dense product: the nn.Linear weight itself ([out][in], forward) or its [in][out] transpose (data
+    gradient), as bfloat16 when DENSE_BF16 is on and the reduction length allows.  A frozen weight (LN-affine adaptation)
+    is prepared once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
     `_version`, and a captured graph must hold the copy launch)."""
+    kred = weight.shape[0] if transposed else weight.shape[1]
+    bf16 = bool(DENSE_BF16 and kred % 64 == 0)
+    if not transposed and not bf16:
+        return weight.detach()
+
+    def make():
+        w = weight.detach().t() if transposed else weight.detach()
+        return w.to(torch.bfloat16).contiguous() if bf16 else w.contiguous()
+
     if weight.requires_grad:
-        return weight.detach().t().contiguous()
+        return make()
     import weakref
-    ent = _WT_CACHE.get(id(weight))
+    key = (id(weight), transposed, bf16)
+    ent = _W_CACHE.get(key)
     if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2].device == weight.device:
         return ent[2]
-    wt = weight.detach().t().contiguous()
-    _WT_CACHE[id(weight)] = (weakref.ref(weight), weight._version, wt)
-    return wt
+    op = make()
+    _W_CACHE[key] = (weakref.ref(weight), weight._version, op)
+    return op
 
 
 def _param_grad(param, needed, value_fn):
@@ -885,7 +900,7 @@ class DenseLinear(torch.autograd.Function):
         x2 = x.reshape(-1, shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        y = gemm_nt(x2, weight, bias)
+        y = gemm_nt(x2, _operand(weight, False), bias)
         ctx.save_for_backward(x2 if weight.requires_grad else None, weight, bias)
         ctx.xshape = shape
         return y.view(shape[:-1] + (weight.shape[0],))
@@ -896,7 +911,7 @@ class DenseLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        dx = gemm_nt(g2, _transposed(weight)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = gemm_nt(g2, _operand(weight, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = _param_grad(weight, ctx.needs_input_grad[1], lambda: g2.t() @ x2)
         db = _param_grad(bias, bias is not None and ctx.needs_input_grad[2], lambda: g2.sum(0))
         return dx, dw, db
@@ -915,8 +930,8 @@ class FusedMlp(torch.autograd.Function):
             x2 = x2.contiguous()
         need = any(ctx.needs_input_grad)
         h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
-        a = gemm_nt(x2, w1, b1, mode=1, pre=h)
-        y = gemm_nt(a, w2, b2)
+        a = gemm_nt(x2, _operand(w1, False), b1, mode=1, pre=h)
+        y = gemm_nt(a, _operand(w2, False), b2)
         train_w = w1.requires_grad or w2.requires_grad
         ctx.save_for_backward(x2 if train_w else None, h, a if train_w else None, w1, b1, w2, b2)
         ctx.xshape = shape
@@ -928,8 +943,8 @@ class FusedMlp(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        gh = gemm_nt(g2, _transposed(w2), mode=2, aux=h)
-        dx = gemm_nt(gh, _transposed(w1)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gh = gemm_nt(g2, _operand(w2, True), mode=2, aux=h)
+        dx = gemm_nt(gh, _operand(w1, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1 = _param_grad(w1, ctx.needs_input_grad[1], lambda: gh.t() @ x2)
         db1 = _param_grad(b1, b1 is not None and ctx.needs_input_grad[2], lambda: gh.sum(0))
         dw2 = _param_grad(w2, ctx.needs_input_grad[3], lambda: g2.t() @ a)

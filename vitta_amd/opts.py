@@ -8,6 +8,8 @@
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 * `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
 * `--tuned_gemms` (extension, default False) loads the measured GEMM-solution table for the Video Swin-B step.
+* `--dense_bf16` (extension, default False) runs Video Swin's dense layers (qkv / proj / MLP / patch merging) on bf16 MFMA
+  operands with fp32 accumulation (vitta_amd/csrc/gemm.hip); the default is the exact-fp32 kernel of the same file.
 * `--wmsa_bf16` (extension, default False) runs Video Swin's window attention on the bf16-operand kernels (fp32 softmax and
   accumulation; BASELINE config 5's recipe), vitta_amd/csrc/wmsa_bf16.hip.
 * `--device_preprocess` (extension, default False) uploads the decoded uint8 frames and runs crop / resize / normalise
@@ -109,6 +111,9 @@ _FLAGS = [
     (("--wmsa_bf16",), dict(type=_bool, default=False,
                             help="(extension) Video Swin-B: window attention with bf16 MFMA operands, fp32 softmax / accumulation "
                                  "(windows up to 800 tokens in one pass; the relative-position table must be frozen)")),
+    (("--dense_bf16",), dict(type=_bool, default=False,
+                             help="(extension) Video Swin-B: qkv / proj / MLP / patch-merging products with bf16 MFMA operands, "
+                                  "fp32 accumulation and epilogues (vitta_gemm_nt_bf16w_f32); default: exact fp32 MFMA")),
     (("--tuned_gemms",), dict(type=_bool, default=False,
                               help="(extension) Video Swin-B: take the measured hipBLASLt / rocBLAS solution per GEMM shape "
                                    "(vitta_amd/tuning) instead of the library's default heuristic")),
