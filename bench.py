@@ -13,7 +13,7 @@ evaluation forward of the same video (centre view).  `value` = videos of all ran
 wall time of the K timed steps (barrier + synchronize on both sides).
 
 Extra objects on the JSON line:
-  roofline      the dominant kernel of the timed step, conv_sk_kernel (vitta_conv_f32: every bottleneck
+  roofline      the dominant kernels of the timed step, conv_pw_kernel + conv_sk_kernel (vitta_conv_f32: every bottleneck
                 convolution of the trunk, forward and data gradient, ~71 % of the step's kernel time), bound
                 "mfma": achieved = algorithmic flops of the step's convolution launches / the sum of their
                 durations, each duration from a hipEvent pair attached to that launch's own dispatch
@@ -78,9 +78,8 @@ def parse():
                    help="adapt(i); eval(i) back to back on one stream instead of eval(i-1) beside adapt(i)")
     p.add_argument("--segmented-graph", action="store_true",
                    help="single GPU: use the data-parallel capture (3 graph segments, exchanges outside) anyway")
-    p.add_argument("--tuned-gemms", action="store_true",
-                   help="--arch swin: the measured GEMM selection table (vitta_amd/tuning) instead of the library default; "
-                        "off by default (see vitta_amd/tuning/__init__.py)")
+    p.add_argument("--dense-bf16", action="store_true",
+                   help="--arch swin: qkv / proj / MLP products with bf16 MFMA operands (gemm.hip); dtype is reported")
     p.add_argument("--wmsa-bf16", action="store_true",
                    help="--arch swin: window attention with bf16 MFMA operands (BASELINE config 5's recipe); dtype is reported")
     p.add_argument("--graph-collectives", action="store_true",
@@ -441,10 +440,9 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)
         else:  # rehearsal of the data-parallel path with several ranks on ONE GPU (RCCL refuses duplicate devices)
             torch.distributed.init_process_group(opt.dist_backend)
-    want_tuned, opt.tuned_gemms = opt.tuned_gemms, False
-    if opt.arch == "swin" and want_tuned and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
-        from vitta_amd import tuning
-        opt.tuned_gemms = tuning.enable_tuned_gemms()
+    if opt.dense_bf16:
+        from vitta_amd import ops as _ops
+        _ops.DENSE_BF16 = True
     if opt.wmsa_bf16:
         from vitta_amd import ops as _ops
         _ops.WMSA_BF16 = True
@@ -501,14 +499,15 @@ def main():
         if conv:
             tf = conv["flops"] / conv["ms"] / 1e9
             conv_pmc = None
-            cpf = os.path.join(ROOT, "profiles", "r2_conv_traffic_pmc.json")
+            cpf = os.path.join(ROOT, "profiles", "r2h_conv_traffic_pmc.json")
             if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
                 conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
-            roofline = {"kernel": "conv_sk_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, forward + "
-                                  "data gradient + evaluation forward)",
+            roofline = {"kernel": "conv_pw_kernel + conv_sk_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, "
+                                  "forward + data gradient + evaluation forward)",
                         "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": tf / MFMA_F32_PEAK_TF, "traffic": conv_pmc,
-                        "traffic_source": "profiles/r2_conv_traffic_pmc.json" if conv_pmc else None,
+                        "traffic_source": "profiles/r2h_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                          "passes, FETCH x2 per the gfx950 note; per launch)" if conv_pmc else None,
                         "launches_per_step": conv["launches"] / conv["steps"],
                         "algorithmic_flops_per_launch": conv["flops"] / conv["launches"],
                         "avg_launch_us": 1e3 * conv["ms"] / conv["launches"],
@@ -554,10 +553,11 @@ def main():
         line["config"]["exchanges"] = "moments all-reduce + gradient all-reduce" if world > 1 else "none"
         line["roofline"]["kernel"] = f"moments_nhwc_partial_kernel ({n_ln} layers, 1 launch)"
         line["config"]["window_attention"] = "bf16 operands, fp32 softmax / accumulation" if opt.wmsa_bf16 else "fp32"
-        if opt.wmsa_bf16:
-            line["dtype"] = "f32 (window attention: bf16 MFMA operands)"
-        line["config"]["gemm_selection"] = ("measured table vitta_amd/tuning (hipBLASLt / rocBLAS solution per shape, no search at "
-                                            "run time)") if opt.tuned_gemms else "library default"
+        line["config"]["dense_layers"] = ("gemm.hip, bf16 operands, fp32 accumulation" if opt.dense_bf16
+                                          else "gemm.hip, exact fp32 MFMA")
+        if opt.wmsa_bf16 or opt.dense_bf16:
+            line["dtype"] = "f32 (bf16 MFMA operands: " + " + ".join(
+                n for n, on in (("window attention", opt.wmsa_bf16), ("dense layers", opt.dense_bf16)) if on) + ")"
         line["roofline"]["note"] = ("stand-alone batched kernel timed on the step's own hooked LayerNorm outputs; in the "
                                     "shipped step these moments ride on the fused LayerNorm pass (ln_fwd_kernel)")
     del adapter

@@ -83,7 +83,7 @@ def test_opts_surface_matches_reference():
     from vitta_amd.opts import get_opts
     ref = json.load(open(H.GOLDEN_DIR + "/opts_defaults.json"))
     mine = {k: repr(v) for k, v in vars(get_opts([])).items()}
-    extensions = {"hip_graph", "overlap_eval", "device_preprocess", "tuned_gemms", "wmsa_bf16", "dense_bf16"}  # flags this build adds on top of the reference surface
+    extensions = {"hip_graph", "overlap_eval", "device_preprocess", "wmsa_bf16", "dense_bf16"}  # flags this build adds on top of the reference surface
     assert set(mine) - set(ref) == extensions
     mine = {k: v for k, v in mine.items() if k not in extensions}
     assert set(ref) == set(mine)

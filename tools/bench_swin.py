@@ -21,7 +21,6 @@ p.add_argument("--no-graph", action="store_true")
 p.add_argument("--sgd", action="store_true")
 p.add_argument("--views", type=int, default=2)
 p.add_argument("--window-depth", type=int, default=8, help="temporal window (16 = the SSv2 recipe of BASELINE config 4)")
-p.add_argument("--tuned-gemms", action="store_true", help="measured GEMM selection table (vitta_amd/tuning); off by default")
 p.add_argument("--blas", default=None, choices=["hipblaslt", "hipblas", "default"], help="torch.backends.cuda.preferred_blas_library")
 p.add_argument("--wmsa-bf16", action="store_true", help="bf16-operand window attention (vitta_wmsa_rel_*_bf16, BASELINE config 5)")
 p.add_argument("--library-dense", action="store_true", help="qkv / proj / MLP on torch's library GEMMs + ATen GELU instead of csrc/gemm.hip")
@@ -30,10 +29,6 @@ p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on o
 opt = p.parse_args()
 if opt.blas:
     torch.backends.cuda.preferred_blas_library(opt.blas)
-tuned = False
-if opt.tuned_gemms and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
-    from vitta_amd import tuning
-    tuned = tuning.enable_tuned_gemms()
 dev = torch.device("cuda:0")
 if opt.library_dense:
     from vitta_amd import swin as _swin
@@ -96,6 +91,6 @@ for i in range(opt.steps):
     one(i)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / opt.steps
-print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph, tuned_gemms=tuned,
+print(json.dumps(dict(arch="swin_b", ms_per_video=1e3 * dt, videos_per_s=1 / dt, graph=not opt.no_graph,
                       frames=opt.frames, size=opt.size, views=opt.views, window=(opt.window_depth, 7, 7), schedule="sequential" if opt.sequential else "overlapped", optimizer="sgd_all" if opt.sgd else "adam_ln_affine", wmsa="bf16 operands" if opt.wmsa_bf16 else "fp32", dense="library" if opt.library_dense else ("gemm.hip bf16 operands" if opt.dense_bf16 else "gemm.hip fp32"),
                       max_mem_GB=torch.cuda.max_memory_allocated() / 1e9)))

@@ -10,7 +10,7 @@ import sys
 def total(db_path, counter):
     db = sqlite3.connect(db_path)
     rows = db.execute("select count(distinct dispatch_id), sum(value) from counters_collection where counter_name = ? and "
-                      "(kernel_name like '%conv_sk_kernel%' or kernel_name like '%conv_igemm_kernel%')", (counter,)).fetchone()
+                      "(kernel_name like '%conv_sk_kernel%' or kernel_name like '%conv_pw_kernel%' or kernel_name like '%conv_igemm_kernel%')", (counter,)).fetchone()
     return int(rows[0] or 0), float(rows[1] or 0.0)
 
 
@@ -19,7 +19,7 @@ def main(fetch_db, write_db, out, launches_per_step=165, flops_per_step=31752978
     nw, w = total(write_db, "WRITE_SIZE")
     rd_raw, rd, wr = f * 1024.0 / nf, 2.0 * f * 1024.0 / nf, w * 1024.0 / nw
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --timed-only --no-graph "
-                     "--sequential --steps 6 --warmup 2 --no-cpu-baseline, MI355X, every conv_sk / conv_igemm dispatch of the run",
+                     "--sequential --steps 6 --warmup 2 --no-cpu-baseline, MI355X, every conv_pw / conv_sk / conv_igemm dispatch of the run",
            "units": "counters are KiB; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 wide-read note, MI355X_MICROARCH.md section HBM; "
                     "the gathered 4-byte loads of the 3x3 launches are outside that calibration)",
            "launches_fetch_pass": nf, "launches_write_pass": nw,

@@ -87,9 +87,6 @@ def eval(args=None, model=None):
             from . import ops
             ops.WMSA_BF16 = bool(getattr(args, "wmsa_bf16", False))
             ops.DENSE_BF16 = bool(getattr(args, "dense_bf16", False))
-        if getattr(args, "tuned_gemms", False) and args.arch == "videoswintransformer":
-            from . import tuning
-            logger.debug(f"tuned GEMM table loaded: {tuning.enable_tuned_gemms()}")
 
     if model is None:
         model = load_checkpoint_into(get_model(args, num_classes, logger), args, logger, device)

@@ -7,7 +7,6 @@
 * `--datatype synthetic` (extension) selects the seeded synthetic video source used by bench.py;
 * `--hip_graph` (extension, default True) lets tta_standard replay the step from captured hipGraphs.
 * `--overlap_eval` (extension, default True) runs the evaluation of a video beside the next video's adaptation.
-* `--tuned_gemms` (extension, default False) loads the measured GEMM-solution table for the Video Swin-B step.
 * `--dense_bf16` (extension, default False) runs Video Swin's dense layers (qkv / proj / MLP / patch merging) on bf16 MFMA
   operands with fp32 accumulation (vitta_amd/csrc/gemm.hip); the default is the exact-fp32 kernel of the same file.
 * `--wmsa_bf16` (extension, default False) runs Video Swin's window attention on the bf16-operand kernels (fp32 softmax and
@@ -114,9 +113,6 @@ _FLAGS = [
     (("--dense_bf16",), dict(type=_bool, default=False,
                              help="(extension) Video Swin-B: qkv / proj / MLP / patch-merging products with bf16 MFMA operands, "
                                   "fp32 accumulation and epilogues (vitta_gemm_nt_bf16w_f32); default: exact fp32 MFMA")),
-    (("--tuned_gemms",), dict(type=_bool, default=False,
-                              help="(extension) Video Swin-B: take the measured hipBLASLt / rocBLAS solution per GEMM shape "
-                                   "(vitta_amd/tuning) instead of the library's default heuristic")),
     (("--n_gradient_steps",), dict(type=int, default=1, help="number of gradient steps per sample")),
     # input / optimiser
     (("--full_res",), dict(action="store_true")),
