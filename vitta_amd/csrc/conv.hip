@@ -611,7 +611,10 @@ int env_int(const char* name, int dflt) {
 }
 // smallest tile count / longest K walk (slabs per tile) conv_pw.hip takes.  Measured with bench.py: 96-192 tiles and 32-64
 // slabs are within noise of each other (148.9-150.3 videos/s); a gathered (3x3) variant of the kernel was measured and
-// dropped (64-channel layer 46.8 vs 47.6 us, 128-channel layer 49.2 vs 47.4 us: the stream-K kernel keeps those).
+// dropped (64-channel layer 46.8 vs 47.6 us, 128-channel layer 49.2 vs 47.4 us: the stream-K kernel keeps those), and so
+// was a shifted-load form of it for the stride-1 3x3 layers (one 16-byte load + four v_cndmask per four pixels instead of four
+// gathered loads: 49.7 vs 47.3 us) -- with 784 / 392 / 196 tiles on 256 CUs a tile-per-workgroup launch is bound by
+// ceil(tiles / CUs) (77 % at best), which is exactly what the stream-K form removes at the price of its partial tiles.
 int pw_min_tiles() {
   static int v = env_int("VITTA_CONV_PW_MIN_TILES", 192);
   return v;
