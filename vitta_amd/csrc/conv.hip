@@ -694,13 +694,17 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // the library and lent a workspace: as many workgroups as the chip holds at once (3 per CU), each walking an equal
   // share of the launch's K-slabs.  Short-K launches (< 4 slabs per tile) and launches with >= 8 tiles per workgroup
   // keep their ranges on tile boundaries (no partial tiles).
-  a.sk_G = a.sk_aligned = a.pw = 0;
+  a.sk_G = a.sk_aligned = a.pw = a.pw_prefetch = 0;
   // Pointwise launches whose tiles fit the chip in one round of four workgroups per CU, with K short enough that a tile
   // is not the whole launch's critical path: conv_pw.hip (VITTA_CONV_PW=0 keeps them on the stream-K kernel)
   if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && pw_enabled() && is_vector_geometry(d) && a.contig &&
       !(d.flags & VITTA_CONV_PRO_BN_RELU) && tiles >= pw_min_tiles() && tiles <= MAX_SPLIT_TILES && nslab <= pw_max_slabs() &&
       (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
     a.pw = 1;
+    // the epilogue's residual / BatchNorm-backward input can be requested at the tile's start (VITTA_CONV_PW_PREFETCH=0: A/B)
+    static const int pf = env_int("VITTA_CONV_PW_PREFETCH", 1);
+    a.pw_prefetch = (pf && ((d.flags & VITTA_CONV_BWD_BN) ||
+                            ((d.flags & VITTA_CONV_RES) && d.res && !(d.flags & VITTA_CONV_RES_HALF)))) ? 1 : 0;
     a.ksplit = 1;
     a.ws_need = 0;
     a.cnt = nullptr;

@@ -23,6 +23,7 @@ struct ConvK {
   size_t ws_need;      // host only
   int sk_G;            // stream-K: persistent workgroups (0: the tile-per-workgroup kernels)
   int sk_aligned;      // stream-K: unit ranges end on tile boundaries (no partial tiles)
+  int pw_prefetch;     // conv_pw.hip: request the epilogue's residual / BatchNorm-backward input at the tile's start
   int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
 };
 

@@ -46,7 +46,10 @@ struct TileEpilogue {
   }
 
   // ---- epilogue of one finished tile (register v: pixel row 8 (v / 4) + 4 lk + (v % 4), channel column li) ------------
-  __device__ __forceinline__ void run(int L, const f32x16& acc) {
+  // p0..p3: the four 16-byte pieces tile_prefetch() requested for this lane at the tile's start (used when has_pre)
+  template <bool PRE = false>
+  __device__ __forceinline__ void run(int L, const f32x16& acc, float4 p0 = float4{}, float4 p1 = float4{}, float4 p2 = float4{},
+                                      float4 p3 = float4{}) {
     const int flags = d.flags;
     const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
     const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
@@ -93,7 +96,9 @@ struct TileEpilogue {
           }
         }
         if (BWD) {
-          const float4 xr = *reinterpret_cast<const float4*>(d.bwd_x + yrow + m);
+          float4 xr;
+          if constexpr (PRE) xr = qd == 0 ? p0 : qd == 1 ? p1 : qd == 2 ? p2 : p3;
+          else xr = *reinterpret_cast<const float4*>(d.bwd_x + yrow + m);
           const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
           if (BRELU && d.bwd_mask) {
@@ -127,7 +132,9 @@ struct TileEpilogue {
             o[e] = APPLY ? z : v[e];
           }
           if (RES) {
-            const float4 r = *reinterpret_cast<const float4*>(d.res + (int64_t)k * a.rP + m);
+            float4 r;
+            if constexpr (PRE) r = qd == 0 ? p0 : qd == 1 ? p1 : qd == 2 ? p2 : p3;
+            else r = *reinterpret_cast<const float4*>(d.res + (int64_t)k * a.rP + m);
             o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
           }
           if (RELU) {
@@ -174,5 +181,23 @@ struct TileEpilogue {
     }
   }
 };
+
+// The epilogue's first input stream of this lane -- the residual of a forward launch, or the BatchNorm-backward input of a
+// data-gradient launch -- requested at the tile's START so that its latency hides under the K walk (conv_pw.hip, launches
+// the host marked with ConvK::pw_prefetch: contiguous output, BWD_BN or RES without RES_HALF; the stream-K kernel cannot
+// afford the sixteen registers at three workgroups per CU).  Rows past Mtot read the last valid quad (never used).
+// (Written without conditionals around the loads: the compiler turns `c ? *p : zero` into a select of ADDRESSES with the
+// zero parked in scratch memory.)
+__device__ __forceinline__ void tile_prefetch(const ConvK& a, int L, int wm, int wn, int li, int lk, float4& p0, float4& p1, float4& p2,
+                                              float4& p3) {
+  const vitta_conv_desc& d = a.d;
+  const bool bwd = d.flags & VITTA_CONV_BWD_BN;
+  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)((L % a.nNt) * 64 + wn * 32 + li) * (bwd ? a.yP : a.rP);
+  const int m = (L / a.nNt) * 64 + wm * 32 + 4 * lk, last = a.Mtot - 4;
+  p0 = *reinterpret_cast<const float4*>(row + min(m, last));
+  p1 = *reinterpret_cast<const float4*>(row + min(m + 8, last));
+  p2 = *reinterpret_cast<const float4*>(row + min(m + 16, last));
+  p3 = *reinterpret_cast<const float4*>(row + min(m + 24, last));
+}
 
 }  // namespace vitta_conv

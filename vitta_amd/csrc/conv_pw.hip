@@ -19,6 +19,8 @@ using namespace vitta_conv;
 
 namespace {
 
+// PRE: the launch's epilogue reads a residual / BatchNorm-backward input that can be requested before the K walk
+template <bool PRE>
 __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvK a) {
   constexpr int BM = 64, BN = 64, BK = 32, NTH = 256;
   constexpr int A4 = BK * BM / 4 / NTH, B4 = BK * BN / 4 / NTH;  // 16-byte staging loads per lane and slab (2 + 2)
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvK a) {
   const int ns = C / BK;
   load_global(0);
   epi.load_consts(L);
+  float4 p0 = {}, p1 = {}, p2 = {}, p3 = {};
+  if constexpr (PRE) tile_prefetch(a, L, wm, wn, li, lk, p0, p1, p2, p3);
   store_lds(0);
   if (ns > 1) load_global(1);
   __syncthreads();
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvK a) {
     slab(s, 0);
     if (s + 1 < ns) slab(s + 1, 1);
   }
-  epi.run(L, acc);
+  epi.template run<PRE>(L, acc, p0, p1, p2, p3);
 }
 
 }  // namespace
@@ -99,8 +103,13 @@ namespace vitta_conv {
 int launch_pointwise(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid((unsigned)(a.nMt * a.nNt)), block(256);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL(conv_pw_kernel, grid, block, 0, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL(conv_pw_kernel, grid, block, 0, st, a);
+  if (a.pw_prefetch) {
+    if (e0) hipExtLaunchKernelGGL(conv_pw_kernel<true>, grid, block, 0, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL(conv_pw_kernel<true>, grid, block, 0, st, a);
+  } else {
+    if (e0) hipExtLaunchKernelGGL(conv_pw_kernel<false>, grid, block, 0, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL(conv_pw_kernel<false>, grid, block, 0, st, a);
+  }
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
