@@ -147,3 +147,35 @@ def test_dense_bf16_flag_switches_module_path_and_stays_close_to_fp32():
     for got, ref in zip(out[True], out[False]):
         err = (got - ref).abs().max().item()
         assert 0 < err <= 2e-2 * ref.abs().max().item()   # bf16 operand rounding: visible, and bounded
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_patch_embedding_as_dense_product_matches_conv3d(train):
+    """PatchEmbed3D (swin_transformer.py:361-399: Conv3d with kernel == stride) on the dense kernel: same tokens as the
+    library convolution, and (SGD over all parameters) the same weight / bias gradients."""
+    from vitta_amd import ops, swin
+    torch.manual_seed(11)
+    pe = swin.PatchEmbed3D(patch_size=(2, 4, 4), in_chans=3, embed_dim=128, norm_layer=torch.nn.LayerNorm).to(_dev())
+    for p in pe.parameters():
+        p.requires_grad_(train)
+    x = torch.randn(2, 3, 8, 32, 32, device=_dev())
+    g = torch.randn(2, 4, 8, 8, 128, device=_dev())
+    res = {}
+    old = ops.DIRECT_PARAM_GRAD
+    ops.DIRECT_PARAM_GRAD = False
+    try:
+        for fused in (True, False):
+            swin.FUSED_DENSE = fused
+            if train:
+                y = pe(x)
+                grads = torch.autograd.grad(y, [pe.proj.weight, pe.proj.bias], g)
+                res[fused] = [y.detach()] + list(grads)
+            else:
+                with torch.no_grad():
+                    res[fused] = [pe(x)]
+    finally:
+        swin.FUSED_DENSE = True
+        ops.DIRECT_PARAM_GRAD = old
+    for got, ref in zip(res[True], res[False]):
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6

@@ -857,13 +857,14 @@ def _operand(weight, transposed):
     gradient), as bfloat16 when DENSE_BF16 is on and the reduction length allows.  A frozen weight (LN-affine adaptation)
     is prepared once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
     `_version`, and a captured graph must hold the copy launch)."""
-    kred = weight.shape[0] if transposed else weight.shape[1]
+    w2d = weight.detach().reshape(weight.shape[0], -1)  # a Conv3d patch-embedding kernel counts as [out][in * kd * kh * kw]
+    kred = w2d.shape[0] if transposed else w2d.shape[1]
     bf16 = bool(DENSE_BF16 and kred % 64 == 0)
     if not transposed and not bf16:
-        return weight.detach()
+        return w2d
 
     def make():
-        w = weight.detach().t() if transposed else weight.detach()
+        w = w2d.t() if transposed else w2d
         return w.to(torch.bfloat16).contiguous() if bf16 else w.contiguous()
 
     if weight.requires_grad:
@@ -878,16 +879,26 @@ def _operand(weight, transposed):
     return op
 
 
-def _param_grad(param, needed, value_fn):
-    """Hand a parameter gradient to its sink (accumulated in place when `.grad` is a live arena view)."""
+def _weight_grad(weight, needed, g2, x2):
+    """g2^T x2 (the library's TN product) handed to the weight's gradient sink: accumulated IN the product (beta = 1) when
+    `.grad` is a live arena view, so no separate add pass runs over the 88 M weights of Swin-B."""
     if not needed:
         return None
-    sink, ret = _grad_sink(param, True, zero=False)
-    val = value_fn()
+    sink, ret = _grad_sink(weight, True, zero=False)
     if ret is None:
-        sink.add_(val.view_as(sink))
+        sink.view(weight.shape[0], -1).addmm_(g2.t(), x2)
         return None
-    return val.view_as(param)
+    return torch.mm(g2.t(), x2, out=ret.view(weight.shape[0], -1)).view_as(weight)
+
+
+def _bias_grad(bias, needed, g2):
+    if not needed:
+        return None
+    sink, ret = _grad_sink(bias, True, zero=False)
+    if ret is None:
+        sink.add_(g2.sum(0))
+        return None
+    return torch.sum(g2, 0, out=ret)
 
 
 class DenseLinear(torch.autograd.Function):
@@ -903,7 +914,7 @@ class DenseLinear(torch.autograd.Function):
         y = gemm_nt(x2, _operand(weight, False), bias)
         ctx.save_for_backward(x2 if weight.requires_grad else None, weight, bias)
         ctx.xshape = shape
-        return y.view(shape[:-1] + (weight.shape[0],))
+        return y.view(shape[:-1] + (weight.shape[0],))  # (weight may be a Conv3d kernel [out, ...]: its flattened form is used)
 
     @staticmethod
     def backward(ctx, gy):
@@ -912,8 +923,8 @@ class DenseLinear(torch.autograd.Function):
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         dx = gemm_nt(g2, _operand(weight, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = _param_grad(weight, ctx.needs_input_grad[1], lambda: g2.t() @ x2)
-        db = _param_grad(bias, bias is not None and ctx.needs_input_grad[2], lambda: g2.sum(0))
+        dw = _weight_grad(weight, ctx.needs_input_grad[1], g2, x2)
+        db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g2)
         return dx, dw, db
 
 
@@ -945,10 +956,10 @@ class FusedMlp(torch.autograd.Function):
             g2 = g2.contiguous()
         gh = gemm_nt(g2, _operand(w2, True), mode=2, aux=h)
         dx = gemm_nt(gh, _operand(w1, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1 = _param_grad(w1, ctx.needs_input_grad[1], lambda: gh.t() @ x2)
-        db1 = _param_grad(b1, b1 is not None and ctx.needs_input_grad[2], lambda: gh.sum(0))
-        dw2 = _param_grad(w2, ctx.needs_input_grad[3], lambda: g2.t() @ a)
-        db2 = _param_grad(b2, b2 is not None and ctx.needs_input_grad[4], lambda: g2.sum(0))
+        dw1 = _weight_grad(w1, ctx.needs_input_grad[1], gh, x2)
+        db1 = _bias_grad(b1, b1 is not None and ctx.needs_input_grad[2], gh)
+        dw2 = _weight_grad(w2, ctx.needs_input_grad[3], g2, a)
+        db2 = _bias_grad(b2, b2 is not None and ctx.needs_input_grad[4], g2)
         return dx, dw1, db1, dw2, db2
 
 

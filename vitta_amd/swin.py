@@ -387,12 +387,25 @@ class PatchEmbed3D(nn.Module):
         p = self.patch_size
         if W % p[2] or H % p[1] or D % p[0]:
             x = F.pad(x, (0, (-W) % p[2], 0, (-H) % p[1], 0, (-D) % p[0]))
-        x = self.proj(x)
-        B, C, D, Hh, Ww = x.shape
-        x = x.flatten(2).transpose(1, 2)  # (B, L, C): the first LayerNorm sees a 3-D tensor, as in the reference
+        B, Cin, D, H, W = x.shape
+        kin = Cin * p[0] * p[1] * p[2]
+        if (FUSED_DENSE and x.is_cuda and x.dtype == torch.float32 and kin % 32 == 0 and tuple(self.proj.stride) == tuple(p)
+                and tuple(self.proj.padding) == (0, 0, 0) and not self.proj._forward_hooks):
+            # kernel == stride: the convolution is a per-patch Linear(kin -> embed_dim).  One gather copy + the dense kernel
+            # (csrc/gemm.hip) instead of the library's im2col + GEMM -- and instead of its NAIVE Conv3d weight-gradient
+            # kernel under SGD over all parameters (7.9 ms per video, 18 % of that step)
+            from . import ops
+            Dd, Hh, Ww = D // p[0], H // p[1], W // p[2]
+            patches = x.view(B, Cin, Dd, p[0], Hh, p[1], Ww, p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, Dd * Hh * Ww, kin)
+            x = ops.DenseLinear.apply(patches, self.proj.weight, self.proj.bias)
+            C = x.shape[-1]
+        else:
+            x = self.proj(x)
+            B, C, Dd, Hh, Ww = x.shape
+            x = x.flatten(2).transpose(1, 2)  # (B, L, C): the first LayerNorm sees a 3-D tensor, as in the reference
         if self.norm is not None:
             x = self.norm(x)
-        return x.reshape(B, D, Hh, Ww, C)
+        return x.reshape(B, Dd, Hh, Ww, C)
 
 
 class SwinTransformer3D(nn.Module):
