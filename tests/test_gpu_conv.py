@@ -319,3 +319,35 @@ def test_stem_backward_and_weight_gradient_match_fp64_autograd(n, h, w):
     gw = base.clone().to(d)
     CV.stem_wgrad(x.to(d), dy, gw)
     _close(gw, wr.grad + base.double(), tol=5e-5, what="dw")
+
+
+def test_repack_of_trainable_weights_matches_the_permutes():
+    """vitta_conv_repack_f32 (one launch over every trainable convolution, LDS-tiled) == pack_fwd / pack_bwd per weight,
+    incl. C * taps not a multiple of the 32-wide tile and 1x1 weights without a backward pack."""
+    import ctypes as C
+    import numpy as np
+    from vitta_amd import conv as CV
+    from vitta_amd._lib import check, lib
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 64, 1, 1), (64, 48, 3, 3), (128, 64, 3, 3), (256, 64, 1, 1), (32, 16, 3, 3), (2048, 512, 1, 1), (96, 80, 3, 3)]
+    ws = [torch.randn(s, generator=g).to(d) for s in shapes]
+    dt = np.dtype([("src", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"), ("first", "<i8"), ("K", "<i4"), ("C", "<i4"), ("taps", "<i4"),
+                   ("pad", "<i4")])
+    tab = np.zeros(len(ws), dtype=dt)
+    outs, first = [], 0
+    for i, w in enumerate(ws):
+        k, c, kh, kw = w.shape
+        taps = kh * kw
+        pf = torch.full((taps, c, k), float("nan"), device=d)
+        pb = torch.full((taps, k, c), float("nan"), device=d) if taps > 1 else None
+        outs.append((pf, pb))
+        tab[i] = (w.data_ptr(), pf.data_ptr(), pb.data_ptr() if pb is not None else 0, first, k, c, taps, 0)
+        first += k * c * taps
+    dtab = torch.from_numpy(tab.view(np.uint8).copy()).to(d)
+    check(lib().vitta_conv_repack_f32(C.c_void_p(dtab.data_ptr()), len(ws), first, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "vitta_conv_repack_f32")
+    for w, (pf, pb) in zip(ws, outs):
+        assert torch.equal(pf, CV.pack_fwd(w).view_as(pf))
+        if pb is not None:
+            assert torch.equal(pb, CV.pack_bwd(w).view_as(pb))
