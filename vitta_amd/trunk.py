@@ -193,10 +193,13 @@ class TrunkRunner:
         return len(engines) <= 1
 
     # -- caches ------------------------------------------------------------------------------------------------
-    def packed(self, conv, kind):
+    def packed(self, conv, kind, adapt=None):
+        """adapt: which re-packed set of a trainable weight -- True: the adaptation pass's (its backward runs with grad mode
+        OFF, so it has to say so: the evaluation pass's set is written by another stream and holds no backward packs),
+        None: by the current grad mode (forward passes)."""
         w = conv.weight
         if w.requires_grad and kind in ("f", "b"):  # trainable: this pass's copies, rebuilt by ONE launch per forward
-            st = self._repack.get(torch.is_grad_enabled())
+            st = self._repack.get(torch.is_grad_enabled() if adapt is None else adapt)
             if st is not None and (id(w), kind) in st["packs"]:
                 return st["packs"][(id(w), kind)]
         if w.requires_grad:  # (stem, or outside a refreshed forward): re-packed on demand
@@ -239,9 +242,11 @@ class TrunkRunner:
                 k, ci, kh, kw = w.shape
                 taps = kh * kw
                 pf = torch.empty(taps, ci, k, dtype=torch.float32, device=device)
-                pb = torch.empty(taps, k, ci, dtype=torch.float32, device=device) if taps > 1 else w.detach().view(1, k, ci)
+                # the data-gradient pack only where a backward can follow (the no_grad set of the evaluation pass skips it)
+                pb = (torch.empty(taps, k, ci, dtype=torch.float32, device=device) if key else None) if taps > 1 \
+                    else w.detach().view(1, k, ci)
                 packs[(id(w), "f")], packs[(id(w), "b")] = pf, pb
-                tab[i] = (w.data_ptr(), pf.data_ptr(), pb.data_ptr() if taps > 1 else 0, first, k, ci, taps, 0)
+                tab[i] = (w.data_ptr(), pf.data_ptr(), pb.data_ptr() if (taps > 1 and pb is not None) else 0, first, k, ci, taps, 0)
                 first += k * ci * taps
             dtab = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
             st = self._repack[key] = dict(sig=sig, packs=packs, table=dtab, n=len(convs), total=first)
@@ -455,7 +460,7 @@ class TrunkRunner:
         # conv3 data gradient, epilogue = bn2 (+ReLU) backward
         dx2 = torch.empty(p, Po, **f)
         i2 = s2.inj if s2 else None
-        CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b"), dx2, 4 * p, p,
+        CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b", True), dx2, 4 * p, p,
                   flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
                   dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias))
         if net.conv3.weight.requires_grad:
@@ -466,7 +471,7 @@ class TrunkRunner:
         # conv2 data gradient -> d a1
         ga1 = torch.empty(p, P, **f)
         for g in self.geo("b", n, h, w, 3, s, 1):
-            CV.launch(g, dx2, self.packed(net.conv2, "b"), ga1, p, p)
+            CV.launch(g, dx2, self.packed(net.conv2, "b", True), ga1, p, p)
         del dx2
         # TAM backward
         bn1p = _bn_ptrs(net.bn1)
@@ -502,11 +507,11 @@ class TrunkRunner:
             if dconv.weight.requires_grad:
                 CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
             gd = torch.empty(cin, Po if ds == 2 else P, **f)
-            CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b"), gd, 4 * p, cin)
+            CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b", True), gd, 4 * p, cin)
             res, rflag = gd, (CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES)
         else:
             res, rflag = g_id, CV.CONV_RES
-        CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b"), gin, p, cin, flags=rflag, res=res)
+        CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
         return gin
 
     def backward(self, ctxd, gfeat, sink):
