@@ -2,7 +2,7 @@
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-T=${1:-r2h}
+T=${1:-r2k}
 timeout 400 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- python bench.py --no-sgd-all > $O/${T}_bench_profiled_run.json 2> $O/${T}_prof.err
 DB=$(ls $O/prof_$T/*.db $O/prof_$T/*/*.db 2>/dev/null | head -1)
