@@ -223,7 +223,7 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
         assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
 
 
-@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("bf16", [False, True, "dense"])
 def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     """BASELINE config 5 shape in small: Video Swin-B, window (16,7,7), 4 views x 32 frames.  N = 784 tokens per
     window at the first stages: the CHUNKED W-MSA kernels (keys / queries walked in chunks of 400, online softmax)
@@ -231,7 +231,8 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     LN-affine Adam step on the GPU (HIP statistics path) == the same step on the CPU with the oracle backend.
     bf16: the bf16-OPERAND attention kernels (ops.WMSA_BF16, BASELINE config 5's "bf16 MFMA W-MSA"; 784 tokens in one
     pass) against the same fp32 CPU path at the tolerance 8-bit operand mantissas allow through 24 blocks: statistics loss
-    rel 2e-3, consistency loss rel 5e-2, sampled gradients 1e-1 of their maximum."""
+    rel 1e-4, consistency loss rel 2e-3, sampled gradients 3e-2 of their maximum (dense: 1e-4 / 5e-3 / 5e-2).  "dense": the bf16-operand dense layers
+    as well (ops.DENSE_BF16, vitta_gemm_nt_bf16w_f32): every matrix product of the backbone on bf16 operands."""
     import numpy as np
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, scripts, tta
@@ -266,7 +267,8 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
         return orig(*a)
 
     setattr(L, entry, spy)
-    old_flag, ops.WMSA_BF16 = ops.WMSA_BF16, bf16
+    old_flag, ops.WMSA_BF16 = ops.WMSA_BF16, bool(bf16)
+    old_dense, ops.DENSE_BF16 = ops.DENSE_BF16, bf16 == "dense"
     try:
         for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
             adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(dev), args, engine_backend=backend)
@@ -279,9 +281,13 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     finally:
         setattr(L, entry, orig)
         ops.WMSA_BF16 = old_flag
+        ops.DENSE_BF16 = old_dense
     assert seen.count(784) == 22, sorted(set(seen))  # stages 1-3 (2 + 2 + 18 blocks): N = 784 (fp32: the chunked kernels)
     c, gdev = res["cpu"], res["cuda"]
-    r0, r1, rg = (2e-3, 5e-2, 1e-1) if bf16 else (2e-5, 1e-3, 2e-2)
+    # measured (r2k): fp32 9e-8 / 2e-7 / 4e-6; bf16 attention 9e-8 / 3e-5 / 3e-3; bf16 attention + dense 2e-6 / 1.3e-4 / 8e-3
+    r0, r1, rg = (1e-4, 5e-3, 5e-2) if bf16 == "dense" else (1e-4, 2e-3, 3e-2) if bf16 else (2e-5, 1e-3, 2e-2)
+    print("config-5 shape, mode", bf16, "loss_reg rel", abs(gdev[0] - c[0]) / abs(c[0]), "loss_consis rel", abs(gdev[1] - c[1]) / max(abs(c[1]), 1e-12),
+          "grad rel", [((a - b).abs().max() / b.abs().max()).item() for a, b in zip(gdev[2:], c[2:])])
     assert gdev[0] == pytest.approx(c[0], rel=r0) and gdev[1] == pytest.approx(c[1], rel=r1, abs=1e-6)
     for a, b in zip(gdev[2:], c[2:]):
         assert (a - b).abs().max().item() <= rg * b.abs().max().item() + 1e-9
