@@ -1,6 +1,9 @@
 """hipGraph capture probe: fork / join of side streams (a) in the capturing thread, (b) inside an autograd Function's backward
 (the engine's worker thread).  python tools/debug/graph_fork_probe.py"""
+import sys
+
 import torch
+MODE = sys.argv[1] if len(sys.argv) > 1 else "global"
 dev = torch.device("cuda:0")
 a = torch.randn(1024, 1024, device=dev)
 sides = [torch.cuda.Stream(dev) for _ in range(3)]
@@ -41,7 +44,7 @@ for nfork, rounds in ((1, 1), (3, 1), (3, 3)):
     for where in ("capturing thread", "autograd backward"):
         g = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=MODE):
                 if where == "capturing thread":
                     o = body(nfork, rounds)
                 else:
@@ -53,3 +56,39 @@ for nfork, rounds in ((1, 1), (3, 1), (3, 3)):
         except Exception as e:
             print("FAIL", where, nfork, rounds, str(e).splitlines()[0][:90])
             torch.cuda.synchronize()
+
+# (c) an OUTER fork (the evaluation stream of the overlapped step) stays open while inner forks / joins happen in a backward
+outer = torch.cuda.Stream(dev)
+many = [torch.cuda.Stream(dev) for _ in range(9)]
+
+
+def nested(n_inner):
+    main = torch.cuda.current_stream(dev)
+    outer.wait_stream(main)
+    with torch.cuda.stream(outer):
+        keep = a @ a
+    x.grad = None
+    sides[:] = many[:3]
+    F.apply(x, 3, 1).sum().backward()
+    if n_inner > 1:
+        sides[:] = many[3:6]
+        F.apply(x, 3, 1).sum().backward()
+        sides[:] = many[6:9]
+        F.apply(x, 3, 1).sum().backward()
+    main.wait_stream(outer)
+    return keep
+
+
+for n_inner in (1, 3):
+    nested(n_inner)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g, capture_error_mode=MODE):
+            o = nested(n_inner)
+        g.replay()
+        torch.cuda.synchronize()
+        print("ok   outer fork open,", n_inner, "x 3 inner streams")
+    except Exception as e:
+        print("FAIL outer fork open,", n_inner, "x 3 inner streams:", str(e).splitlines()[0][:90])
+        torch.cuda.synchronize()
