@@ -9,12 +9,14 @@
 // floats: 9 (odd) sixteen-byte units, so the 16 lanes a ds_read_b128 services per cycle start in 16 different bank quads,
 // and a global 16-byte load lands as one conflict-free ds_write_b128.
 //
-// Workgroup = 256 lanes = 2 x 2 waves over a BM x 128 output tile (BM = 128: every wave owns 2 x 2 accumulator blocks of
-// 32 x 32, i.e. 16 MFMAs per pair of 16-byte reads -- the matrix pipe, not LDS or issue, is what is busy; BM = 64 for
-// launches that would otherwise leave CUs idle; 64 x 64: one block per wave).  K is walked in slabs of 32 through two LDS stages; the global loads of
-// slab s + 2 are in flight in registers while slab s is multiplied: one barrier per slab (4096 matrix-pipe cycles at
-// BM = 128).  Tiles are numbered n-fastest and handed to XCDs in contiguous ranges (a token tile's rows are re-read by
-// the n-tiles of one L2).
+// Workgroup = 256 lanes = 2 x 2 waves over a BM x BN output tile: 64 x 64 (one 32 x 32 accumulator block per wave, 37 KB of
+// LDS, four workgroups per CU), 64 x 128 or 128 x 128 (2 x 2 blocks per wave: 16 MFMAs per pair of 16-byte reads).  K is
+// walked in slabs of 32 through two LDS stages; the global loads of slab s + 2 are in flight in registers while slab s is
+// multiplied: one barrier per slab.  Tiles are numbered n-fastest and handed to XCDs in contiguous ranges (a token tile's
+// rows are re-read by the n-tiles of one L2).  MEASURED on the 20 shapes of the Swin-B step (profiles/r2k_gemm_bench.json):
+// the 64 x 64 tile wins everywhere -- at 1.6-6.6 GFLOP per launch four co-resident workgroups hiding each other's staging
+// and epilogue latencies matter more than operand reuse, and ceil(tiles / 256 CUs) quantises the coarse tiles harder -- so
+// choose_tile() returns it unless a cost model with the measured penalties says otherwise; the coarse tiles stay selectable.
 //
 // Epilogues (lane = output column, so every store instruction writes two full 128-byte lines):
 //   mode 0  y = acc (+ bias[n])
