@@ -451,6 +451,11 @@ typedef struct vitta_conv_desc {
   int32_t ksplit; /* 0: library's choice; 1: never split; n: exactly n slices (VITTA_ERR_WORKSPACE if it does not fit) */
   void* workspace;
   int64_t workspace_bytes;
+  /* Optional split-bf16 image of the same weights (vitta_conv_pack_b3 of the packed [n_wtaps][C][K] array).  When given
+   * and the shape qualifies (C % 32 == 0, K % 64 == 0, no VITTA_CONV_PRO_BN_RELU, tile 0 or 128 x 64) the launch runs on
+   * the bf16 matrix pipe with every fp32 operand split into three bf16 terms and six products per multiply-add (fp32
+   * accumulation; error of the fp32-roundoff class, see conv_b3.hip); `w` is then not read.  NULL: exact fp32 MFMA. */
+  const void* w_b3;
 } vitta_conv_desc;
 
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */
@@ -464,6 +469,12 @@ int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_s
 int64_t vitta_conv_flops(const vitta_conv_desc* h_desc);
 /* Workspace the library's split choice (or h_desc->ksplit) needs for this descriptor; 0 = none. */
 size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
+/* Which kernel family the launch of this descriptor runs on (tests assert the path under test; -1: unsupported). */
+#define VITTA_CONV_KERNEL_TILE 0 /* conv.hip: exact fp32 MFMA, tile per workgroup (+ split K) */
+#define VITTA_CONV_KERNEL_SK 1   /* conv_sk.hip: exact fp32 MFMA, persistent stream-K */
+#define VITTA_CONV_KERNEL_PW 2   /* conv_pw.hip: exact fp32 MFMA, pointwise tile per workgroup */
+#define VITTA_CONV_KERNEL_B3 3   /* conv_b3.hip: split-bf16 operands on the bf16 matrix pipe */
+int vitta_conv_kernel(const vitta_conv_desc* h_desc);
 /* Workgroups the launch of this descriptor would use (for tile selection / tests). */
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
 
@@ -500,6 +511,22 @@ typedef struct vitta_wgrad_desc {
   int64_t workspace_bytes;
 } vitta_wgrad_desc;
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
+
+/* Split-bf16 weight image for vitta_conv_desc::w_b3.  d_src: fp32 [taps][R][O] (R = reduction channels, O = output
+ * channels: the packed forward / data-gradient arrays of vitta_conv_desc::w), R % 32 == 0.
+ * d_dst: [taps][R / 32][3 planes hi | mid | lo][4 channel octets][O][8] bfloat16 = vitta_conv_pack_b3_bytes() bytes,
+ * x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round to nearest even).
+ * _table: many weights in one launch (trainable weights are re-split every step); entries ordered by first_unit =
+ * number of 16-byte units (taps * R / 8 * O each) of all entries before this one. */
+typedef struct vitta_pack_b3_entry {
+  const float* src;
+  void* dst;
+  int64_t first_unit;
+  int32_t taps, R, O, pad;
+} vitta_pack_b3_entry;
+size_t vitta_conv_pack_b3_bytes(int32_t taps, int32_t R, int32_t O);
+int vitta_conv_pack_b3(const float* d_src, void* d_dst, int32_t taps, int32_t R, int32_t O, void* stream);
+int vitta_conv_pack_b3_table(const vitta_pack_b3_entry* d_table, int32_t n_entries, int64_t total_units, void* stream);
 
 /* Packed copies of MANY convolution weights in one launch (trainable weights are re-packed every step).  d_table: device
  * array of entries; `first` = number of weight elements of all entries before this one (entries ordered by it);

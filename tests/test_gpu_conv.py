@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+@pytest.fixture(params=["b3", "f32"], autouse=True)
+def arith(request):
+    """Every test of this file runs in both arithmetic forms of vitta_conv_f32: split-bf16 operands on the bf16 matrix pipe
+    (conv_b3.hip, the default) and exact-fp32 MFMA; same bounds."""
+    from vitta_amd import conv as CV
+    old, CV.ARITH = CV.ARITH, request.param
+    yield request.param
+    CV.ARITH = old
+
+
 def _dev():
     return torch.device("cuda:0")
 
@@ -351,3 +361,30 @@ def test_repack_of_trainable_weights_matches_the_permutes():
         assert torch.equal(pf, CV.pack_fwd(w).view_as(pf))
         if pb is not None:
             assert torch.equal(pb, CV.pack_bwd(w).view_as(pb))
+
+
+def test_pack_b3_reconstructs_the_weights_and_the_split_kernel_is_the_path(arith):
+    """vitta_conv_pack_b3: hi + mid + lo of the [tap][slab][plane][octet][O][8] image gives the fp32 weight back to 2^-23
+    relative, hi alone is its bf16 rounding; and a qualifying launch runs on conv_b3.hip exactly when the arithmetic
+    mode says so (vitta_conv_kernel)."""
+    from vitta_amd import _lib, conv as CV
+    d = _dev()
+    g = torch.Generator().manual_seed(5)
+    taps, r, o = 9, 64, 128
+    wp = (torch.randn(taps, r, o, generator=g) * torch.rand(taps, r, o, generator=g).exp()).to(d)
+    img = CV.pack_b3(wp).view(torch.bfloat16).view(taps, r // 32, 3, 4, o, 8).float()
+    planes = img.permute(2, 0, 1, 3, 5, 4).reshape(3, taps, r, o)  # [plane][tap][slab * 32 + octet * 8 + j][o]
+    assert torch.equal(planes[0], wp.to(torch.bfloat16).float())
+    rec = planes[0].double() + planes[1].double() + planes[2].double()
+    assert ((rec - wp.double()).abs() <= 2.0 ** -23 * wp.double().abs()).all()
+    n, c, k, h = 4, 64, 128, 28
+    x = torch.randn(c, n * h * h, device=d)
+    w = torch.randn(k, c, 1, 1, device=d)
+    y = torch.empty(k, n * h * h, device=d)
+    CV.KERNEL_COUNTS = {}
+    try:
+        CV.launch(CV.Geometry.forward(n, h, h), x, CV.pack_fwd(w), y, c, k)
+        counts = dict(CV.KERNEL_COUNTS)
+    finally:
+        CV.KERNEL_COUNTS = None
+    assert (counts.get(_lib.CONV_KERNEL_B3, 0) == 1) == (arith == "b3"), counts

@@ -35,16 +35,29 @@ def trunk_convs():
 
 
 def time_it(fn, reps):
+    """us per call of fn, device time: `reps` calls captured into one hipGraph (eager launches through ctypes are host-bound
+    below ~20 us per call), the replay timed with events."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(reps):
-        fn()
+    graph.replay()
+    graph.replay()
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / reps * 1e3  # us
+    return a.elapsed_time(b) / (2 * reps) * 1e3  # us
 
 
 def main():
@@ -54,12 +67,17 @@ def main():
     ap.add_argument("--out", default="gpurun_out/conv_bench.json")
     ap.add_argument("--tiles", default="", help="comma list of BMxBN to sweep instead of the library's choice")
     ap.add_argument("--no-vendor", action="store_true")
+    ap.add_argument("--arith", default="", help="comma list of arithmetic forms to time side by side (f32,b3); default: the library's")
+    ap.add_argument("--only", default="", help="substring filter on layer names")
     opt = ap.parse_args()
     d = torch.device("cuda:0")
     n = opt.frames
     rows, seen = [], {}
     tiles = [0] + [(int(t.split("x")[0]) << 16) | int(t.split("x")[1]) for t in opt.tiles.split(",") if t]
+    ariths = [a for a in opt.arith.split(",") if a] or [CV.ARITH]
     for name, c, k, h, ksz, s in trunk_convs():
+        if opt.only and opt.only not in name:
+            continue
         key = (c, k, h, ksz, s)
         if key in seen:
             seen[key]["count"] += 1
@@ -74,8 +92,9 @@ def main():
         gx = torch.empty(c, n * h * h, device=d)
         flops = 2.0 * n * ho * ho * c * k * ksz * ksz
         row = dict(name=name, C=c, K=k, H=h, k=ksz, stride=s, count=1, gflop=flops / 1e9)
-        for tile in tiles:
-            tag = "" if tile == 0 else f"_{tile >> 16}x{tile & 0xffff}"
+        for tile, arith in [(t, a) for t in tiles for a in ariths]:
+            CV.ARITH = arith
+            tag = ("" if tile == 0 else f"_{tile >> 16}x{tile & 0xffff}") + (f"_{arith}" if len(ariths) > 1 else "")
             if tile and (k % (tile & 0xffff) or c % (tile & 0xffff)):
                 continue
             t_f = time_it(lambda: CV.launch(gf, x, wf, y, c, k, tile=tile), opt.reps)
@@ -107,9 +126,12 @@ def main():
         stem["vendor_fwd_us"], stem["vendor_fwd_tf"] = t_v, sflops / t_v / 1e6
     print({kk: (round(v, 1) if isinstance(v, float) else v) for kk, v in stem.items()}, flush=True)
     tot = lambda f: sum(r[f] * r["count"] for r in rows if f in r)
-    summary = dict(frames=n, fwd_ms=tot("fwd_us") / 1e3, dgrad_ms=tot("dgrad_us") / 1e3, vendor_fwd_ms=tot("vendor_fwd_us") / 1e3,
-                   gflop=tot("gflop"), fwd_tf=tot("gflop") / tot("fwd_us") * 1e3, dgrad_tf=tot("gflop") / tot("dgrad_us") * 1e3,
-                   peak_tf=PEAK)
+    summary = dict(frames=n, gflop=tot("gflop"), peak_tf=PEAK, vendor_fwd_ms=tot("vendor_fwd_us") / 1e3)
+    for a in ariths:
+        t = f"_{a}" if len(ariths) > 1 else ""
+        summary.update({f"fwd_ms{t}": tot(f"fwd_us{t}") / 1e3, f"dgrad_ms{t}": tot(f"dgrad_us{t}") / 1e3,
+                        f"fwd_tf{t}": tot("gflop") / max(tot(f"fwd_us{t}"), 1e-9) * 1e3,
+                        f"dgrad_tf{t}": tot("gflop") / max(tot(f"dgrad_us{t}"), 1e-9) * 1e3})
     print(summary)
     os.makedirs(os.path.dirname(opt.out) or ".", exist_ok=True)
     json.dump(dict(summary=summary, stem=stem, rows=rows), open(opt.out, "w"), indent=1)

@@ -24,7 +24,7 @@ def summarise(path, out_json, trace=None):
     calls = defaultdict(set)
     for r in rows:
         name = r["Kernel_Name"]
-        if "conv_igemm" not in name:
+        if "conv_" not in name or "pack" in name:
             continue
         k = name.split("(")[0].split("::")[-1] + " grid=" + r.get("Grid_Size", "?")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])

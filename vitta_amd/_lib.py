@@ -33,6 +33,7 @@ class WgradDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
 CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU = 16, 32, 64, 128
+CONV_KERNEL_TILE, CONV_KERNEL_SK, CONV_KERNEL_PW, CONV_KERNEL_B3 = 0, 1, 2, 3
 
 
 class ConvDesc(C.Structure):
@@ -50,7 +51,7 @@ class ConvDesc(C.Structure):
                 ("ntaps", C.c_int32),
                 ("dh", C.c_int8 * CONV_MAX_TAPS), ("dw", C.c_int8 * CONV_MAX_TAPS), ("wt", C.c_int8 * CONV_MAX_TAPS),
                 ("flags", C.c_int32), ("tile", C.c_int32),
-                ("ksplit", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("ksplit", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("w_b3", C.c_void_p)]
 
 
 _p = C.c_void_p
@@ -129,8 +130,12 @@ SIGNATURES = {
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
     "vitta_conv_repack_f32": (C.c_int, [_p, _i32, _i64, _p]),
+    "vitta_conv_pack_b3_bytes": (_sz, [_i32, _i32, _i32]),
+    "vitta_conv_pack_b3": (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),
+    "vitta_conv_pack_b3_table": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
     "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
+    "vitta_conv_kernel": (C.c_int, [C.POINTER(ConvDesc)]),
     "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "vitta_stem_conv7_wgrad_workspace_bytes": (_sz, []),
     "vitta_stem_conv7_wgrad_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _sz, _p]),

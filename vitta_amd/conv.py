@@ -11,6 +11,8 @@ Packed weights (made once per weight version, `pack_fwd` / `pack_bwd`):
     backward: [kh*kw][K][C]   (w.permute(2, 3, 0, 1)); the tap table supplies the flip of the transposed convolution.
 """
 import ctypes as C
+import os
+import weakref
 
 import torch
 
@@ -38,6 +40,62 @@ def pack_fwd(w):
 def pack_bwd(w):
     k, c, kh, kw = w.shape
     return w.detach().permute(2, 3, 0, 1).reshape(kh * kw, k, c).contiguous()
+
+
+# Arithmetic of vitta_conv_f32 launches: "b3" = split-bf16 operands on the bf16 matrix pipe (conv_b3.hip: three bf16 terms per
+# fp32 operand, six products per multiply-add, fp32 accumulation -- fp32-roundoff-class error) wherever the shape qualifies,
+# "f32" = the exact-fp32 MFMA kernels everywhere.  The reference computes in fp32 (cuDNN / PyTorch default, no TF32 on the
+# parts it was published on); both forms are held to the same bound against fp64 (tests/test_gpu_conv.py).
+ARITH = os.environ.get("VITTA_CONV_ARITH", "b3")
+
+
+class Pack:
+    """A packed weight: .f32 [taps][R][O] fp32 (vitta_conv_desc::w) and .b3, its split-bf16 image (::w_b3) or None."""
+    __slots__ = ("f32", "b3")
+
+    def __init__(self, f32, b3=None):
+        self.f32, self.b3 = f32, b3
+
+
+def b3_eligible(wp):
+    return wp.dim() == 3 and wp.shape[1] % 32 == 0 and wp.shape[2] % 64 == 0
+
+
+def pack_b3(wp, out=None):
+    """Split-bf16 image (uint8 tensor) of a packed fp32 weight [taps][R][O] (`vitta_conv_pack_b3`)."""
+    if not wp.is_cuda or wp.dtype != torch.float32 or not wp.is_contiguous():
+        raise _lib.VittaHipError("pack_b3: contiguous fp32 tensor on the GPU")
+    taps, r, o = wp.shape
+    nbytes = int(lib().vitta_conv_pack_b3_bytes(taps, r, o))
+    if nbytes == 0:
+        raise _lib.VittaHipError("pack_b3: the reduction axis must be a multiple of 32")
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=wp.device)
+    check(lib().vitta_conv_pack_b3(C.c_void_p(wp.data_ptr()), C.c_void_p(out.data_ptr()), taps, r, o,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_pack_b3")
+    return out
+
+
+def make_pack(wp):
+    """Pack of a fp32 packed weight, with the split image where the arithmetic mode and the shape allow it."""
+    return Pack(wp, pack_b3(wp) if (ARITH == "b3" and b3_eligible(wp)) else None)
+
+
+_derived = {}  # id(fp32 pack) -> (weakref, version, b3 image): launches handed a bare fp32 pack (tests, tools)
+
+
+def _derive(wp):
+    if ARITH != "b3" or not b3_eligible(wp):
+        return None
+    hit = _derived.get(id(wp))
+    if hit is not None and hit[0]() is wp and hit[1] == wp._version:
+        return hit[2]
+    if len(_derived) > 256:
+        for k in [k for k, v in _derived.items() if v[0]() is None]:
+            del _derived[k]
+    b3 = pack_b3(wp)
+    _derived[id(wp)] = (weakref.ref(wp), wp._version, b3)
+    return b3
 
 
 def out_size(h, k, s, p):
@@ -140,13 +198,18 @@ def workspace(device):
 
 def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,
            stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0):
-    """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K], y [K, *].
+    """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K] (fp32 tensor or Pack), y [K, *].
     stats = (shift, s1, s2); inj = (mu, a, b, gscale)."""
+    if isinstance(wp, Pack):
+        wp, b3 = wp.f32, wp.b3
+    else:
+        b3 = _derive(wp) if (wp.is_cuda and wp.dtype == torch.float32 and wp.is_contiguous()) else None
     for t in (x, wp, y):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
     d = ConvDesc()
     d.x, d.w, d.y, d.y_raw, d.res = x.data_ptr(), wp.data_ptr(), y.data_ptr(), _ptr(y_raw), _ptr(res)
+    d.w_b3 = _ptr(b3) if ARITH == "b3" else None
     _bn4(d.pro_bn, pro_bn)
     _bn4(d.epi_bn, epi_bn)
     _bn4(d.bwd_bn, bwd_bn)
@@ -163,6 +226,9 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
         ws = workspace(x.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if KERNEL_COUNTS is not None:  # tests: which kernel family ran (vitta_conv_kernel)
+        kid = int(lib().vitta_conv_kernel(C.byref(d)))
+        KERNEL_COUNTS[kid] = KERNEL_COUNTS.get(kid, 0) + 1
     if TIMING is not None:  # bench.py: one event pair per launch, attached to the kernel's dispatch
         ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg))
         check(lib().vitta_conv_timed_f32(C.byref(d), st, ev.start, ev.stop), "vitta_conv_timed_f32")
@@ -216,6 +282,8 @@ def stem_wgrad(x, dy, grad_w):
 
 # callable(flops, shape_key) -> ops.KernelEventPair, or None (the product never sets it)
 TIMING = None
+# dict {kernel family id (_lib.CONV_KERNEL_*): launches} filled while it is not None (tests assert the path under test)
+KERNEL_COUNTS = None
 
 
 def pack_stem(w):
@@ -240,5 +308,5 @@ def stem_conv(x, wp):
     return y
 
 
-__all__ = ["Geometry", "launch", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
+__all__ = ["Geometry", "launch", "Pack", "pack_b3", "make_pack", "b3_eligible", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
            "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

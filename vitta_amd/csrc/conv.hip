@@ -564,6 +564,17 @@ bool is_vector_geometry(const vitta_conv_desc& d) {
          d.Hy == d.Hg && d.Wy == d.Wg;
 }
 
+// conv_b3.hip's patch form: taps are shifts inside one flat pixel range of the source planes -- the source grid is the
+// output grid (stride 1) and every shift dh * Ws + dw stays inside the halo (63 pixels: 128 x 64 tiles, 32: 128 x 128)
+bool b3_patch_geometry(const vitta_conv_desc& d, int halo) {
+  if (d.sstride != 1 || d.Hg != d.Hs || d.Wg != d.Ws) return false;
+  for (int t = 0; t < d.ntaps; ++t) {
+    const int sh = d.dh[t] * d.Ws + d.dw[t];
+    if (sh < -halo || sh > halo) return false;
+  }
+  return true;
+}
+
 // Tile choice: the largest tile that still gives the launch about two workgroups per CU; small problems fall through to
 // 64 x 64 / 64 x 32 (more, shorter workgroups).  BN must divide K.
 // The counters sit in a FIXED prefix of the workspace: launches with different tile counts share one workspace, and a
@@ -583,6 +594,17 @@ int resident_slots() {
     slots = 3 * cus;
   }
   return slots;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return (e && e[0]) ? atoi(e) : dflt;
+}
+
+// VITTA_CONV_B3=0: exact-fp32 MFMA kernels even where a split-bf16 weight image is supplied (A/B measurements)
+bool b3_enabled() {
+  static const int on = env_int("VITTA_CONV_B3", 1);
+  return on != 0;
 }
 
 // VITTA_CONV_STREAM_K=0 keeps the tile-per-workgroup kernels (A/B measurements)
@@ -605,10 +627,6 @@ bool pw_enabled() {
   return on == 1;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return (e && e[0]) ? atoi(e) : dflt;
-}
 // smallest tile count / longest K walk (slabs per tile) conv_pw.hip takes.  Measured with bench.py: 96-192 tiles and 32-64
 // slabs are within noise of each other (148.9-150.3 videos/s); a gathered (3x3) variant of the kernel was measured and
 // dropped (64-channel layer 46.8 vs 47.6 us, 128-channel layer 49.2 vs 47.4 us: the stream-K kernel keeps those), and so
@@ -638,7 +656,7 @@ void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
 }
 
 int fill(const vitta_conv_desc* h, ConvK& a) {
-  if (!h || !h->x || !h->w || !h->y) return VITTA_ERR_INVALID_ARG;
+  if (!h || !h->x || (!h->w && !h->w_b3) || !h->y) return VITTA_ERR_INVALID_ARG;
   a.d = *h;
   const vitta_conv_desc& d = a.d;
   if (d.C <= 0 || d.K <= 0 || d.N <= 0 || d.ntaps < 1 || d.ntaps > VITTA_CONV_MAX_TAPS || d.sstride < 1 || d.ostride < 1 ||
@@ -665,6 +683,51 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   if ((d.flags & VITTA_CONV_BWD_BN) && (d.flags & (VITTA_CONV_STATS | VITTA_CONV_EPI_APPLY | VITTA_CONV_EPI_RELU)))
     return VITTA_ERR_INVALID_ARG;
   if ((d.flags & (VITTA_CONV_RES | VITTA_CONV_RES_HALF)) && !d.res) return VITTA_ERR_INVALID_ARG;
+  a.sk_G = a.sk_aligned = a.pw = a.pw_prefetch = a.b3 = 0;
+  // Split-bf16 operands on the bf16 matrix pipe (conv_b3.hip) whenever the caller supplied the split weight image and the
+  // shape fits its one configuration: 128 x 64 tiles, 32-channel slabs (VITTA_CONV_B3=0 keeps the exact-fp32 kernels)
+  if (d.w_b3 && b3_enabled() && d.C % 32 == 0 && d.K % 64 == 0 && !(d.flags & VITTA_CONV_PRO_BN_RELU) &&
+      (h->tile == 0 || h->tile == ((128 << 16) | 64) || (h->tile == ((128 << 16) | 128) && d.K % 128 == 0)) &&
+      (int64_t)d.C * a.xP * 4 < (1ll << 31) && (is_vector_geometry(d) || b3_patch_geometry(d, 63))) {
+    // 128 x 128 tiles (wave = 32 rows x 128 channels: the activation split feeds twice the MFMAs) on request only (tile
+    // field, or VITTA_CONV_B3_WIDE=1 for A/B measurements): measured slower on the trunk's shapes -- half the tiles means
+    // twice the K split, and the last arriver of a tile then sums up to sixteen 64 KB partial tiles alone (layer3 3x3:
+    // 41.9 vs 33.1 us, layer2 3x3: 38.6 vs 32.0 us)
+    static const int wide_on = env_int("VITTA_CONV_B3_WIDE", 0);
+    const bool wide_ok = d.K % 128 == 0 && (is_vector_geometry(d) || b3_patch_geometry(d, 32));
+    const bool wide = h->tile ? (h->tile & 0xffff) == 128 && wide_ok : (wide_on && wide_ok);
+    if (h->tile && (h->tile & 0xffff) == 128 && !wide_ok) return VITTA_ERR_UNSUPPORTED;
+    const int bm = 128, bn = wide ? 128 : 64;
+    a.nMt = (int)((M + bm - 1) / bm);
+    a.nNt = d.K / bn;
+    a.d.tile = (bm << 16) | bn;
+    // K is split over CHANNEL slabs (a slice walks all taps of its slabs): aim at >= ~1.5 workgroups per CU
+    const int ncs = d.C / 32, tiles = a.nMt * a.nNt;
+    int ks = 1;
+    if (tiles > MAX_SPLIT_TILES) ks = 1;
+    else if (d.ksplit > 0) ks = d.ksplit;
+    else {
+      static const int min_wgs = env_int("VITTA_CONV_B3_MIN_WGS", 384), min_steps = env_int("VITTA_CONV_B3_MIN_STEPS", 4);
+      while (tiles * ks < min_wgs && (ncs / (ks * 2)) * d.ntaps >= min_steps && ncs % (ks * 2) == 0 && ks < 16) ks *= 2;
+    }
+    if (ks > ncs) ks = ncs;
+    const size_t need = ks > 1 ? counter_bytes(tiles) + (size_t)tiles * ks * bm * bn * sizeof(float) : 0;
+    if (ks > 1 && (!d.workspace || (size_t)d.workspace_bytes < need)) {
+      if (d.ksplit > 0) return VITTA_ERR_WORKSPACE;
+      ks = 1;
+    }
+    a.ksplit = ks;
+    a.ws_need = need;
+    a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
+    a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
+    a.b3 = 1;
+    static const int pf = env_int("VITTA_CONV_PW_PREFETCH", 1);
+    a.pw_prefetch = (pf && a.contig &&
+                     ((d.flags & VITTA_CONV_BWD_BN) || ((d.flags & VITTA_CONV_RES) && d.res && !(d.flags & VITTA_CONV_RES_HALF)))) ? 1 : 0;
+    for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t)
+      a.tap[t] = t < d.ntaps ? ((d.dh[t] & 0xff) | ((d.dw[t] & 0xff) << 8) | ((int)d.wt[t] << 16)) : 0;
+    return VITTA_OK;
+  }
   int bm = 64, bn = 32;
   choose_tile(d, M, bm, bn);
   if (d.K % bn) return VITTA_ERR_UNSUPPORTED;
@@ -694,7 +757,6 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // the library and lent a workspace: as many workgroups as the chip holds at once (3 per CU), each walking an equal
   // share of the launch's K-slabs.  Short-K launches (< 4 slabs per tile) and launches with >= 8 tiles per workgroup
   // keep their ranges on tile boundaries (no partial tiles).
-  a.sk_G = a.sk_aligned = a.pw = a.pw_prefetch = 0;
   // Pointwise launches whose tiles fit the chip in one round of four workgroups per CU, with K short enough that a tile
   // is not the whole launch's critical path: conv_pw.hip (VITTA_CONV_PW=0 keeps them on the stream-K kernel)
   if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && pw_enabled() && is_vector_geometry(d) && a.contig &&
@@ -757,6 +819,12 @@ size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc) {
   return a.ws_need;
 }
 
+int vitta_conv_kernel(const vitta_conv_desc* h_desc) {
+  ConvK a;
+  if (fill(h_desc, a) != VITTA_OK) return -1;
+  return a.b3 ? VITTA_CONV_KERNEL_B3 : a.pw ? VITTA_CONV_KERNEL_PW : a.sk_G ? VITTA_CONV_KERNEL_SK : VITTA_CONV_KERNEL_TILE;
+}
+
 int64_t vitta_conv_flops(const vitta_conv_desc* h_desc) {
   ConvK a;
   if (fill(h_desc, a) != VITTA_OK) return -1;
@@ -773,6 +841,8 @@ int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_s
   hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool gather = !is_vector_geometry(a.d);
+  if (a.b3) return launch_b3(a, gather, st, e0, e1);  // gathered = the patch form
+  if (!a.d.w) return VITTA_ERR_UNSUPPORTED;  // only the split image was given and the shape does not qualify for it
   if (a.pw) return launch_pointwise(a, st, e0, e1);
   if (a.sk_G) return launch_stream_k(a, gather, st, e0, e1);
   const int bm = a.d.tile >> 16, bn = a.d.tile & 0xffff;

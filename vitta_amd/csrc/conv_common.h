@@ -25,6 +25,7 @@ struct ConvK {
   int sk_aligned;      // stream-K: unit ranges end on tile boundaries (no partial tiles)
   int pw_prefetch;     // conv_pw.hip: request the epilogue's residual / BatchNorm-backward input at the tile's start
   int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
+  int b3;              // 1: conv_b3.hip (split-bf16 operands on the bf16 matrix pipe, 128 x 64 tiles)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -35,6 +36,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 
 // conv_pw.hip
 int launch_pointwise(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+
+// conv_b3.hip
+int launch_b3(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
 // conv_sk.hip
 int launch_stream_k(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

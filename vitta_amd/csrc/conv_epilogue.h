@@ -14,12 +14,55 @@ struct TileEpilogue {
   float* red;  // LDS [2][32][2]: per-channel sums of the upper pixel half of a tile
   int wm, wn, li, lk;
   bool BWD;
-  static constexpr int BM = 64, BN = 64;
+  int BM = 64;  // pixel rows of the workgroup's tile: wave row wm covers [wm * BM / 2, (wm + 1) * BM / 2) in 32-row blocks
+  int BN = 64;  // output channels of the tile: column block wn covers [32 wn, 32 wn + 32)
   // constants of the current tile's channel of this lane: loaded at the tile's start, used at its end
   float c_gam = 1.f, c_bet = 0.f, c_mean = 0.f, c_var = 1.f, c_sh = 0.f, c_a = 0.f, c_b = 0.f, c_mu = 0.f, c_gs = 0.f;
 
-  __device__ __forceinline__ TileEpilogue(const ConvK& a_, float* red_, int wm_, int wn_, int li_, int lk_)
-      : a(a_), d(a_.d), red(red_), wm(wm_), wn(wn_), li(li_), lk(lk_), BWD(a_.d.flags & VITTA_CONV_BWD_BN) {}
+  __device__ __forceinline__ TileEpilogue(const ConvK& a_, float* red_, int wm_, int wn_, int li_, int lk_, int bm_ = 64, int bn_ = 64)
+      : a(a_), d(a_.d), red(red_), wm(wm_), wn(wn_), li(li_), lk(lk_), BWD(a_.d.flags & VITTA_CONV_BWD_BN), BM(bm_), BN(bn_) {}
+
+  // The nine per-channel constants of the tile's columns staged in LDS at the tile's start (cst[9][BN], filled by
+  // stage_consts with one lane per column) instead of held in registers through the K walk.
+  static __device__ __forceinline__ void stage_consts(const ConvK& a, int L, int bn, float* cst, int col) {
+    const vitta_conv_desc& d = a.d;
+    const int k = (L % a.nNt) * bn + col;
+    float v[9] = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // gam bet mean var sh a b mu gs
+    if (d.flags & VITTA_CONV_BWD_BN) {
+      v[0] = d.bwd_bn[0][k];
+      v[1] = d.bwd_bn[1][k];
+      v[2] = d.bwd_bn[2][k];
+      v[3] = d.bwd_bn[3][k];
+      if (d.inj_mu) {
+        v[8] = d.inj_gscale ? d.inj_gscale[0] : 1.f;
+        v[5] = d.inj_a[k];
+        v[6] = d.inj_b[k];
+        v[7] = d.inj_mu[k];
+      }
+    } else {
+      if (d.epi_bn[0]) {
+        v[0] = d.epi_bn[0][k];
+        v[1] = d.epi_bn[1][k];
+        v[2] = d.epi_bn[2][k];
+        v[3] = d.epi_bn[3][k];
+      }
+      if (d.st_shift) v[4] = d.st_shift[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cst[i * bn + col] = v[i];
+  }
+  __device__ __forceinline__ void consts_from_lds(const float* cst) {
+    const int col = wn * 32 + li;
+    c_gam = cst[col];
+    c_bet = cst[BN + col];
+    c_mean = cst[2 * BN + col];
+    c_var = cst[3 * BN + col];
+    c_sh = cst[4 * BN + col];
+    c_a = cst[5 * BN + col];
+    c_b = cst[6 * BN + col];
+    c_mu = cst[7 * BN + col];
+    c_gs = cst[8 * BN + col];
+  }
 
   __device__ __forceinline__ void load_consts(int L) {
     const int k = (L % a.nNt) * BN + wn * 32 + li;
@@ -50,6 +93,15 @@ struct TileEpilogue {
   template <bool PRE = false>
   __device__ __forceinline__ void run(int L, const f32x16& acc, float4 p0 = float4{}, float4 p1 = float4{}, float4 p2 = float4{},
                                       float4 p3 = float4{}) {
+    float r1 = 0.f, r2 = 0.f;
+    body<PRE>(L, 0, acc, r1, r2, p0, p1, p2, p3);
+    finish(L, r1, r2);
+  }
+
+  // one 32 x 32 accumulator block (block xb of this wave's rows); r1 / r2 collect the lane's per-channel sums
+  template <bool PRE = false>
+  __device__ __forceinline__ void body(int L, int xb, const f32x16& acc, float& r1, float& r2, float4 p0 = float4{}, float4 p1 = float4{},
+                                       float4 p2 = float4{}, float4 p3 = float4{}) {
     const int flags = d.flags;
     const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
     const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
@@ -73,11 +125,10 @@ struct TileEpilogue {
       es = c_gam * rsqrtf(c_var + d.epi_eps);
       et = c_bet - c_mean * es;
     }
-    float r1 = 0.f, r2 = 0.f;
     const int64_t yrow = (int64_t)k * a.yP;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      const int m = m0 + wm * 32 + 8 * qd + 4 * lk;
+      const int m = m0 + wm * (BM >> 1) + 32 * xb + 8 * qd + 4 * lk;
       if (m >= a.Mtot) continue;
       float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
       if (a.contig) {
@@ -155,6 +206,12 @@ struct TileEpilogue {
         }
       }
     }
+  }
+
+  // per-channel sums of the tile -> statistics / d gamma, d beta
+  __device__ __forceinline__ void finish(int L, float r1, float r2) {
+    const bool STATS = (d.flags & VITTA_CONV_STATS) && d.st_s1;
+    const int k = (L % a.nNt) * BN + wn * 32 + li;
     if (STATS || BWD) {
       // per-channel sums: lanes of a wave, then the two waves that share the channels (pixel halves wm = 0 / 1) through
       // LDS, then ONE atomic per (tile, channel) -- same-address atomics serialise at ~8 ns each, and a 64-channel layer
@@ -189,11 +246,11 @@ struct TileEpilogue {
 // (Written without conditionals around the loads: the compiler turns `c ? *p : zero` into a select of ADDRESSES with the
 // zero parked in scratch memory.)
 __device__ __forceinline__ void tile_prefetch(const ConvK& a, int L, int wm, int wn, int li, int lk, float4& p0, float4& p1, float4& p2,
-                                              float4& p3) {
+                                              float4& p3, int bm = 64, int xb = 0) {
   const vitta_conv_desc& d = a.d;
   const bool bwd = d.flags & VITTA_CONV_BWD_BN;
   const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)((L % a.nNt) * 64 + wn * 32 + li) * (bwd ? a.yP : a.rP);
-  const int m = (L / a.nNt) * 64 + wm * 32 + 4 * lk, last = a.Mtot - 4;
+  const int m = (L / a.nNt) * bm + wm * (bm >> 1) + 32 * xb + 4 * lk, last = a.Mtot - 4;
   p0 = *reinterpret_cast<const float4*>(row + min(m, last));
   p1 = *reinterpret_cast<const float4*>(row + min(m + 8, last));
   p2 = *reinterpret_cast<const float4*>(row + min(m + 16, last));

@@ -194,7 +194,9 @@ class TrunkRunner:
 
     # -- caches ------------------------------------------------------------------------------------------------
     def packed(self, conv, kind, adapt=None):
-        """adapt: which re-packed set of a trainable weight -- True: the adaptation pass's (its backward runs with grad mode
+        """Packed weight of `conv` (kind "f" forward, "b" data gradient: conv.Pack with the split-bf16 image where the shape
+        qualifies; "s": the stem's [148][64] array).
+        adapt: which re-packed set of a trainable weight -- True: the adaptation pass's (its backward runs with grad mode
         OFF, so it has to say so: the evaluation pass's set is written by another stream and holds no backward packs),
         None: by the current grad mode (forward passes)."""
         w = conv.weight
@@ -207,20 +209,21 @@ class TrunkRunner:
             hit = self._step_packs.get(key)
             if hit is None:
                 with torch.no_grad():
-                    hit = self._step_packs[key] = CV.pack_stem(w) if kind == "s" else CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w)
+                    hit = self._step_packs[key] = CV.pack_stem(w) if kind == "s" else CV.make_pack(CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
             return hit
-        key = (id(w), kind)
+        key = (id(w), kind, CV.ARITH)
         tag = (w.data_ptr(), w._version, tuple(w.shape))
         hit = self._packed.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                hit = (tag, CV.pack_stem(w) if kind == "s" else CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w))
+                hit = (tag, CV.pack_stem(w) if kind == "s" else CV.make_pack(CV.pack_fwd(w) if kind == "f" else CV.pack_bwd(w)))
             self._packed[key] = hit
         return hit[1]
 
     def refresh_packs(self, device):
-        """Trainable convolution weights: rebuild the packed copies (`vitta_conv_repack_f32`, one launch over all of them).
-        Two sets, created once (before any graph capture: the table is a host -> device copy): one for passes under
+        """Trainable convolution weights: rebuild the packed copies (`vitta_conv_repack_f32`, one launch over all of them, and
+        `vitta_conv_pack_b3_table`, one launch for their split-bf16 images).
+        Two sets, created once (before any graph capture: the tables are host -> device copies): one for passes under
         autograd (adaptation), one for no_grad passes (the evaluation, which may run beside it on a second stream)."""
         convs = []
         for b in self.blocks():
@@ -229,14 +232,15 @@ class TrunkRunner:
         if not convs:
             return
         key = torch.is_grad_enabled()
-        st = self._repack.get(key)
+        st = self._repack.get((key, CV.ARITH))
         sig = tuple((c.weight.data_ptr(), tuple(c.weight.shape)) for c in convs)
         if st is None or st["sig"] != sig:
             import numpy as np
             dt = np.dtype([("src", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"), ("first", "<i8"), ("K", "<i4"), ("C", "<i4"), ("taps", "<i4"),
                            ("pad", "<i4")])
+            dt3 = np.dtype([("src", "<u8"), ("dst", "<u8"), ("first", "<i8"), ("taps", "<i4"), ("R", "<i4"), ("O", "<i4"), ("pad", "<i4")])
             tab = np.zeros(len(convs), dtype=dt)
-            packs, first = {}, 0
+            packs, first, b3rows, units = {}, 0, [], 0
             for i, c in enumerate(convs):
                 w = c.weight
                 k, ci, kh, kw = w.shape
@@ -245,12 +249,26 @@ class TrunkRunner:
                 # the data-gradient pack only where a backward can follow (the no_grad set of the evaluation pass skips it)
                 pb = (torch.empty(taps, k, ci, dtype=torch.float32, device=device) if key else None) if taps > 1 \
                     else w.detach().view(1, k, ci)
-                packs[(id(w), "f")], packs[(id(w), "b")] = pf, pb
+                for kind, pk in (("f", pf), ("b", pb)):
+                    if pk is None:
+                        packs[(id(w), kind)] = None
+                        continue
+                    b3 = None
+                    if CV.ARITH == "b3" and CV.b3_eligible(pk) and (kind == "f" or key):
+                        b3 = torch.empty(pk.numel() * 6, dtype=torch.uint8, device=device)
+                        b3rows.append((pk.data_ptr(), b3.data_ptr(), units, pk.shape[0], pk.shape[1], pk.shape[2], 0))
+                        units += pk.numel() // 8
+                    packs[(id(w), kind)] = CV.Pack(pk, b3)
                 tab[i] = (w.data_ptr(), pf.data_ptr(), pb.data_ptr() if (taps > 1 and pb is not None) else 0, first, k, ci, taps, 0)
                 first += k * ci * taps
             dtab = torch.from_numpy(tab.view(np.uint8).copy()).to(device)
-            st = self._repack[key] = dict(sig=sig, packs=packs, table=dtab, n=len(convs), total=first)
+            dtab3 = torch.from_numpy(np.array(b3rows, dtype=dt3).view(np.uint8).copy()).to(device) if b3rows else None
+            st = self._repack[(key, CV.ARITH)] = dict(sig=sig, packs=packs, table=dtab, n=len(convs), total=first, table3=dtab3, n3=len(b3rows),
+                                                      units=units)
+        self._repack[key] = st
         check(lib().vitta_conv_repack_f32(_p(st["table"]), st["n"], st["total"], _stream()), "vitta_conv_repack_f32")
+        if st["table3"] is not None:
+            check(lib().vitta_conv_pack_b3_table(_p(st["table3"]), st["n3"], st["units"], _stream()), "vitta_conv_pack_b3_table")
 
     def geo(self, kind, n, h, w, k=1, stride=1, pad=0):
         key = (kind, n, h, w, k, stride, pad)
