@@ -139,7 +139,8 @@ def test_two_ranks_on_one_gpu_equal_reference_batch_of_two(tmp_path):
             # moments (per-rank partials + all-reduce vs the reference's one batch) can flip the sign of a channel whose
             # difference is at round-off, which moves ONE row of a weight gradient by a fixed quantum (measured: 3 % of
             # the sampled elements of layer3.5.conv2.weight, up to 2.2e-2 of max|g|, tools/debug/dp_grad_probe.py)
-            assert (err > bound).mean() <= 0.05 and err.max() <= max(bound, 5e-2 * np.abs(ref_g).max()), (i, name)
+            # (at most 5 % of the sampled elements, but never fewer than one: the sampled bias tensors have four elements)
+            assert (err > bound).sum() <= max(1, int(0.05 * err.size)) and err.max() <= max(bound, 5e-2 * np.abs(ref_g).max()), (i, name)
             np.testing.assert_allclose(r0[f"step{i}_grad::{name}"], r1[f"step{i}_grad::{name}"], rtol=0, atol=0)
 
 

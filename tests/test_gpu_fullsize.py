@@ -1,14 +1,17 @@
-"""The BENCHMARKED workloads at full size against the CPU oracle path: one adaptation step + the evaluation forward of
-BASELINE config 2 (TANet-R50, 2 views x 8 frames x 224^2, 101 classes, Adam on the BN affine parameters) and config 3
-(Video Swin-B, 2 views x 16 frames x 224^2, LN affine) -- HIP path (hand-written trunk / fused W-MSA + LayerNorm) vs
-the same step on the CPU with the oracle backend (stock torch ops in the reference's op order, oracle/), identical
-weights and clips, dropout / DropPath off.
+"""The BENCHMARKED workloads at full size: one adaptation step + the evaluation forward of BASELINE config 2 (TANet-R50,
+2 views x 8 frames x 224^2, 101 classes, Adam on the BN affine parameters), of config 4's per-GPU workload (the same with
+the 400-class head; and two ranks against one process holding both videos), of config 3 (Video Swin-B, 2 views x 16
+frames x 224^2, LN affine) -- HIP path vs the same step on the CPU with the oracle backend (stock torch ops in the
+reference's op order, oracle/), identical weights and clips, dropout / DropPath off -- and of config 5 (Video Swin-B, 4
+views x 32 frames x 224^2, window (16, 7, 7)) between the exact-fp32 kernels and the bf16-operand recipe.
 
-Tolerances (fp32 both sides, different reduction orders):
-  loss_reg rel 5e-5, loss_consis rel 1e-3; gradients of the norm-affine parameters: cosine of the whole gradient >= 0.999
-  and per sampled tensor |d| <= 2e-2 max|g| (the L1 objective's sign(.) coefficients make single channels flip, so the
-  direction of the whole gradient is the stronger statement); evaluation logits after the update |d| <= 2e-3 max|logit|,
-  identical top-1.
+Tolerances (fp32 both sides, different reduction orders; the TANet convolutions run in the split-bf16 form of
+conv_b3.hip, fp32-roundoff class):
+  loss_reg rel 5e-5, loss_consis rel 1e-3; gradients of the norm-affine parameters: EVERY element within 5e-3 of its
+  tensor's max|g| except a counted, bounded set of outliers (the L1 objective's sign(.) coefficients flip for channels
+  whose ema - source difference sits at round-off; each such element must still be within 5e-2), cosine of the whole
+  gradient >= 0.9999; evaluation logits after the update |d| <= 2e-3 max|logit|, identical top-1.  Every test asserts
+  that the hand-written kernels ran (tests/conftest.py::abi_calls).
 """
 import numpy as np
 import pytest
@@ -24,34 +27,51 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _compare(res, sampled, loss_reg_rel=5e-5):
+def _compare(res, sampled, loss_reg_rel=5e-5, grad_frac=5e-3, max_outliers=0):
+    """Losses, EVERY gradient tensor element-wise, logits.  grad_frac: |g_gpu - g_cpu| <= grad_frac * max|g_cpu| per tensor.
+    max_outliers: how many ELEMENTS of the whole gradient may exceed that (an L1 alignment term back-propagates
+    sign(ema - source) per channel: a channel whose difference sits at round-off may take the other sign on the other
+    device, which moves that channel's affine gradients by a fixed quantum); outliers are counted, printed, bounded by
+    max_outliers and by 5e-2 of the tensor's maximum.  `sampled` tensors must be present (named in the assertion messages)."""
     c, g = res["cpu"], res["cuda"]
     assert g["loss_reg"] == pytest.approx(c["loss_reg"], rel=loss_reg_rel), (g["loss_reg"], c["loss_reg"])
     assert g["loss_consis"] == pytest.approx(c["loss_consis"], rel=1e-3, abs=1e-6), (g["loss_consis"], c["loss_consis"])
     keys = sorted(c["grads"])
-    assert keys == sorted(g["grads"]) and len(keys) > 0
+    assert keys == sorted(g["grads"]) and len(keys) > 0 and all(k in c["grads"] for k in sampled)
     va = torch.cat([g["grads"][k].flatten() for k in keys]).double()
     vb = torch.cat([c["grads"][k].flatten() for k in keys]).double()
     assert torch.isfinite(va).all() and vb.norm() > 0
     cos = float(torch.dot(va, vb) / (va.norm() * vb.norm()))
-    assert cos >= 0.999, cos
-    for k in sampled:
-        a, b = g["grads"][k], c["grads"][k]
-        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-9, (k, (a - b).abs().max().item(), b.abs().max().item())
+    assert cos >= 0.9999, cos
+    outliers, worst, worst_ok = [], 0.0, 0.0
+    for k in keys:
+        a, b = g["grads"][k].double(), c["grads"][k].double()
+        scale = b.abs().max().item() + 1e-30
+        e = (a - b).abs() / scale
+        bad = e > grad_frac
+        worst_ok = max(worst_ok, e[~bad].max().item() if (~bad).any() else 0.0)
+        if bad.any():
+            outliers.append((k, int(bad.sum()), e.max().item()))
+            worst = max(worst, e.max().item())
+    n_out = sum(n for _, n, _ in outliers)
+    print("gradient elements", va.numel(), "cosine", cos, "largest in-bound error / max|g|", worst_ok, "outliers", n_out, outliers[:8])
+    assert n_out <= max_outliers and worst <= 5e-2, (n_out, worst, outliers[:8])
     le, lc = g["logits"], c["logits"]
     assert (le - lc).abs().max().item() <= 2e-3 * lc.abs().max().item(), ((le - lc).abs().max().item(), lc.abs().max().item())
     assert int(le.argmax()) == int(lc.argmax())
 
 
-def test_config2_tanet_full_size_step_matches_cpu_oracle(tmp_path):
-    """TANet-R50 2 x 8 x 224^2, K = 101: the exact workload bench.py times."""
+@pytest.mark.parametrize("classes", [101, 400])
+def test_config2_tanet_full_size_step_matches_cpu_oracle(tmp_path, classes, abi_calls):
+    """TANet-R50 2 x 8 x 224^2: K = 101 is the exact workload bench.py times (BASELINE config 2), K = 400 the per-GPU
+    workload of BASELINE config 4 (Kinetics-400 head)."""
     from oracle import cpu_path
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, trunk, tta
-    T, size = 8, 224
+    T, size, K = 8, 224, classes
     # source statistics: the moments of a seeded calibration clip on the 53 BatchNorm2d outputs (as compute_statistics
     # would write them), perturbed so that every channel has a non-trivial alignment term
-    model0 = H.build_tanet(101, T, 0)
+    model0 = H.build_tanet(K, T, 0)
     bn2d = [m for m in model0.modules() if isinstance(m, nn.BatchNorm2d)]
     g = torch.Generator().manual_seed(11)
     means = [(torch.randn(b.num_features, generator=g) * 0.2).numpy() for b in bn2d]
@@ -59,11 +79,11 @@ def test_config2_tanet_full_size_step_matches_cpu_oracle(tmp_path):
     mp, vp = H.write_stat_files(str(tmp_path), means, vars_)
     args = H.tanet_args(tmp_path, clip_length=T, input_size=size, batch_size=1, spatiotemp_mean_clean_file=mp,
                         spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=5e-5)
-    x = data.SyntheticVideoDataset(1, 2, T, size, 101, "tanet", seed0=21)[0][0].unsqueeze(0)
-    xe = data.SyntheticVideoDataset(1, 1, T, size, 101, "tanet", seed0=21)[0][0].unsqueeze(0)
+    x = data.SyntheticVideoDataset(1, 2, T, size, K, "tanet", seed0=21)[0][0].unsqueeze(0)
+    xe = data.SyntheticVideoDataset(1, 1, T, size, K, "tanet", seed0=21)[0][0].unsqueeze(0)
     res = {}
     for dev, backend in ((torch.device("cpu"), OracleBackend()), (_dev(), None)):
-        model = H.build_tanet(101, T, 0)
+        model = H.build_tanet(K, T, 0)
         model.base_model.fc = nn.Identity()  # dropout off: both sides see the same forward
         if dev.type == "cpu":
             adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args, engine_backend=backend, use_engine=False)
@@ -80,10 +100,14 @@ def test_config2_tanet_full_size_step_matches_cpu_oracle(tmp_path):
         res[dev.type] = dict(loss_reg=float(loss_reg), loss_consis=float(loss_consis), grads=grads, logits=logits)
     sampled = ["module.base_model.layer4.2.net.bn3.weight", "module.base_model.layer3.0.net.bn2.bias",
                "module.base_model.layer1.1.net.bn1.weight", "module.base_model.bn1.bias"]
-    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]])
+    abi_calls.assert_tanet_trunk()
+    # measured (r3, K = 101 / 400): 48 / 2 of 55 520 elements over 5e-3 of their tensor's max|g| (worst 1.2e-2 / 5.4e-3; with
+    # the exact-fp32 kernels, VITTA_CONV_ARITH=f32: 31 / 3, worst 9.1e-3 / 6.2e-3 -- a property of the L1 sign flips in the
+    # early layers, whose gradients cross the whole trunk, not of the arithmetic form), cosine 0.99999
+    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], grad_frac=5e-3, max_outliers=128)
 
 
-def test_config3_swin_full_size_step_matches_cpu_oracle(tmp_path):
+def test_config3_swin_full_size_step_matches_cpu_oracle(tmp_path, abi_calls):
     """Video Swin-B 2 x 16 x 224^2, window (8, 7, 7), K = 101 (tta_swin_ucf101.py:27-40)."""
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, scripts, tta
@@ -118,4 +142,146 @@ def test_config3_swin_full_size_step_matches_cpu_oracle(tmp_path):
         res[dev.type] = dict(loss_reg=float(loss_reg), loss_consis=float(loss_consis), grads=grads, logits=logits)
     sampled = ["module.backbone.layers.2.blocks.4.norm1.weight", "module.backbone.norm.bias",
                "module.backbone.layers.3.blocks.1.norm2.weight", "module.backbone.layers.2.blocks.17.norm2.bias"]
-    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], loss_reg_rel=1e-4)
+    abi_calls.assert_swin_kernels()
+    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], loss_reg_rel=1e-4, grad_frac=5e-3, max_outliers=32)
+
+
+def _dp_rank(rank, world, port, tmp, classes):
+    """One rank of the 2-rank full-size run below (gloo; both ranks share the box's GPU)."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from vitta_amd import data, tta
+    T, size = 8, 224
+    dev = torch.device("cuda:0")
+    args = _tanet_args(os.path.join(tmp, f"r{rank}"), T, size, classes, batch_size=1)
+    model = H.build_tanet(classes, T, 0)
+    model.base_model.fc = nn.Identity()
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(dev), args)
+    assert adapter.world == 2 and adapter.engine.distributed
+    adapter.set_adapt_mode()
+    x = data.SyntheticVideoDataset(2, 2, T, size, classes, "tanet", seed0=21)[rank][0].unsqueeze(0)
+    _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(dev)))
+    grads = {k: v.grad.detach().cpu().numpy() for k, v in adapter.model.named_parameters() if v.requires_grad and v.grad is not None}
+    np.savez(os.path.join(tmp, f"dp{rank}.npz"), loss_reg=float(loss_reg), loss_consis=float(loss_consis), **grads)
+    torch.distributed.destroy_process_group()
+
+
+def _tanet_args(tmp, T, size, classes, batch_size):
+    import os
+    os.makedirs(str(tmp), exist_ok=True)
+    bn2d = [m for m in H.build_tanet(classes, T, 0).modules() if isinstance(m, nn.BatchNorm2d)]
+    g = torch.Generator().manual_seed(11)
+    means = [(torch.randn(b.num_features, generator=g) * 0.2).numpy() for b in bn2d]
+    vars_ = [(torch.rand(b.num_features, generator=g) + 0.5).numpy() for b in bn2d]
+    mp, vp = H.write_stat_files(str(tmp), means, vars_)
+    return H.tanet_args(tmp, clip_length=T, input_size=size, batch_size=batch_size, spatiotemp_mean_clean_file=mp,
+                        spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=5e-5)
+
+
+def test_config4_two_ranks_at_full_size_equal_one_process_batch_of_two(tmp_path):
+    """BASELINE config 4's step at its real size (TANet-R50, K = 400, 2 views x 8 frames x 224^2 per GPU): two ranks with one
+    video each -- packed-moments all-reduce before the EMA, SUM all-reduce of the gradient arena -- give the statistics
+    loss, the summed consistency loss and the gradients of ONE process adapting the batch of the same two videos (the
+    reference's semantics with batch_size = 2, pinned at 64^2 by tests/test_dist_cpu.py and test_gpu_entrypoints.py).
+    gloo over one shared GPU: RCCL refuses two ranks on one device."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    from test_dist_cpu import _free_port
+    from vitta_amd import data, tta
+    classes, T, size = 400, 8, 224
+    mp.spawn(_dp_rank, args=(2, _free_port(), str(tmp_path), classes), nprocs=2, join=True)
+    r = [np.load(str(tmp_path / f"dp{i}.npz")) for i in range(2)]
+    dev = _dev()
+    args = _tanet_args(tmp_path / "one", T, size, classes, batch_size=2)
+    model = H.build_tanet(classes, T, 0)
+    model.base_model.fc = nn.Identity()
+    adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(dev), args)
+    adapter.set_adapt_mode()
+    ds = data.SyntheticVideoDataset(2, 2, T, size, classes, "tanet", seed0=21)
+    x = torch.stack([ds[0][0], ds[1][0]])
+    _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(dev)))
+    assert float(r[0]["loss_reg"]) == pytest.approx(float(r[1]["loss_reg"]), rel=1e-6)  # same reduced moments on both ranks
+    assert float(r[0]["loss_reg"]) == pytest.approx(float(loss_reg), rel=2e-5)
+    assert float(r[0]["loss_consis"]) + float(r[1]["loss_consis"]) == pytest.approx(float(loss_consis), rel=1e-4, abs=1e-7)
+    named = {k: v.grad.detach().cpu().double() for k, v in adapter.model.named_parameters() if v.requires_grad and v.grad is not None}
+    va = torch.cat([torch.from_numpy(r[0][k]).double().flatten() for k in sorted(named)])
+    vb = torch.cat([named[k].flatten() for k in sorted(named)])
+    np.testing.assert_array_equal(r[0][sorted(named)[0]], r[1][sorted(named)[0]])  # replicas hold the same reduced gradient
+    cos = float(torch.dot(va, vb) / (va.norm() * vb.norm()))
+    n_bad = 0
+    for k in named:
+        e = (torch.from_numpy(r[0][k]).double() - named[k]).abs() / (named[k].abs().max().item() + 1e-30)
+        n_bad += int((e > 5e-3).sum())
+        assert e.max().item() <= 5e-2, (k, e.max().item())
+    print("two ranks vs batch of two: cosine", cos, "elements over 5e-3 of max|g|:", n_bad, "of", va.numel())
+    assert cos >= 0.9999 and n_bad <= 32, (cos, n_bad)
+
+
+def test_config5_swin_at_full_size_bf16_recipe_agrees_with_fp32(tmp_path, abi_calls):
+    """BASELINE config 5 at its real size on the GPU: Video Swin-B, K = 174, 4 views x 32 frames x 224^2, window (16, 7, 7)
+    (recognizer3d.py:36-40).  The CPU oracle path is out of reach at this size (5 TFLOP per step), so the check is between
+    the product's arithmetic forms: the exact-fp32 kernels (pinned to the oracle at 112^2 by
+    test_swin_config5_shape_gpu_equals_cpu_oracle_path) against the bf16-operand attention and dense kernels of the
+    recipe -- finite everywhere, statistics loss rel 1e-3, consistency loss rel 2e-2, whole-gradient cosine >= 0.999, per-tensor
+    max error / max|g| median <= 2e-2 and 95th percentile <= 2e-1, evaluation logits within 2e-2 of their maximum and the
+    SAME top-1."""
+    from vitta_amd import data, ops, scripts, tta
+    from vitta_amd.bns_utils import choose_layers
+    T, size, views, K = 32, 224, 4, 174
+    Q50, Q95 = 2e-2, 2e-1  # measured (r3): median 6.0e-3, 95 % 9.3e-2 (worst tensor 0.36: layers.3.blocks.0.norm2.bias), cosine 0.99998
+
+    def build():
+        m = H.build_swin(K, 0, window_size=(16, 7, 7), drop_path_rate=0.0)
+        m.cls_head.dropout = None
+        return m
+
+    lns = [m for _, m in choose_layers(build(), [nn.LayerNorm])][1:]
+    g = torch.Generator().manual_seed(3)
+    mp, vp = H.write_stat_files(str(tmp_path), [torch.randn(m.normalized_shape[0], generator=g).numpy() * 0.1 for m in lns],
+                                [torch.rand(m.normalized_shape[0], generator=g).numpy() + 0.5 for m in lns])
+    args = scripts.swin_ucf101_args([])
+    args.dataset, args.num_classes, args.datatype = "somethingv2", K, "synthetic"
+    args.clip_length, args.n_augmented_views, args.window_size = T, views, (16, 7, 7)
+    args.input_size, args.scale_size, args.workers, args.verbose, args.result_dir = size, size, 0, False, str(tmp_path)
+    args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+    args.update_only_bn_affine, args.lr = True, 1e-5
+    x = data.SyntheticVideoDataset(1, views, T, size, K, "swin", seed0=40)[0][0].unsqueeze(0)
+    xe = data.SyntheticVideoDataset(1, 1, T, size, K, "swin", seed0=40)[0][0].unsqueeze(0)
+    res = {}
+    old = (ops.WMSA_BF16, ops.DENSE_BF16)
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.WMSA_BF16 = ops.DENSE_BF16 = mode == "bf16"
+            adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(build()).to(_dev()), args)
+            adapter.set_adapt_mode()
+            _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x.to(_dev())))
+            grads = {k: v.grad.detach().cpu().double() for k, v in adapter.model.named_parameters() if v.requires_grad and v.grad is not None}
+            adapter.close_hooks()
+            logits = adapter.evaluate(adapter.shape_eval_input(xe.to(_dev()))).detach().cpu().double()
+            res[mode] = (float(loss_reg), float(loss_consis), grads, logits)
+            del adapter
+            torch.cuda.empty_cache()
+    finally:
+        ops.WMSA_BF16, ops.DENSE_BF16 = old
+    abi_calls.assert_swin_kernels()
+    assert abi_calls.abi.get("vitta_gemm_nt_bf16w_f32", 0) > 0 and abi_calls.abi.get("vitta_wmsa_rel_fwd_bf16", 0) > 0, abi_calls.abi
+    f, b = res["fp32"], res["bf16"]
+    keys = sorted(f[2])
+    va = torch.cat([b[2][k].flatten() for k in keys])
+    vb = torch.cat([f[2][k].flatten() for k in keys])
+    assert torch.isfinite(va).all() and torch.isfinite(vb).all() and torch.isfinite(b[3]).all() and len(keys) > 50
+    cos = float(torch.dot(va, vb) / (va.norm() * vb.norm()))
+    rel = sorted((((b[2][k] - f[2][k]).abs().max() / (f[2][k].abs().max() + 1e-30)).item(), k) for k in keys)
+    q50, q95, worst = rel[len(rel) // 2][0], rel[(len(rel) * 95) // 100][0], rel[-1]
+    lerr = ((b[3] - f[3]).abs().max() / f[3].abs().max()).item()
+    print("config 5 at 224^2: loss_reg", f[0], b[0], "loss_consis", f[1], b[1], "gradient cosine", cos, "per-tensor max error / max|g|: median", q50,
+          "95 %", q95, "worst", worst, "logits", lerr)
+    assert b[0] == pytest.approx(f[0], rel=1e-3) and b[1] == pytest.approx(f[1], rel=2e-2, abs=1e-6)
+    assert cos >= 0.999 and q50 <= Q50 and q95 <= Q95, (cos, q50, q95, worst)
+    assert lerr <= 2e-2 and int(b[3].argmax()) == int(f[3].argmax())

@@ -39,18 +39,21 @@ def test_tanet_forward_matches_reference_on_gpu():
 
 @pytest.mark.parametrize("mode", ["sgd", "adam"])
 @pytest.mark.parametrize("use_engine", [True, False])
-def test_three_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine):
+def test_three_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine, abi_calls):
     g = H.golden("tta3.npz")
     recs = run_product_tta(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
     report = check_tta_records(g, mode, recs, BASE_GPU)
     for row in report:
         print("step %d %-60s err %.3e bound %.3e" % row)
+    if use_engine:  # the hand-written trunk (stand-alone hooks are foreign to it: that mode checks the module path)
+        abi_calls.assert_tanet_trunk()
 
 
-def test_batch_of_two_matches_reference_on_gpu(tmp_path):
+def test_batch_of_two_matches_reference_on_gpu(tmp_path, abi_calls):
     g = H.golden("tta3_bz2.npz")
     recs = run_product_tta(g, "sgd", tmp_path, _dev(), None, batch_size=2)
     check_tta_records(g, "sgd", recs, BASE_GPU)
+    abi_calls.assert_tanet_trunk()
 
 
 def test_engine_equals_standalone_hooks_on_gpu(tmp_path):
@@ -148,11 +151,12 @@ def test_swin_forward_matches_reference_on_gpu():
 
 
 @pytest.mark.parametrize("mode,use_engine", [("sgd", True), ("adam", True), ("sgd", False)])
-def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine):
+def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine, abi_calls):
     from test_swin_cpu import run_product_tta_swin
     g = H.golden("tta3_swin.npz")
     recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
     check_tta_records(g, mode, recs, BASE_GPU)
+    abi_calls.assert_swin_kernels()
 
 
 def test_swin_fused_attention_equals_composed_ops_on_gpu():

@@ -201,7 +201,13 @@ def lib():
     return _LIB
 
 
+# {ABI entry point name: calls} while it is a dict (tests assert which path ran; the product leaves it None)
+CALL_COUNTS = None
+
+
 def check(status, what=""):
+    if CALL_COUNTS is not None:
+        CALL_COUNTS[what] = CALL_COUNTS.get(what, 0) + 1
     if status != 0:
         msg = lib().vitta_status_string(status).decode()
         raise VittaHipError(f"{what}: {msg} (status {status})")
