@@ -12,14 +12,26 @@ affine parameters (--update_only_bn_affine).  A "step" is the reference's per-vi
 evaluation forward of the same video (centre view).  `value` = videos of all ranks / max-over-ranks
 wall time of the K timed steps (barrier + synchronize on both sides).
 
+`ms_per_step`: the K timed steps form one BLOCK (barrier + synchronize on both sides, max over ranks); the block is
+repeated until >= 1 s has been timed and the MEDIAN block is reported (`blocks` = how many, `ms_per_step_first_block` =
+the contract's single block).
+
 Extra objects on the JSON line:
-  roofline      the dominant kernels of the timed step, conv_pw_kernel + conv_sk_kernel (vitta_conv_f32: every bottleneck
-                convolution of the trunk, forward and data gradient, ~71 % of the step's kernel time), bound
-                "mfma": achieved = algorithmic flops of the step's convolution launches / the sum of their
+  roofline      the dominant kernels of the timed step, the convolution family behind vitta_conv_f32 (every bottleneck
+                convolution of the trunk, forward, data gradient and evaluation forward), bound "mfma": achieved =
+                algorithmic flops (2 x positions x C x K x taps) of the step's convolution launches / the sum of their
                 durations, each duration from a hipEvent pair attached to that launch's own dispatch
                 (vitta_conv_timed_f32 -> hipExtLaunchKernelGGL; a kernel inside a replayed hipGraph cannot carry
-                events, so the timed steps are repeated eagerly with the same kernels for this); peak = 157.3
-                TFLOP/s, the fp32 matrix rate (v_mfma_f32_32x32x2_f32, the instruction the kernel issues).
+                events, so the timed steps are repeated eagerly with the same kernels for this).  The family issues two
+                instructions: conv_b3.hip v_mfma_f32_32x32x16_bf16 on split-bf16 operands, SIX products per fp32-grade
+                multiply-add (peak 2500 / 6 = 416.7 TFLOP/s of algorithmic flops), the stride-2 gathers conv_sk / conv_pw
+                v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s).  `peak` = the flop-weighted peak of the step's launches, `frac` =
+                (sum over launches of flops / that launch's peak) / (sum of durations); `frac_of_fp32_matrix_peak` =
+                achieved / 157.3, the yardstick of the exact-fp32 rounds.
+  swin, swin_c5_bf16   the same per-video iteration on Video Swin-B: BASELINE config 3's shape (2 views x 16 frames x
+                224^2, window (8,7,7), exact-fp32 kernels) and config 5's (4 views x 32 frames x 224^2, window (16,7,7), the
+                bf16-operand attention + dense kernels), each with the achieved TFLOP/s of its dense (gemm.hip) and window
+                attention launches against the matrix peak of the instruction they issue (157.3 / 2500).
                 roofline.moments: the north-star statistics kernel, moments_nchw_partial_kernel (one launch over all
                 29 hooked layers; in the TANet step its work rides in the convolution epilogues, so it is timed
                 stand-alone): `one_video` = 178 MB (4 B x 44 556 288 hooked elements; fits the Infinity
@@ -48,6 +60,8 @@ if ROOT not in sys.path:
 HOOKED_ELEMENTS_PER_VIDEO = 44556288  # 29 BN2d outputs of layer3/4 at 2x8x224^2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3  # same guide: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4), 155 TF measured
+MFMA_BF16_PEAK_TF = 2500.0  # same guide: bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16), 2495 TF measured
+B3_PRODUCTS = 6             # conv_b3.hip: bf16 MFMA products per fp32-grade multiply-add
 
 
 _T0 = time.time()
@@ -68,6 +82,8 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--no-streaming", action="store_true")
     p.add_argument("--no-sgd-all", action="store_true", help="skip the second (SGD over all parameters) timing")
+    p.add_argument("--no-swin", action="store_true", help="skip the Video Swin-B legs (configs 3 and 5)")
+    p.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed")
     p.add_argument("--timed-only", action="store_true",
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
                         "the tail of a rocprofv3 trace is the shipped hipGraph replay and nothing else")
@@ -247,21 +263,32 @@ def run_gpu(opt, rank, world, device):
     log("warm-up done")
     if not use_graph:
         adapter.engine.timing_events = new_events
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(opt.steps):
-        one_step(opt.warmup + i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    log(f"timed region done: {elapsed:.3f}s for {opt.steps} steps ({'hipGraph replay' if use_graph else 'eager'})")
+    def timed_block(b):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(opt.steps):
+            one_step(opt.warmup + b * opt.steps + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:  # the block's time is the slowest rank's
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    blocks = [timed_block(0)]
+    # every rank derives the same block count from the same (reduced) first block
+    n_blocks = 1 if opt.timed_only else max(1, min(40, int(np.ceil(opt.min_seconds / max(blocks[0], 1e-6)))))
+    for b in range(1, n_blocks):
+        blocks.append(timed_block(b))
+    elapsed = float(np.median(blocks))
+    run_gpu.blocks = blocks
+    log(f"timed region done: {len(blocks)} blocks of {opt.steps} steps, median {elapsed:.3f}s, first {blocks[0]:.3f}s "
+        f"({'hipGraph replay' if use_graph else 'eager'})")
     eager_elapsed = float("nan")
     run_gpu.conv = None
     if opt.timed_only:
         run_gpu.mode, run_gpu.eager_ms = ("hipGraph replay" if use_graph else "eager launches"), None
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
         return elapsed, float("nan"), float("nan"), None, adapter
     conv_events = []
     if use_graph:
@@ -280,6 +307,7 @@ def run_gpu(opt, rank, world, device):
                 conv_events.append((flops, key, ev))
                 return ev
             CV.TIMING = conv_timing
+            CV.KERNEL_TRACE = []  # kernel family of every launch, in launch order
         barrier()
         te = time.perf_counter()
         n_rep = opt.steps if opt.arch == "swin" else min(opt.steps, 12)
@@ -288,6 +316,7 @@ def run_gpu(opt, rank, world, device):
         barrier()
         eager_elapsed = (time.perf_counter() - te) * opt.steps / n_rep
         CV.TIMING = None
+        families, CV.KERNEL_TRACE = (CV.KERNEL_TRACE or []), None
         adapter._graph = graph
         adapter.engine.plan = plan_of_graph
         fused_bn.ENABLED = fused_ln.ENABLED = True
@@ -298,24 +327,24 @@ def run_gpu(opt, rank, world, device):
             fl = np.array([f for f, _, _ in conv_events], dtype=np.float64)
             ms = np.array([ev.elapsed_ms() for _, _, ev in conv_events], dtype=np.float64)
             by_shape = {}
-            for (f, key, _), t in zip(conv_events, ms):
-                r = by_shape.setdefault(key, [0, 0.0, 0.0])
+            fam = families if len(families) == len(conv_events) else [None] * len(conv_events)
+            b3 = np.array([k == 3 for k in fam])  # _lib.CONV_KERNEL_B3
+            peak = np.where(b3, MFMA_BF16_PEAK_TF / B3_PRODUCTS, MFMA_F32_PEAK_TF)
+            for (f, key, _), t, kid in zip(conv_events, ms, fam):
+                r = by_shape.setdefault(key + (kid,), [0, 0.0, 0.0])
                 r[0] += 1
                 r[1] += f
                 r[2] += t
+            names = {0: "conv_igemm (fp32)", 1: "conv_sk (fp32)", 2: "conv_pw (fp32)", 3: "conv_b3 (split bf16)", None: "?"}
             run_gpu.conv = dict(launches=len(fl), steps=n_rep, flops=float(fl.sum()), ms=float(ms.sum()),
-                                by_shape=[dict(C=k[0], K=k[1], taps=k[2], positions=k[3], launches_per_step=v[0] / n_rep,
-                                               avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9)
+                                ms_at_peak=float((fl / (peak * 1e9)).sum()), b3_launches=int(b3.sum()), b3_flops=float(fl[b3].sum()),
+                                by_shape=[dict(C=k[0], K=k[1], taps=k[2], positions=k[3], kernel=names.get(k[4], str(k[4])),
+                                               launches_per_step=v[0] / n_rep, avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9)
                                           for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][2])])
             conv_events.clear()
     adapter.engine.timing_events = None
     torch.cuda.synchronize()
     kern_ms = float(np.mean([p.elapsed_ms() for p in pairs])) if pairs else float("nan")
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # adapt-only timing (no evaluation forward), same videos, for the report
     adapt_only = float("nan")
@@ -384,6 +413,112 @@ def streaming_moments(adapter, device, copies=16, reps=20, target_blocks=4096):
     ms = float(np.mean(times))
     return dict(bytes=nbytes, ms=ms, achieved=nbytes / ms / 1e6, frac=nbytes / ms / 1e6 / HBM_PEAK_GBS,
                 workgroups=plan.num_blocks)
+
+
+
+class _StreamTimer:
+    """start / stop events on the current stream around one launch (ops.KTIMING): the launch's duration plus the few
+    microseconds of the event records -- small against the 50-500 us dense and attention launches of Video Swin-B."""
+    records = None
+
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def stop(self):
+        self.b.record()
+        _StreamTimer.records.append(self)
+
+
+def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3):
+    """One Video Swin-B configuration: per-video iteration (adapt step + evaluation forward, overlapped schedule, hipGraph
+    replay) timed over `steps` videos, then two eager steps with every dense (gemm.hip) and window attention launch
+    bracketed by stream events."""
+    from vitta_amd import data, ops, scripts, tta
+    from vitta_amd import synthetic as S
+    from vitta_amd.bns_utils import choose_layers
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    tmp = tempfile.mkdtemp(prefix="vitta_bench_swin_")
+    old = (ops.WMSA_BF16, ops.DENSE_BF16)
+    ops.WMSA_BF16 = ops.DENSE_BF16 = bool(bf16)
+    try:
+        size = 224
+        model = S.build_swin(classes, 0, window_size=(window_depth, 7, 7)).to(device)
+        lns = [m for _, m in choose_layers(model, [nn.LayerNorm])][1:]
+        hooks = [ComputeNormStatsHook(m, clip_len=frames, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
+        with torch.no_grad():
+            model(S.seeded_randn((1, 1, 3, frames, size, size), 1000, device))
+        means, vars_ = [h.batch_mean.cpu().numpy() for h in hooks], [h.batch_var.cpu().numpy() for h in hooks]
+        for h in hooks:
+            h.close()
+        mp, vp = S.write_stat_files(tmp, means, vars_, tag="swin")
+        args = scripts.swin_ucf101_args([])
+        args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "synthetic", size, size, 0, False
+        args.clip_length, args.result_dir, args.num_classes = frames, tmp, classes
+        args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
+        args.update_only_bn_affine = True
+        args.n_augmented_views, args.window_size = views, (window_depth, 7, 7)
+        n_videos = 4
+        args.synthetic_n_videos, args.synthetic_device = n_videos, device
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+        tta_set = data.build_videoswin_dataset(args, "val", "tta")
+        eval_set = data.build_videoswin_dataset(args, "val", "eval")
+
+        def one(i):
+            adapter.set_adapt_mode()
+            return adapter.step(tta_set[i % n_videos][0].unsqueeze(0), eval_set[(i - 1) % n_videos][0].unsqueeze(0))
+
+        for i in range(warmup):
+            one(i)
+        torch.cuda.synchronize()
+        adapter.capture_graphs(tta_set[0][0].unsqueeze(0), eval_set[0][0].unsqueeze(0), overlap_eval=True)
+        one(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        # per-kernel figures: two eager steps with stream events around the dense and attention launches
+        graph, adapter._graph = adapter._graph, None
+        _StreamTimer.records, ops.KTIMING = [], _StreamTimer
+        for i in range(2):
+            one(i)
+        torch.cuda.synchronize()
+        ops.KTIMING = None
+        adapter._graph = graph
+        kinds = {}
+        for r in _StreamTimer.records:
+            k = kinds.setdefault(r.kind, [0, 0.0, 0.0])
+            k[0] += 1
+            k[1] += r.flops
+            k[2] += r.a.elapsed_time(r.b)
+        _StreamTimer.records = None
+        roof = {}
+        for kind, (n, fl, ms) in sorted(kinds.items()):
+            peak = MFMA_BF16_PEAK_TF if kind.endswith("bf16") else MFMA_F32_PEAK_TF
+            tf = fl / ms / 1e9
+            roof[kind] = {"launches_per_step": n / 2, "gflop_per_step": fl / 2e9, "ms_per_step": ms / 2, "achieved": tf, "peak": peak,
+                          "unit": "TFLOP/s", "frac": tf / peak}
+        out = {"value": 1.0 / dt, "unit": "videos/s", "ms_per_step": 1e3 * dt, "steps": steps, "launch_mode": "hipGraph replay",
+               "dtype": "f32 (bf16 MFMA operands: window attention + dense layers; fp32 softmax / accumulation / epilogues)" if bf16 else "f32",
+               "config": {"workload": f"Video Swin-B ViTTA online TTA, per-video iteration = adapt step ({views} views x {frames} frames x "
+                                      f"224^2, window ({window_depth},7,7), {len(adapter.engine.hooks)} hooked LayerNorm layers, l1 stat "
+                                      f"alignment + prediction consistency, backward, Adam on LN affine) + eval forward (1 view), "
+                                      f"{classes} classes",
+                          "schedule": "overlapped"},
+               "roofline": roof,
+               "roofline_note": "dense (gemm.hip) and window attention launches of two eager steps bracketed by stream events; flops = "
+                                "2 M N K per product, 4 / 14 x tokens^2 x head_dim per (window, head) forward / backward; peak = the "
+                                "matrix rate of the instruction the kernel issues (157.3 fp32, 2500 bf16 dense)",
+               "max_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+        del adapter, model
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        ops.WMSA_BF16, ops.DENSE_BF16 = old
+        ops.KTIMING = None
 
 
 def run_cpu_baseline(opt):
@@ -499,14 +634,19 @@ def main():
         if conv:
             tf = conv["flops"] / conv["ms"] / 1e9
             conv_pmc = None
-            cpf = os.path.join(ROOT, "profiles", "r2h_conv_traffic_pmc.json")
+            cpf = os.path.join(ROOT, "profiles", "r3_conv_traffic_pmc.json")
             if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
                 conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
-            roofline = {"kernel": "conv_pw_kernel + conv_sk_kernel (vitta_conv_f32: every bottleneck convolution of the trunk, "
-                                  "forward + data gradient + evaluation forward)",
-                        "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": tf / MFMA_F32_PEAK_TF, "traffic": conv_pmc,
-                        "traffic_source": "profiles/r2h_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+            frac = conv["ms_at_peak"] / conv["ms"]
+            roofline = {"kernel": "conv_b3_kernel (+ conv_sk / conv_pw for the stride-2 gathers) behind vitta_conv_f32: every "
+                                  "bottleneck convolution of the trunk, forward + data gradient + evaluation forward",
+                        "bound": "mfma", "achieved": tf, "peak": tf / frac, "unit": "TFLOP/s", "frac": frac,
+                        "frac_of_fp32_matrix_peak": tf / MFMA_F32_PEAK_TF,
+                        "peaks": {"conv_b3 (v_mfma_f32_32x32x16_bf16, 6 split products per multiply-add)": MFMA_BF16_PEAK_TF / B3_PRODUCTS,
+                                  "fp32 kernels (v_mfma_f32_32x32x2_f32)": MFMA_F32_PEAK_TF},
+                        "split_bf16_share_of_flops": conv["b3_flops"] / conv["flops"],
+                        "traffic": conv_pmc,
+                        "traffic_source": "profiles/r3_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                           "passes, FETCH x2 per the gfx950 note; per launch)" if conv_pmc else None,
                         "launches_per_step": conv["launches"] / conv["steps"],
                         "algorithmic_flops_per_launch": conv["flops"] / conv["launches"],
@@ -516,9 +656,11 @@ def main():
                         "share_of_step": conv["ms"] / conv["steps"] / (1e3 * elapsed / opt.steps),
                         "note": "per-launch durations from hipEvent pairs attached to each dispatch in an eager repeat of "
                                 "the timed steps (a replayed hipGraph cannot carry events); flops = 2 x output positions "
-                                "x C x K x taps per launch (vitta_conv_flops); share_of_step > what a serial schedule "
-                                "would allow where the evaluation stream overlaps the adaptation stream",
-                        "by_shape": conv["by_shape"][:12], "moments": moments, "streaming": streaming}
+                                "x C x K x taps per launch (vitta_conv_flops), whatever the instruction; peak = flops / "
+                                "(sum over launches of flops / the peak of the instruction that launch issues); "
+                                "share_of_step > what a serial schedule would allow where the evaluation stream overlaps "
+                                "the adaptation stream",
+                        "by_shape": conv["by_shape"][:14], "moments": moments, "streaming": streaming}
         else:
             ov = one_video or {}
             roofline = {"kernel": moments["kernel"], "bound": "hbm", "achieved": ov.get("achieved"), "peak": HBM_PEAK_GBS,
@@ -529,7 +671,11 @@ def main():
         "metric": f"videos/sec TTA step (TANet-R50, 2x{opt.clip_length}x{opt.size}^2), whole job", "value": value,
         "unit": "videos/s",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if (opt.arch == "swin" or os.environ.get("VITTA_CONV_ARITH", "b3") != "b3") else
+                 "f32 (convolutions: operands split into three bf16 terms, six bf16-MFMA products per multiply-add, fp32 accumulation)",
+        "data": "synthetic", "blocks": len(getattr(run_gpu, "blocks", [])) or 1,
+        "ms_per_step_first_block": 1e3 * getattr(run_gpu, "blocks", [elapsed])[0] / opt.steps,
         "config": {"workload": "TANet-R50 UCF101 ViTTA online TTA, per-video iteration = adapt step (2 views x "
                                f"{opt.clip_length} frames x {opt.size}^2, 29 hooked BN2d layers, l1 stat alignment + "
                                "prediction consistency, backward, optimizer) + eval forward (1 view)",
@@ -573,6 +719,19 @@ def main():
                            "optimizer": "SGD all parameters (reference default, corpus/basics.py:547-560)",
                            "launch_mode": run_gpu.mode}
         torch.cuda.empty_cache()
+    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_swin and not opt.timed_only and world == 1 \
+            and opt.size == 224:
+        # the other half of north_star: Video Swin-B at BASELINE config 3's and config 5's shapes, in the same run
+        for key, cfg in (("swin", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=8)),
+                         ("swin_c5_bf16", dict(views=4, frames=32, window_depth=16, classes=174, bf16=True, steps=4))):
+            try:
+                log(f"Video Swin-B leg {key} ...")
+                line[key] = swin_leg(device, **cfg)
+                log(f"  {line[key]['ms_per_step']:.2f} ms per video")
+            except Exception as e:  # noqa: BLE001  (a leg must never cost the headline line)
+                log(f"leg {key} failed: {e!r}")
+                line[key] = {"error": repr(e)}
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not opt.no_cpu_baseline and opt.arch == "tanet":
         log("cpu baseline ...")
         line["cpu_baseline"] = run_cpu_baseline(opt)

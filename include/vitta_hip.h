@@ -267,6 +267,11 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  * the first half's tiles finish).  d_sync: >= 2 * N uint32, ZERO when first used (the kernels leave it zero), not shared by
  * launches that may run concurrently (one per stream).  Results are bit-identical to the unfused entry points.
  * VITTA_ERR_UNSUPPORTED when the launch could not be resident at once (N * tiles > 512 or LDS > 160 KiB). */
+/* 1 if the fused forward AND backward launches below can hold every workgroup of N clips resident (they meet on a device
+ * counter per clip): grid <= half of (occupancy query per CU x CUs), the other half being left to a second fused launch on
+ * another stream.  0: use the two-launch forms (vitta_tam_branch_fwd_f32 / _bwd_f32); the fused entry points return
+ * VITTA_ERR_UNSUPPORTED themselves when asked anyway. */
+int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T);
 int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,

@@ -230,6 +230,8 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
         kid = int(lib().vitta_conv_kernel(C.byref(d)))
         KERNEL_COUNTS[kid] = KERNEL_COUNTS.get(kid, 0) + 1
     if TIMING is not None:  # bench.py: one event pair per launch, attached to the kernel's dispatch
+        if KERNEL_TRACE is not None:
+            KERNEL_TRACE.append(int(lib().vitta_conv_kernel(C.byref(d))))
         ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg))
         check(lib().vitta_conv_timed_f32(C.byref(d), st, ev.start, ev.stop), "vitta_conv_timed_f32")
         return y
@@ -284,6 +286,8 @@ def stem_wgrad(x, dy, grad_w):
 TIMING = None
 # dict {kernel family id (_lib.CONV_KERNEL_*): launches} filled while it is not None (tests assert the path under test)
 KERNEL_COUNTS = None
+# list of the kernel family of every TIMED launch, in order, while it is not None (bench.py: which peak a launch is held to)
+KERNEL_TRACE = None
 
 
 def pack_stem(w):

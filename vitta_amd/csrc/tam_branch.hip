@@ -614,6 +614,40 @@ inline bool tb_bad(const TamBranchArgs& a) {
 
 }  // namespace
 
+namespace {
+
+// The fused launches spin in clip_meet until every workgroup of a clip has arrived: the WHOLE grid has to be resident.
+// Capacity = what the occupancy query admits per CU for this kernel and LDS size, times the CUs, HALVED: the overlapped
+// schedule may run the evaluation pass's fused launch beside the adaptation pass's on a second stream.
+template <typename Kern>
+int64_t fused_capacity(Kern kernel, size_t lds) {
+  // (one entry per kernel instantiation: the answer for the last LDS size asked, which repeats launch after launch)
+  static size_t last_lds = 0;
+  static int64_t last_cap = -1;
+  if (last_cap >= 0 && last_lds == lds) return last_cap;
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBW, lds) != hipSuccess || per_cu <= 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  last_lds = lds;
+  last_cap = (int64_t)per_cu * cus / 2;
+  return last_cap;
+}
+
+int fused_geometry(int32_t N, int32_t C, int32_t T, bool bwd, int& nt1, int& nt2, size_t& l1, size_t& lds) {
+  if (!vitta_tam_branch_supported(C, T) || N < 1 || N > 32) return 0;
+  const int O = C / 4;
+  nt1 = bwd ? (O + OBB - 1) / OBB : (O + OBF - 1) / OBF;
+  nt2 = bwd ? (C + CBB - 1) / CBB : (C + CB - 1) / CB;
+  l1 = ((bwd ? b1_lds(C, T) : f1_lds(C, T)) + 15) / 16 * 16;
+  lds = l1 + (bwd ? b2_lds(C, T) : f2_lds(C, T));
+  return lds <= 160 * 1024 ? 1 : 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int vitta_tam_branch_supported(int32_t C, int32_t T) {
@@ -640,6 +674,19 @@ int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const fl
   return VITTA_OK;
 }
 
+int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T) {
+  int nt1, nt2;
+  size_t l1, lds;
+  for (int bwd = 0; bwd < 2; ++bwd) {
+    if (!fused_geometry(N, C, T, bwd, nt1, nt2, l1, lds)) return 0;
+    const bool ok = bwd ? set_lds(tam_branch_bwd_fused_kernel, lds) : set_lds(tam_branch_fwd_fused_kernel, lds);
+    if (!ok) return 0;
+    const int64_t cap = bwd ? fused_capacity(tam_branch_bwd_fused_kernel, lds) : fused_capacity(tam_branch_fwd_fused_kernel, lds);
+    if ((int64_t)N * (nt1 > nt2 ? nt1 : nt2) > cap) return 0;
+  }
+  return 1;
+}
+
 int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
@@ -649,10 +696,12 @@ int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, co
   TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
                   BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
   if (tb_bad(a)) return VITTA_ERR_INVALID_ARG;
-  const int O = C / 4, nt1 = (O + OBF - 1) / OBF, nt2 = (C + CB - 1) / CB;
-  const size_t l1 = (f1_lds(C, T) + 15) / 16 * 16, lds = l1 + f2_lds(C, T);
-  if (lds > 160 * 1024 || (int64_t)N * (nt1 > nt2 ? nt1 : nt2) > 512) return VITTA_ERR_UNSUPPORTED;  // every workgroup resident
+  const int O = C / 4;
+  int nt1, nt2;
+  size_t l1, lds;
+  if (!fused_geometry(N, C, T, false, nt1, nt2, l1, lds)) return VITTA_ERR_UNSUPPORTED;
   if (!set_lds(tam_branch_fwd_fused_kernel, lds)) return VITTA_ERR_LAUNCH;
+  if ((int64_t)N * (nt1 > nt2 ? nt1 : nt2) > fused_capacity(tam_branch_fwd_fused_kernel, lds)) return VITTA_ERR_UNSUPPORTED;  // every workgroup resident
   float* d_hact = d_hpre + (int64_t)N * O * T;
   VITTA_LAUNCH(tam_branch_fwd_fused_kernel, dim3(N, nt1 > nt2 ? nt1 : nt2), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern,
                d_hpre, d_hact, d_gate, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4));
@@ -672,10 +721,12 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
   if (tb_bad(a) || !h_dbn[0] || !h_dbn[1] || !h_dbn[2] || !h_dbn[3]) return VITTA_ERR_INVALID_ARG;
   TamBranchGrads g{d_gpooled, h_dbn[0], h_dbn[1], h_dbn[2], h_dbn[3], h_dw ? h_dw[0] : nullptr, h_dw ? h_dw[1] : nullptr,
                    h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};
-  const int O = C / 4, nt1 = (O + OBB - 1) / OBB, nt2 = (C + CBB - 1) / CBB;
-  const size_t l1 = (b1_lds(C, T) + 15) / 16 * 16, lds = l1 + b2_lds(C, T);
-  if (lds > 160 * 1024 || (int64_t)N * (nt1 > nt2 ? nt1 : nt2) > 512) return VITTA_ERR_UNSUPPORTED;
+  const int O = C / 4;
+  int nt1, nt2;
+  size_t l1, lds;
+  if (!fused_geometry(N, C, T, true, nt1, nt2, l1, lds)) return VITTA_ERR_UNSUPPORTED;
   if (!set_lds(tam_branch_bwd_fused_kernel, lds)) return VITTA_ERR_LAUNCH;
+  if ((int64_t)N * (nt1 > nt2 ? nt1 : nt2) > fused_capacity(tam_branch_bwd_fused_kernel, lds)) return VITTA_ERR_UNSUPPORTED;
   const float* d_hact = d_hpre + (int64_t)N * O * T;
   float* d_dpre = d_gpooled + (int64_t)N * C * T;
   VITTA_LAUNCH(tam_branch_bwd_fused_kernel, dim3(N, nt1 > nt2 ? nt1 : nt2), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern,

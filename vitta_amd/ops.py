@@ -466,9 +466,12 @@ class WindowAttentionRel(torch.autograd.Function):
         nw = region.shape[0] if region is not None else 1
         bf16 = bool(WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0]))
         fwd = lib().vitta_wmsa_rel_fwd_bf16 if bf16 else lib().vitta_wmsa_rel_fwd_f32
+        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 4.0 * n * n * hd * b_ * num_heads) if KTIMING is not None else None
         check(fwd(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
                   b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
                   _stream()), "vitta_wmsa_rel_fwd_bf16" if bf16 else "vitta_wmsa_rel_fwd_f32")
+        if tm is not None:
+            tm.stop()
         ctx.save_for_backward(qkv, table, code, region, rowmap, out, lse)
         ctx.meta = (int(code_off), float(scale), num_heads, hd, nw, b_, n, nwm, tokens, bf16)
         return out
@@ -480,15 +483,20 @@ class WindowAttentionRel(torch.autograd.Function):
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
+        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 14.0 * n * n * hd * b_ * nh) if KTIMING is not None else None
         if bf16:
             check(lib().vitta_wmsa_rel_bwd_bf16(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                                 hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
                                                 _p(dqkv), _stream()), "vitta_wmsa_rel_bwd_bf16")
+            if tm is not None:
+                tm.stop()
             return dqkv, None, None, None, None, None, None, None
         dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         check(lib().vitta_wmsa_rel_bwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                            hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
                                            _p(dqkv), _p(dtable), _stream()), "vitta_wmsa_rel_bwd_f32")
+        if tm is not None:
+            tm.stop()
         return dqkv, r_table, None, None, None, None, None, None
 
 
@@ -579,6 +587,18 @@ class FusedBNAct(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 def tam_branch_supported(c, t):
     return bool(lib().vitta_tam_branch_supported(int(c), int(t)))
+
+
+_fused_ok = {}
+
+
+def tam_branch_fused_supported(n, c, t):
+    """The one-launch TAM branch passes hold every workgroup resident for n clips (`vitta_tam_branch_fused_supported`)."""
+    key = (int(n), int(c), int(t))
+    hit = _fused_ok.get(key)
+    if hit is None:
+        hit = _fused_ok[key] = bool(lib().vitta_tam_branch_fused_supported(*key))
+    return hit
 
 
 def _ptr4(*tensors):
@@ -826,6 +846,9 @@ def head_linear_supported(x, linear):
 # ------------------------------------------------------------------------------------------------
 # dense layers of Video Swin-B (csrc/gemm.hip): qkv / proj / Mlp / PatchMerging.reduction
 # ------------------------------------------------------------------------------------------------
+# callable(kind, flops) -> object with .stop(), or None (the product never sets it): bench.py brackets the dense and window
+# attention launches of an eager repeat with stream events to report their achieved TFLOP/s
+KTIMING = None
 GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128) / 3 (64 x 64)
 DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
 _W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, operand copy): frozen weights are prepared once
@@ -848,7 +871,10 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     y = out if out is not None else torch.empty(m, n, dtype=torch.float32, device=a.device)
     fn, name = (lib().vitta_gemm_nt_f32, "vitta_gemm_nt_f32") if b.dtype == torch.float32 else \
         (lib().vitta_gemm_nt_bf16w_f32, "vitta_gemm_nt_bf16w_f32")
+    tm = KTIMING("gemm_bf16" if b.dtype == torch.bfloat16 else "gemm_f32", 2.0 * m * n * k) if KTIMING is not None else None
     check(fn(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()), name)
+    if tm is not None:
+        tm.stop()
     return y
 
 

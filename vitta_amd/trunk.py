@@ -132,6 +132,15 @@ class TrunkRunner:
         net = self.net
         if not (ENABLED and fused_bn.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
             return False
+        if x.requires_grad:  # the node hands no gradient back to the clip
+            return False
+        # pixel counts of every stage must be multiples of four (16-byte epilogue accesses): frames x H x W after the stem,
+        # after each stride-2 stage
+        hh, ww = CV.out_size(CV.out_size(x.shape[2], 7, 2, 3), 3, 2, 1), CV.out_size(CV.out_size(x.shape[3], 7, 2, 3), 3, 2, 1)
+        for _ in range(4):
+            if (x.shape[0] * hh * ww) % 4:
+                return False
+            hh, ww = CV.out_size(hh, 3, 2, 1), CV.out_size(ww, 3, 2, 1)
         grad = torch.is_grad_enabled()
         mp, c1 = net.maxpool, net.conv1
         if net._forward_hooks or net._forward_pre_hooks or not isinstance(mp, nn.MaxPool2d) or mp._forward_hooks \
@@ -158,7 +167,8 @@ class TrunkRunner:
             if n.downsample is not None:
                 ds = n.downsample
                 if not (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d)
-                        and isinstance(ds[1], nn.BatchNorm2d) and not ds._forward_hooks):
+                        and isinstance(ds[1], nn.BatchNorm2d) and not ds._forward_hooks
+                        and ds[0].kernel_size == (1, 1) and ds[0].padding == (0, 0) and ds[0].stride == n.conv2.stride):
                     return False
                 convs.append(ds[0])
                 bns.append(ds[1])
@@ -166,7 +176,8 @@ class TrunkRunner:
                 if cv.bias is not None or cv._forward_hooks or cv._forward_pre_hooks \
                         or cv.groups != 1 or cv.dilation != (1, 1):
                     return False
-            if (n.conv1.kernel_size, n.conv1.stride) != ((1, 1), (1, 1)) or (n.conv3.kernel_size, n.conv3.stride) != ((1, 1), (1, 1)) \
+            if n.conv1.padding != (0, 0) or n.conv3.padding != (0, 0) or n.conv1.in_channels % 16 or n.conv1.out_channels % 32 \
+                    or (n.conv1.kernel_size, n.conv1.stride) != ((1, 1), (1, 1)) or (n.conv3.kernel_size, n.conv3.stride) != ((1, 1), (1, 1)) \
                     or n.conv2.kernel_size != (3, 3) or n.conv2.padding != (1, 1) or n.conv2.stride[0] != n.conv2.stride[1] \
                     or n.conv2.stride[0] not in (1, 2) or n.relu._forward_hooks:
                 return False
@@ -181,8 +192,7 @@ class TrunkRunner:
             tam = b.tam
             bg, bl = tam.G[1], tam.L[1]
             if bg.training or bl.training or not _noop_hooks_only(bg) or not _noop_hooks_only(bl) \
-                    or not ops.tam_branch_supported(n.conv1.out_channels, t) \
-                    or (x.shape[0] // t) * max(n.conv1.out_channels // 8, n.conv1.out_channels // 16, 1) > 512:
+                    or not ops.tam_branch_supported(n.conv1.out_channels, t) or x.shape[0] // t > 32:
                 return False
             for m in (tam.G[0], tam.G[3], tam.L[0], tam.L[3]):
                 if m._forward_hooks:
@@ -196,12 +206,12 @@ class TrunkRunner:
     def packed(self, conv, kind, adapt=None):
         """Packed weight of `conv` (kind "f" forward, "b" data gradient: conv.Pack with the split-bf16 image where the shape
         qualifies; "s": the stem's [148][64] array).
-        adapt: which re-packed set of a trainable weight -- True: the adaptation pass's (its backward runs with grad mode
-        OFF, so it has to say so: the evaluation pass's set is written by another stream and holds no backward packs),
-        None: by the current grad mode (forward passes)."""
+        adapt: which re-packed set of a trainable weight -- True: the adaptation pass's (forward AND backward name it: the
+        grad mode is off inside TrunkFunction.forward and inside autograd's backward, so it cannot tell the passes apart),
+        False / None: the evaluation pass's, which another stream may be re-packing and which holds no backward packs."""
         w = conv.weight
         if w.requires_grad and kind in ("f", "b"):  # trainable: this pass's copies, rebuilt by ONE launch per forward
-            st = self._repack.get(torch.is_grad_enabled() if adapt is None else adapt)
+            st = self._repack.get(bool(adapt))
             if st is not None and (id(w), kind) in st["packs"]:
                 return st["packs"][(id(w), kind)]
         if w.requires_grad:  # (stem, or outside a refreshed forward): re-packed on demand
@@ -220,18 +230,19 @@ class TrunkRunner:
             self._packed[key] = hit
         return hit[1]
 
-    def refresh_packs(self, device):
+    def refresh_packs(self, device, adapt=False):
         """Trainable convolution weights: rebuild the packed copies (`vitta_conv_repack_f32`, one launch over all of them, and
         `vitta_conv_pack_b3_table`, one launch for their split-bf16 images).
         Two sets, created once (before any graph capture: the tables are host -> device copies): one for passes under
-        autograd (adaptation), one for no_grad passes (the evaluation, which may run beside it on a second stream)."""
+        autograd (adaptation: `adapt`, with the data-gradient packs), one for the evaluation pass, which may run beside it on
+        a second stream.  The caller names the pass: TrunkFunction.forward runs with grad mode off like the evaluation."""
         convs = []
         for b in self.blocks():
             convs += [b.net.conv1, b.net.conv2, b.net.conv3] + ([b.net.downsample[0]] if b.net.downsample is not None else [])
         convs = [c for c in convs if c.weight.requires_grad]
         if not convs:
             return
-        key = torch.is_grad_enabled()
+        key = bool(adapt)
         st = self._repack.get((key, CV.ARITH))
         sig = tuple((c.weight.data_ptr(), tuple(c.weight.shape)) for c in convs)
         if st is None or st["sig"] != sig:
@@ -368,7 +379,7 @@ class TrunkRunner:
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
-        CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f"), x1, cin, p, flags=CV.CONV_STATS if s1 else 0,
+        CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=CV.CONV_STATS if s1 else 0,
                   epi_bn=_bn_t(net.bn1) if s1 else None, eps=net.bn1.eps, stats=s1.stats if s1 else None)
         # TAM on relu(bn1(x1))
         bn1p = _bn_ptrs(net.bn1)
@@ -377,11 +388,18 @@ class TrunkRunner:
         bg, bl = tam.G[1], tam.L[1]
         kern, gate, hpre = torch.empty(nb * p, 3, **f), torch.empty(nb, p, t, **f), torch.empty(2, nb, p // 4, t, **f)
         from .ops import _ptr4
-        check(L.vitta_tam_branch_fwd_fused_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                               float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                               _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                               _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), st),
-              "vitta_tam_branch_fwd_fused_f32")  # (eligible() admits only shapes the fused launch holds resident)
+        from .ops import tam_branch_fused_supported
+        if tam_branch_fused_supported(nb, p, t):  # every workgroup of the one-launch form resident (also beside the other stream's)
+            check(L.vitta_tam_branch_fwd_fused_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                                   float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                                   _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                                   _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), st),
+                  "vitta_tam_branch_fwd_fused_f32")
+        else:  # two launches, no device-side meeting point
+            check(L.vitta_tam_branch_fwd_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                             float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                             _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                             _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
         a1 = torch.empty(p, P, **f)
         check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
               "vitta_tam_agg_fwd_cm_f32")
@@ -393,7 +411,7 @@ class TrunkRunner:
         Po = n * ho * wo
         a2 = torch.empty(p, Po, **f)
         x2 = torch.empty(p, Po, **f) if keep else None
-        CV.launch(g2, a1, self.packed(net.conv2, "f"), a2, p, p,
+        CV.launch(g2, a1, self.packed(net.conv2, "f", keep), a2, p, p,
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | (CV.CONV_STATS if s2 else 0), y_raw=x2,
                   epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None)
         # identity path
@@ -403,7 +421,7 @@ class TrunkRunner:
             sd = sites.get(id(dbn))
             ident = torch.empty(4 * p, Po, **f)
             xd = torch.empty(4 * p, Po, **f) if keep else None
-            CV.launch(self.geo("f", n, h, w, 1, dconv.stride[0], 0), xin, self.packed(dconv, "f"), ident, cin, 4 * p,
+            CV.launch(self.geo("f", n, h, w, 1, dconv.stride[0], 0), xin, self.packed(dconv, "f", keep), ident, cin, 4 * p,
                       flags=CV.CONV_EPI_APPLY | (CV.CONV_STATS if sd else 0), y_raw=xd, epi_bn=_bn_t(dbn), eps=dbn.eps,
                       stats=sd.stats if sd else None)
         else:
@@ -411,7 +429,7 @@ class TrunkRunner:
         # conv3 -> x3 raw, out
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
-        CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f"), out, p, 4 * p,
+        CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f", keep), out, p, 4 * p,
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if s3 else 0),
                   y_raw=x3, res=ident, epi_bn=_bn_t(net.bn3), eps=net.bn3.eps, stats=s3.stats if s3 else None)
         saved = None
@@ -426,7 +444,8 @@ class TrunkRunner:
         [N, 64, h, w] computed outside (trainable stem convolution); the tape then ends at it."""
         cur_stream = torch.cuda.current_stream(x.device).cuda_stream
         self._step_packs = {k: v for k, v in self._step_packs.items() if k[2] != cur_stream}  # this stream's packs are stale
-        self.refresh_packs(x.device)
+        self.refresh_packs(x.device, adapt=keep)
+        self._adapt_pass = keep
         sites = self.open_sites(x) if keep else {}
         if pooled_in is None:
             y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
@@ -502,14 +521,22 @@ class TrunkRunner:
         bg, bl = tam.G[1], tam.L[1]
         from .ops import _ptr4
         gbuf = torch.empty(nb * p * t + nb * (p // 4) * t, **f)  # d pooled | scratch
-        check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                               float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                               _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                               _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
-                                               _p(ggate), _p(gbuf), _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias)),
-                                               _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), sink(tam.L[0].weight),
-                                                     sink(tam.L[3].weight)), _p(_sync(dev)), st),
-              "vitta_tam_branch_bwd_fused_f32")
+        from .ops import tam_branch_fused_supported
+        bn_sinks = _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias))
+        w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), sink(tam.L[0].weight), sink(tam.L[3].weight))
+        if tam_branch_fused_supported(nb, p, t):
+            check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                                   float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                                   _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                                   _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                                   _p(ggate), _p(gbuf), bn_sinks, w_sinks, _p(_sync(dev)), st),
+                  "vitta_tam_branch_bwd_fused_f32")
+        else:
+            check(L.vitta_tam_branch_bwd_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
+                                             float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
+                                             _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
+                                             _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                             _p(ggate), _p(gbuf), bn_sinks, w_sinks, st), "vitta_tam_branch_bwd_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
         dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w)
         del ga
@@ -600,7 +627,10 @@ def run(resnet, x):
                    b.net.conv1.weight, b.net.conv2.weight, b.net.conv3.weight]
         if b.net.downsample is not None:
             params.append(b.net.downsample[0].weight)
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params + [resnet.conv1.weight]):
+    # under autograd the node form runs whenever something trains OR statistics hooks are bound to the engine (their sites are
+    # opened and deposited by the keep = True forward even if only parameters outside the trunk are adapted)
+    hooked = torch.is_grad_enabled() and any(_engine_hook(m)[1] is not None for m in runner.bn2d_modules())
+    if torch.is_grad_enabled() and (hooked or any(p.requires_grad for p in params + [resnet.conv1.weight])):
         pooled = None
         y_w = (x.shape[3] - 1) // 2 + 1
         if resnet.conv1.weight.requires_grad and (y_w % 4 or y_w > 256):  # stem gradient kernels: tiled path only
