@@ -418,6 +418,10 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
 #define VITTA_CONV_RES_HALF 32 /* res is a half-resolution tensor [K][N * ceil(Hy/2) * ceil(Wy/2)] added at even (h, w) */
 #define VITTA_CONV_BWD_BN 64
 #define VITTA_CONV_BWD_RELU 128
+/* The four parity classes of a stride-2 data gradient in ONE launch (conv_b3.hip only; vitta_conv_supported says whether
+ * the descriptor qualifies): ostride must be 2, the taps are listed class by class -- class c = 2 a + b writes output
+ * pixels (2 i + a, 2 j + b) and owns cls_ntaps[c] >= 1 consecutive entries of the tap table (oa / ob are ignored). */
+#define VITTA_CONV_PARITY4 256
 #define VITTA_CONV_MAX_TAPS 9
 
 typedef struct vitta_conv_desc {
@@ -461,6 +465,7 @@ typedef struct vitta_conv_desc {
    * the bf16 matrix pipe with every fp32 operand split into three bf16 terms and six products per multiply-add (fp32
    * accumulation; error of the fp32-roundoff class, see conv_b3.hip); `w` is then not read.  NULL: exact fp32 MFMA. */
   const void* w_b3;
+  int8_t cls_ntaps[4]; /* VITTA_CONV_PARITY4: taps of class 0..3 (sum = ntaps) */
 } vitta_conv_desc;
 
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */

@@ -49,7 +49,10 @@ def _bn_apply(x, bn, eps=1e-5):
     (4, 128, 128, 56, 3, 2, 0), (8, 256, 256, 28, 3, 2, 0), (8, 512, 512, 14, 3, 2, 0), (4, 256, 512, 56, 1, 2, 0),
     (8, 1024, 2048, 14, 1, 2, 0), (4, 64, 64, 13, 3, 1, 0), (4, 32, 32, 9, 3, 2, 0),
     (4, 128, 128, 28, 1, 1, (128 << 16) | 128), (4, 128, 128, 28, 3, 1, (128 << 16) | 64), (4, 128, 128, 28, 3, 1, (64 << 16) | 64),
-    (4, 128, 128, 28, 1, 1, (64 << 16) | 32), (4, 128, 128, 28, 3, 1, (128 << 16) | 128)])
+    (4, 128, 128, 28, 1, 1, (64 << 16) | 32), (4, 128, 128, 28, 3, 1, (128 << 16) | 128),
+    # the 64^2-input shapes of the golden step tests (planes of 16 / 8 / 4 / 2 pixels a side, 32 frames)
+    (32, 64, 64, 16, 3, 1, 0), (32, 128, 128, 16, 3, 2, 0), (32, 256, 256, 8, 3, 2, 0), (32, 512, 512, 4, 3, 2, 0),
+    (32, 512, 512, 2, 3, 1, 0), (32, 1024, 2048, 4, 1, 2, 0), (32, 2048, 512, 2, 1, 1, 0), (32, 256, 512, 16, 1, 2, 0)])
 def test_forward_matches_fp64_conv(n, c, k, h, ksz, stride, tile):
     from vitta_amd import conv as CV
     g = torch.Generator().manual_seed(n * 1000 + c + k + h + ksz)
@@ -388,3 +391,35 @@ def test_pack_b3_reconstructs_the_weights_and_the_split_kernel_is_the_path(arith
     finally:
         CV.KERNEL_COUNTS = None
     assert (counts.get(_lib.CONV_KERNEL_B3, 0) == 1) == (arith == "b3"), counts
+
+
+@pytest.mark.parametrize("n,c,k,h", [(4, 128, 128, 28), (8, 512, 512, 14), (4, 64, 64, 7), (4, 64, 128, 9), (16, 256, 256, 28),
+                                     (32, 512, 512, 4), (32, 256, 256, 8), (32, 128, 128, 16), (16, 512, 512, 2)])
+def test_parity_merged_stride2_data_gradient_is_one_launch(n, c, k, h, arith):
+    """d input of conv(3x3, stride 2, pad 1) with the four parity classes of the input pixel in ONE launch
+    (VITTA_CONV_PARITY4, conv_b3.hip): same result as fp64 autograd; the exact-fp32 arithmetic keeps one launch per class
+    (the merged descriptor is refused there)."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n + c + k + h)
+    x = torch.randn(n, c, h, h, generator=g).double().requires_grad_(True)
+    w = torch.randn(k, c, 3, 3, generator=g) * (c * 9) ** -0.5
+    out = F.conv2d(x, w.double(), stride=2, padding=1)
+    gy = torch.randn(out.shape, generator=g)
+    out.backward(gy.double())
+    d = _dev()
+    pack = CV.make_pack(CV.pack_bwd(w.to(d)))
+    gm = CV.Geometry.dgrad_merged(n, h, h, 3, 2, 1)
+    assert gm is not None and sum(gm.cls_ntaps) == 9
+    ok = CV.merged_dgrad_supported(gm, pack, k, c)
+    assert ok == (arith == "b3")
+    if not ok:
+        return
+    gx = torch.full((c, n * h * h), float("nan"), device=d)
+    CV.KERNEL_COUNTS = {}
+    try:
+        CV.launch(gm, CV.to_cm(gy.to(d)), pack, gx, k, c)
+        counts = dict(CV.KERNEL_COUNTS)
+    finally:
+        CV.KERNEL_COUNTS = None
+    assert sum(counts.values()) == 1
+    _close(CV.from_cm(gx, n, h, h), x.grad)

@@ -172,7 +172,14 @@ def assert_logits_close_abs(got, ref, bound):
         assert a == b or (row_ref[b] - row_ref[a]).item() <= 2 * bound, (a, b)
 
 
-def check_tta_records(g, mode, records, base, floor_mult=4.0):
+def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=False):
+    """common_floor (GPU suites): the noise floor of a sampled gradient on steps AFTER the first is at least the MEDIAN, over
+    the sampled tensors of that step, of noise / max|g|.  The fixtures hold ONE perturbed re-run of the reference per step:
+    by the third step its deviations are 3-30 % of max|g| for most tensors (the trajectory is chaotic: L1 sign terms, SGD
+    on every weight), but a single sample can come out 10x smaller for one tensor (layer4.2.net.bn3.bias, batch of two:
+    0.6 % where its neighbours show 3-30 %), and any other summation order then lands outside "4 x its own floor" --
+    tools/debug/bz2_step_probe.py prints the table for the arithmetic forms.  The first step (identical weights) keeps the
+    strict per-tensor bounds."""
     rows = int(g["sample_rows"])
     cfg = json.loads(str(g["config"]))
     lr = cfg["lr_sgd"] if mode == "sgd" else cfg["lr_adam"]
@@ -188,6 +195,9 @@ def check_tta_records(g, mode, records, base, floor_mult=4.0):
         bound = max(base["logit_frac"] * ref.abs().max().item(), floor_mult * float(g[k + "noise_eval_logits"]))
         assert_logits_close_abs(rec["eval_logits"], ref, bound)
         report.append((i, "eval_logits", (rec["eval_logits"] - ref).abs().max().item(), bound))
+        rel = [float(g[k + f"noise_grad::{n_}"]) / max(float(np.abs(g[k + f"grad::{n_}"]).max()), 1e-30)
+               for n_ in rec["grads"] if k + f"grad::{n_}" in g.files]
+        rel_floor = float(np.median(rel)) if rel else 0.0
         for name, gr in rec["grads"].items():
             key = k + f"grad::{name}"
             if key not in g.files:
@@ -195,6 +205,8 @@ def check_tta_records(g, mode, records, base, floor_mult=4.0):
                 continue
             ref = torch.from_numpy(g[key])
             bound = max(base["grad_frac"] * ref.abs().max().item(), floor_mult * float(g[k + f"noise_grad::{name}"])) + 1e-10
+            if i > 0 and common_floor:
+                bound = max(bound, floor_mult * rel_floor * ref.abs().max().item())
             err = (gr[:rows] - ref).abs().max().item()
             assert err <= bound, (i, name, err, bound)
             report.append((i, "grad " + name, err, bound))

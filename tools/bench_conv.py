@@ -101,7 +101,15 @@ def main():
             geoms = CV.Geometry.dgrad(n, h, h, ksz, s, pad)
             gdst = torch.empty(c, n * ho * ho, device=d) if (s == 2 and ksz == 1) else gx
 
+            wbp = CV.make_pack(wb)
+            gm = CV.Geometry.dgrad_merged(n, h, h, ksz, s, pad) if (s == 2 and ksz == 3 and tile == 0) else None
+            if gm is not None and not CV.merged_dgrad_supported(gm, wbp, k, c):
+                gm = None
+
             def dgrad():
+                if gm is not None:  # stride 2: the four parity classes in one launch
+                    CV.launch(gm, y, wbp, gdst, k, c)
+                    return
                 for g in geoms:
                     CV.launch(g, y, wb, gdst, k, c, tile=tile)
             t_b = time_it(dgrad, opt.reps)

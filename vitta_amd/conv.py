@@ -115,9 +115,10 @@ def _bn4(arr, bn):
 class Geometry:
     """Tap table + grids of one launch (see the header comment of vitta_conv_desc)."""
 
-    def __init__(self, n, hs, ws, hg, wg, hy, wy, taps, sstride=1, ostride=1, oa=0, ob=0):
+    def __init__(self, n, hs, ws, hg, wg, hy, wy, taps, sstride=1, ostride=1, oa=0, ob=0, cls_ntaps=None):
         self.n, self.hs, self.ws, self.hg, self.wg, self.hy, self.wy = n, hs, ws, hg, wg, hy, wy
         self.taps, self.sstride, self.ostride, self.oa, self.ob = taps, sstride, ostride, oa, ob
+        self.cls_ntaps = cls_ntaps  # parity-merged data gradient: taps per class (VITTA_CONV_PARITY4)
 
     @staticmethod
     def forward(n, h, w, k=1, stride=1, pad=0):
@@ -155,6 +156,19 @@ class Geometry:
                 out.append(Geometry(n, ho, wo, (h + 1) // 2, (w + 1) // 2, h, w, taps, ostride=2, oa=a, ob=b))
         return out
 
+    @staticmethod
+    def dgrad_merged(n, h, w, k=3, stride=2, pad=1):
+        """The four parity classes of Geometry.dgrad(stride 2) as ONE launch (VITTA_CONV_PARITY4; conv_b3.hip), or None
+        where a class would be empty."""
+        classes = Geometry.dgrad(n, h, w, k, stride, pad)
+        if stride != 2 or len(classes) != 4 or any(len(g.taps) < 1 for g in classes):
+            return None
+        g0 = classes[0]
+        taps = [t for g in classes for t in g.taps]
+        if len(taps) > 9:
+            return None
+        return Geometry(n, g0.hs, g0.ws, g0.hg, g0.wg, h, w, taps, ostride=2, cls_ntaps=[len(g.taps) for g in classes])
+
     def wgrad_tables(self, device):
         """(src_off, src_mask) int32 [N * Hg * Wg] of vitta_wgrad_desc for this (forward) geometry, built once."""
         key = str(device)
@@ -180,6 +194,9 @@ class Geometry:
         d.sstride, d.ostride, d.oa, d.ob, d.ntaps = self.sstride, self.ostride, self.oa, self.ob, len(self.taps)
         for i, (dh, dw, wt) in enumerate(self.taps):
             d.dh[i], d.dw[i], d.wt[i] = dh, dw, wt
+        if self.cls_ntaps is not None:
+            for i, nt in enumerate(self.cls_ntaps):
+                d.cls_ntaps[i] = nt
 
 
 WORKSPACE_BYTES = 48 << 20
@@ -220,7 +237,7 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if inj is not None:
         d.inj_mu, d.inj_a, d.inj_b, d.inj_gscale = (_ptr(t) for t in inj)
     d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
-    d.C, d.K, d.flags, d.tile, d.ksplit = int(c), int(k), int(flags), int(tile), int(ksplit)
+    d.C, d.K, d.flags, d.tile, d.ksplit = int(c), int(k), int(flags) | (_lib.CONV_PARITY4 if geom.cls_ntaps is not None else 0), int(tile), int(ksplit)
     geom.fill(d)
     if ksplit != 1:
         ws = workspace(x.device)
@@ -237,6 +254,20 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
         return y
     check(lib().vitta_conv_f32(C.byref(d), st), "vitta_conv_f32")
     return y
+
+
+def merged_dgrad_supported(geom, wp, c, k):
+    """True when the parity-merged data gradient `geom` (Geometry.dgrad_merged) can run as one launch with this weight."""
+    if geom is None or geom.cls_ntaps is None or ARITH != "b3" or os.environ.get("VITTA_CONV_B3_MERGED", "1") == "0":
+        return False
+    b3 = wp.b3 if isinstance(wp, Pack) else None
+    if b3 is None:
+        return False
+    d = ConvDesc()
+    d.x = d.y = d.w_b3 = b3.data_ptr()  # (only non-null pointers matter to the query)
+    d.C, d.K, d.flags = int(c), int(k), _lib.CONV_PARITY4
+    geom.fill(d)
+    return bool(lib().vitta_conv_supported(C.byref(d)))
 
 
 def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5):

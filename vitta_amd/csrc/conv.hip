@@ -688,27 +688,44 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // shape fits its one configuration: 128 x 64 tiles, 32-channel slabs (VITTA_CONV_B3=0 keeps the exact-fp32 kernels)
   if (d.w_b3 && b3_enabled() && d.C % 32 == 0 && d.K % 64 == 0 && !(d.flags & VITTA_CONV_PRO_BN_RELU) &&
       (h->tile == 0 || h->tile == ((128 << 16) | 64) || (h->tile == ((128 << 16) | 128) && d.K % 128 == 0)) &&
-      (int64_t)d.C * a.xP * 4 < (1ll << 31) && (is_vector_geometry(d) || b3_patch_geometry(d, 63))) {
+      (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
+    // form: pointwise rows, one patch per channel slab (stride-1 taps inside the halo), or gathered (anything else)
+    const int form = is_vector_geometry(d) ? 1 : b3_patch_geometry(d, 63) ? 2 : 3;
+    static const int gather_on = env_int("VITTA_CONV_B3_GATHER", 1);  // 0: gathered geometries stay on the exact-fp32 kernels (A/B)
+    if (form == 3 && !gather_on) goto exact_fp32;
+    const bool parity4 = d.flags & VITTA_CONV_PARITY4;
+    if (parity4) {
+      int sum = 0;
+      for (int c = 0; c < 4; ++c) {
+        if (d.cls_ntaps[c] < 1) return VITTA_ERR_INVALID_ARG;
+        sum += d.cls_ntaps[c];
+      }
+      if (sum != d.ntaps || d.ostride != 2 || form != 2 || (h->tile && (h->tile & 0xffff) != 64)) return VITTA_ERR_UNSUPPORTED;
+    }
     // 128 x 128 tiles (wave = 32 rows x 128 channels: the activation split feeds twice the MFMAs) on request only (tile
     // field, or VITTA_CONV_B3_WIDE=1 for A/B measurements): measured slower on the trunk's shapes -- half the tiles means
     // twice the K split, and the last arriver of a tile then sums up to sixteen 64 KB partial tiles alone (layer3 3x3:
     // 41.9 vs 33.1 us, layer2 3x3: 38.6 vs 32.0 us)
     static const int wide_on = env_int("VITTA_CONV_B3_WIDE", 0);
-    const bool wide_ok = d.K % 128 == 0 && (is_vector_geometry(d) || b3_patch_geometry(d, 32));
-    const bool wide = h->tile ? (h->tile & 0xffff) == 128 && wide_ok : (wide_on && wide_ok);
+    const bool wide_ok = d.K % 128 == 0 && (form == 1 || b3_patch_geometry(d, 32));
+    const bool wide = !parity4 && (h->tile ? (h->tile & 0xffff) == 128 && wide_ok : (wide_on && wide_ok));
     if (h->tile && (h->tile & 0xffff) == 128 && !wide_ok) return VITTA_ERR_UNSUPPORTED;
     const int bm = 128, bn = wide ? 128 : 64;
     a.nMt = (int)((M + bm - 1) / bm);
     a.nNt = d.K / bn;
     a.d.tile = (bm << 16) | bn;
     // K is split over CHANNEL slabs (a slice walks all taps of its slabs): aim at >= ~1.5 workgroups per CU
-    const int ncs = d.C / 32, tiles = a.nMt * a.nNt;
+    const int ncs = d.C / 32, tiles = a.nMt * a.nNt * (parity4 ? 4 : 1);
+    a.cls_tiles = parity4 ? a.nMt * a.nNt : 0;
+    a.cls_tap0[0] = 0;
+    for (int c = 0; c < 4; ++c) a.cls_tap0[c + 1] = a.cls_tap0[c] + (parity4 ? d.cls_ntaps[c] : 0);
     int ks = 1;
     if (tiles > MAX_SPLIT_TILES) ks = 1;
     else if (d.ksplit > 0) ks = d.ksplit;
     else {
       static const int min_wgs = env_int("VITTA_CONV_B3_MIN_WGS", 384), min_steps = env_int("VITTA_CONV_B3_MIN_STEPS", 4);
-      while (tiles * ks < min_wgs && (ncs / (ks * 2)) * d.ntaps >= min_steps && ncs % (ks * 2) == 0 && ks < 16) ks *= 2;
+      const int taps_min = parity4 ? 1 : d.ntaps;  // (the lightest class of a parity-merged launch has one tap)
+      while (tiles * ks < min_wgs && (ncs / (ks * 2)) * taps_min >= min_steps && ncs % (ks * 2) == 0 && ks < 16) ks *= 2;
     }
     if (ks > ncs) ks = ncs;
     const size_t need = ks > 1 ? counter_bytes(tiles) + (size_t)tiles * ks * bm * bn * sizeof(float) : 0;
@@ -720,7 +737,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     a.ws_need = need;
     a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
     a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
-    a.b3 = 1;
+    a.b3 = form;
     static const int pf = env_int("VITTA_CONV_PW_PREFETCH", 1);
     a.pw_prefetch = (pf && a.contig &&
                      ((d.flags & VITTA_CONV_BWD_BN) || ((d.flags & VITTA_CONV_RES) && d.res && !(d.flags & VITTA_CONV_RES_HALF)))) ? 1 : 0;
@@ -728,6 +745,9 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
       a.tap[t] = t < d.ntaps ? ((d.dh[t] & 0xff) | ((d.dw[t] & 0xff) << 8) | ((int)d.wt[t] << 16)) : 0;
     return VITTA_OK;
   }
+exact_fp32:
+  if (d.flags & VITTA_CONV_PARITY4) return VITTA_ERR_UNSUPPORTED;  // one launch per parity class on the exact-fp32 kernels
+  a.cls_tiles = 0;
   int bm = 64, bn = 32;
   choose_tile(d, M, bm, bn);
   if (d.K % bn) return VITTA_ERR_UNSUPPORTED;
@@ -805,7 +825,7 @@ int vitta_conv_supported(const vitta_conv_desc* h_desc) {
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc) {
   ConvK a;
   if (fill(h_desc, a) != VITTA_OK) return -1;
-  return (int64_t)a.nMt * a.nNt;
+  return (int64_t)a.nMt * a.nNt * (a.cls_tiles ? 4 : 1);
 }
 
 size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc) {
@@ -828,7 +848,7 @@ int vitta_conv_kernel(const vitta_conv_desc* h_desc) {
 int64_t vitta_conv_flops(const vitta_conv_desc* h_desc) {
   ConvK a;
   if (fill(h_desc, a) != VITTA_OK) return -1;
-  return 2ll * a.Mtot * a.d.K * a.d.C * a.d.ntaps;
+  return 2ll * a.Mtot * a.d.K * a.d.C * a.d.ntaps;  // (parity-merged: Mtot positions per class x the classes' taps = the same sum)
 }
 
 int vitta_conv_f32(const vitta_conv_desc* h_desc, void* stream) { return vitta_conv_timed_f32(h_desc, stream, nullptr, nullptr); }
@@ -841,7 +861,7 @@ int vitta_conv_timed_f32(const vitta_conv_desc* h_desc, void* stream, void* ev_s
   hipEvent_t e0 = static_cast<hipEvent_t>(ev_start), e1 = static_cast<hipEvent_t>(ev_stop);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool gather = !is_vector_geometry(a.d);
-  if (a.b3) return launch_b3(a, gather, st, e0, e1);  // gathered = the patch form
+  if (a.b3) return launch_b3(a, st, e0, e1);
   if (!a.d.w) return VITTA_ERR_UNSUPPORTED;  // only the split image was given and the shape does not qualify for it
   if (a.pw) return launch_pointwise(a, st, e0, e1);
   if (a.sk_G) return launch_stream_k(a, gather, st, e0, e1);

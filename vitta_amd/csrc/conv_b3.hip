@@ -51,14 +51,18 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 // pixel range [m0 - 64, m0 + 192) of each channel row (the tile's 128 pixels + a halo that covers every tap shift
 // dh * W + dw for W <= 62), loaded ONCE per channel slab; a tap is an address shift of the operand reads, and a lane whose
 // tap falls outside the plane reads position 0 of the row instead, which the DMA keeps at zero.
-// !PATCH: pointwise, the A image is the tile's 128 pixels, two stages.
+// MODE 0: pointwise, the A image is the tile's 128 pixels, two stages.  MODE 2: any other tap set (strided 3x3, strided
+// pointwise, planes wider than the halo): the A image of a (channel slab, tap) step is GATHERED, four bytes per lane
+// (one instruction = 64 pixels of one channel row; a pixel whose tap falls outside the plane requests out of range and
+// lands as zero), two stages like the pointwise form.
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-template <bool PATCH, bool PRE, int NB>
+template <int MODE, bool PRE, int NB>
 __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
+  constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
   constexpr int BM = 128, BN = 64, BK = 32, HALO = 64;
   constexpr int PL = PATCH ? 256 : 128;   // pixels per channel row of the A image
   constexpr int NA = PATCH ? 1 : NB;      // A stages (B: NB)
-  constexpr int PER_STEP = PATCH ? 3 : 7; // LDS-DMA instructions of a wave per step
+  constexpr int PER_STEP = PATCH ? 3 : GATHER ? 19 : 7;  // LDS-DMA instructions of a wave per step
   constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Ab = lds;                        // [NA][BK][PL] fp32
@@ -71,15 +75,22 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   const int li = lane & 31, lk = lane >> 5;
   const int C = d.C, K = d.K;
   const int Lz = xcd_remap(blockIdx.x, gridDim.x);
-  const int L = Lz / a.ksplit, kz = Lz - L * a.ksplit;
+  const int Lg = Lz / a.ksplit, kz = Lz - Lg * a.ksplit;  // tile of the launch (arrival counter, partial tiles)
+  // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table
+  const int cls = a.cls_tiles ? Lg / a.cls_tiles : 0, L = Lg - cls * a.cls_tiles;
+  const int tap0 = a.cls_tiles ? a.cls_tap0[cls] : 0, ntaps = a.cls_tiles ? a.cls_tap0[cls + 1] - tap0 : d.ntaps;
   const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
-  const int ncs = C / BK, ntaps = d.ntaps;
+  const int ncs = C / BK;
   const int cs0 = (int)(((int64_t)ncs * kz) / a.ksplit), cs1 = (int)(((int64_t)ncs * (kz + 1)) / a.ksplit);
   const int S = (cs1 - cs0) * ntaps;  // steps = (channel slab, tap) pairs
 
   // wave w owns pixel rows 32 w .. 32 w + 31 and all 64 output channels (two 32 x 32 accumulators)
   TileEpilogue epi0(a, red, wave >> 1, 0, li, lk, BM), epi1(a, red, wave >> 1, 1, li, lk, BM);
   const int xb = wave & 1;
+  if (a.cls_tiles) {
+    epi0.oa = epi1.oa = cls >> 1;
+    epi0.ob = epi1.ob = cls & 1;
+  }
 
   __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)((int64_t)C * a.xP * 4), 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_b3), 0, 0x7fffffff, 0x00020000);
@@ -91,10 +102,35 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   // A, patch: one instruction = one channel row (256 pixels; lane 0 out of range: positions 0..3 stay zero); wave w loads
   // rows 8 w .. 8 w + 7.  A, pointwise: one instruction = two channel rows (2 x 128 pixels), four per wave.
   const int voff_a = PATCH ? (lane == 0 ? OOB : (m0 - HALO + 4 * lane) * 4) : lk * row_bytes + min(m0 + 4 * li, a.Mtot - 4) * 4;
-  auto dma_a = [&](int cs, int stage) __attribute__((always_inline)) {
+  // gathered: the lane's two pixels (lane, lane + 64 of the tile): source offset of tap (0, 0), validity bit per tap
+  int g_base[2] = {0, 0};
+  unsigned g_valid[2] = {0, 0};
+  if constexpr (GATHER) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int m = m0 + lane + 64 * hh;
+      const int hw = d.Hg * d.Wg, mm = m < a.Mtot ? m : 0;
+      const int n = mm / hw, r = mm - n * hw, gi = r / d.Wg, gj = r - gi * d.Wg;
+      g_base[hh] = (n * d.Hs * d.Ws + gi * d.sstride * d.Ws + gj * d.sstride) * 4;
+      for (int t = 0; t < ntaps; ++t) {
+        const int tp = a.tap[tap0 + t];
+        const int sh = gi * d.sstride + (int)(int8_t)(tp & 0xff), sw = gj * d.sstride + (int)(int8_t)((tp >> 8) & 0xff);
+        if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) g_valid[hh] |= 1u << t;
+      }
+    }
+  }
+  auto dma_a = [&](int cs, int stage, int tp = 0, int t = 0) __attribute__((always_inline)) {
     unsigned char* dst = Ab + stage * A_BYTES + wave * 8 * PL * 4;
     const int c0 = cs * BK + wave * 8;
-    if constexpr (PATCH) {
+    if constexpr (GATHER) {
+      const int sh = ((int)(int8_t)(tp & 0xff) * d.Ws + (int)(int8_t)((tp >> 8) & 0xff)) * 4;
+      const int v0 = ((g_valid[0] >> t) & 1) ? g_base[0] + sh : OOB, v1 = ((g_valid[1] >> t) & 1) ? g_base[1] + sh : OOB;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 512), 4, v0, (c0 + i) * row_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 512 + 256), 4, v1, (c0 + i) * row_bytes, 0, 0);
+      }
+    } else if constexpr (PATCH) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c0 + i) * row_bytes, 0, 0);
@@ -123,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     const int r = mm % hw, h = r / d.Ws, w = r - h * d.Ws;
     valid = 0;
     for (int t = 0; t < ntaps; ++t) {
-      const int tp = a.tap[t];
+      const int tp = a.tap[tap0 + t];
       const int sh = h + (int)(int8_t)(tp & 0xff), sw = w + (int)(int8_t)((tp >> 8) & 0xff);
       if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) valid |= 1u << t;
     }
@@ -220,9 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits)
   int cs_q = cs0, t_q = 0, q = 0;
   auto request = [&](int stage, bool with_a) __attribute__((always_inline)) {
-    dma_b(cs_q, a.tap[t_q], stage);
+    dma_b(cs_q, a.tap[tap0 + t_q], stage);
     if constexpr (!PATCH) {
-      if (with_a) dma_a(cs_q, stage);
+      if (with_a) dma_a(cs_q, stage, a.tap[tap0 + t_q], t_q);
     }
     const bool adv = q + 1 < S;
     q += adv ? 1 : 0;
@@ -230,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     t_q = adv ? (wrap ? 0 : t_q + 1) : t_q;
     cs_q += wrap ? 1 : 0;
   };
-  dma_a(cs0, 0);
+  dma_a(cs0, 0, a.tap[tap0], 0);
 #pragma unroll
   for (int i = 0; i < NB; ++i) request(i, i > 0);
   epi0.load_consts(L);
@@ -244,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   barrier();
   float raw[8];
   bf16x8 fa0[3], fa1[3], fb0[2][3], fb1[2][3];
-  read_ops(a_addr(a.tap[0], 0, 0), Bb, 0, raw, fb0);
+  read_ops(a_addr(a.tap[tap0], 0, 0), Bb, 0, raw, fb0);
   split(raw, fa0);
   int st = 0;  // stage of the current step
   // one step whose successor's images are (or will be, after the barrier) in the ring: both k-steps covered
@@ -272,9 +308,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     mfma12(fa1, fb1);
   } else {
     for (int cs = cs0; cs < cs1; ++cs) {
-      int tp = a.tap[0];
+      int tp = a.tap[tap0];
       for (int t = 0; t + 1 < ntaps; ++t) {
-        const int tp1 = a.tap[t + 1];
+        const int tp1 = a.tap[tap0 + t + 1];
         full_step(tp, t, tp1, t + 1);
         tp = tp1;
       }
@@ -292,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
         mfma12(fa1, fb1);
         wait_all();
         barrier();
-        read_ops(a_addr(a.tap[0], 0, 0), Bb + st1 * B_BYTES, 0, raw, fb0);
+        read_ops(a_addr(a.tap[tap0], 0, 0), Bb + st1 * B_BYTES, 0, raw, fb0);
         split(raw, fa0);
         st = st1;
       } else {
@@ -306,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   // ---- split K: partial tiles meet in the last-arriving workgroup (write-through slabs, ticket; as conv.hip) --------
   if (a.ksplit > 1) {
     constexpr int tile_bytes = BM * BN * 4;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)L * a.ksplit * (BM * BN), 0, a.ksplit * tile_bytes,
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)Lg * a.ksplit * (BM * BN), 0, a.ksplit * tile_bytes,
                                                                   0x00020000);
 #pragma unroll
     for (int y = 0; y < 2; ++y)
@@ -318,9 +354,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(a.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ticket = __hip_atomic_fetch_add(a.cnt + Lg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(a.ksplit - 1);
-      if (last) __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (last) __hip_atomic_store(a.cnt + Lg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = last ? 1 : 0;
     }
     __syncthreads();
@@ -744,21 +780,21 @@ int launch_wide(const ConvK& a, bool patch, hipStream_t st, hipEvent_t e0, hipEv
 
 #undef SGB
 
-template <bool PATCH, bool PRE>
+template <int MODE, bool PRE>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr int NB = PATCH ? 3 : 2;
-  constexpr size_t lds = (size_t)(PATCH ? 1 : NB) * 32 * (PATCH ? 256 : 128) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
+  constexpr int NB = MODE == 1 ? 3 : 2;
+  constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 128) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<PATCH, PRE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return VITTA_ERR_LAUNCH;
     raised = true;
   }
-  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit)), block(256);
+  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit * (a.cls_tiles ? 4 : 1))), block(256);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<PATCH, PRE, NB>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3_kernel<PATCH, PRE, NB>), grid, block, lds, st, a);
+  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB>), grid, block, lds, st, a);
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
@@ -816,10 +852,11 @@ __global__ __launch_bounds__(256) void pack_b3_table_kernel(const PackB3* __rest
 
 namespace vitta_conv {
 
-int launch_b3(const ConvK& a, bool patch, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  if ((a.d.tile & 0xffff) == 128) return launch_wide(a, patch, st, e0, e1);
-  if (patch) return a.pw_prefetch ? launch_one<true, true>(a, st, e0, e1) : launch_one<true, false>(a, st, e0, e1);
-  return a.pw_prefetch ? launch_one<false, true>(a, st, e0, e1) : launch_one<false, false>(a, st, e0, e1);
+int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  if ((a.d.tile & 0xffff) == 128) return launch_wide(a, a.b3 == 2, st, e0, e1);
+  if (a.b3 == 2) return a.pw_prefetch ? launch_one<1, true>(a, st, e0, e1) : launch_one<1, false>(a, st, e0, e1);
+  if (a.b3 == 3) return a.pw_prefetch ? launch_one<2, true>(a, st, e0, e1) : launch_one<2, false>(a, st, e0, e1);
+  return a.pw_prefetch ? launch_one<0, true>(a, st, e0, e1) : launch_one<0, false>(a, st, e0, e1);
 }
 
 }  // namespace vitta_conv

@@ -25,7 +25,9 @@ struct ConvK {
   int sk_aligned;      // stream-K: unit ranges end on tile boundaries (no partial tiles)
   int pw_prefetch;     // conv_pw.hip: request the epilogue's residual / BatchNorm-backward input at the tile's start
   int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
-  int b3;              // 1: conv_b3.hip (split-bf16 operands on the bf16 matrix pipe, 128 x 64 tiles)
+  int cls_tiles;       // VITTA_CONV_PARITY4: tiles (nMt * nNt) per parity class; 0: one class
+  int cls_tap0[5];     // ... first tap of class c (and the end of the last)
+  int b3;              // conv_b3.hip (split-bf16 operands on the bf16 matrix pipe): 1 pointwise, 2 patch (3x3), 3 gathered; 0: not
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -38,7 +40,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 int launch_pointwise(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
 // conv_b3.hip
-int launch_b3(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
+int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1);
 
 // conv_sk.hip
 int launch_stream_k(const ConvK& a, bool gather, hipStream_t st, hipEvent_t e0, hipEvent_t e1);

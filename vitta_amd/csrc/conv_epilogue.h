@@ -16,11 +16,12 @@ struct TileEpilogue {
   bool BWD;
   int BM = 64;  // pixel rows of the workgroup's tile: wave row wm covers [wm * BM / 2, (wm + 1) * BM / 2) in 32-row blocks
   int BN = 64;  // output channels of the tile: column block wn covers [32 wn, 32 wn + 32)
+  int oa, ob;   // scattered output (ostride 2): row / column offset of this tile's parity class
   // constants of the current tile's channel of this lane: loaded at the tile's start, used at its end
   float c_gam = 1.f, c_bet = 0.f, c_mean = 0.f, c_var = 1.f, c_sh = 0.f, c_a = 0.f, c_b = 0.f, c_mu = 0.f, c_gs = 0.f;
 
   __device__ __forceinline__ TileEpilogue(const ConvK& a_, float* red_, int wm_, int wn_, int li_, int lk_, int bm_ = 64, int bn_ = 64)
-      : a(a_), d(a_.d), red(red_), wm(wm_), wn(wn_), li(li_), lk(lk_), BWD(a_.d.flags & VITTA_CONV_BWD_BN), BM(bm_), BN(bn_) {}
+      : a(a_), d(a_.d), red(red_), wm(wm_), wn(wn_), li(li_), lk(lk_), BWD(a_.d.flags & VITTA_CONV_BWD_BN), BM(bm_), BN(bn_), oa(a_.d.oa), ob(a_.d.ob) {}
 
   // The nine per-channel constants of the tile's columns staged in LDS at the tile's start (cst[9][BN], filled by
   // stage_consts with one lane per column) instead of held in registers through the K walk.
@@ -201,7 +202,7 @@ struct TileEpilogue {
         for (int e = 0; e < 4; ++e) {
           const int p = m + e;
           const int n = p / hwg, r = p - n * hwg, gi = r / d.Wg, gj = r - gi * d.Wg;
-          const int h = gi * d.ostride + d.oa, w = gj * d.ostride + d.ob;
+          const int h = gi * d.ostride + oa, w = gj * d.ostride + ob;
           if (h < d.Hy && w < d.Wy) d.y[yrow + (int64_t)n * HWy + h * d.Wy + w] = v[e];
         }
       }

@@ -285,9 +285,17 @@ class TrunkRunner:
         key = (kind, n, h, w, k, stride, pad)
         g = self._geo.get(key)
         if g is None:
-            g = CV.Geometry.forward(n, h, w, k, stride, pad) if kind == "f" else CV.Geometry.dgrad(n, h, w, k, stride, pad)
+            g = CV.Geometry.forward(n, h, w, k, stride, pad) if kind == "f" else \
+                CV.Geometry.dgrad_merged(n, h, w, k, stride, pad) if kind == "bm" else CV.Geometry.dgrad(n, h, w, k, stride, pad)
             self._geo[key] = g
         return g
+
+    def merged_ok(self, geom, pack, c):
+        key = (id(geom), c, CV.ARITH, getattr(pack, "b3", None) is not None)
+        hit = self._geo.get(key)
+        if hit is None:
+            hit = self._geo[key] = CV.merged_dgrad_supported(geom, pack, c, c)
+        return hit
 
     # -- statistics sites --------------------------------------------------------------------------------------
     def open_sites(self, x):
@@ -507,8 +515,13 @@ class TrunkRunner:
             CV.wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p)
         # conv2 data gradient -> d a1
         ga1 = torch.empty(p, P, **f)
-        for g in self.geo("b", n, h, w, 3, s, 1):
-            CV.launch(g, dx2, self.packed(net.conv2, "b", True), ga1, p, p)
+        wb2 = self.packed(net.conv2, "b", True)
+        gm = self.geo("bm", n, h, w, 3, s, 1) if s == 2 else None
+        if gm is not None and self.merged_ok(gm, wb2, p):
+            CV.launch(gm, dx2, wb2, ga1, p, p)  # stride 2: the four parity classes of the input pixel in one launch
+        else:
+            for g in self.geo("b", n, h, w, 3, s, 1):
+                CV.launch(g, dx2, wb2, ga1, p, p)
         del dx2
         # TAM backward
         bn1p = _bn_ptrs(net.bn1)
