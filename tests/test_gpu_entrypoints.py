@@ -25,7 +25,7 @@ def _args(tmp_path, **over):
 
 
 @pytest.mark.parametrize("affine_only", [True, False])
-def test_eval_statistics_then_tta_online_on_gpu(tmp_path, affine_only):
+def test_eval_statistics_then_tta_online_on_gpu(tmp_path, affine_only, abi_calls):
     from corpus.main_eval import eval as run_eval
     model = H.build_tanet(101, 8, 0)
     ckpt = os.path.join(str(tmp_path), "tanet_synth.pth.tar")
@@ -36,6 +36,7 @@ def test_eval_statistics_then_tta_online_on_gpu(tmp_path, affine_only):
     sargs.val_vid_list, sargs.result_dir = "unused", os.path.join(str(tmp_path), "stats_run")
     res, _ = run_eval(args=sargs)
     assert res is None
+    abi_calls.assert_tanet_trunk()  # the statistics producer ran on the hand-written trunk (no library convolution)
     mean_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_mean_*.npy"))[0]
     var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
     assert len(np.load(mean_file, allow_pickle=True)) == 53
@@ -76,6 +77,7 @@ def test_eval_statistics_then_tta_online_swin_on_gpu(tmp_path):
     sargs.val_vid_list, sargs.result_dir = "unused", os.path.join(str(tmp_path), "stats_run")
     res, _ = run_eval(args=sargs)
     assert res is None
+    abi_calls.assert_tanet_trunk()  # the statistics producer ran on the hand-written trunk (no library convolution)
     mean_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_mean_*.npy"))[0]
     var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
     assert len(np.load(mean_file, allow_pickle=True)) == 52

@@ -135,3 +135,38 @@ def test_sgd_all_step_equals_module_path(tmp_path):
               "module.base_model.conv1.weight", "module.base_model.layer2.1.tam.L.0.weight", "module.new_fc.weight"):
         assert (a[2][k] - b[2][k]).norm().item() <= 2e-2 * b[2][k].norm().item() + 1e-9, k
     assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
+
+
+@pytest.mark.parametrize("before_norm", [False, True])
+def test_source_statistics_producer_runs_on_the_trunk_node(before_norm, abi_calls):
+    """compute_statistics' hooks (ComputeNormStatsHook on all 53 BatchNorm2d, corpus/basics.py:220-307,
+    utils/norm_stats_utils.py:18-101): the node supplies every hook's batch moments from the convolution epilogues (the stem's
+    from its raw output), of the BN output or -- before_norm -- of its input through the inverse affine map; same numbers as
+    the module-by-module path (library convolutions + the stand-alone moments kernel on every materialised feature)."""
+    from vitta_amd import trunk
+    from vitta_amd.norm_stats import ComputeNormStatsHook
+    dev = torch.device("cuda:0")
+    model = H.build_tanet(11, 8, 0).to(dev).eval()
+    x = H.seeded_randn((2, 8, 3, 64, 64), 5).to(dev)
+    bn2d = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    res = {}
+    for on in (True, False):
+        hooks = [ComputeNormStatsHook(m, clip_len=8, stat_type="spatiotemp", before_norm=before_norm, batch_size=2) for m in bn2d]
+        old, trunk.ENABLED = trunk.ENABLED, on
+        try:
+            if on:
+                assert trunk.TrunkRunner(model.base_model).eligible(x.view(-1, 3, 64, 64))
+            with torch.no_grad():
+                model(x)
+        finally:
+            trunk.ENABLED = old
+        res[on] = ([h.batch_mean.cpu().double() for h in hooks], [h.batch_var.cpu().double() for h in hooks])
+        for h in hooks:
+            h.close()
+        if on:
+            abi_calls.assert_tanet_trunk()
+    assert len(res[True][0]) == 53
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
+    for a, b in zip(res[True][1], res[False][1]):
+        assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-7

@@ -70,12 +70,27 @@ def _bn_t(bn):
     return (bn.weight, bn.bias, bn.running_mean, bn.running_var)
 
 
-def _engine_hook(bn):
-    """(ok, hook): the engine-bound statistics hook of a BatchNorm2d, or None; ok False if the module carries any other
-    forward hook (those need the module-by-module path)."""
-    hook = None
+def _producer_hooks(bn):
+    """The ComputeNormStatsHook objects (source-statistics producer, utils/norm_stats_utils.py:18-101) on a BatchNorm2d whose
+    moments the node can supply from a convolution epilogue: product backend, spatio-temporal statistics."""
+    from .norm_stats import ComputeNormStatsHook, HipBackend
+    out = []
     for fn in bn._forward_hooks.values():
         owner = getattr(fn, "__self__", None)
+        if isinstance(owner, ComputeNormStatsHook) and isinstance(owner.backend, HipBackend) and owner.stat_type == "spatiotemp":
+            out.append(owner)
+    return out
+
+
+def _engine_hook(bn):
+    """(ok, hook): the engine-bound statistics hook of a BatchNorm2d, or None; ok False if the module carries any forward
+    hook besides that one and the producer hooks of _producer_hooks (those need the module-by-module path)."""
+    hook = None
+    producers = _producer_hooks(bn)
+    for fn in bn._forward_hooks.values():
+        owner = getattr(fn, "__self__", None)
+        if owner is not None and any(owner is p for p in producers):
+            continue
         if (owner is not None and getattr(owner, "engine", None) is not None and hasattr(owner, "index")
                 and getattr(owner, "kind", None) == "bn2d" and not owner.before_norm and hook is None):
             hook = owner
@@ -100,6 +115,32 @@ class Site:
         sl = plan.channel_slice(index)
         self.stats = (engine.src_mean[sl], plan.s1[sl], plan.s2[sl])
         self.inj = (plan.mu[sl], plan.coef_a[sl], plan.coef_b[sl], engine.gscale)
+
+
+class ProducerSite:
+    """A BatchNorm2d carrying ComputeNormStatsHook objects: the convolution epilogue deposits sum(z - k), sum (z - k)^2 of
+    z = bn(conv output) with k = the BN's bias; finish() turns them into the hooks' batch_mean / batch_var -- of z, or of
+    the BN INPUT (before_norm) through the inverse of the eval-mode affine map z = gamma (x - rm) / sqrt(rv + eps) + beta."""
+    inj = None
+
+    def __init__(self, bn, hooks, device):
+        c = bn.num_features
+        self.bn, self.hooks = bn, hooks
+        self.s = torch.zeros(2, c, dtype=torch.float32, device=device)
+        self.stats = (bn.bias.detach(), self.s[0], self.s[1])
+
+    def finish(self, count):
+        bn = self.bn
+        d1 = self.s[0].double() / count
+        mean_z = bn.bias.detach().double() + d1
+        var_z = (self.s[1].double() / count - d1 * d1).clamp_(min=0.0)
+        for h in self.hooks:
+            if h.before_norm:
+                inv = torch.sqrt(bn.running_var.double() + bn.eps) / bn.weight.detach().double()
+                h.batch_mean = (bn.running_mean.double() + (mean_z - bn.bias.detach().double()) * inv).float()
+                h.batch_var = (var_z * inv * inv).float()
+            else:
+                h.batch_mean, h.batch_var = mean_z.float(), var_z.float()
 
 
 class TrunkRunner:
@@ -198,8 +239,12 @@ class TrunkRunner:
                 if m._forward_hooks:
                     return False
         ok, hook = _engine_hook(net.bn1)
-        if not ok or hook is not None:  # a hooked stem BN takes the module path (the shipped configuration hooks layer3/4)
-            return False
+        if not ok or hook is not None:  # an ENGINE hook on the stem BN takes the module path (the shipped configuration hooks
+            return False                # layer3/4); producer hooks get the stem's moments from its raw output
+        for bn in [net.bn1] + [m for b in blocks for m in ([b.net.bn1, b.net.bn2, b.net.bn3] + ([b.net.downsample[1]] if b.net.downsample is not None else []))]:
+            for h in _producer_hooks(bn):
+                if h.before_norm and bool((bn.weight.detach() == 0).any()):
+                    return False  # the inverse affine map needs gamma != 0
         return len(engines) <= 1
 
     # -- caches ------------------------------------------------------------------------------------------------
@@ -298,6 +343,15 @@ class TrunkRunner:
         return hit
 
     # -- statistics sites --------------------------------------------------------------------------------------
+    def open_producer_sites(self, x):
+        """{id(bn): ProducerSite} for the BatchNorm2d modules of the blocks that carry source-statistics producer hooks."""
+        out = {}
+        for bn in self.bn2d_modules()[1:]:
+            hooks = _producer_hooks(bn)
+            if hooks:
+                out[id(bn)] = ProducerSite(bn, hooks, x.device)
+        return out
+
     def open_sites(self, x):
         """{bn module: Site} for this step; the engine is switched to direct deposit (conv epilogues add into [s1 | s2])."""
         hooked, engine = [], None
@@ -345,6 +399,20 @@ class TrunkRunner:
         check(lib().vitta_stem_bn_relu_pool_fwd_f32(_p(y), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
                                                     n, c, h, w, _p(pooled), _stream()), "vitta_stem_bn_relu_pool_fwd_f32")
         return y, pooled
+
+    def stem_producer(self, y, hooks):
+        from . import ops
+        bn = self.net.bn1
+        if y is None:
+            raise RuntimeError("statistics-producer hooks on the stem BatchNorm need the stem inside the node")
+        mean_x, var_x = ops.moments(y, "bn2d")
+        scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        for h in hooks:
+            if h.before_norm:
+                h.batch_mean, h.batch_var = mean_x, var_x
+            else:
+                h.batch_mean = (bn.bias.detach().double() + (mean_x.double() - bn.running_mean.double()) * scale).float()
+                h.batch_var = (var_x.double() * scale * scale).float()
 
     def stem_backward(self, y, gpool, sink, x=None):
         from .ops import _ptr4
@@ -455,6 +523,11 @@ class TrunkRunner:
         self.refresh_packs(x.device, adapt=keep)
         self._adapt_pass = keep
         sites = self.open_sites(x) if keep else {}
+        producers = self.open_producer_sites(x)
+        if producers:
+            if any(k in sites for k in producers):
+                raise RuntimeError("a BatchNorm2d carries both an engine hook and a statistics-producer hook: use the module path")
+            sites = {**sites, **producers}
         if pooled_in is None:
             y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
         else:
@@ -468,6 +541,15 @@ class TrunkRunner:
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
+        if producers:  # source-statistics producer: hand every hook its batch moments
+            shapes = self.feature_shapes(x)
+            for site in producers.values():
+                frames, _, hw, _ = shapes[id(site.bn)]
+                site.finish(frames * hw)
+            stem_hooks = _producer_hooks(self.net.bn1)
+            if stem_hooks:  # the stem's BN output is never materialised: moments of the raw 7x7 output, mapped through the BN
+                self.stem_producer(y, stem_hooks)
+            sites = {k: v for k, v in sites.items() if k not in producers}
         return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None,
                           x=x if (keep and pooled_in is None and self.net.conv1.weight.requires_grad) else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
                           last=(c, n, h, w))
