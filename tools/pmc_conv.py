@@ -14,7 +14,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def summarise(path, out_json, trace=None):
+    """Per (kernel instantiation, grid): the counters averaged over the launches, plus ratios that need no clock assumption
+    (everything per wave: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles --
+    MI355X_MICROARCH.md, table of per-instruction constants) and one that does (mfma_busy_fraction_of_kernel: 2.4 GHz)."""
     import json
+    import re
     rows = list(csv.DictReader(open(path)))
     dur = {}
     if trace:
@@ -26,7 +30,8 @@ def summarise(path, out_json, trace=None):
         name = r["Kernel_Name"]
         if "conv_" not in name or "pack" in name:
             continue
-        k = name.split("(")[0].split("::")[-1] + " grid=" + r.get("Grid_Size", "?")
+        m = re.search(r"(conv_\w+_kernel<[^>]*>|conv_\w+_kernel)", name)
+        k = (m.group(1) if m else name[:60]) + " workgroups=" + str(int(r.get("Grid_Size", "0")) // 256)
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in calls[k] and r["Dispatch_Id"] in dur:
             agg[k]["duration_us"] += dur[r["Dispatch_Id"]]
@@ -36,17 +41,27 @@ def summarise(path, out_json, trace=None):
         n = len(calls[k])
         d = {name: v / n for name, v in c.items()}
         d["launches"] = n
-        if d.get("SQ_BUSY_CU_CYCLES"):
-            d["mfma_busy_fraction_of_busy_cu_time"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * d["SQ_BUSY_CU_CYCLES"])
-        if d.get("GRBM_GUI_ACTIVE") and d.get("duration_us"):
-            d["clock_ghz"] = d["GRBM_GUI_ACTIVE"] / d["duration_us"] / 1e3
-            if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-                d["mfma_busy_fraction_of_kernel"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * d["GRBM_GUI_ACTIVE"])
+        waves = 4.0 * int(k.rsplit("=", 1)[1])
         if d.get("SQ_WAVE_CYCLES"):
+            life = 4.0 * d["SQ_WAVE_CYCLES"] / waves
+            d["cycles_per_wave_lifetime"] = life
             for nm in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_LDS",
-                       "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_VALU_MFMA_F32"):
+                       "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"):
                 if nm in d:
                     d[nm + "/wave_cycles"] = d[nm] / d["SQ_WAVE_CYCLES"]
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+                # one wave's MFMAs occupy its SIMD's matrix pipe for this share of the wave's lifetime; two workgroups per CU
+                # = two waves per SIMD: the pipe is busy about twice that while the waves are alive
+                d["mfma_cycles_per_wave"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / waves
+                d["mfma_share_of_wave_lifetime"] = d["mfma_cycles_per_wave"] / life
+        for nm in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_MFMA"):
+            if nm in d:
+                d[nm + "_per_wave"] = d[nm] / waves
+        if d.get("duration_us") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            d["mfma_busy_fraction_of_kernel"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * d["duration_us"] * 2400.0)
+            d["mfma_busy_fraction_note"] = "matrix-pipe busy cycles / (1024 SIMDs x kernel duration at 2.4 GHz)"
+        if d.get("SQ_LDS_IDX_ACTIVE"):
+            d["lds_bank_conflict_share"] = d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"]
         out[k] = d
     json.dump(out, open(out_json, "w"), indent=1)
     print(json.dumps(out, indent=1))

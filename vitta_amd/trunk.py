@@ -150,6 +150,7 @@ class TrunkRunner:
         self._step_packs = {}
         self._repack = {}
         self._geo = {}
+        self.after_block = None  # callable(block index) run after each block's backward (tta: bucketed gradient exchange)
 
     # -- structure ---------------------------------------------------------------------------------------------
     def blocks(self):
@@ -659,9 +660,12 @@ class TrunkRunner:
         G = torch.empty(c, n * h * w, dtype=torch.float32, device=gfeat.device)
         check(lib().vitta_avgpool_cm_bwd_f32(_p(gfeat.contiguous()), c, n, h * w, _p(G), _stream()), "vitta_avgpool_cm_bwd_f32")
         blocks = self.blocks()
-        for b, sv in zip(reversed(blocks), reversed(ctxd["tape"])):
-            G = self.block_backward(b, sv, G, ctxd["sites"], sink)
+        for i in range(len(blocks) - 1, -1, -1):
+            sv = ctxd["tape"][i]
+            G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink)
             sv.clear()
+            if self.after_block is not None:
+                self.after_block(i)
         h0, w0 = ctxd["pooled_hw"]
         if ctxd["stem"] is None:  # the stem ran outside (trainable 7x7 convolution): hand its output gradient back
             return CV.from_cm(G, n, h0, w0)

@@ -17,6 +17,7 @@ without resetting the model), same log-line formats.  MI355X-first differences:
 * no per-video host synchronisation: per-video metrics are read back with a lag (DeferredLog).
 """
 import copy as cp
+import os
 import os.path as osp
 import time
 
@@ -167,9 +168,12 @@ class FlatArena:
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         self._all_views, self._learnt = [], False
+        self.ranges = {}  # id(param) -> (first float, end) in the arena
+        self._pending = []  # async bucket reductions of the running step
         with torch.no_grad():
             for p in self.params:
                 k = p.numel()
+                self.ranges[id(p)] = (off, off + pad(k))
                 flat[off:off + k].copy_(p.data.reshape(-1))
                 p.data = flat[off:off + k].view_as(p)
                 p.grad = self.grad[off:off + k].view_as(p)
@@ -210,6 +214,34 @@ class FlatArena:
 
     def all_reduce(self):
         torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+
+    # -- bucketed exchange: slices of the arena reduced as soon as their gradients are final ----------------------------
+    def span(self, params):
+        """[lo, hi) of the arena covered by `params` (None if none of them is trainable); they must be contiguous."""
+        r = [self.ranges[id(p)] for p in params if id(p) in self.ranges]
+        if not r:
+            return None
+        lo, hi = min(a for a, _ in r), max(b for _, b in r)
+        if sum(b - a for a, b in r) != hi - lo:
+            raise ValueError("the parameters of a bucket must be contiguous in the arena")
+        return lo, hi
+
+    def all_direct(self, params):
+        """Every trainable parameter of the group has its gradient written straight into the arena by our kernels (known
+        after the first backward): only then is the slice final when the group's backward has run."""
+        return self._learnt and all(getattr(p, "_vitta_direct_grad", False) for p in params if id(p) in self.ranges)
+
+    def reduce_range(self, lo, hi, async_op=True):
+        if hi <= lo:
+            return
+        w = torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM, async_op=async_op)
+        if async_op and w is not None:
+            self._pending.append(w)
+
+    def wait_pending(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
 
 class DeferredLog:
@@ -302,6 +334,14 @@ class ViTTAAdapter:
                                                  weight_decay=args.weight_decay)
         self.params = self.arena.params
         self.bucket = self.arena if (self.world > 1 or FORCE_EXCHANGES) else None
+        # SGD over all parameters exchanges 100 MB (TANet) per step: the arena is cut at bottleneck-block boundaries into
+        # `grad_buckets` slices, each all-reduced from INSIDE the backward as soon as its blocks are done (reverse layer
+        # order), so the exchange runs beside the remaining data / weight gradient launches; the affine-only arena (0.2 MB)
+        # stays one all-reduce.  VITTA_GRAD_BUCKETS=1: one monolithic all-reduce after the backward.
+        self.grad_buckets = int(os.environ.get("VITTA_GRAD_BUCKETS", "4")) if not getattr(args, "update_only_bn_affine", False) else 1
+        self._bucket_plan = None
+        self._armed = None
+        self.n_from_backward = 0  # bucket reductions launched from inside a backward so far (tests)
 
         self.n_clips = _n_clips(args)
         self.if_pred_consistency = args.if_pred_consistency if args.if_sample_tta_aug_views else False
@@ -440,8 +480,8 @@ class ViTTAAdapter:
                 g["seg_fwd"].replay()
                 self.engine.exchange()
                 g["seg_bwd"].replay()
-                if self.bucket is not None:
-                    self.bucket.all_reduce()
+                self._armed = None
+                self._exchange_end(ran_backward=False)
                 g["seg_opt"].replay()
             return g["adapt_out"], g["eval_out_overlapped"]
         return self._step_eager(tta_input, eval_input, has_video)
@@ -475,6 +515,71 @@ class ViTTAAdapter:
         out = self._adapt_step_eager(tta_input, has_video, join=side)
         return out, ev
 
+    # -- gradient exchange --------------------------------------------------------------------------------------------
+    def bucket_plan(self):
+        """[(first block index, lo, hi)] in LAUNCH order (last blocks first) + the complement ranges reduced after the
+        backward; None when the exchange stays monolithic (one rank, affine-only mode, no hand-written trunk)."""
+        if self.bucket is None or self.grad_buckets <= 1 or self.args.arch != "tanet":
+            return None
+        if self._bucket_plan is not None:
+            return self._bucket_plan
+        runner = getattr(self.model.module.base_model, "_vitta_trunk", None)
+        if runner is None:
+            return None
+        blocks = runner.blocks()
+        spans = [self.arena.span(list(b.parameters())) for b in blocks]
+        if any(sp is None for sp in spans) or any(spans[i][1] != spans[i + 1][0] for i in range(len(spans) - 1)):
+            return None
+        total = spans[-1][1] - spans[0][0]
+        plan, hi, acc = [], spans[-1][1], 0
+        for i in range(len(blocks) - 1, -1, -1):  # walk the blocks the way the backward does
+            acc += spans[i][1] - spans[i][0]
+            if acc >= total / self.grad_buckets or i == 0:
+                plan.append((i, spans[i][0], hi))
+                hi, acc = spans[i][0], 0
+        n = self.arena.grad.numel()
+        self._bucket_plan = dict(buckets=plan, rest=[(0, spans[0][0]), (spans[-1][1], n)], blocks=blocks)
+        return self._bucket_plan
+
+    def _exchange_begin(self):
+        """Before the backward: arm the trunk so that a bucket is reduced the moment its first block's backward returns."""
+        plan = self.bucket_plan()
+        self._armed = None
+        if plan is None:
+            return
+        runner = self.model.module.base_model._vitta_trunk
+        if not all(self.arena.all_direct(list(b.parameters())) for b in plan["blocks"]):
+            return  # (first step, or a block with an autograd-accumulated parameter): everything after the backward
+        first = {i: (lo, hi) for i, lo, hi in plan["buckets"]}
+
+        def after_block(index):
+            if index in first:
+                self.arena.reduce_range(*first[index], async_op=True)
+                self.n_from_backward += 1
+
+        runner.after_block = after_block
+        self._armed = runner
+
+    def _exchange_end(self, ran_backward=True):
+        """After the backward (+ the copy of autograd-accumulated gradients into the arena): whatever was not reduced from
+        inside it, in the same order on every rank; then every pending reduction joins the stream."""
+        if self.bucket is None:
+            return
+        plan = self.bucket_plan()
+        if plan is None:
+            self.bucket.all_reduce()
+            return
+        armed = self._armed is not None and ran_backward
+        if self._armed is not None:
+            self._armed.after_block = None
+            self._armed = None
+        if not armed:  # same collectives, same order as the armed ranks issue them
+            for _, lo, hi in plan["buckets"]:
+                self.arena.reduce_range(lo, hi, async_op=True)
+        for lo, hi in plan["rest"]:
+            self.arena.reduce_range(lo, hi, async_op=True)
+        self.arena.wait_pending()
+
     def adapt_step(self, input, has_video=True):
         """One gradient step on one (already device-resident, already reshaped) TTA input.
         `has_video=False`: ragged tail of a data-parallel run -- this rank only takes part in the two
@@ -490,8 +595,8 @@ class ViTTAAdapter:
                 g["seg_fwd"].replay()
                 self.engine.exchange()
                 g["seg_bwd"].replay()
-                if self.bucket is not None:
-                    self.bucket.all_reduce()
+                self._armed = None
+                self._exchange_end(ran_backward=False)
                 g["seg_opt"].replay()
             return g["adapt_out"]
         return self._adapt_step_eager(input, has_video)
@@ -504,14 +609,15 @@ class ViTTAAdapter:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
             output, loss_reg, loss_consis = self.forward_losses(input, actual_bz)
             self.arena.before_backward()
+            self._exchange_begin()
             self.total_loss(loss_reg, loss_consis).backward()
             self.arena.after_backward()
         else:
             if self.engine is None:
                 raise RuntimeError("ragged data-parallel steps need the batched engine")
             loss_reg = self.engine.finish_empty()
-        if self.bucket is not None:
-            self.bucket.all_reduce()
+            self._armed = None
+        self._exchange_end(ran_backward=has_video)
         if join is not None:  # an evaluation on a side stream still reads the weights this update overwrites
             torch.cuda.current_stream().wait_stream(join)
         self.optimizer.step()
@@ -555,7 +661,7 @@ class ViTTAAdapter:
             self.optimizer.step()
         g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
 
-    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False, collectives_in_graph=False):
+    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False, collectives_in_graph=None):
         """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
         evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
         the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
@@ -569,6 +675,22 @@ class ViTTAAdapter:
                                "EMA scalars that cannot be captured)")
         if self.engine.plan is None:
             raise RuntimeError("run at least one eager step before capturing")
+        if collectives_in_graph is None:
+            # data-parallel over RCCL: ONE graph with both all-reduces (and the bucketed gradient exchange inside the
+            # backward) captured -- no host round trip between segments; gloo (host collectives) and
+            # VITTA_GRAPH_COLLECTIVES=0 keep three segments with the exchanges launched eagerly between them
+            collectives_in_graph = (self.bucket is not None and not segmented and torch.distributed.is_initialized()
+                                    and torch.distributed.get_backend() == "nccl" and os.environ.get("VITTA_GRAPH_COLLECTIVES", "1") != "0")
+        if collectives_in_graph:
+            try:
+                return self._capture(tta_input, eval_input, segmented, overlap_eval, True)
+            except Exception as e:  # noqa: BLE001  (a capture the collectives library refuses must not cost the run)
+                import warnings
+                warnings.warn(f"data-parallel step not captured as one graph ({e!r}); using three segments")
+                torch.cuda.synchronize()
+        return self._capture(tta_input, eval_input, segmented, overlap_eval, False)
+
+    def _capture(self, tta_input, eval_input, segmented, overlap_eval, collectives_in_graph):
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
         self.set_adapt_mode()
