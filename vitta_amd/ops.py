@@ -851,6 +851,26 @@ def head_linear_supported(x, linear):
 KTIMING = None
 GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128) / 3 (64 x 64)
 DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
+# fp32-accuracy dense layers on the bf16 matrix pipe (gemm_b3.hip: operands split into three bf16 terms, six products per
+# multiply-add -- the arithmetic of conv_b3.hip) wherever the weight is frozen (its split image is made once) and the shape
+# qualifies; VITTA_DENSE_ARITH=f32: the exact-fp32 MFMA kernel everywhere
+DENSE_B3 = __import__("os").environ.get("VITTA_DENSE_ARITH", "b3") == "b3"
+
+
+class B3Operand:
+    """Split-bf16 image of a dense layer's B operand [N][K] (vitta_gemm_pack_b3)."""
+    __slots__ = ("img", "n", "k")
+
+    def __init__(self, b):
+        n, k = b.shape
+        self.n, self.k = int(n), int(k)
+        self.img = torch.empty(int(lib().vitta_gemm_pack_b3_bytes(self.n, self.k)), dtype=torch.uint8, device=b.device)
+        check(lib().vitta_gemm_pack_b3(_p(b), _p(self.img), self.n, self.k, _stream()), "vitta_gemm_pack_b3")
+
+    @property
+    def shape(self):
+        return (self.n, self.k)
+
 _W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, operand copy): frozen weights are prepared once
 
 
@@ -863,6 +883,16 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     gelu'(aux)).  b float32: vitta_gemm_nt_f32 (exact fp32 MFMA); b bfloat16: vitta_gemm_nt_bf16w_f32 (a is rounded to
     bf16 while staged)."""
     _require_cuda_f32(a, "a")
+    if isinstance(b, B3Operand):
+        m, k = a.shape
+        assert a.is_contiguous() and k == b.k
+        y = out if out is not None else torch.empty(m, b.n, dtype=torch.float32, device=a.device)
+        tm = KTIMING("gemm_b3", 2.0 * m * b.n * k) if KTIMING is not None else None
+        check(lib().vitta_gemm_nt_b3_f32(_p(a), _p(b.img), _p(bias), _p(aux), _p(y), _p(pre), m, b.n, k, mode, _stream()),
+              "vitta_gemm_nt_b3_f32")
+        if tm is not None:
+            tm.stop()
+        return y
     if not b.is_cuda or b.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.VittaHipError(f"b must be a float32 or bfloat16 device tensor (got {b.dtype} on {b.device})")
     m, k = a.shape
@@ -878,27 +908,36 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     return y
 
 
-def _operand(weight, transposed):
+def _operand(weight, transposed, m_rows=None):
     """The B operand of a dense product: the nn.Linear weight itself ([out][in], forward) or its [in][out] transpose (data
     gradient), as bfloat16 when DENSE_BF16 is on and the reduction length allows.  A frozen weight (LN-affine adaptation)
     is prepared once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
     `_version`, and a captured graph must hold the copy launch)."""
     w2d = weight.detach().reshape(weight.shape[0], -1)  # a Conv3d patch-embedding kernel counts as [out][in * kd * kh * kw]
     kred = w2d.shape[0] if transposed else w2d.shape[1]
+    nout = w2d.shape[1] if transposed else w2d.shape[0]
     bf16 = bool(DENSE_BF16 and kred % 64 == 0)
-    if not transposed and not bf16:
+    # gemm_b3.hip's 128 x 128 tiles pay off where the launch has enough of them and a long enough K walk (measured on the
+    # Swin-B shapes, tools/debug/gemm_b3_probe.py: +10-15 % at >= 192 tiles and K >= 256, behind the 64 x 64 fp32 tiles
+    # below that; 210 vs 136 TF on 100+ GFLOP products)
+    b3 = bool(DENSE_B3 and not bf16 and not weight.requires_grad and m_rows is not None and kred >= 256
+              and ((int(m_rows) + 127) // 128) * (int(nout) // 128) >= 192
+              and lib().vitta_gemm_b3_supported(int(m_rows), int(nout), int(kred)))
+    if not transposed and not bf16 and not b3:
         return w2d
 
     def make():
         w = w2d.t() if transposed else w2d
+        if b3:
+            return B3Operand(w.contiguous())
         return w.to(torch.bfloat16).contiguous() if bf16 else w.contiguous()
 
     if weight.requires_grad:
         return make()
     import weakref
-    key = (id(weight), transposed, bf16)
+    key = (id(weight), transposed, bf16, b3)
     ent = _W_CACHE.get(key)
-    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2].device == weight.device:
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version and (b3 or ent[2].device == weight.device):
         return ent[2]
     op = make()
     _W_CACHE[key] = (weakref.ref(weight), weight._version, op)
@@ -944,7 +983,7 @@ class DenseLinear(torch.autograd.Function):
         x2 = x.reshape(-1, shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        y = gemm_nt(x2, _operand(weight, False), bias)
+        y = gemm_nt(x2, _operand(weight, False, x2.shape[0]), bias)
         ctx.save_for_backward(x2 if weight.requires_grad else None, weight, bias)
         ctx.xshape = shape
         return y.view(shape[:-1] + (weight.shape[0],))  # (weight may be a Conv3d kernel [out, ...]: its flattened form is used)
@@ -955,7 +994,7 @@ class DenseLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        dx = gemm_nt(g2, _operand(weight, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = gemm_nt(g2, _operand(weight, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw = _weight_grad(weight, ctx.needs_input_grad[1], g2, x2)
         db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g2)
         return dx, dw, db
@@ -974,8 +1013,8 @@ class FusedMlp(torch.autograd.Function):
             x2 = x2.contiguous()
         need = any(ctx.needs_input_grad)
         h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
-        a = gemm_nt(x2, _operand(w1, False), b1, mode=1, pre=h)
-        y = gemm_nt(a, _operand(w2, False), b2)
+        a = gemm_nt(x2, _operand(w1, False, x2.shape[0]), b1, mode=1, pre=h)
+        y = gemm_nt(a, _operand(w2, False, x2.shape[0]), b2)
         train_w = w1.requires_grad or w2.requires_grad
         ctx.save_for_backward(x2 if train_w else None, h, a if train_w else None, w1, b1, w2, b2)
         ctx.xshape = shape
@@ -987,8 +1026,8 @@ class FusedMlp(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        gh = gemm_nt(g2, _operand(w2, True), mode=2, aux=h)
-        dx = gemm_nt(gh, _operand(w1, True)).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gh = gemm_nt(g2, _operand(w2, True, g2.shape[0]), mode=2, aux=h)
+        dx = gemm_nt(gh, _operand(w1, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1 = _weight_grad(w1, ctx.needs_input_grad[1], gh, x2)
         db1 = _bias_grad(b1, b1 is not None and ctx.needs_input_grad[2], gh)
         dw2 = _weight_grad(w2, ctx.needs_input_grad[3], g2, a)
