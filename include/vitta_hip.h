@@ -457,7 +457,8 @@ typedef struct vitta_conv_desc {
    * is caller-owned, must be ZERO when first used (its first 64 KiB hold the counters, which return to zero after every
    * launch; slabs follow), >= 256-byte aligned,
    * and must not be shared by launches that may run concurrently (one per stream).  NULL / too small: no split. */
-  int32_t ksplit; /* 0: library's choice; 1: never split; n: exactly n slices (VITTA_ERR_WORKSPACE if it does not fit) */
+  int32_t ksplit; /* 0: library's choice; 1: never split; n: exactly n slices (VITTA_ERR_WORKSPACE if it does not fit);
+                   * -1: never split, and persistent workgroups where the split-bf16 pointwise form has them (tools / tests) */
   void* workspace;
   int64_t workspace_bytes;
   /* Optional split-bf16 image of the same weights (vitta_conv_pack_b3 of the packed [n_wtaps][C][K] array).  When given

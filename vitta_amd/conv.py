@@ -239,7 +239,7 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
     d.C, d.K, d.flags, d.tile, d.ksplit = int(c), int(k), int(flags) | (_lib.CONV_PARITY4 if geom.cls_ntaps is not None else 0), int(tile), int(ksplit)
     geom.fill(d)
-    if ksplit != 1:
+    if ksplit not in (1, -1):
         ws = workspace(x.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -687,7 +687,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // Split-bf16 operands on the bf16 matrix pipe (conv_b3.hip) whenever the caller supplied the split weight image and the
   // shape fits its one configuration: 128 x 64 tiles, 32-channel slabs (VITTA_CONV_B3=0 keeps the exact-fp32 kernels)
   if (d.w_b3 && b3_enabled() && d.C % 32 == 0 && d.K % 64 == 0 && !(d.flags & VITTA_CONV_PRO_BN_RELU) &&
-      (h->tile == 0 || h->tile == ((128 << 16) | 64) || (h->tile == ((128 << 16) | 128) && d.K % 128 == 0)) &&
+      (h->tile == 0 || h->tile == ((128 << 16) | 64) || h->tile == ((64 << 16) | 64) || (h->tile == ((128 << 16) | 128) && d.K % 128 == 0)) &&
       (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
     // form: pointwise rows, one patch per channel slab (stride-1 taps inside the halo), or gathered (anything else)
     const int form = is_vector_geometry(d) ? 1 : b3_patch_geometry(d, 63) ? 2 : 3;
@@ -710,7 +710,12 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     const bool wide_ok = d.K % 128 == 0 && (form == 1 || b3_patch_geometry(d, 32));
     const bool wide = !parity4 && (h->tile ? (h->tile & 0xffff) == 128 && wide_ok : (wide_on && wide_ok));
     if (h->tile && (h->tile & 0xffff) == 128 && !wide_ok) return VITTA_ERR_UNSUPPORTED;
-    const int bm = 128, bn = wide ? 128 : 64;
+    // 64 x 64 tiles (two-wave workgroups, four per CU) for pointwise launches: on request, or (VITTA_CONV_B3_BM64=1) always;
+    // measured 15-40 % SLOWER than 128 x 64 on every pointwise layer of the trunk (the weight image is re-read per 64 rows)
+    static const int bm64_on = env_int("VITTA_CONV_B3_BM64", 0);
+    if (h->tile == ((64 << 16) | 64) && form != 1) goto exact_fp32;  // (64 x 64 tiles of a 3x3: the exact-fp32 kernels)
+    const bool small = form == 1 && !parity4 && (h->tile ? (h->tile >> 16) == 64 : bm64_on != 0);
+    const int bm = small ? 64 : 128, bn = wide ? 128 : 64;
     a.nMt = (int)((M + bm - 1) / bm);
     a.nNt = d.K / bn;
     a.d.tile = (bm << 16) | bn;
@@ -721,7 +726,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     for (int c = 0; c < 4; ++c) a.cls_tap0[c + 1] = a.cls_tap0[c] + (parity4 ? d.cls_ntaps[c] : 0);
     int ks = 1;
     if (tiles > MAX_SPLIT_TILES) ks = 1;
-    else if (d.ksplit > 0) ks = d.ksplit;
+    else if (d.ksplit != 0) ks = d.ksplit > 0 ? d.ksplit : 1;
     else {
       static const int min_wgs = env_int("VITTA_CONV_B3_MIN_WGS", 384), min_steps = env_int("VITTA_CONV_B3_MIN_STEPS", 4);
       const int taps_min = parity4 ? 1 : d.ntaps;  // (the lightest class of a parity-merged launch has one tap)
@@ -738,6 +743,13 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
     a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
     a.b3 = form;
+    // pointwise launches with more tiles than resident workgroups (two per CU) can run the persistent form of conv_b3.hip,
+    // every workgroup a contiguous range of tiles with the request ring running on across tile boundaries -- on request
+    // only (ksplit = -1, or VITTA_CONV_B3_PERSIST=1): measured EQUAL to one tile per workgroup on the trunk's shapes (64 ->
+    // 256 at 56 x 56: 28.9 vs 28.8 us; the per-step request latency, not the per-tile prologue, sets the pace)
+    static const int persist_on = env_int("VITTA_CONV_B3_PERSIST", 0);
+    if ((persist_on || d.ksplit == -1) && form == 1 && !wide && !small && ks == 1 && !parity4 && a.contig && tiles > 2 * resident_slots() / 3)
+      a.sk_G = 2 * resident_slots() / 3;
     static const int pf = env_int("VITTA_CONV_PW_PREFETCH", 1);
     a.pw_prefetch = (pf && a.contig &&
                      ((d.flags & VITTA_CONV_BWD_BN) || ((d.flags & VITTA_CONV_RES) && d.res && !(d.flags & VITTA_CONV_RES_HALF)))) ? 1 : 0;

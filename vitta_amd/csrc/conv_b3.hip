@@ -56,18 +56,22 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 // (one instruction = 64 pixels of one channel row; a pixel whose tap falls outside the plane requests out of range and
 // lands as zero), two stages like the pointwise form.
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-template <int MODE, bool PRE, int NB>
-__global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
+// NW = waves per workgroup = 32-row blocks of the tile: 4 (128 x 64 tiles, two workgroups per CU) or, pointwise only, 2
+// (64 x 64 tiles, 40 KB of LDS: FOUR workgroups per CU -- twice the independent request chains for the same wave count)
+template <int MODE, bool PRE, int NB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
-  constexpr int BM = 128, BN = 64, BK = 32, HALO = 64;
-  constexpr int PL = PATCH ? 256 : 128;   // pixels per channel row of the A image
+  static_assert(NW == 4 || (NW == 2 && MODE == 0), "two-wave workgroups: pointwise form only");
+  constexpr int BM = 32 * NW, BN = 64, BK = 32, HALO = 64, NTHR = 64 * NW;
+  constexpr int PL = PATCH ? 256 : BM;    // pixels per channel row of the A image
   constexpr int NA = PATCH ? 1 : NB;      // A stages (B: NB)
-  constexpr int PER_STEP = PATCH ? 3 : GATHER ? 19 : 7;  // LDS-DMA instructions of a wave per step
+  constexpr int PER_STEP = PATCH ? 12 / NW : GATHER ? 16 + 12 / NW : 4 + 12 / NW;  // LDS-DMA instructions of a wave per step
+  constexpr int RPW = BK / NW;            // channel rows of an A stage a wave requests
   constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Ab = lds;                        // [NA][BK][PL] fp32
   unsigned char* const Bb = lds + NA * A_BYTES;         // [NB][3 planes][4 channel octets][BN][8] bf16
-  float* const red = reinterpret_cast<float*>(Bb + NB * B_BYTES);  // [3][2][32][2]
+  float* const red = reinterpret_cast<float*>(Bb + NB * B_BYTES);  // [NW - 1][2][32][2]
   int* const flag = reinterpret_cast<int*>(red + 384);
 
   const vitta_conv_desc& d = a.d;
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   const int S = (cs1 - cs0) * ntaps;  // steps = (channel slab, tap) pairs
 
   // wave w owns pixel rows 32 w .. 32 w + 31 and all 64 output channels (two 32 x 32 accumulators)
-  TileEpilogue epi0(a, red, wave >> 1, 0, li, lk, BM), epi1(a, red, wave >> 1, 1, li, lk, BM);
-  const int xb = wave & 1;
+  TileEpilogue epi0(a, red, NW == 4 ? wave >> 1 : wave, 0, li, lk, BM), epi1(a, red, NW == 4 ? wave >> 1 : wave, 1, li, lk, BM);
+  const int xb = NW == 4 ? wave & 1 : 0;
   if (a.cls_tiles) {
     epi0.oa = epi1.oa = cls >> 1;
     epi0.ob = epi1.ob = cls & 1;
@@ -101,7 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   // ---- LDS-DMA side ----------------------------------------------------------------------------------------------------
   // A, patch: one instruction = one channel row (256 pixels; lane 0 out of range: positions 0..3 stay zero); wave w loads
   // rows 8 w .. 8 w + 7.  A, pointwise: one instruction = two channel rows (2 x 128 pixels), four per wave.
-  const int voff_a = PATCH ? (lane == 0 ? OOB : (m0 - HALO + 4 * lane) * 4) : lk * row_bytes + min(m0 + 4 * li, a.Mtot - 4) * 4;
+  // (pointwise: one instruction = 256 / PL channel rows of PL pixels)
+  const int voff_a = PATCH ? (lane == 0 ? OOB : (m0 - HALO + 4 * lane) * 4)
+                           : (lane / (PL / 4)) * row_bytes + min(m0 + 4 * (lane % (PL / 4)), a.Mtot - 4) * 4;
   // gathered: the lane's two pixels (lane, lane + 64 of the tile): source offset of tap (0, 0), validity bit per tap
   int g_base[2] = {0, 0};
   unsigned g_valid[2] = {0, 0};
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     }
   }
   auto dma_a = [&](int cs, int stage, int tp = 0, int t = 0) __attribute__((always_inline)) {
-    unsigned char* dst = Ab + stage * A_BYTES + wave * 8 * PL * 4;
-    const int c0 = cs * BK + wave * 8;
+    unsigned char* dst = Ab + stage * A_BYTES + wave * RPW * PL * 4;
+    const int c0 = cs * BK + wave * RPW;
     if constexpr (GATHER) {
       const int sh = ((int)(int8_t)(tp & 0xff) * d.Ws + (int)(int8_t)((tp >> 8) & 0xff)) * 4;
       const int v0 = ((g_valid[0] >> t) & 1) ? g_base[0] + sh : OOB, v1 = ((g_valid[1] >> t) & 1) ? g_base[1] + sh : OOB;
@@ -137,15 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c0 + 2 * i) * row_bytes, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c0 + (256 / PL) * i) * row_bytes, 0, 0);
     }
   };
   // B: the slab image of this tile's 64 output channels = 12 runs (plane, channel octet) of 64 x 16 bytes, three per wave
   auto dma_b = [&](int cs, int tp, int stage) __attribute__((always_inline)) {
-    unsigned char* dst = Bb + stage * B_BYTES + wave * 3 * 1024;
-    const int run0 = (((tp >> 16) * ncs + cs) * 12 + wave * 3);
+    unsigned char* dst = Bb + stage * B_BYTES + wave * (12 / NW) * 1024;
+    const int run0 = (((tp >> 16) * ncs + cs) * 12 + wave * (12 / NW));
 #pragma unroll
-    for (int u = 0; u < 3; ++u)
+    for (int u = 0; u < 12 / NW; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + u * 1024), 16, lane * 16, ((run0 + u) * K + k0) * 16, 0, 0);
   };
 
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   epi1.load_consts(L);
   if constexpr (PRE) {
 #pragma unroll
-    for (int y = 0; y < 2; ++y) tile_prefetch(a, L, wave >> 1, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
+    for (int y = 0; y < 2; ++y) tile_prefetch(a, L, NW == 4 ? wave >> 1 : wave, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
   }
   // step 0 (requested first) has landed; loads the compiler placed behind the requests only make this wait longer
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PER_STEP) : "memory");
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const f32x4 v = {acc[y][4 * qd], acc[y][4 * qd + 1], acc[y][4 * qd + 2], acc[y][4 * qd + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((y * 4 + qd) * 256 + tid) * 16, kz * tile_bytes, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((y * 4 + qd) * NTHR + tid) * 16, kz * tile_bytes, 16);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     for (int z = 0; z < a.ksplit; ++z) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * 256 + tid) * 16, z * tile_bytes, 16));
+        const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTHR + tid) * 16, z * tile_bytes, 16));
         acc[i / 4][4 * (i % 4)] += pv.x;
         acc[i / 4][4 * (i % 4) + 1] += pv.y;
         acc[i / 4][4 * (i % 4) + 2] += pv.z;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
       for (int y = 0; y < 2; ++y) {
         float s1 = r1[y], s2 = r2[y];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 0; w < NW - 1; ++w) {
           s1 += red[((w * 2 + y) * 32 + li) * 2];
           s2 += red[((w * 2 + y) * 32 + li) * 2 + 1];
         }
@@ -417,6 +423,220 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     }
   }
 }
+// ---- pointwise launches with more tiles than resident workgroups: persistent form ----------------------------------------
+// A pointwise tile of a short-K layer is two to eight steps: with one tile per workgroup the launch is a chain of
+// request latency -> a few steps -> epilogue per workgroup, three rounds of it on the 64 -> 256 layer at 56 x 56 (1568 tiles on
+// 512 resident workgroups, 23 us with the output stores removed).  Here a workgroup owns a contiguous range of tiles and the
+// request ring simply runs on across tile boundaries: the next tile's first images are in flight under the current tile's
+// last MFMAs and land during its epilogue; the operand reads never depend on the tile (a wave's rows are rows 32 w .. of
+// whatever the stage holds), only the request addresses and the epilogue do.
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_b3p_kernel(const ConvK a) {
+  constexpr int BM = 128, BN = 64, BK = 32, PL = 128, NB = 2;
+  constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* const Ab = lds;
+  unsigned char* const Bb = lds + NB * A_BYTES;
+  float* const red = reinterpret_cast<float*>(Bb + NB * B_BYTES);
+
+  const vitta_conv_desc& d = a.d;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int li = lane & 31, lk = lane >> 5;
+  const int C = d.C, K = d.K, ncs = C / BK;
+  const int tiles = a.nMt * a.nNt, G = (int)gridDim.x;
+  const int g = xcd_remap(blockIdx.x, G);
+  const int T0 = (int)((int64_t)g * tiles / G), T1 = (int)((int64_t)(g + 1) * tiles / G);
+  if (T1 <= T0) return;
+  const int S = (T1 - T0) * ncs;  // steps of this workgroup = (tile, channel slab)
+  const int wslot = a.tap[0] >> 16;
+
+  TileEpilogue epi0(a, red, wave >> 1, 0, li, lk, BM), epi1(a, red, wave >> 1, 1, li, lk, BM);
+  const int xb = wave & 1;
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)((int64_t)C * a.xP * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_b3), 0, 0x7fffffff, 0x00020000);
+  const int row_bytes = (int)(a.xP * 4);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  // ---- requests: (tile Lq, channel slab csq), clamped to the range's last step --------------------------------------------
+  int q = 0, Lq = T0, csq = 0;
+  auto tile_voff = [&](int Lx) __attribute__((always_inline)) { return lk * row_bytes + min((Lx / a.nNt) * BM + 4 * li, a.Mtot - 4) * 4; };
+  int voff_q = tile_voff(Lq);
+  auto request = [&](int stage) __attribute__((always_inline)) {
+    const int k0q = (Lq % a.nNt) * BN;
+    unsigned char* db = Bb + stage * B_BYTES + wave * 3 * 1024;
+    const int run0 = (wslot * ncs + csq) * 12 + wave * 3;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(db + u * 1024), 16, lane * 16, ((run0 + u) * K + k0q) * 16, 0, 0);
+    unsigned char* da = Ab + stage * A_BYTES + wave * 8 * PL * 4;
+    const int c0 = csq * BK + wave * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(da + i * 1024), 16, voff_q, (c0 + 2 * i) * row_bytes, 0, 0);
+    if (q + 1 < S) {
+      ++q;
+      if (++csq == ncs) {
+        csq = 0;
+        ++Lq;
+        voff_q = tile_voff(Lq);
+      }
+    }
+  };
+
+  // ---- operands (tile independent) ---------------------------------------------------------------------------------------------
+  const int a_lane = (8 * lk * PL + 32 * wave + li) * 4, b_lane = (lk * BN + li) * 16;
+  f32x16 acc[2];
+  auto read_ops = [&](int stage, int ks, float (&raw)[8], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+    const float* ap = reinterpret_cast<const float*>(Ab + stage * A_BYTES + a_lane);
+    const unsigned char* bs_ = Bb + stage * B_BYTES;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = ap[(16 * ks + j) * PL];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + ((p * 4 + 2 * ks) * BN + 32 * y) * 16);
+  };
+  auto split = [&](const float (&raw)[8], bf16x8 (&fa)[3]) __attribute__((always_inline)) {
+    u32x4 sp[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      unsigned h_, m_, l_;
+      split2(raw[2 * j], raw[2 * j + 1], h_, m_, l_);
+      sp[0][j] = h_;
+      sp[1][j] = m_;
+      sp[2][j] = l_;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fa[p] = __builtin_bit_cast(bf16x8, sp[p]);
+  };
+  auto mfma12 = [&](const bf16x8 (&fa)[3], const bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#define B3_MFMA(PA, PB)                                                                                  \
+  _Pragma("unroll") for (int y = 0; y < 2; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[y][PB], acc[y], 0, 0, 0)
+    B3_MFMA(2, 0);
+    B3_MFMA(0, 2);
+    B3_MFMA(1, 1);
+    B3_MFMA(1, 0);
+    B3_MFMA(0, 1);
+    B3_MFMA(0, 0);
+#undef B3_MFMA
+  };
+  auto interleave = [&]() __attribute__((always_inline)) {
+    SGB(0x100, 10);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      SGB(0x008, 1);
+      SGB(0x002, 4);
+    }
+  };
+  auto barrier_all_landed = [&]() __attribute__((always_inline)) {  // NB = 2: every request of this wave has landed
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  request(0);
+  request(1);
+  barrier_all_landed();
+  float raw[8];
+  bf16x8 fa0[3], fa1[3], fb0[2][3], fb1[2][3];
+  read_ops(0, 0, raw, fb0);
+  split(raw, fa0);
+  int st = 0, s = 0;
+  for (int L = T0; L < T1; ++L) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
+    epi0.load_consts(L);
+    epi1.load_consts(L);
+    float4 pre[2][4] = {};
+    if constexpr (PRE) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) tile_prefetch(a, L, wave >> 1, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
+    }
+    for (int cs = 0; cs < ncs; ++cs, ++s) {
+      read_ops(st, 1, raw, fb1);
+      split(raw, fa1);
+      mfma12(fa0, fb0);
+      interleave();
+      if (s + 1 < S) {  // the next step (of this tile or the next) is in the other stage once the barrier is passed
+        barrier_all_landed();
+        request(st);
+        read_ops(st ^ 1, 0, raw, fb0);
+        split(raw, fa0);
+        mfma12(fa1, fb1);
+        interleave();
+        st ^= 1;
+      } else {
+        mfma12(fa1, fb1);
+      }
+    }
+    float r1[2] = {0.f, 0.f}, r2[2] = {0.f, 0.f};
+    epi0.template body<PRE>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
+    epi1.template body<PRE>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
+    const bool BWD = d.flags & VITTA_CONV_BWD_BN;
+    if (((d.flags & VITTA_CONV_STATS) && d.st_s1) || BWD) {
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        r1[y] += __shfl_xor(r1[y], 32, 64);
+        r2[y] += __shfl_xor(r2[y], 32, 64);
+      }
+      if (wave > 0 && lk == 0) {
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          red[(((wave - 1) * 2 + y) * 32 + li) * 2] = r1[y];
+          red[(((wave - 1) * 2 + y) * 32 + li) * 2 + 1] = r2[y];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (wave == 0 && lk == 0) {
+        const int k0 = (L % a.nNt) * BN;
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          float s1 = r1[y], s2 = r2[y];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            s1 += red[((w * 2 + y) * 32 + li) * 2];
+            s2 += red[((w * 2 + y) * 32 + li) * 2 + 1];
+          }
+          const int k = k0 + 32 * y + li;
+          if (BWD) {
+            if (d.dgamma) atomicAdd(d.dgamma + k, s1);
+            if (d.dbeta) atomicAdd(d.dbeta + k, s2);
+          } else {
+            atomicAdd(d.st_s1 + k, s1);
+            atomicAdd(d.st_s2 + k, s2);
+          }
+        }
+      }
+      // (`red` is written again only after the next tile's barriers)
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <bool PRE>
+int launch_persistent(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  constexpr size_t lds = (size_t)2 * 32 * 128 * 4 + 2 * 12 * 64 * 16 + 384 * 4 + 16;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3p_kernel<PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return VITTA_ERR_LAUNCH;
+    raised = true;
+  }
+  const dim3 grid((unsigned)a.sk_G), block(256);
+  (void)hipGetLastError();
+  if (e0) hipExtLaunchKernelGGL((conv_b3p_kernel<PRE>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3p_kernel<PRE>), grid, block, lds, st, a);
+  return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
+}
+
 // ---- 128 x 128 tiles ("wide"): a wave = 32 pixel rows x 128 output channels, four accumulators --------------------------
 // The split of the activations (44 vector instructions per 32 rows x 16 channels) is the same whatever the tile's width:
 // with four column blocks it feeds 24 MFMAs (768 matrix-pipe cycles) instead of 12, and the step overheads (requests,
@@ -780,21 +1000,21 @@ int launch_wide(const ConvK& a, bool patch, hipStream_t st, hipEvent_t e0, hipEv
 
 #undef SGB
 
-template <int MODE, bool PRE>
+template <int MODE, bool PRE, int NW = 4>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NB = MODE == 1 ? 3 : 2;
-  constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 128) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
+  constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 32 * NW) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return VITTA_ERR_LAUNCH;
     raised = true;
   }
-  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit * (a.cls_tiles ? 4 : 1))), block(256);
+  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit * (a.cls_tiles ? 4 : 1))), block(64 * NW);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB>), grid, block, lds, st, a);
+  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW>), grid, block, lds, st, a);
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
@@ -853,9 +1073,11 @@ __global__ __launch_bounds__(256) void pack_b3_table_kernel(const PackB3* __rest
 namespace vitta_conv {
 
 int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  if (a.sk_G > 0) return a.pw_prefetch ? launch_persistent<true>(a, st, e0, e1) : launch_persistent<false>(a, st, e0, e1);
   if ((a.d.tile & 0xffff) == 128) return launch_wide(a, a.b3 == 2, st, e0, e1);
   if (a.b3 == 2) return a.pw_prefetch ? launch_one<1, true>(a, st, e0, e1) : launch_one<1, false>(a, st, e0, e1);
   if (a.b3 == 3) return a.pw_prefetch ? launch_one<2, true>(a, st, e0, e1) : launch_one<2, false>(a, st, e0, e1);
+  if ((a.d.tile >> 16) == 64) return a.pw_prefetch ? launch_one<0, true, 2>(a, st, e0, e1) : launch_one<0, false, 2>(a, st, e0, e1);
   return a.pw_prefetch ? launch_one<0, true>(a, st, e0, e1) : launch_one<0, false>(a, st, e0, e1);
 }
 
