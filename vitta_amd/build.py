@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, ".build")
 OUT = os.path.join(CSRC, "libvitta_hip.so")
 KEYFILE = OUT + ".sha256"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("VITTA_EXTRA_CFLAGS", "").split()  # (experiments)
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC"]
 JOBS = int(os.environ.get("VITTA_BUILD_JOBS", "6"))
 

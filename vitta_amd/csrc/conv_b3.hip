@@ -200,6 +200,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
         fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + ((p * 4 + 2 * ks) * BN + 32 * y) * 16);
   };
   auto split = [&](const float (&raw)[8], bf16x8 (&fa)[3]) __attribute__((always_inline)) {
+#ifdef B3_ABL_NOSPLIT
+    {
+      const u32x4 v0 = {__builtin_bit_cast(unsigned, raw[0]), __builtin_bit_cast(unsigned, raw[1]), __builtin_bit_cast(unsigned, raw[2]),
+                        __builtin_bit_cast(unsigned, raw[3])};
+      const u32x4 v1 = {__builtin_bit_cast(unsigned, raw[4]), __builtin_bit_cast(unsigned, raw[5]), __builtin_bit_cast(unsigned, raw[6]),
+                        __builtin_bit_cast(unsigned, raw[7])};
+      fa[0] = __builtin_bit_cast(bf16x8, v0);
+      fa[1] = __builtin_bit_cast(bf16x8, v1);
+      fa[2] = __builtin_bit_cast(bf16x8, v0);
+      return;
+    }
+#endif
     u32x4 sp[3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -214,6 +226,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   };
   // six products per accumulator, small terms first; the two accumulators alternate
   auto mfma12 = [&](const bf16x8 (&fa)[3], const bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
+#ifdef B3_ABL_NOMFMA
+    asm volatile("" ::"v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fb[0][0]), "v"(fb[0][1]), "v"(fb[0][2]), "v"(fb[1][0]), "v"(fb[1][1]), "v"(fb[1][2]));
+    return;
+#endif
 #define B3_MFMA(PA, PB)                                                                                  \
   _Pragma("unroll") for (int y = 0; y < 2; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[y][PB], acc[y], 0, 0, 0)
     B3_MFMA(2, 0);
@@ -262,6 +278,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits)
   int cs_q = cs0, t_q = 0, q = 0;
   auto request = [&](int stage, bool with_a) __attribute__((always_inline)) {
+#ifdef B3_ABL_NODMA
+    if (q >= NB) return;
+#endif
     dma_b(cs_q, a.tap[tap0 + t_q], stage);
     if constexpr (!PATCH) {
       if (with_a) dma_a(cs_q, stage, a.tap[tap0 + t_q], t_q);
