@@ -28,6 +28,7 @@ kernel does not bump tensor versions), the backward adds their gradients with `v
 stem pass does not cover).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -44,6 +45,52 @@ def _stream():
 
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# measured (round 3, same box, hipGraph replay): 5.88 ms per step without, 6.00 ms with either fork -- the event edges
+# cost more than the overlap returns; opt-in ("f" forward, "b" backward, "1" both)
+_SIDE = os.environ.get("VITTA_TRUNK_SIDE_STREAM", "0")
+SIDE_FWD, SIDE_BWD = _SIDE in ("1", "f"), _SIDE in ("1", "b")
+_side_streams = {}
+_side_pool = {}
+
+
+class _Fork:
+    """The downsample path of a block's first bottleneck beside its conv1 -> TAM -> conv2 chain: a helper stream that waits
+    for the work queued so far on the current stream, and that the current stream waits for at `join()`.  Every launch at
+    these sizes is latency-bound, so two independent chains side by side should cost little more than the longer one (they
+    do not: see VITTA_TRUNK_SIDE_STREAM).  Works the
+    same eagerly and under hipGraph capture (the helper stream is pulled into the capture by the first wait and leaves it
+    at the join).  Tensors the helper's kernels touch are allocated by the caller on the main stream and outlive the join."""
+
+    def __init__(self, device):
+        self.main = torch.cuda.current_stream(device)
+        key = (device.index, self.main.cuda_stream)
+        self.side = _side_streams.get(key)
+        if self.side is None:  # helper streams are created ahead, outside any capture; here one is only assigned
+            pool = _side_pool.get(device.index)
+            if pool is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("vitta_amd.trunk: run one eager step before capturing (helper streams are created eagerly)")
+                pool = _side_pool[device.index] = [torch.cuda.Stream(device) for _ in range(8)]
+            used = sum(1 for k in _side_streams if k[0] == device.index)
+            self.side = _side_streams[key] = pool[used % len(pool)]
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+
+    def __enter__(self):
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+    def join(self):
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        self.main.wait_event(ev)
 
 
 _sync_bufs = {}
@@ -454,6 +501,29 @@ class TrunkRunner:
         st = _stream()
         P = n * h * w
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
+        # identity path (first bottleneck of a stage: 1x1 convolution + BN, beside the main chain)
+        xd, fork = None, None
+        if net.downsample is not None:
+            dconv, dbn = net.downsample[0], net.downsample[1]
+            sd = sites.get(id(dbn))
+            gdn = self.geo("f", n, h, w, 1, dconv.stride[0], 0)
+            Pd = n * gdn.hy * gdn.wy
+            ident = torch.empty(4 * p, Pd, **f)
+            xd = torch.empty(4 * p, Pd, **f) if keep else None
+            wd = self.packed(dconv, "f", keep)
+
+            def identity_path():
+                CV.launch(gdn, xin, wd, ident, cin, 4 * p, flags=CV.CONV_EPI_APPLY | (CV.CONV_STATS if sd else 0), y_raw=xd,
+                          epi_bn=_bn_t(dbn), eps=dbn.eps, stats=sd.stats if sd else None)
+            if SIDE_FWD and keep:  # the evaluation pass already runs beside the adaptation pass (a fork nested in that fork
+                # crashes hipStreamEndCapture on ROCm 7.2)
+                fork = _Fork(dev)
+                with fork:
+                    identity_path()
+            else:
+                identity_path()
+        else:
+            ident = xin
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
         CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=CV.CONV_STATS if s1 else 0,
@@ -491,19 +561,9 @@ class TrunkRunner:
         CV.launch(g2, a1, self.packed(net.conv2, "f", keep), a2, p, p,
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | (CV.CONV_STATS if s2 else 0), y_raw=x2,
                   epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None)
-        # identity path
-        xd = None
-        if net.downsample is not None:
-            dconv, dbn = net.downsample[0], net.downsample[1]
-            sd = sites.get(id(dbn))
-            ident = torch.empty(4 * p, Po, **f)
-            xd = torch.empty(4 * p, Po, **f) if keep else None
-            CV.launch(self.geo("f", n, h, w, 1, dconv.stride[0], 0), xin, self.packed(dconv, "f", keep), ident, cin, 4 * p,
-                      flags=CV.CONV_EPI_APPLY | (CV.CONV_STATS if sd else 0), y_raw=xd, epi_bn=_bn_t(dbn), eps=dbn.eps,
-                      stats=sd.stats if sd else None)
-        else:
-            ident = xin
         # conv3 -> x3 raw, out
+        if fork is not None:
+            fork.join()
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
         CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f", keep), out, p, 4 * p,
@@ -573,8 +633,9 @@ class TrunkRunner:
         P, Po = n * h * w, n * ho * wo
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
 
-        def bn_bwd(g, x, bn, site, relu, mask=None, gm=None, rowadd=None, c=None, hw=None):
-            dx = torch.empty_like(x)
+        def bn_bwd(g, x, bn, site, relu, mask=None, gm=None, rowadd=None, c=None, hw=None, dx=None):
+            dx = torch.empty_like(x) if dx is None else dx
+            st = _stream()
             dg, db = sink(bn.weight), sink(bn.bias)
             inj = site.inj if site else (None, None, None, None)
             check(L.vitta_bn_bwd_cm_f32(_p(g), None, _p(x), _p(mask), _p(rowadd), (1.0 / hw) if rowadd is not None else 0.0,
@@ -585,6 +646,27 @@ class TrunkRunner:
         # bn3 (+ identity add + ReLU) backward
         g_id = torch.empty_like(G)
         dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo)
+        # identity / downsample path of a stage's first bottleneck, beside the main chain: bn_d backward, its data gradient
+        fork = None
+        if net.downsample is not None:
+            dconv, dbn = net.downsample[0], net.downsample[1]
+            sd = sites.get(id(dbn))
+            ds = dconv.stride[0]
+            dxd = torch.empty_like(sv["xd"])
+            gd = torch.empty(cin, Po if ds == 2 else P, **f)
+            wdb = self.packed(dconv, "b", True)
+
+            def identity_path():
+                bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo, dx=dxd)
+                if dconv.weight.requires_grad:
+                    CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
+                CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, wdb, gd, 4 * p, cin)
+            if SIDE_BWD:
+                fork = _Fork(dev)
+                with fork:
+                    identity_path()
+            else:
+                identity_path()
         # conv3 data gradient, epilogue = bn2 (+ReLU) backward
         dx2 = torch.empty(p, Po, **f)
         i2 = s2.inj if s2 else None
@@ -638,17 +720,11 @@ class TrunkRunner:
         del ga
         if net.conv1.weight.requires_grad:
             CV.wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p)
-        # identity / downsample path
+        # join the identity / downsample path
         gin = torch.empty(cin, P, **f)
         if net.downsample is not None:
-            dconv, dbn = net.downsample[0], net.downsample[1]
-            sd = sites.get(id(dbn))
-            dxd = bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo)
-            ds = dconv.stride[0]
-            if dconv.weight.requires_grad:
-                CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
-            gd = torch.empty(cin, Po if ds == 2 else P, **f)
-            CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, self.packed(dconv, "b", True), gd, 4 * p, cin)
+            if fork is not None:
+                fork.join()
             res, rflag = gd, (CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES)
         else:
             res, rflag = g_id, CV.CONV_RES
