@@ -259,9 +259,11 @@ int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const fl
                              float* d_hpre, void* stream);
 int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                             const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
+                             const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                              float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* stream);
+/* N_saved >= N: clips of the forward launch that wrote d_hpre (its second plane starts N_saved * (C/4) * T floats in); the
+ * backward covers the first N of them (d_pooled / d_kern / d_gate are clip-major, so their first N clips are a prefix). */
 /* The same two passes with their two launches each fused into ONE (F1 -> F2, B1 -> B2): the workgroups of a clip meet on a
  * device-scope counter inside the launch (the second half's staging -- and in the backward the whole G branch -- runs while
  * the first half's tiles finish).  d_sync: >= 2 * N uint32, ZERO when first used (the kernels leave it zero), not shared by
@@ -278,7 +280,7 @@ int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, co
                                    float* d_hpre, void* d_sync, void* stream);
 int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                                   const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                                    float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, void* stream);
 
@@ -467,6 +469,13 @@ typedef struct vitta_conv_desc {
    * accumulation; error of the fp32-roundoff class, see conv_b3.hip); `w` is then not read.  NULL: exact fp32 MFMA. */
   const void* w_b3;
   int8_t cls_ntaps[4]; /* VITTA_CONV_PARITY4: taps of class 0..3 (sum = ntaps) */
+  /* A pass over the FIRST frames of tensors that hold more frames per channel row (the adaptation backward of a forward that
+   * also carried the evaluation clip, vitta_amd/trunk.py): pixels between consecutive channel rows, 0 = compact.
+   *   bwd_ld  rows of `bwd_x` / `bwd_mask` (VITTA_CONV_BWD_BN)        (vitta_wgrad_desc::x_ld is the same for wgrad's x)
+   * and the converse for the forward of such a batch:
+   *   stat_m  VITTA_CONV_STATS counts, and y_raw is written for, output pixels m < stat_m only (0 = all; a multiple of 4;
+   *           contiguous forward outputs). */
+  int64_t bwd_ld, stat_m;
 } vitta_conv_desc;
 
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */
@@ -520,6 +529,7 @@ typedef struct vitta_wgrad_desc {
    * added to grad_w with atomics (thousands of adds per weight on the small early layers) */
   void* workspace;
   int64_t workspace_bytes;
+  int64_t x_ld; /* pixels between consecutive channel rows of x when it holds more than N frames per row; 0 = compact */
 } vitta_wgrad_desc;
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
 
@@ -577,6 +587,17 @@ int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, c
                         float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
                         const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
                         float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream);
+/* The same two passes over the FIRST N * T frames of saved tensors whose channel rows hold more frames (the adaptation backward
+ * after a forward that also carried the evaluation clip): x_ld = pixels between consecutive channel rows of d_x (and d_mask),
+ * 0 = compact.  Gradient tensors (d_g, d_gout, d_dx, d_ga, d_gm) are compact [C][N * T * HW]. */
+int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* const* h_bn, float eps, const float* d_gate,
+                                const float* d_kern, const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga,
+                                float* d_ggate, float* d_gkern, void* stream);
+int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, int64_t x_ld,
+                           const float* d_rowadd, float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu,
+                           const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx,
+                           float* d_gm, float* d_dgamma, float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW,
+                           void* stream);
 int vitta_avgpool_cm_f32(const float* d_x, int32_t C, int32_t F, int32_t HW, float* d_feat, void* stream);
 int vitta_avgpool_cm_bwd_f32(const float* d_gfeat, int32_t C, int32_t F, int32_t HW, float* d_gx, void* stream);
 

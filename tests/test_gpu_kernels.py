@@ -774,7 +774,7 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
         gbuf = torch.empty(n * c * t + n * o * t, device=d)
         dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
         dw = [torch.zeros_like(wg1), torch.zeros_like(wg3), torch.zeros_like(w0), torch.zeros_like(w3)]
-        bargs = args + (_p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
+        bargs = args + (n, _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
         if fused:
             _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), _stream()), "bwd fused")
         else:

@@ -126,11 +126,12 @@ struct TileEpilogue {
       es = c_gam * rsqrtf(c_var + d.epi_eps);
       et = c_bet - c_mean * es;
     }
-    const int64_t yrow = (int64_t)k * a.yP;
+    const int64_t yrow = (int64_t)k * a.yP, brow = (int64_t)k * a.bP;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int m = m0 + wm * (BM >> 1) + 32 * xb + 8 * qd + 4 * lk;
       if (m >= a.Mtot) continue;
+      const bool head = m < a.statM, counted = STATS && head;
       float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
       if (a.contig) {
         float* yp = d.y + yrow + m;
@@ -150,11 +151,11 @@ struct TileEpilogue {
         if (BWD) {
           float4 xr;
           if constexpr (PRE) xr = qd == 0 ? p0 : qd == 1 ? p1 : qd == 2 ? p2 : p3;
-          else xr = *reinterpret_cast<const float4*>(d.bwd_x + yrow + m);
+          else xr = *reinterpret_cast<const float4*>(d.bwd_x + brow + m);
           const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
           float mk[4] = {1.f, 1.f, 1.f, 1.f};
           if (BRELU && d.bwd_mask) {
-            const float4 mr = *reinterpret_cast<const float4*>(d.bwd_mask + yrow + m);
+            const float4 mr = *reinterpret_cast<const float4*>(d.bwd_mask + brow + m);
             mk[0] = mr.x > 0.f; mk[1] = mr.y > 0.f; mk[2] = mr.z > 0.f; mk[3] = mr.w > 0.f;
           }
           float o[4], gm[4];
@@ -171,12 +172,12 @@ struct TileEpilogue {
           *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
           if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(gm[0], gm[1], gm[2], gm[3]);
         } else {
-          if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
+          if (d.y_raw && head) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float z = fmaf(v[e], es, et);
-            if (STATS) {
+            if (counted) {
               const float dd = z - sh;
               r1 += dd;
               r2 = fmaf(dd, dd, r2);
@@ -250,7 +251,7 @@ __device__ __forceinline__ void tile_prefetch(const ConvK& a, int L, int wm, int
                                               float4& p3, int bm = 64, int xb = 0) {
   const vitta_conv_desc& d = a.d;
   const bool bwd = d.flags & VITTA_CONV_BWD_BN;
-  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)((L % a.nNt) * 64 + wn * 32 + li) * (bwd ? a.yP : a.rP);
+  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)((L % a.nNt) * 64 + wn * 32 + li) * (bwd ? a.bP : a.rP);
   const int m = (L / a.nNt) * bm + wm * (bm >> 1) + 32 * xb + 4 * lk, last = a.Mtot - 4;
   p0 = *reinterpret_cast<const float4*>(row + min(m, last));
   p1 = *reinterpret_cast<const float4*>(row + min(m + 8, last));

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __res
 template <int LPR>
 __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
                                                               const float* __restrict__ kern, const float* __restrict__ gout,
-                                                              int C, int N, int T, int HW, float* __restrict__ ga,
+                                                              int C, int N, int T, int HW, int64_t xld, float* __restrict__ ga,
                                                               float* __restrict__ dots) {
   int sub;
   const Row r = row_of<LPR>(C, N, T, &sub);
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __res
     const float v1 = gt * k[1];
     const float v2 = hp ? gt * k[2] : 0.f;  // multiplies gout[t-1]
     const int64_t off = ((int64_t)r.c * N * T + r.f) * HW;
-    const float* xc = x + off;
+    const float* xc = x + (int64_t)r.c * xld + (int64_t)r.f * HW;
     const float* gc = gout + off;
     const float* gn = hn ? gc + HW : gc;
     const float* gp = hp ? gc - HW : gc;
@@ -226,13 +226,14 @@ struct BnBwd {
   float* gm;           // optional [C][P]  (g + g2 + rowadd) * mask
   float *dgamma, *dbeta;
   int C, N, T, HW, relu;
+  int64_t xld;         // pixels between channel rows of x / mask (P unless they hold more frames)
 };
 
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
   __shared__ float red[2][VITTA_BLOCK / VITTA_WAVE];
   const int c = blockIdx.y;
   const int64_t P = (int64_t)a.N * a.T * a.HW;
-  const int64_t base = (int64_t)c * P;
+  const int64_t base = (int64_t)c * P, xbase = (int64_t)c * a.xld;
   const float rstd = rsqrtf(a.bn.v[c] + a.bn.eps);
   const float s = a.bn.g[c] * rstd, t = a.bn.b[c] - a.bn.m[c] * s, rm = a.bn.m[c];
   float ia = 0.f, ib = 0.f, mu = 0.f;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
     const int64_t p = p0 + (int64_t)u * VITTA_BLOCK * 4;
     if (p >= P) break;
     const float4 gv = *reinterpret_cast<const float4*>(a.g + base + p);
-    const float4 xv = *reinterpret_cast<const float4*>(a.x + base + p);
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + xbase + p);
     float g[4] = {gv.x, gv.y, gv.z, gv.w};
     const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
     if (a.g2) {
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
     }
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
     if (a.relu && a.mask) {
-      const float4 mv = *reinterpret_cast<const float4*>(a.mask + base + p);
+      const float4 mv = *reinterpret_cast<const float4*>(a.mask + xbase + p);
       mk[0] = mv.x > 0.f; mk[1] = mv.y > 0.f; mk[2] = mv.z > 0.f; mk[3] = mv.w > 0.f;
     }
     float o[4], gmv[4];
@@ -363,29 +364,39 @@ int vitta_tam_agg_fwd_cm_f32(const float* d_x, const float* const* h_bn, float e
   return VITTA_OK;
 }
 
-int vitta_tam_agg_bwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
-                             const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga, float* d_ggate,
-                             float* d_gkern, void* stream) {
+int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* const* h_bn, float eps, const float* d_gate,
+                                const float* d_kern, const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga,
+                                float* d_ggate, float* d_gkern, void* stream) {
   if (!d_x || !bn_ok(h_bn) || !d_gate || !d_kern || !d_gout || !d_ga || !d_ggate || !d_gkern || bad(C, N, T, HW))
     return VITTA_ERR_INVALID_ARG;
+  const int64_t xld = x_ld ? x_ld : (int64_t)N * T * HW;
+  if (xld < (int64_t)N * T * HW || ((HW & 3) == 0 && (xld & 3))) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BN bn{h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps};
   float* dots = d_ggate + (int64_t)N * C * T;  // the caller gives d_ggate room for N*C*T*4 floats
   CM_DISPATCH(agg_bwd_kernel, (int64_t)C * N * T, HW, st, d_x, bn, d_gate, d_kern, d_gout, (int)C, (int)N, (int)T, (int)HW,
-              d_ga, dots);
+              xld, d_ga, dots);
   const int64_t NC = (int64_t)N * C;
   VITTA_LAUNCH(finish_kernel, dim3((unsigned)((NC + VITTA_BLOCK - 1) / VITTA_BLOCK)), dim3(VITTA_BLOCK), 0, st, d_gate,
                d_kern, dots, NC, (int)T, d_ggate, d_gkern);
   return VITTA_OK;
 }
 
-int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, const float* d_rowadd,
-                        float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
-                        const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
-                        float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream) {
+int vitta_tam_agg_bwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
+                             const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga, float* d_ggate,
+                             float* d_gkern, void* stream) {
+  return vitta_tam_agg_bwd_cm_ld_f32(d_x, 0, h_bn, eps, d_gate, d_kern, d_gout, C, N, T, HW, d_ga, d_ggate, d_gkern, stream);
+}
+
+int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, int64_t x_ld,
+                           const float* d_rowadd, float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu,
+                           const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx,
+                           float* d_gm, float* d_dgamma, float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW,
+                           void* stream) {
   if (!d_g || !d_x || !bn_ok(h_bn) || !d_dx || bad(C, N, T, HW) || C > 65535) return VITTA_ERR_INVALID_ARG;
   const int64_t P = (int64_t)N * T * HW;
   if (P % 4) return VITTA_ERR_UNSUPPORTED;
+  if (x_ld && (x_ld < P || x_ld % 4)) return VITTA_ERR_INVALID_ARG;
   if (d_mu && (!d_coef_a || !d_coef_b)) return VITTA_ERR_INVALID_ARG;
   BnBwd a;
   a.g = d_g; a.g2 = d_g2; a.x = d_x; a.mask = d_mask; a.rowadd = d_rowadd; a.rowadd_scale = rowadd_scale;
@@ -393,10 +404,19 @@ int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, c
   a.mu = d_mu; a.ca = d_coef_a; a.cb = d_coef_b; a.gs = d_gscale;
   a.dx = d_dx; a.gm = d_gm; a.dgamma = d_dgamma; a.dbeta = d_dbeta;
   a.C = C; a.N = N; a.T = T; a.HW = HW; a.relu = relu;
+  a.xld = x_ld ? x_ld : P;
   const int64_t per = (int64_t)VITTA_BLOCK * BB_UNROLL * 4;
   VITTA_LAUNCH(bn_bwd_kernel, dim3((unsigned)((P + per - 1) / per), (unsigned)C), dim3(VITTA_BLOCK), 0,
                static_cast<hipStream_t>(stream), a);
   return VITTA_OK;
+}
+
+int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, const float* d_rowadd,
+                        float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
+                        const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
+                        float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream) {
+  return vitta_bn_bwd_cm_ld_f32(d_g, d_g2, d_x, d_mask, 0, d_rowadd, rowadd_scale, h_bn, eps, d_mu, d_coef_a, d_coef_b, d_gscale, relu,
+                                d_dx, d_gm, d_dgamma, d_dbeta, C, N, T, HW, stream);
 }
 
 int vitta_avgpool_cm_f32(const float* d_x, int32_t C, int32_t F, int32_t HW, float* d_feat, void* stream) {
