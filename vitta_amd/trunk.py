@@ -51,6 +51,9 @@ def _p(t):
 # cost more than the overlap returns; opt-in ("f" forward, "b" backward, "1" both)
 _SIDE = os.environ.get("VITTA_TRUNK_SIDE_STREAM", "0")
 SIDE_FWD, SIDE_BWD = _SIDE in ("1", "f"), _SIDE in ("1", "b")
+# weight gradients (SGD over all parameters) on a helper stream beside the data-gradient chain: nothing in the backward waits
+# for them, so a block's three or four wgrad + reduce launches run while the main stream is already in the next block
+WGRAD_SIDE = os.environ.get("VITTA_TRUNK_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 _side_pool = {}
 
@@ -63,9 +66,9 @@ class _Fork:
     same eagerly and under hipGraph capture (the helper stream is pulled into the capture by the first wait and leaves it
     at the join).  Tensors the helper's kernels touch are allocated by the caller on the main stream and outlive the join."""
 
-    def __init__(self, device):
+    def __init__(self, device, role=0):
         self.main = torch.cuda.current_stream(device)
-        key = (device.index, self.main.cuda_stream)
+        key = (device.index, self.main.cuda_stream, role)
         self.side = _side_streams.get(key)
         if self.side is None:  # helper streams are created ahead, outside any capture; here one is only assigned
             pool = _side_pool.get(device.index)
@@ -197,6 +200,7 @@ class TrunkRunner:
         self._step_packs = {}
         self._repack = {}
         self._geo = {}
+        self._wgrad_pending = []
         self.after_block = None  # callable(block index) run after each block's backward (tta: bucketed gradient exchange)
 
     # -- structure ---------------------------------------------------------------------------------------------
@@ -634,6 +638,13 @@ class TrunkRunner:
         t = b.n_segment
         n, h, w, ho, wo = sv["dims"]
         nb = n // t
+        wq = []  # this block's weight-gradient launches (argument tuples keep their tensors alive until the helper is joined)
+
+        def wgrad(*a, **kw):
+            if WGRAD_SIDE:
+                wq.append((a, kw))
+            else:
+                CV.wgrad(*a, **kw)
         fr = sv["frames"]  # frames per channel row of the saved tensors (> n when an evaluation clip rode along)
         ldP, ldPo = (fr * h * w, fr * ho * wo) if fr != n else (0, 0)
         cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
@@ -670,7 +681,7 @@ class TrunkRunner:
             def identity_path():
                 bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo, dx=dxd, ld=ldPo)
                 if dconv.weight.requires_grad:
-                    CV.wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p, x_ld=ldP)
+                    wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p, x_ld=ldP)
                 CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, wdb, gd, 4 * p, cin)
             if SIDE_BWD:
                 fork = _Fork(dev)
@@ -685,10 +696,10 @@ class TrunkRunner:
                   flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
                   dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias), bwd_ld=ldPo)
         if net.conv3.weight.requires_grad:
-            CV.wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p, x_ld=ldPo)
+            wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p, x_ld=ldPo)
         del dx3
         if net.conv2.weight.requires_grad:
-            CV.wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p, x_ld=ldP)
+            wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p, x_ld=ldP)
         # conv2 data gradient -> d a1
         ga1 = torch.empty(p, P, **f)
         wb2 = self.packed(net.conv2, "b", True)
@@ -730,7 +741,7 @@ class TrunkRunner:
         dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w, ld=ldP)
         del ga
         if net.conv1.weight.requires_grad:
-            CV.wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p, x_ld=ldP)
+            wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p, x_ld=ldP)
         # join the identity / downsample path
         gin = torch.empty(cin, P, **f)
         if net.downsample is not None:
@@ -740,7 +751,19 @@ class TrunkRunner:
         else:
             res, rflag = g_id, CV.CONV_RES
         CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
+        if wq:
+            helper = _Fork(dev, role=1)  # waits for everything this block has queued
+            with helper:
+                for wa, wkw in wq:
+                    CV.wgrad(*wa, **wkw)
+            self._wgrad_pending.append((helper, wq))
         return gin
+
+    def join_wgrads(self):
+        """The current stream waits for the weight gradients issued on the helper stream; their operands may be freed."""
+        if self._wgrad_pending:
+            self._wgrad_pending[-1][0].join()  # one helper stream, in order: its last launch covers the earlier ones
+            self._wgrad_pending = []
 
     def backward(self, ctxd, gfeat, sink):
         c, n, h, w = ctxd["last"]  # n: frames of the adaptation batch (frames that rode along have no backward)
@@ -752,7 +775,9 @@ class TrunkRunner:
             G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink)
             sv.clear()
             if self.after_block is not None:
+                self.join_wgrads()  # a gradient bucket may leave now
                 self.after_block(i)
+        self.join_wgrads()
         h0, w0 = ctxd["pooled_hw"]
         if ctxd["stem"] is None:  # the stem ran outside (trainable 7x7 convolution): hand its output gradient back
             return CV.from_cm(G, n, h0, w0)
