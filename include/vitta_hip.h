@@ -523,7 +523,7 @@ typedef struct vitta_wgrad_desc {
   int32_t sstride;
   int32_t ntaps, wtaps;
   int8_t dh[VITTA_CONV_MAX_TAPS], dw[VITTA_CONV_MAX_TAPS], wt[VITTA_CONV_MAX_TAPS];
-  int32_t flags; /* VITTA_CONV_PRO_BN_RELU or 0 */
+  int32_t flags; /* VITTA_CONV_PRO_BN_RELU, VITTA_WGRAD_DEFER_REDUCE or 0 */
   /* optional scratch (>= 768 x 32 KiB = 24 MiB on an MI355X; no initial content required, one per stream): the workgroups'
    * partial tiles meet there and a second launch adds them to grad_w in a fixed order; without it every partial tile is
    * added to grad_w with atomics (thousands of adds per weight on the small early layers) */
@@ -532,6 +532,12 @@ typedef struct vitta_wgrad_desc {
   int64_t x_ld; /* pixels between consecutive channel rows of x when it holds more than N frames per row; 0 = compact */
 } vitta_wgrad_desc;
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
+/* VITTA_WGRAD_DEFER_REDUCE in flags: vitta_conv_wgrad_f32 leaves its partial tiles in `workspace` and skips the second launch;
+ * vitta_conv_wgrad_reduce_f32 then adds the partial tiles of up to four such launches (the SAME descriptors, each with a
+ * workspace of its own, all issued earlier on this stream) to their grad_w in ONE launch -- the weight gradients of one
+ * bottleneck are four launches + one instead of four + four. */
+#define VITTA_WGRAD_DEFER_REDUCE 1024
+int vitta_conv_wgrad_reduce_f32(const vitta_wgrad_desc* const* h_descs, int32_t n, void* stream);
 
 /* Split-bf16 weight image for vitta_conv_desc::w_b3.  d_src: fp32 [taps][R][O] (R = reduction channels, O = output
  * channels: the packed forward / data-gradient arrays of vitta_conv_desc::w), R % 32 == 0.

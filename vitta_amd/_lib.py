@@ -33,6 +33,7 @@ class WgradDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("x_ld", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
 CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4 = 16, 32, 64, 128, 256
+WGRAD_DEFER_REDUCE = 1024
 CONV_KERNEL_TILE, CONV_KERNEL_SK, CONV_KERNEL_PW, CONV_KERNEL_B3 = 0, 1, 2, 3
 
 
@@ -131,6 +132,7 @@ SIGNATURES = {
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
+    "vitta_conv_wgrad_reduce_f32": (C.c_int, [C.POINTER(C.POINTER(WgradDesc)), _i32, _p]),
     "vitta_conv_repack_f32": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_pack_b3_bytes": (_sz, [_i32, _i32, _i32]),
     "vitta_conv_pack_b3": (C.c_int, [_p, _p, _i32, _i32, _i32, _p]),

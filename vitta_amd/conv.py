@@ -272,10 +272,34 @@ def merged_dgrad_supported(geom, wp, c, k):
     return bool(lib().vitta_conv_supported(C.byref(d)))
 
 
-def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, x_ld=0):
+WGRAD_SLOT_BYTES = 25 << 20  # 768 workgroups x 2 partial tiles x 16 KiB, rounded up
+WGRAD_SLOTS = 4
+_wgrad_workspaces = {}
+
+
+def wgrad_workspace(device):
+    """Partial-tile areas of DEFERRED weight-gradient launches on the current stream (one slot per launch of a group)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_workspaces.get(key)
+    if ws is None:
+        ws = _wgrad_workspaces[key] = torch.empty(WGRAD_SLOTS * WGRAD_SLOT_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
+def wgrad_reduce(descs):
+    """One launch adding the partial tiles of the deferred launches `descs` (wgrad(..., defer=slot)) to their gradients."""
+    if not descs:
+        return
+    arr = (C.POINTER(_lib.WgradDesc) * len(descs))(*[C.pointer(d) for d in descs])
+    check(lib().vitta_conv_wgrad_reduce_f32(arr, len(descs), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "vitta_conv_wgrad_reduce_f32")
+
+
+def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, x_ld=0, defer=None):
     """grad_w [K, C, kh, kw] += weight gradient of the convolution with FORWARD geometry `geom` (Geometry.forward):
     x [C, *] its input planes (raw, with pro_bn = the BatchNorm whose relu(bn(.)) the forward applied on load),
-    dy [K, *] the gradient of its raw output (`vitta_conv_wgrad_f32`)."""
+    dy [K, *] the gradient of its raw output (`vitta_conv_wgrad_f32`).  defer = slot 0..3: leave the partial tiles in that
+    slot of the stream's wgrad workspace and return the descriptor for `wgrad_reduce` (one launch for a group)."""
     for t in (x, dy, grad_w):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
             raise _lib.VittaHipError("convolution operands must be contiguous fp32 tensors on the GPU (no CPU fallback)")
@@ -294,11 +318,16 @@ def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, x_ld=0):
     if not pointwise:
         off, mask = geom.wgrad_tables(x.device)
         d.src_off, d.src_mask = off.data_ptr(), mask.data_ptr()
-    ws = workspace(x.device)
-    # the partial tiles use the slab region of the split-K workspace (its first 64 KiB are the convolutions' counters)
-    d.workspace, d.workspace_bytes = ws.data_ptr() + 65536, ws.numel() - 65536
+    if defer is not None:
+        ws = wgrad_workspace(x.device)
+        d.flags |= _lib.WGRAD_DEFER_REDUCE
+        d.workspace, d.workspace_bytes = ws.data_ptr() + int(defer) * WGRAD_SLOT_BYTES, WGRAD_SLOT_BYTES
+    else:
+        ws = workspace(x.device)
+        # the partial tiles use the slab region of the split-K workspace (its first 64 KiB are the convolutions' counters)
+        d.workspace, d.workspace_bytes = ws.data_ptr() + 65536, ws.numel() - 65536
     check(lib().vitta_conv_wgrad_f32(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vitta_conv_wgrad_f32")
-    return grad_w
+    return d if defer is not None else grad_w
 
 
 def stem_wgrad(x, dy, grad_w):

@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK a) {
 // grid (tiles, 16): thread = one element of a 64 x 64 tile of one tap; sums the partial tiles of the workgroups whose
 // ranges cover the tile and adds the result to dW (one writer per element, or gridDim.z atomic adds where a tile has
 // hundreds of partials)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK a) {
+__device__ __forceinline__ void wgrad_reduce_tile(const WgradK& a, int L, int Z, int bz) {
   const vitta_wgrad_desc& d = a.d;
-  const int L = blockIdx.x, G = a.G;
+  const int G = a.G;
   const int T = d.ntaps * a.nCt * a.nKt;
   const int64_t U = (int64_t)T * a.nslab;
   const int e = blockIdx.y * 256 + threadIdx.x;  // element index in register order: ((qd * 256 + tid) * 4 + j)
@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK a) {
   const int g_first = (int)((((int64_t)L * a.nslab + 1) * G + U - 1) / U) - 1;
   const int g_last = (int)(((((int64_t)L + 1) * a.nslab) * G + U - 1) / U) - 1;
   float s = 0.f;
-  const int Z = (int)gridDim.z;  // tiles covered by many ranges (few tiles, long pixel walks) split their partial list Z ways
-  for (int gg = g_first + (int)blockIdx.z; gg <= g_last; gg += Z) {
+  // Z: tiles covered by many ranges (few tiles, long pixel walks) split their partial list Z ways
+  for (int gg = g_first + bz; gg <= g_last; gg += Z) {
     const int first_tile = (int)(((int64_t)gg * U / G) / a.nslab);
     s += a.partials[((int64_t)gg * 2 + (L - first_tile)) * 4096 + e];
   }
@@ -304,6 +304,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK a) {
     if (Z > 1) atomicAdd(dst, s);
     else *dst += s;
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradK a) { wgrad_reduce_tile(a, blockIdx.x, gridDim.z, blockIdx.z); }
+
+// the reductions of up to four weight gradients (the convolutions of one bottleneck) as ONE launch
+constexpr int REDUCE_MAX = 4;
+struct WgradReduceMulti {
+  WgradK a[REDUCE_MAX];
+  int n;
+  int tile_end[REDUCE_MAX];  // running tile counts
+  int z[REDUCE_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradReduceMulti m) {
+  int i = 0;
+  while (i + 1 < m.n && (int)blockIdx.x >= m.tile_end[i]) ++i;
+  if ((int)blockIdx.z >= m.z[i]) return;
+  wgrad_reduce_tile(m.a[i], (int)blockIdx.x - (i ? m.tile_end[i - 1] : 0), m.z[i], blockIdx.z);
 }
 
 int fill(const vitta_wgrad_desc* h, WgradK& a) {
@@ -342,6 +359,12 @@ int fill(const vitta_wgrad_desc* h, WgradK& a) {
   return VITTA_OK;
 }
 
+int reduce_z(const WgradK& a) {
+  const int T = a.d.ntaps * a.nCt * a.nKt, per_tile = (a.G + T - 1) / T;
+  const int z = per_tile / 8;
+  return z < 1 ? 1 : (z > 32 ? 32 : z);
+}
+
 template <bool GATHER, bool PRO>
 int launch_one(const WgradK& a, hipStream_t st) {
   const size_t lds = sizeof(float) * (6 * 64 * 33 + (PRO ? 2 * a.d.C : 0));
@@ -353,10 +376,8 @@ int launch_one(const WgradK& a, hipStream_t st) {
     raised = true;
   }
   VITTA_LAUNCH((conv_wgrad_kernel<GATHER, PRO>), dim3((unsigned)a.G), dim3(256), lds, st, a);
-  if (a.partials) {
-    const int T = a.d.ntaps * a.nCt * a.nKt, per_tile = (a.G + T - 1) / T;
-    int z = per_tile / 8;
-    z = z < 1 ? 1 : (z > 32 ? 32 : z);
+  if (a.partials && !(a.d.flags & VITTA_WGRAD_DEFER_REDUCE)) {
+    const int T = a.d.ntaps * a.nCt * a.nKt, z = reduce_z(a);
     VITTA_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)T, 16, (unsigned)z), dim3(256), 0, st, a);
   }
   return VITTA_OK;
@@ -365,6 +386,34 @@ int launch_one(const WgradK& a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+int vitta_conv_wgrad_reduce_f32(const vitta_wgrad_desc* const* h_descs, int32_t n, void* stream) {
+  if (!h_descs || n < 1 || n > REDUCE_MAX) return VITTA_ERR_INVALID_ARG;
+  WgradReduceMulti m;
+  m.n = 0;
+  int tiles = 0, zmax = 1;
+  for (int i = 0; i < n; ++i) {
+    WgradK a;
+    const int rc = fill(h_descs[i], a);
+    if (rc != VITTA_OK) return rc;
+    if (!a.partials) continue;  // that launch added its partial tiles with atomics: nothing left to do
+    for (int j = 0; j < m.n; ++j)
+      if (m.a[j].partials == a.partials) return VITTA_ERR_INVALID_ARG;  // deferred launches need a workspace each
+    m.a[m.n] = a;
+    tiles += a.d.ntaps * a.nCt * a.nKt;
+    m.tile_end[m.n] = tiles;
+    m.z[m.n] = reduce_z(a);
+    zmax = m.z[m.n] > zmax ? m.z[m.n] : zmax;
+    ++m.n;
+  }
+  if (!m.n) return VITTA_OK;
+  for (int i = m.n; i < REDUCE_MAX; ++i) {
+    m.tile_end[i] = tiles;
+    m.z[i] = 0;
+  }
+  VITTA_LAUNCH(wgrad_reduce_multi_kernel, dim3((unsigned)tiles, 16, (unsigned)zmax), dim3(256), 0, static_cast<hipStream_t>(stream), m);
+  return VITTA_OK;
+}
 
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream) {
   WgradK a;

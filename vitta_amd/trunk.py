@@ -201,6 +201,10 @@ class TrunkRunner:
         self._repack = {}
         self._geo = {}
         self._wgrad_pending = []
+        # tta.py, for the span of one overlapped step: the adaptation set of packs was rebuilt on the main stream BEFORE the
+        # evaluation stream forked and the weights do not change until both passes are done -- neither pass re-packs, the
+        # evaluation reads the adaptation set's forward packs
+        self.prepacked = False
         self.after_block = None  # callable(block index) run after each block's backward (tta: bucketed gradient exchange)
 
     # -- structure ---------------------------------------------------------------------------------------------
@@ -340,6 +344,11 @@ class TrunkRunner:
         if not convs:
             return
         key = bool(adapt)
+        if self.prepacked:
+            if self._repack.get(True) is None:
+                raise RuntimeError("vitta_amd.trunk: prepacked without a rebuilt adaptation set")
+            self._repack[key] = self._repack[True]
+            return
         st = self._repack.get((key, CV.ARITH))
         sig = tuple((c.weight.data_ptr(), tuple(c.weight.shape)) for c in convs)
         if st is None or st["sig"] != sig:
@@ -753,9 +762,8 @@ class TrunkRunner:
         CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
         if wq:
             helper = _Fork(dev, role=1)  # waits for everything this block has queued
-            with helper:
-                for wa, wkw in wq:
-                    CV.wgrad(*wa, **wkw)
+            with helper:  # four launches + ONE reduction of their partial tiles
+                CV.wgrad_reduce([CV.wgrad(*wa, defer=i, **wkw) for i, (wa, wkw) in enumerate(wq)])
             self._wgrad_pending.append((helper, wq))
         return gin
 

@@ -16,6 +16,7 @@ without resetting the model), same log-line formats.  MI355X-first differences:
   video is exactly the reference run with batch_size = R (SURVEY section 8e);
 * no per-video host synchronisation: per-video metrics are read back with a lag (DeferredLog).
 """
+import contextlib
 import copy as cp
 import os
 import os.path as osp
@@ -46,6 +47,8 @@ CAPTURE_MODE = "thread_local"
 # evaluation on its own stream hides in the adaptation pass's idle slots while riding along lengthens the critical path.
 # Opt-in.
 RIDE_ALONG = os.environ.get("VITTA_EVAL_RIDE_ALONG", "0") != "0"
+# overlapped step with trainable convolution weights: pack them once per step, not once per pass (ViTTAAdapter._prepacked)
+PREPACK = os.environ.get("VITTA_PREPACK", "1") != "0"
 
 NUM_CLASSES = {"ucf101": 101, "hmdb51": 51, "kinetics": 400, "somethingv2": 174, "kth": 6, "u2h": 12, "h2u": 12}
 
@@ -512,6 +515,28 @@ class ViTTAAdapter:
             return g["adapt_out"], g["eval_out_overlapped"]
         return self._step_eager(tta_input, eval_input, has_video)
 
+    @contextlib.contextmanager
+    def _prepacked(self):
+        """Trainable trunk convolutions (SGD over all parameters): rebuild their packed copies ONCE, on the current stream,
+        before the evaluation forks -- both passes of the step read the same weights -- instead of once per pass."""
+        runner = None
+        if PREPACK and self.args.arch == "tanet" and self.device.type == "cuda":
+            from . import trunk
+            net = self.model.module if isinstance(self.model, SingleDeviceParallel) else self.model
+            base = getattr(net, "base_model", None)
+            if base is not None and trunk.ENABLED:
+                runner = trunk.runner_of(base)
+        if runner is None:
+            yield
+            return
+        runner.prepacked = False
+        runner.refresh_packs(self.device, adapt=True)
+        runner.prepacked = runner._repack.get(True) is not None
+        try:
+            yield
+        finally:
+            runner.prepacked = False
+
     def _fork_eval(self, eval_input):
         """Issue the evaluation forward on the side stream (hooks closed, model.eval()); the caller joins."""
         cur = torch.cuda.current_stream()
@@ -540,8 +565,9 @@ class ViTTAAdapter:
         if has_video and self.ride_along_ok(tta_input, eval_input):
             out = self._adapt_step_eager(tta_input, True, rider=eval_input)
             return out, self._rider_out
-        ev, side = self._fork_eval(eval_input)
-        out = self._adapt_step_eager(tta_input, has_video, join=side)
+        with self._prepacked():
+            ev, side = self._fork_eval(eval_input)
+            out = self._adapt_step_eager(tta_input, has_video, join=side)
         return out, ev
 
     # -- gradient exchange --------------------------------------------------------------------------------------------
@@ -675,10 +701,11 @@ class ViTTAAdapter:
         ride = overlap_eval and self.ride_along_ok(x, g["eval_in"])
         g["ride_along"] = ride
         with torch.cuda.graph(g["seg_fwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
-            if overlap_eval and not ride:  # the evaluation of the previous video rides beside the adaptation forward
-                g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
-            self.arena.zero_grad()
-            output, loss_consis = self.forward_local(x, actual_bz, g["eval_in"] if ride else None)
+            with self._prepacked() if (overlap_eval and not ride) else contextlib.nullcontext():
+                if overlap_eval and not ride:  # the evaluation of the previous video rides beside the adaptation forward
+                    g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
+                self.arena.zero_grad()
+                output, loss_consis = self.forward_local(x, actual_bz, g["eval_in"] if ride else None)
             if ride:  # ... or inside it
                 g["eval_out_overlapped"] = self._rider_out
             elif overlap_eval:
@@ -742,8 +769,9 @@ class ViTTAAdapter:
                     g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, rider=g["eval_in"])
                     g["eval_out_overlapped"] = self._rider_out
                 else:
-                    g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
-                    g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
+                    with self._prepacked():
+                        g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
+                        g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
             g["ride_along"] = ride
         else:
             g["adapt"] = torch.cuda.CUDAGraph()
