@@ -278,6 +278,33 @@ def test_leading_frames_only_statistics_raw_output_and_pitched_backward_inputs(n
         assert (gw_p - gw_c).abs().max().item() <= 1e-5 * gw_c.abs().max().item() + 1e-7
 
 
+def test_deferred_weight_gradient_reductions_of_a_group_equal_the_immediate_ones():
+    """vitta_conv_wgrad_f32 with VITTA_WGRAD_DEFER_REDUCE + ONE vitta_conv_wgrad_reduce_f32 over the group (the convolutions of a
+    bottleneck, trunk.py) == the same launches each followed by its own reduction, accumulated onto non-zero buffers."""
+    from vitta_amd import conv as CV
+    gen = torch.Generator().manual_seed(77)
+    d = _dev()
+    n, h = 4, 28
+    group = [(64, 256, 1), (64, 64, 3), (256, 64, 1), (256, 512, 1)]
+    geoms, xs, dys, bases = [], [], [], []
+    for c, k, ksz in group:
+        geoms.append(CV.Geometry.forward(n, h, h, ksz, 1, ksz // 2))
+        xs.append(torch.randn(c, n * h * h, generator=gen).to(d))
+        dys.append(torch.randn(k, n * h * h, generator=gen).to(d))
+        bases.append((torch.randn(k, c, ksz, ksz, generator=gen) * 0.1).to(d))
+    now = [b.clone() for b in bases]
+    for g, x, dy, gw, (c, k, _) in zip(geoms, xs, dys, now, group):
+        CV.wgrad(g, x, dy, gw, c, k)
+    later = [b.clone() for b in bases]
+    descs = [CV.wgrad(g, x, dy, gw, c, k, defer=i) for i, (g, x, dy, gw, (c, k, _)) in enumerate(zip(geoms, xs, dys, later, group))]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(later, bases))   # nothing added yet
+    CV.wgrad_reduce(descs)
+    torch.cuda.synchronize()
+    for a, b, base in zip(now, later, bases):
+        assert (a - b).abs().max().item() <= 1e-5 * (a - base).abs().max().item()
+
+
 def test_unsupported_shapes_are_refused_not_miscomputed():
     from vitta_amd import _lib, conv as CV
     d = _dev()

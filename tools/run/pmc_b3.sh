@@ -23,5 +23,5 @@ for f in sorted(glob.glob("$O/${T}_conv_pmc_sq*.json")):
     d=json.load(open(f))
     for k,v in d.items():
         print(f.split('_')[-1], k)
-        print("   ", {a: (round(b,3) if b<100 else int(b)) for a,b in v.items()})
+        print("   ", {a: (b if not isinstance(b, (int, float)) else round(b,3) if b<100 else int(b)) for a,b in v.items()})
 PY
