@@ -215,11 +215,12 @@ def test_gemm_b3_modes_vs_fp64(m, n, k):
     _close(y2, lin * dg, rel=4e-5)
 
 
-def test_frozen_dense_layers_take_the_split_bf16_kernel_and_trainable_ones_the_fp32_kernel(abi_calls):
-    """ops.DenseLinear / FusedMlp: a frozen weight (LN-affine adaptation) is split once and runs on gemm_b3.hip, forward and
-    data gradient; a trainable weight (SGD over all parameters) stays on the exact-fp32 kernel (its image would have to be
-    re-made every step).  Same outputs and input gradients either way."""
+def test_frozen_dense_layers_take_the_split_bf16_kernel_and_trainable_ones_the_fp32_kernel(abi_calls, monkeypatch):
+    """ops.DenseLinear / FusedMlp with VITTA_DENSE_ARITH=b3 (opt-in): a frozen weight (LN-affine adaptation) is split once and
+    runs on gemm_b3.hip, forward and data gradient; a trainable weight (SGD over all parameters) stays on the exact-fp32
+    kernel (its image would have to be re-made every step).  Same outputs and input gradients either way."""
     from vitta_amd import ops
+    monkeypatch.setattr(ops, "DENSE_B3", True)
     dev = _dev()
     g = torch.Generator().manual_seed(7)
     x = torch.randn(2, 3136, 512, generator=g).to(dev)  # 6272 tokens x 1024 outputs: 392 tiles of 128 x 128, K = 512

@@ -853,8 +853,10 @@ GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64
 DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
 # fp32-accuracy dense layers on the bf16 matrix pipe (gemm_b3.hip: operands split into three bf16 terms, six products per
 # multiply-add -- the arithmetic of conv_b3.hip) wherever the weight is frozen (its split image is made once) and the shape
-# qualifies; VITTA_DENSE_ARITH=f32: the exact-fp32 MFMA kernel everywhere
-DENSE_B3 = __import__("os").environ.get("VITTA_DENSE_ARITH", "b3") == "b3"
+# qualifies.  Opt-in (VITTA_DENSE_ARITH=b3): on large products the kernel's main loop runs at 210 TF-equivalent against 136 TF for
+# the fp32 kernel, but at Video Swin-B's token counts (3136 .. 196 x 16 rows per product) it reaches the same ~80 TF as the
+# fp32 kernel and the step measures slower with it (C3 shape, same box, round 3: 22.9 ms against 20.9)
+DENSE_B3 = __import__("os").environ.get("VITTA_DENSE_ARITH", "f32") == "b3"
 
 
 class B3Operand:
