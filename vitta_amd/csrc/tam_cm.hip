@@ -123,11 +123,16 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __res
   }
 }
 
-template <int LPR>
+// FIN: the block holds whole (c, n) groups of T rows (rows per block % T == 0): d gate / d K of its groups are finished here
+// from LDS (the arithmetic of finish_kernel, same order) instead of by a second launch
+template <int LPR, bool FIN>
 __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
                                                               const float* __restrict__ kern, const float* __restrict__ gout,
                                                               int C, int N, int T, int HW, int64_t xld, float* __restrict__ ga,
-                                                              float* __restrict__ dots) {
+                                                              float* __restrict__ dots, float* __restrict__ ggate,
+                                                              float* __restrict__ gkern) {
+  constexpr int RPB = VITTA_BLOCK / LPR;
+  __shared__ float sd[FIN ? RPB * 3 : 1];
   int sub;
   const Row r = row_of<LPR>(C, N, T, &sub);
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -180,11 +185,41 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __res
   d0 = group_sum<LPR>(d0);
   d1 = group_sum<LPR>(d1);
   d2 = group_sum<LPR>(d2);
-  if (r.ok && sub == 0) {
-    float* d = dots + (((int64_t)r.n * C + r.c) * T + r.t) * 3;
-    d[0] = d0;
-    d[1] = d1;
-    d[2] = d2;
+  if constexpr (FIN) {
+    const int rl = threadIdx.x / LPR;
+    if (sub == 0) {
+      sd[rl * 3] = r.ok ? d0 : 0.f;
+      sd[rl * 3 + 1] = r.ok ? d1 : 0.f;
+      sd[rl * 3 + 2] = r.ok ? d2 : 0.f;
+    }
+    __syncthreads();
+    const int g = threadIdx.x;  // one lane per (c, n) group of the block
+    const int64_t row0 = (int64_t)blockIdx.x * RPB + (int64_t)g * T;
+    if (g < RPB / T && row0 < (int64_t)C * N * T) {
+      const int F = N * T;
+      const int c = (int)(row0 / F), n = (int)((row0 - (int64_t)c * F) / T);
+      const int64_t i = (int64_t)n * C + c;
+      const float k0 = kern[i * 3], k1 = kern[i * 3 + 1], k2 = kern[i * 3 + 2];
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const float* d = sd + (g * T + t) * 3;
+        const float gt = gate[i * T + t];
+        ggate[i * T + t] = k0 * d[0] + k1 * d[1] + k2 * d[2];
+        g0 = fmaf(gt, d[0], g0);
+        g1 = fmaf(gt, d[1], g1);
+        g2 = fmaf(gt, d[2], g2);
+      }
+      gkern[i * 3] = g0;
+      gkern[i * 3 + 1] = g1;
+      gkern[i * 3 + 2] = g2;
+    }
+  } else {
+    if (r.ok && sub == 0) {
+      float* d = dots + (((int64_t)r.n * C + r.c) * T + r.t) * 3;
+      d[0] = d0;
+      d[1] = d1;
+      d[2] = d2;
+    }
   }
 }
 
@@ -374,8 +409,24 @@ int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* con
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BN bn{h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps};
   float* dots = d_ggate + (int64_t)N * C * T;  // the caller gives d_ggate room for N*C*T*4 floats
-  CM_DISPATCH(agg_bwd_kernel, (int64_t)C * N * T, HW, st, d_x, bn, d_gate, d_kern, d_gout, (int)C, (int)N, (int)T, (int)HW,
-              xld, d_ga, dots);
+  const int64_t rows = (int64_t)C * N * T;
+  // whole (c, n) groups per workgroup -> d gate / d K finished in the same launch (T = 8: 32 or 16 lanes per row)
+  if (HW > 256 && (VITTA_BLOCK / 32) % T == 0) {
+    VITTA_LAUNCH((agg_bwd_kernel<32, true>), dim3(row_grid(rows, 32)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
+    return VITTA_OK;
+  }
+  if (HW <= 256 && (VITTA_BLOCK / 16) % T == 0) {
+    VITTA_LAUNCH((agg_bwd_kernel<16, true>), dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
+    return VITTA_OK;
+  }
+  if (HW > 256)
+    VITTA_LAUNCH((agg_bwd_kernel<64, false>), dim3(row_grid(rows, 64)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
+  else
+    VITTA_LAUNCH((agg_bwd_kernel<16, false>), dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
   const int64_t NC = (int64_t)N * C;
   VITTA_LAUNCH(finish_kernel, dim3((unsigned)((NC + VITTA_BLOCK - 1) / VITTA_BLOCK)), dim3(VITTA_BLOCK), 0, st, d_gate,
                d_kern, dots, NC, (int)T, d_ggate, d_gkern);

@@ -742,6 +742,12 @@ class ViTTAAdapter:
             collectives_in_graph = (self.bucket is not None and not segmented and torch.distributed.is_initialized()
                                     and torch.distributed.get_backend() == "nccl" and os.environ.get("VITTA_GRAPH_COLLECTIVES", "1") != "0")
         if collectives_in_graph:
+            # The collectives' own stream joins the capture.  torch's process-group watchdog polls the end events of the EAGER
+            # collectives it still lists (every 100 ms); an event query on a stream that is capturing at that moment is
+            # hipErrorCapturedEvent and the watchdog thread takes the process down (seen in about one run of four).  Let it
+            # retire what the eager steps left before the capture starts.
+            torch.cuda.synchronize()
+            time.sleep(0.35)
             try:
                 return self._capture(tta_input, eval_input, segmented, overlap_eval, True)
             except Exception as e:  # noqa: BLE001  (a capture the collectives library refuses must not cost the run)
