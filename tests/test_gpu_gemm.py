@@ -237,8 +237,30 @@ def test_frozen_dense_layers_take_the_split_bf16_kernel_and_trainable_ones_the_f
         y.square().sum().backward()
         n_b3 = abi_calls.abi.get("vitta_gemm_nt_b3_f32", 0) - before.get("vitta_gemm_nt_b3_f32", 0)
         assert n_b3 == (0 if train else 2), (train, abi_calls.abi)  # (the data gradient: 6272 x 512 outputs, K = 1024: 196 tiles)
+        # the trainable weight's gradient g^T x: one pointwise vitta_conv_f32 launch (tokens as channel axis), no library product
+        n_dw = abi_calls.abi.get("vitta_conv_f32", 0) - before.get("vitta_conv_f32", 0)
+        assert n_dw == (1 if train else 0), (train, abi_calls.abi)
+        if train:
+            _close(lin.weight.grad, (2 * y.detach().double().cpu().reshape(-1, 1024)).t() @ x.double().cpu().reshape(-1, 512), rel=4e-5)
         res[train] = (y.detach().cpu().double(), xi.grad.cpu().double())
         g = torch.Generator().manual_seed(7)  # same weights for the second pass
         torch.randn(2, 3136, 512, generator=g)
     _close(res[False][0].float(), res[True][0], rel=2e-5)
     _close(res[False][1].float(), res[True][1], rel=4e-5)
+
+
+@pytest.mark.parametrize("m,n,k,acc", [(6272, 384, 128, True), (784, 1024, 4096, True), (3136, 512, 2048, False), (50176, 128, 96, True),
+                                       (1568, 2048, 512, False)])
+def test_dense_weight_gradient_on_the_convolution_kernel_vs_fp64(m, n, k, acc):
+    """ops._weight_grad_conv: dW [N, K] (+)= g^T x of an nn.Linear (swin_transformer.py:30-35, 144, 165, 304-311 under SGD over
+    all parameters, corpus/basics.py:547-560) as a pointwise `vitta_conv_f32` launch with the tokens as channel axis."""
+    from vitta_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + n + k)
+    g2, x2 = torch.randn(m, n, generator=gen).to(dev), torch.randn(m, k, generator=gen).to(dev)
+    base = torch.randn(n, k, generator=gen).to(dev)
+    out = base.clone()
+    assert ops._weight_grad_conv(g2, x2, out, acc)
+    ref = g2.double().t().cpu() @ x2.double().cpu() + (base.double().cpu() if acc else 0)
+    _close(out, ref, rel=3e-5)
+    assert not ops._weight_grad_conv(g2[:, :n - 1].contiguous(), x2, out[:n - 1].contiguous(), acc)  # N % 32: declined, not miscomputed

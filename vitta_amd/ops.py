@@ -946,15 +946,44 @@ def _operand(weight, transposed, m_rows=None):
     return op
 
 
+DENSE_WGRAD = __import__("os").environ.get("VITTA_DENSE_WGRAD", "conv") != "library"
+
+
+def _weight_grad_conv(g2, x2, out, accumulate):
+    """out [N, K] (+)= g2^T x2 on the hand-written convolution kernel: with the TOKENS as its channel axis a pointwise
+    convolution IS this product -- x2 [M, K] read as planes `[C = M][P = K]`, g2 [M, N] as the packed weight `[1][C = M][N]`,
+    the channel-major output `[N][P = K]` is the nn.Linear weight layout -- and its stream-K form (conv_sk.hip) was built for
+    few tiles with a long reduction.  `accumulate`: the existing content of `out` enters as the epilogue's residual
+    (same address, same lane).  False when the shape does not qualify (the caller falls back to the library product)."""
+    from . import conv as CV
+    m, n = g2.shape
+    k = x2.shape[1]
+    if m % 16 or n % 32 or k % 4 or m * k * 4 >= (1 << 31) or not (g2.is_contiguous() and x2.is_contiguous() and out.is_contiguous()):
+        return False
+    geom = _WGRAD_GEOMS.get(k)
+    if geom is None:
+        geom = _WGRAD_GEOMS[k] = CV.Geometry.forward(1, 1, k)
+    CV.launch(geom, x2, CV.Pack(g2, None), out.view(n, k), m, n, flags=CV.CONV_RES if accumulate else 0,
+              res=out.view(n, k) if accumulate else None)
+    return True
+
+
+_WGRAD_GEOMS = {}
+
+
 def _weight_grad(weight, needed, g2, x2):
-    """g2^T x2 (the library's TN product) handed to the weight's gradient sink: accumulated IN the product (beta = 1) when
-    `.grad` is a live arena view, so no separate add pass runs over the 88 M weights of Swin-B."""
+    """g2^T x2 handed to the weight's gradient sink: accumulated IN the product when `.grad` is a live arena view, so no
+    separate add pass runs over the 88 M weights of Swin-B.  The product runs on `vitta_conv_f32` (_weight_grad_conv);
+    VITTA_DENSE_WGRAD=library or a shape it declines: the library's TN product."""
     if not needed:
         return None
     sink, ret = _grad_sink(weight, True, zero=False)
     if ret is None:
-        sink.view(weight.shape[0], -1).addmm_(g2.t(), x2)
+        if not (DENSE_WGRAD and _weight_grad_conv(g2, x2, sink.view(weight.shape[0], -1), True)):
+            sink.view(weight.shape[0], -1).addmm_(g2.t(), x2)
         return None
+    if DENSE_WGRAD and _weight_grad_conv(g2, x2, ret.view(weight.shape[0], -1), False):
+        return ret.view_as(weight)
     return torch.mm(g2.t(), x2, out=ret.view(weight.shape[0], -1)).view_as(weight)
 
 
