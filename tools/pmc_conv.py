@@ -13,7 +13,7 @@ from collections import defaultdict
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def summarise(path, out_json, trace=None):
+def summarise(path, out_json, trace=None, match=None):
     """Per (kernel instantiation, grid): the counters averaged over the launches, plus ratios that need no clock assumption
     (everything per wave: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles --
     MI355X_MICROARCH.md, table of per-instruction constants) and one that does (mfma_busy_fraction_of_kernel: 2.4 GHz)."""
@@ -26,12 +26,21 @@ def summarise(path, out_json, trace=None):
             dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     agg = defaultdict(lambda: defaultdict(float))
     calls = defaultdict(set)
+    waves_of = defaultdict(float)
     for r in rows:
         name = r["Kernel_Name"]
-        if "conv_" not in name or "pack" in name:
-            continue
-        m = re.search(r"(conv_\w+_kernel<[^>]*>|conv_\w+_kernel)", name)
-        k = (m.group(1) if m else name[:60]) + " workgroups=" + str(int(r.get("Grid_Size", "0")) // 256)
+        wg = int(r.get("Workgroup_Size", "256") or 256)
+        if match:  # other kernel families (tools/run/pmc_swin.sh): one entry per kernel instantiation, launches of all grids pooled
+            m = re.search(match, name)
+            if not m:
+                continue
+            k = m.group(0)
+            waves_of[k] += (int(r.get("Grid_Size", "0")) // wg) * (wg // 64) if r["Dispatch_Id"] not in calls[k] else 0
+        else:
+            if "conv_" not in name or "pack" in name:
+                continue
+            m = re.search(r"(conv_\w+_kernel<[^>]*>|conv_\w+_kernel)", name)
+            k = (m.group(1) if m else name[:60]) + " workgroups=" + str(int(r.get("Grid_Size", "0")) // 256)
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Dispatch_Id"] not in calls[k] and r["Dispatch_Id"] in dur:
             agg[k]["duration_us"] += dur[r["Dispatch_Id"]]
@@ -41,7 +50,8 @@ def summarise(path, out_json, trace=None):
         n = len(calls[k])
         d = {name: v / n for name, v in c.items()}
         d["launches"] = n
-        waves = 4.0 * int(k.rsplit("=", 1)[1])
+        waves = waves_of[k] / n if match else 4.0 * int(k.rsplit("=", 1)[1])
+        d["waves_per_launch"] = waves
         if d.get("SQ_WAVE_CYCLES"):
             life = 4.0 * d["SQ_WAVE_CYCLES"] / waves
             d["cycles_per_wave_lifetime"] = life
@@ -69,7 +79,7 @@ def summarise(path, out_json, trace=None):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
-        summarise(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+        summarise(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None, os.environ.get("PMC_MATCH"))
         sys.exit(0)
     import torch
     from vitta_amd import conv as CV
