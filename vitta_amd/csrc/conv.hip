@@ -733,8 +733,13 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     else if (d.ksplit != 0) ks = d.ksplit > 0 ? d.ksplit : 1;
     else {
       static const int min_wgs = env_int("VITTA_CONV_B3_MIN_WGS", 384), min_steps = env_int("VITTA_CONV_B3_MIN_STEPS", 4);
+      // tools/debug/b3_ks_sweep.sh forces a factor for a per-layer sweep.  Round 3: the best factor per layer beats this
+      // heuristic by 1.2 % (16 frames) / 6 % (8 frames) stand-alone and by nothing measurable in the step (5.83 vs 5.84 ms
+      // with the twelve differing entries as a table) -- no table kept
+      static const int force_ks = env_int("VITTA_CONV_B3_FORCE_KS", 0);
       const int taps_min = parity4 ? 1 : d.ntaps;  // (the lightest class of a parity-merged launch has one tap)
       while (tiles * ks < min_wgs && (ncs / (ks * 2)) * taps_min >= min_steps && ncs % (ks * 2) == 0 && ks < 16) ks *= 2;
+      if (force_ks > 0) ks = force_ks;
     }
     if (ks > ncs) ks = ncs;
     const size_t need = ks > 1 ? counter_bytes(tiles) + (size_t)tiles * ks * bm * bn * sizeof(float) : 0;
