@@ -658,6 +658,7 @@ void choose_tile(const vitta_conv_desc& d, int64_t M, int& bm, int& bn) {
 int fill(const vitta_conv_desc* h, ConvK& a) {
   if (!h || !h->x || (!h->w && !h->w_b3) || !h->y) return VITTA_ERR_INVALID_ARG;
   a.d = *h;
+  a.nfast = 0;
   const vitta_conv_desc& d = a.d;
   if (d.C <= 0 || d.K <= 0 || d.N <= 0 || d.ntaps < 1 || d.ntaps > VITTA_CONV_MAX_TAPS || d.sstride < 1 || d.ostride < 1 ||
       d.ostride > 2)
@@ -752,6 +753,12 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
     a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
     a.b3 = form;
+    {
+      // operand bytes one XCD pulls through its L2 under either tile order: its share of one operand, all of the other
+      static const int nfast_mode = env_int("VITTA_CONV_B3_NFAST", -1);  // -1: by operand size, 0 / 1: forced
+      const double w_bytes = 6.0 * d.C * d.K * d.ntaps, a_bytes = 4.0 * d.C * (double)a.xP;
+      a.nfast = (nfast_mode < 0 ? (w_bytes > 1.5 * a_bytes && a.nNt >= 8) : nfast_mode) && !wide && !small ? 1 : 0;
+    }
     // pointwise launches with more tiles than resident workgroups (two per CU) can run the persistent form of conv_b3.hip,
     // every workgroup a contiguous range of tiles with the request ring running on across tile boundaries -- on request
     // only (ksplit = -1, or VITTA_CONV_B3_PERSIST=1): measured EQUAL to one tile per workgroup on the trunk's shapes (64 ->

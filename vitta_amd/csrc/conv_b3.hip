@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   const int Lz = xcd_remap(blockIdx.x, gridDim.x);
   const int Lg = Lz / a.ksplit, kz = Lz - Lg * a.ksplit;  // tile of the launch (arrival counter, partial tiles)
   // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table
-  const int cls = a.cls_tiles ? Lg / a.cls_tiles : 0, L = Lg - cls * a.cls_tiles;
+  const int cls = a.cls_tiles ? Lg / a.cls_tiles : 0, Lc = Lg - cls * a.cls_tiles;
+  // which tile: an XCD owns a contiguous range of logical ids (xcd_remap).  With column tiles fastest (default) that range is a
+  // few pixel tiles x ALL output channels -- every XCD pulls the whole weight image through its own L2; where the image is the
+  // larger operand (layer 4: 14 MB against 1.6 MB of activations) the host asks for pixel tiles fastest instead (a.nfast):
+  // an XCD then covers all pixels of a few column tiles and reads only their share of the weights
+  const int L = a.nfast ? (Lc % a.nMt) * a.nNt + Lc / a.nMt : Lc;
   const int tap0 = a.cls_tiles ? a.cls_tap0[cls] : 0, ntaps = a.cls_tiles ? a.cls_tap0[cls + 1] - tap0 : d.ntaps;
   const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
   const int ncs = C / BK;
