@@ -389,14 +389,18 @@ class PatchEmbed3D(nn.Module):
             x = F.pad(x, (0, (-W) % p[2], 0, (-H) % p[1], 0, (-D) % p[0]))
         B, Cin, D, H, W = x.shape
         kin = Cin * p[0] * p[1] * p[2]
+        from . import ops as _ops
         if (FUSED_DENSE and x.is_cuda and x.dtype == torch.float32 and kin % 32 == 0 and tuple(self.proj.stride) == tuple(p)
-                and tuple(self.proj.padding) == (0, 0, 0) and not self.proj._forward_hooks):
+                and tuple(self.proj.kernel_size) == tuple(p) and tuple(self.proj.padding) == (0, 0, 0)
+                and tuple(self.proj.dilation) == (1, 1, 1) and self.proj.groups == 1 and not self.proj._forward_hooks
+                and not self.proj._forward_pre_hooks
+                and _ops.gemm_nt_supported(B * (D // p[0]) * (H // p[1]) * (W // p[2]), self.proj.weight.shape[0], kin)):
             # kernel == stride: the convolution is a per-patch Linear(kin -> embed_dim).  One gather copy + the dense kernel
             # (csrc/gemm.hip) instead of the library's im2col + GEMM -- and instead of its NAIVE Conv3d weight-gradient
             # kernel under SGD over all parameters (7.9 ms per video, 18 % of that step)
             from . import ops
             Dd, Hh, Ww = D // p[0], H // p[1], W // p[2]
-            patches = x.view(B, Cin, Dd, p[0], Hh, p[1], Ww, p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, Dd * Hh * Ww, kin)
+            patches = x.reshape(B, Cin, Dd, p[0], Hh, p[1], Ww, p[2]).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, Dd * Hh * Ww, kin)
             x = ops.DenseLinear.apply(patches, self.proj.weight, self.proj.bias)
             C = x.shape[-1]
         else:
