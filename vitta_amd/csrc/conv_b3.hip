@@ -58,6 +58,19 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 // NW = waves per workgroup = 32-row blocks of the tile: 4 (128 x 64 tiles, two workgroups per CU) or, pointwise only, 2
 // (64 x 64 tiles, 40 KB of LDS: FOUR workgroups per CU -- twice the independent request chains for the same wave count)
+#ifdef B3_TRACE
+// tools/debug/b3_trace.py: shader-clock stamps of wave 0 at the phase boundaries of a workgroup, 16 words per workgroup
+__device__ unsigned long long b3_trace_buf[16 * 8192];
+#define B3_STAMP(i)                                                                                      \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) b3_trace_buf[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define B3_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
+
 template <int MODE, bool PRE, int NB, int NW = 4>
 __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
@@ -78,6 +91,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, lk = lane >> 5;
   const int C = d.C, K = d.K;
+  B3_STAMP(0);
   const int Lz = xcd_remap(blockIdx.x, gridDim.x);
   const int Lg = Lz / a.ksplit, kz = Lz - Lg * a.ksplit;  // tile of the launch (arrival counter, partial tiles)
   // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table
@@ -306,8 +320,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
     for (int y = 0; y < 2; ++y) tile_prefetch(a, L, NW == 4 ? wave >> 1 : wave, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
   }
   // step 0 (requested first) has landed; loads the compiler placed behind the requests only make this wait longer
+  B3_STAMP(1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PER_STEP) : "memory");
   barrier();
+  B3_STAMP(2);
   float raw[8];
   bf16x8 fa0[3], fa1[3], fb0[2][3], fb1[2][3];
   read_ops(a_addr(a.tap[tap0], 0, 0), Bb, 0, raw, fb0);
@@ -366,8 +382,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
       }
     }
   }
+  B3_STAMP(3);
   wait_all();       // the tail's surplus requests: nothing may land in LDS that the next workgroup of this CU owns
   __syncthreads();
+  B3_STAMP(4);
+#ifdef B3_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    b3_trace_buf[blockIdx.x * 16 + 12] = ((unsigned long long)xcc << 32) | (unsigned)(kz | (a.ksplit << 8) | (S << 16));
+  }
+#endif
 
   // ---- split K: partial tiles meet in the last-arriving workgroup (write-through slabs, ticket; as conv.hip) --------
   if (a.ksplit > 1) {
@@ -383,6 +408,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    B3_STAMP(5);
     if (tid == 0) {
       const unsigned ticket = __hip_atomic_fetch_add(a.cnt + Lg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)(a.ksplit - 1);
@@ -390,27 +416,52 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
       flag[0] = last ? 1 : 0;
     }
     __syncthreads();
+    B3_STAMP(6);
     if (flag[0] == 0) return;
 #pragma unroll
     for (int y = 0; y < 2; ++y)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
-    for (int z = 0; z < a.ksplit; ++z) {
+    // the slices' tiles are added in slice order (the result does not depend on who arrived last).  This re-read takes 2.0 /
+    // 3.9 / 7.6 us for 2 / 4 / 8 slices (tools/debug/b3_trace.py) -- ~1 us per 32 KB slice; B3_RU slices in flight together
+    // change nothing (launch totals 1.427 / 1.421 / 1.448 ms for 1 / 2 / 4): the consumer CU's memory queue, not the
+    // round-trip latency, sets the pace (MI355X_MICROARCH.md "handoff-payload": 47-75 GB/s per block at these sizes)
+#ifndef B3_RU
+#define B3_RU 1
+#endif
+    for (int z0 = 0; z0 < a.ksplit; z0 += B3_RU) {
+      f32x4 pv[B3_RU][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTHR + tid) * 16, z * tile_bytes, 16));
-        acc[i / 4][4 * (i % 4)] += pv.x;
-        acc[i / 4][4 * (i % 4) + 1] += pv.y;
-        acc[i / 4][4 * (i % 4) + 2] += pv.z;
-        acc[i / 4][4 * (i % 4) + 3] += pv.w;
+      for (int u = 0; u < B3_RU; ++u) {
+        const int z = min(z0 + u, a.ksplit - 1);  // (past the end: a valid address, the value is not added)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          pv[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTHR + tid) * 16, z * tile_bytes, 16));
+      }
+#pragma unroll
+      for (int u = 0; u < B3_RU; ++u) {
+        if (z0 + u < a.ksplit) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            acc[i / 4][4 * (i % 4)] += pv[u][i].x;
+            acc[i / 4][4 * (i % 4) + 1] += pv[u][i].y;
+            acc[i / 4][4 * (i % 4) + 2] += pv[u][i].z;
+            acc[i / 4][4 * (i % 4) + 3] += pv[u][i].w;
+          }
+        }
       }
     }
   }
 
   // ---- epilogue: the wave's two column blocks; per-channel sums of the four waves meet in LDS ----------------------------
+  B3_STAMP(7);
   float r1[2] = {0.f, 0.f}, r2[2] = {0.f, 0.f};
   epi0.template body<PRE>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
   epi1.template body<PRE>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
+#ifdef B3_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  B3_STAMP(8);
+#endif
   const bool BWD = d.flags & VITTA_CONV_BWD_BN;
   if (((d.flags & VITTA_CONV_STATS) && d.st_s1) || BWD) {
 #pragma unroll
@@ -1132,3 +1183,16 @@ int vitta_conv_pack_b3_table(const vitta_pack_b3_entry* d_table, int32_t n_entri
 }
 
 }  // extern "C"
+
+#ifdef B3_TRACE
+extern "C" int vitta_conv_b3_trace_read(void* h_dst, int64_t bytes, int32_t clear) {
+  if (hipDeviceSynchronize() != hipSuccess) return VITTA_ERR_LAUNCH;
+  if (h_dst && hipMemcpyFromSymbol(h_dst, HIP_SYMBOL(b3_trace_buf), (size_t)bytes) != hipSuccess) return VITTA_ERR_LAUNCH;
+  if (clear) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(b3_trace_buf)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * 16 * 8192) != hipSuccess)
+      return VITTA_ERR_LAUNCH;
+  }
+  return VITTA_OK;
+}
+#endif
