@@ -190,13 +190,21 @@ __global__ __launch_bounds__(WTH) void stem_wgrad_kernel(const StemWgradArgs a) 
   }
 }
 
+// grid (37, Z): the partial list of an element is cut Z ways (one thread walking all G partials was a chain of G dependent
+// loads on 37 workgroups: 119 us per step); the Z sums meet in dW by atomics
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const StemWgradArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;  // (t, k)
   if (i >= 147 * 64) return;
   const int t = i >> 6, k = i & 63;
-  float s = 0.f;
-  for (int g = 0; g < a.G; ++g) s += a.partial[((int64_t)g * 160 + t) * 64 + k];
-  a.dw[k * 147 + t] += s;
+  float s0 = 0.f, s1 = 0.f;
+  const int Z = (int)gridDim.y;
+  int g = (int)blockIdx.y;
+  for (; g + Z < a.G; g += 2 * Z) {
+    s0 += a.partial[((int64_t)g * 160 + t) * 64 + k];
+    s1 += a.partial[((int64_t)(g + Z) * 160 + t) * 64 + k];
+  }
+  if (g < a.G) s0 += a.partial[((int64_t)g * 160 + t) * 64 + k];
+  atomicAdd(a.dw + k * 147 + t, s0 + s1);
 }
 
 }  // namespace
@@ -239,7 +247,7 @@ int vitta_stem_conv7_wgrad_f32(const float* d_x, const float* d_dy, int64_t N, i
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   VITTA_LAUNCH(stem_wgrad_kernel, dim3((unsigned)a.G), dim3(WTH), lds, st, a);
-  VITTA_LAUNCH(stem_wgrad_reduce_kernel, dim3((147 * 64 + 255) / 256), dim3(256), 0, st, a);
+  VITTA_LAUNCH(stem_wgrad_reduce_kernel, dim3((147 * 64 + 255) / 256, a.G >= 64 ? 16 : 1), dim3(256), 0, st, a);
   return VITTA_OK;
 }
 
