@@ -57,7 +57,6 @@ def run(name, n, c, k, h, ksz, stride=1, dgrad=False, flags=0):
     def stat(label, v):
         v = v * tick
         print(f"   {label:46s} mean {v.mean():6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
-    stat("workgroup start after the first of its XCD", start)
     stat("entry -> requests issued", t[:, 1] - t[:, 0])
     stat("requests issued -> first stage landed", t[:, 2] - t[:, 1])
     stat("main loop", t[:, 3] - t[:, 2])
@@ -71,7 +70,6 @@ def run(name, n, c, k, h, ksz, stride=1, dgrad=False, flags=0):
         stat("(no split)", (t[:, 7] - t[:, 4]))
     stat("epilogue until its stores have landed", (t[:, 8] - t[:, 7])[last])
     stat("lifetime of the workgroups that write the output", (t[:, 8] - t[:, 0])[last])
-    stat("workgroup end after the first start of its XCD", end)
 
 
 if __name__ == "__main__":
