@@ -58,6 +58,12 @@ def run(name, n, c, k, h, ksz, stride=1, dgrad=False, flags=0):
         v = v * tick
         print(f"   {label:46s} mean {v.mean():6.2f}  median {np.median(v):6.2f}  p90 {np.percentile(v, 90):6.2f}  max {v.max():6.2f} us")
     stat("entry -> requests issued", t[:, 1] - t[:, 0])
+    if (t[:, 9] > 0).all():
+        stat("  entry -> tile / slice indices known", t[:, 9] - t[:, 0])
+        stat("  -> epilogue objects, buffer descriptors", t[:, 10] - t[:, 9])
+        stat("  -> request offsets, tap validity", t[:, 11] - t[:, 10])
+        stat("  -> first NB stages requested", t[:, 13] - t[:, 11])
+        stat("  -> epilogue constants / input stream requested", t[:, 1] - t[:, 13])
     stat("requests issued -> first stage landed", t[:, 2] - t[:, 1])
     stat("main loop", t[:, 3] - t[:, 2])
     stat("ring drained", t[:, 4] - t[:, 3])

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   const int ncs = C / BK;
   const int cs0 = (int)(((int64_t)ncs * kz) / a.ksplit), cs1 = (int)(((int64_t)ncs * (kz + 1)) / a.ksplit);
   const int S = (cs1 - cs0) * ntaps;  // steps = (channel slab, tap) pairs
+  B3_STAMP(9);
 
   // wave w owns pixel rows 32 w .. 32 w + 31 and all 64 output channels (two 32 x 32 accumulators)
   TileEpilogue epi0(a, red, NW == 4 ? wave >> 1 : wave, 0, li, lk, BM), epi1(a, red, NW == 4 ? wave >> 1 : wave, 1, li, lk, BM);
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   constexpr int OOB = (int)0x80000000u;
   const int row_bytes = (int)(a.xP * 4);
   typedef __attribute__((address_space(3))) void* lds_ptr;
+  B3_STAMP(10);
 
   // ---- LDS-DMA side ----------------------------------------------------------------------------------------------------
   // A, patch: one instruction = one channel row (256 pixels; lane 0 out of range: positions 0..3 stay zero); wave w loads
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
       if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) valid |= 1u << t;
     }
   }
+  B3_STAMP(11);
   const int a_lane = (8 * lk * PL + pos) * 4;   // byte offset of the lane's first operand word in an A stage
   const int a_zero = 8 * lk * PL * 4;           // ... of the always-zero position of the same rows
   const int b_lane = (lk * BN + li) * 16;       // ... of its first B operand in a B stage
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   dma_a(cs0, 0, a.tap[tap0], 0);
 #pragma unroll
   for (int i = 0; i < NB; ++i) request(i, i > 0);
+  B3_STAMP(13);
   epi0.load_consts(L);
   epi1.load_consts(L);
   if constexpr (PRE) {
