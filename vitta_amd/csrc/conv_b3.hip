@@ -95,7 +95,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   const int Lz = xcd_remap(blockIdx.x, gridDim.x);
   const int Lg = Lz / a.ksplit, kz = Lz - Lg * a.ksplit;  // tile of the launch (arrival counter, partial tiles)
   // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table
-  const int cls = a.cls_tiles ? Lg / a.cls_tiles : 0, Lc = Lg - cls * a.cls_tiles;
+  // (class fastest: the classes have 1, 2, 2 and 4 taps -- as four contiguous blocks of ids the XCDs, which own contiguous id
+  // ranges, would get one class each: a 4x imbalance between them; interleaved, every XCD holds all four classes of its
+  // tiles, which also read the same input pixels)
+  const int cls = a.cls_tiles ? (Lg & 3) : 0, Lc = a.cls_tiles ? (Lg >> 2) : Lg;
   // which tile: an XCD owns a contiguous range of logical ids (xcd_remap).  With column tiles fastest (default) that range is a
   // few pixel tiles x ALL output channels -- every XCD pulls the whole weight image through its own L2; where the image is the
   // larger operand (layer 4: 14 MB against 1.6 MB of activations) the host asks for pixel tiles fastest instead (a.nfast):
