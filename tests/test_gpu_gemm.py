@@ -264,3 +264,26 @@ def test_dense_weight_gradient_on_the_convolution_kernel_vs_fp64(m, n, k, acc):
     ref = g2.double().t().cpu() @ x2.double().cpu() + (base.double().cpu() if acc else 0)
     _close(out, ref, rel=3e-5)
     assert not ops._weight_grad_conv(g2[:, :n - 1].contiguous(), x2, out[:n - 1].contiguous(), acc)  # N % 32: declined, not miscomputed
+
+
+@pytest.mark.parametrize("m,n,k,bias", [(256, 128, 64, False), (3136, 1536, 512, True), (12544, 512, 2048, True), (1000, 384, 128, False),
+                                         (50176, 384, 128, True), (129, 256, 192, True)])
+def test_gemm_bf16x_vs_fp64_of_the_rounded_operands(m, n, k, bias):
+    """gemm_bf16x.hip: y = a b^T (+ bias) on bfloat16 operands in memory (LDS-DMA of both, 128 x 128 tiles, fp32
+    accumulation) against the fp64 product of the same bf16 values: only the accumulation order differs (ragged M included)."""
+    from vitta_amd import _lib
+    import ctypes as C
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=gen).to(dev).to(torch.bfloat16)
+    b = (torch.randn(n, k, generator=gen) * k ** -0.5).to(dev).to(torch.bfloat16)
+    bv = torch.randn(n, generator=gen).to(dev) if bias else None
+    y = torch.full((m, n), float("nan"), device=dev)
+    L = _lib.lib()
+    assert L.vitta_gemm_bf16x_supported(m, n, k)
+    _lib.check(L.vitta_gemm_nt_bf16x_f32(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(bv.data_ptr() if bias else 0),
+                                         C.c_void_p(y.data_ptr()), m, n, k, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "vitta_gemm_nt_bf16x_f32")
+    ref = a.double().cpu() @ b.double().cpu().t() + (bv.double().cpu() if bias else 0)
+    _close(y, ref, rel=2e-5)
+    assert not L.vitta_gemm_bf16x_supported(m, n + 64, k) and not L.vitta_gemm_bf16x_supported(m, n, k + 32)

@@ -132,6 +132,8 @@ SIGNATURES = {
     "vitta_conv_f32": (C.c_int, [C.POINTER(ConvDesc), _p]),
     "vitta_conv_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
+    "vitta_gemm_bf16x_supported": (C.c_int, [_i64, _i64, _i64]),
+    "vitta_gemm_nt_bf16x_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
     "vitta_conv_wgrad_reduce_f32": (C.c_int, [C.POINTER(C.POINTER(WgradDesc)), _i32, _p]),
     "vitta_conv_repack_f32": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_pack_b3_bytes": (_sz, [_i32, _i32, _i32]),
