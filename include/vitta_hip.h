@@ -703,7 +703,7 @@ int vitta_gemm_nt_bf16w_f32(const float* d_a, const uint16_t* d_b_bf16, const fl
 /* The dense product on bfloat16 operands IN MEMORY (gemm_bf16x.hip; the bf16 recipe of BASELINE config 5,
  * swin_transformer.py:30-35, 144, 165, 304-311 under recognizer3d.py:36-40's fp16 / bf16 wrapper):
  *   y[m][n] = sum_k a[m][k] b[n][k] (+ bias[n]),   d_a [M][K] bf16, d_b [N][K] bf16 (nn.Linear's own layout), d_y [M][N] fp32.
- * Both operands reach LDS by LDS-DMA, 128 x 128 tiles, 64-wide k-steps.  N % 128 == 0, K % 64 == 0 (vitta_gemm_bf16x_supported). */
+ * Both operands reach LDS by LDS-DMA, 128 x 128 tiles, 32-wide k-steps in a three-stage ring.  N % 128 == 0, K % 32 == 0 (vitta_gemm_bf16x_supported). */
 int vitta_gemm_bf16x_supported(int64_t M, int64_t N, int64_t K);
 int vitta_gemm_nt_bf16x_f32(const void* d_a, const void* d_b, const float* d_bias, float* d_y, int64_t M, int64_t N, int64_t K,
                             void* stream);

@@ -286,4 +286,4 @@ def test_gemm_bf16x_vs_fp64_of_the_rounded_operands(m, n, k, bias):
                "vitta_gemm_nt_bf16x_f32")
     ref = a.double().cpu() @ b.double().cpu().t() + (bv.double().cpu() if bias else 0)
     _close(y, ref, rel=2e-5)
-    assert not L.vitta_gemm_bf16x_supported(m, n + 64, k) and not L.vitta_gemm_bf16x_supported(m, n, k + 32)
+    assert not L.vitta_gemm_bf16x_supported(m, n + 64, k) and not L.vitta_gemm_bf16x_supported(m, n, k + 16)
