@@ -659,6 +659,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   if (!h || !h->x || (!h->w && !h->w_b3) || !h->y) return VITTA_ERR_INVALID_ARG;
   a.d = *h;
   a.nfast = 0;
+  a.q = 0;
   const vitta_conv_desc& d = a.d;
   if (d.C <= 0 || d.K <= 0 || d.N <= 0 || d.ntaps < 1 || d.ntaps > VITTA_CONV_MAX_TAPS || d.sstride < 1 || d.ostride < 1 ||
       d.ostride > 2)
@@ -753,6 +754,12 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     a.cnt = ks > 1 ? static_cast<unsigned*>(d.workspace) : nullptr;
     a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
     a.b3 = form;
+    {
+      // opt-in: equal over the trunk's fifteen pointwise shapes (1.43 vs 1.41 ms per 16-frame pass; better by 5-11 % where a
+      // launch has >= 1500 tiles or very short slices, worse by 3-8 % elsewhere)
+      static const int q_on = env_int("VITTA_CONV_B3_Q", 0);
+      a.q = (q_on && form == 1 && !wide && !small && a.sk_G == 0) ? 1 : 0;
+    }
     {
       // operand bytes one XCD pulls through its L2 under either tile order: its share of one operand, all of the other
       static const int nfast_mode = env_int("VITTA_CONV_B3_NFAST", -1);  // -1: by operand size, 0 / 1: forced

@@ -71,16 +71,21 @@ __device__ unsigned long long b3_trace_buf[16 * 8192];
   } while (0)
 #endif
 
-template <int MODE, bool PRE, int NB, int NW = 4>
-__global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
+// Q (pointwise, four waves): THREE stages of SIXTEEN channels (14 KB each, 44 KB with the epilogue scratch: three workgroups per
+// CU) and one barrier per 16-channel step -- behind it every wave has the step's images and has finished reading the stage of
+// the step before, which takes the request of the step after next: two steps of requests in flight.  The pipeline of
+// gemm_bf16x.hip, where it was worth 14 % against two 64-wide stages at two workgroups per CU.
+template <int MODE, bool PRE, int NB, int NW = 4, bool Q = false>
+__global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
   static_assert(NW == 4 || (NW == 2 && MODE == 0), "two-wave workgroups: pointwise form only");
+  static_assert(!Q || (MODE == 0 && NW == 4 && NB == 3), "Q: the pointwise form with three stages");
   constexpr int BM = 32 * NW, BN = 64, BK = 32, HALO = 64, NTHR = 64 * NW;
   constexpr int PL = PATCH ? 256 : BM;    // pixels per channel row of the A image
   constexpr int NA = PATCH ? 1 : NB;      // A stages (B: NB)
-  constexpr int PER_STEP = PATCH ? 12 / NW : GATHER ? 16 + 12 / NW : 4 + 12 / NW;  // LDS-DMA instructions of a wave per step
-  constexpr int RPW = BK / NW;            // channel rows of an A stage a wave requests
-  constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
+  constexpr int PER_STEP = Q ? 4 : PATCH ? 12 / NW : GATHER ? 16 + 12 / NW : 4 + 12 / NW;  // LDS-DMA instructions of a wave per step
+  constexpr int RPW = (Q ? 16 : BK) / NW;  // channel rows of an A stage a wave requests
+  constexpr int A_BYTES = (Q ? 16 : BK) * PL * 4, B_BYTES = (Q ? 6 : 12) * BN * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Ab = lds;                        // [NA][BK][PL] fp32
   unsigned char* const Bb = lds + NA * A_BYTES;         // [NB][3 planes][4 channel octets][BN][8] bf16
@@ -108,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
   const int ncs = C / BK;
   const int cs0 = (int)(((int64_t)ncs * kz) / a.ksplit), cs1 = (int)(((int64_t)ncs * (kz + 1)) / a.ksplit);
-  const int S = (cs1 - cs0) * ntaps;  // steps = (channel slab, tap) pairs
+  const int S = (cs1 - cs0) * ntaps * (Q ? 2 : 1);  // steps = (channel slab, tap) pairs (Q: 16-channel halves of a slab)
   B3_STAMP(9);
 
   // wave w owns pixel rows 32 w .. 32 w + 31 and all 64 output channels (two 32 x 32 accumulators)
@@ -164,6 +169,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c0 + i) * row_bytes, 0, 0);
+    } else if constexpr (Q) {  // cs = 16-channel step: the wave's four channel rows, two per instruction
+      const int c16 = cs * 16 + wave * RPW;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c16 + 2 * i) * row_bytes, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -172,6 +182,17 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   };
   // B: the slab image of this tile's 64 output channels = 12 runs (plane, channel octet) of 64 x 16 bytes, three per wave
   auto dma_b = [&](int cs, int tp, int stage) __attribute__((always_inline)) {
+    if constexpr (Q) {
+      // cs = 16-channel step: the two octets 2 h, 2 h + 1 of each plane of slab cs / 2 = six runs, LDS order (plane, octet).
+      // Waves 0, 1 bring two runs each, waves 2, 3 one each -- issued TWICE, so that every wave has the same number of
+      // instructions in flight for the counted waits (same bytes to the same place)
+      const int h = cs & 1, r0 = wave < 2 ? 2 * wave : 2 + wave, r1 = wave < 2 ? r0 + 1 : r0;
+      const int base = ((tp >> 16) * ncs + (cs >> 1)) * 12 + 2 * h;
+      unsigned char* dst = Bb + stage * B_BYTES;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + r0 * 1024), 16, lane * 16, ((base + (r0 >> 1) * 4 + (r0 & 1)) * K + k0) * 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + r1 * 1024), 16, lane * 16, ((base + (r1 >> 1) * 4 + (r1 & 1)) * K + k0) * 16, 0, 0);
+      return;
+    }
     unsigned char* dst = Bb + stage * B_BYTES + wave * (12 / NW) * 1024;
     const int run0 = (((tp >> 16) * ncs + cs) * 12 + wave * (12 / NW));
 #pragma unroll
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
   float4 pre[2][4] = {};
   // requests run NB steps ahead: (cs_q, t_q) = the step to request next, clamped to the slice's last step (the tail
   // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits)
-  int cs_q = cs0, t_q = 0, q = 0;
+  int cs_q = Q ? 2 * cs0 : cs0, t_q = 0, q = 0;
   auto request = [&](int stage, bool with_a) __attribute__((always_inline)) {
 #ifdef B3_ABL_NODMA
     if (q >= NB) return;
@@ -316,9 +337,14 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
     t_q = adv ? (wrap ? 0 : t_q + 1) : t_q;
     cs_q += wrap ? 1 : 0;
   };
-  dma_a(cs0, 0, a.tap[tap0], 0);
+  if constexpr (Q) {
+    request(0, true);
+    request(1, true);
+  } else {
+    dma_a(cs0, 0, a.tap[tap0], 0);
 #pragma unroll
-  for (int i = 0; i < NB; ++i) request(i, i > 0);
+    for (int i = 0; i < NB; ++i) request(i, i > 0);
+  }
   B3_STAMP(13);
   epi0.load_consts(L);
   epi1.load_consts(L);
@@ -326,6 +352,30 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
 #pragma unroll
     for (int y = 0; y < 2; ++y) tile_prefetch(a, L, NW == 4 ? wave >> 1 : wave, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
   }
+  if constexpr (Q) {
+    float raw[8];
+    bf16x8 fa[3], fb[2][3];
+    int st = 0;
+    B3_STAMP(1);
+    for (int s = 0; s < S; ++s) {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");  // step s has landed (step s + 1 may be in flight)
+      barrier();
+      if (s == 0) B3_STAMP(2);
+      request(st >= 1 ? st - 1 : 2, true);  // step s + 2 into the stage of step s - 1
+      const float* ap = reinterpret_cast<const float*>(Ab + st * A_BYTES + a_lane);
+      const unsigned char* bs_ = Bb + st * B_BYTES;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = ap[j * PL];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + (p * 2 * BN + 32 * y) * 16);
+      split(raw, fa);
+      mfma12(fa, fb);
+      st = st == 2 ? 0 : st + 1;
+    }
+  } else {
   // step 0 (requested first) has landed; loads the compiler placed behind the requests only make this wait longer
   B3_STAMP(1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PER_STEP) : "memory");
@@ -388,6 +438,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_b3_kernel(const ConvK a) {
         mfma12(fa1, fb1);
       }
     }
+  }
   }
   B3_STAMP(3);
   wait_all();       // the tail's surplus requests: nothing may land in LDS that the next workgroup of this CU owns
@@ -1082,21 +1133,22 @@ int launch_wide(const ConvK& a, bool patch, hipStream_t st, hipEvent_t e0, hipEv
 
 #undef SGB
 
-template <int MODE, bool PRE, int NW = 4>
+template <int MODE, bool PRE, int NW = 4, bool Q = false>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr int NB = MODE == 1 ? 3 : 2;
-  constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 32 * NW) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
+  constexpr int NB = Q ? 3 : MODE == 1 ? 3 : 2;
+  constexpr size_t lds = Q ? (size_t)3 * (16 * 128 * 4 + 6 * 64 * 16) + 384 * 4 + 16
+                           : (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 32 * NW) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB, NW, Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return VITTA_ERR_LAUNCH;
     raised = true;
   }
   const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit * (a.cls_tiles ? 4 : 1))), block(64 * NW);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW>), grid, block, lds, st, a);
+  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW, Q>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW, Q>), grid, block, lds, st, a);
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
@@ -1160,6 +1212,7 @@ int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   if (a.b3 == 2) return a.pw_prefetch ? launch_one<1, true>(a, st, e0, e1) : launch_one<1, false>(a, st, e0, e1);
   if (a.b3 == 3) return a.pw_prefetch ? launch_one<2, true>(a, st, e0, e1) : launch_one<2, false>(a, st, e0, e1);
   if ((a.d.tile >> 16) == 64) return a.pw_prefetch ? launch_one<0, true, 2>(a, st, e0, e1) : launch_one<0, false, 2>(a, st, e0, e1);
+  if (a.q) return a.pw_prefetch ? launch_one<0, true, 4, true>(a, st, e0, e1) : launch_one<0, false, 4, true>(a, st, e0, e1);
   return a.pw_prefetch ? launch_one<0, true>(a, st, e0, e1) : launch_one<0, false>(a, st, e0, e1);
 }
 

@@ -29,6 +29,7 @@ struct ConvK {
   int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
   int cls_tiles;       // VITTA_CONV_PARITY4: tiles (nMt * nNt) per parity class; 0: one class
   int cls_tap0[5];     // ... first tap of class c (and the end of the last)
+  int q;               // conv_b3.hip: the pointwise form as three 16-channel stages, three workgroups per CU
   int nfast;           // conv_b3.hip: logical ids walk pixel tiles fastest (an XCD = all pixels of a few column tiles)
   int b3;              // conv_b3.hip (split-bf16 operands on the bf16 matrix pipe): 1 pointwise, 2 patch (3x3), 3 gathered; 0: not
 };
