@@ -3,6 +3,12 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Started without a launcher (`WORLD_SIZE` unset) and with --gpus N > 1 it starts the N ranks itself: it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and passes
+rank 0's JSON line through; `n_gpus` is the world size the ranks gathered, `ranks` lists every rank's device, and `dp_graph`
+says which capture form the data-parallel step replayed ("one" graph with the RCCL all-reduces captured | "segments" with
+the exchanges launched eagerly between three graphs | "eager").
+
 Workload (BASELINE.json configs[1]): TANet-R50 (random init of the real architecture, BN statistics
 calibrated), UCF101 head (101 classes), one video per GPU and step = 2 temporally augmented views x 8
 frames x 3 x 224 x 224 fp32 synthetic N(0,1) clips resident in HBM, statistics alignment (l1_loss,
@@ -104,6 +110,9 @@ def parse():
                    help="single process: form a ONE-rank RCCL group and run the data-parallel step (segmented graphs, both "
                         "all-reduces) anyway -- exercises the RCCL calls on a one-GPU box")
     p.add_argument("--miopen-find", action="store_true", help="cudnn.benchmark=True (MIOpen find mode) like main_eval.py:77")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="start / join the ranks, gather what every rank sees, print the line's `n_gpus` / `ranks` part and stop "
+                        "(needs no GPU with --dist-backend gloo: the launch logic's own test)")
     p.add_argument("--size", type=int, default=224)
     p.add_argument("--clip-length", type=int, default=None, help="frames per view (default 8 TANet / 16 Swin)")
     p.add_argument("--arch", default="tanet", choices=["tanet", "swin"],
@@ -330,16 +339,27 @@ def run_gpu(opt, rank, world, device):
             fam = families if len(families) == len(conv_events) else [None] * len(conv_events)
             b3 = np.array([k == 3 for k in fam])  # _lib.CONV_KERNEL_B3
             peak = np.where(b3, MFMA_BF16_PEAK_TF / B3_PRODUCTS, MFMA_F32_PEAK_TF)
-            for (f, key, _), t, kid in zip(conv_events, ms, fam):
-                r = by_shape.setdefault(key + (kid,), [0, 0.0, 0.0])
+            # per launch: the composite bound t_roof = max(flops / the instruction's matrix peak, algorithmic bytes / 8 TB/s) --
+            # the 64 -> 256 layer at 56 x 56 is bandwidth-bound, layer 4 matrix-bound; frac_roof = t_roof / duration
+            by = np.array([key[4] for _, key, _ in conv_events], dtype=np.float64)
+            t_roof = np.maximum(fl / (peak * 1e9), by / (HBM_PEAK_GBS * 1e6))  # ms
+            for (f, key, _), t, kid, tr in zip(conv_events, ms, fam, t_roof):
+                r = by_shape.setdefault(key[:4] + (kid,), [0, 0.0, 0.0, 0.0, 0.0])
                 r[0] += 1
                 r[1] += f
                 r[2] += t
+                r[3] += key[4]
+                r[4] += tr
             names = {0: "conv_igemm (fp32)", 1: "conv_sk (fp32)", 2: "conv_pw (fp32)", 3: "conv_b3 (split bf16)", None: "?"}
             run_gpu.conv = dict(launches=len(fl), steps=n_rep, flops=float(fl.sum()), ms=float(ms.sum()),
                                 ms_at_peak=float((fl / (peak * 1e9)).sum()), b3_launches=int(b3.sum()), b3_flops=float(fl[b3].sum()),
+                                bytes=float(by.sum()), ms_at_roof=float(t_roof.sum()),
+                                hbm_bound_launches=int((by / (HBM_PEAK_GBS * 1e6) > fl / (peak * 1e9)).sum()),
                                 by_shape=[dict(C=k[0], K=k[1], taps=k[2], positions=k[3], kernel=names.get(k[4], str(k[4])),
-                                               launches_per_step=v[0] / n_rep, avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9)
+                                               launches_per_step=v[0] / n_rep, avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9,
+                                               algorithmic_mb=v[3] / v[0] / 1e6, t_roof_us=1e3 * v[4] / v[0],
+                                               bound="hbm" if v[3] / (HBM_PEAK_GBS * 1e6) > v[1] / (1e9 * (MFMA_BF16_PEAK_TF / B3_PRODUCTS if k[4] == 3 else MFMA_F32_PEAK_TF)) else "mfma",
+                                               frac_roof=v[4] / v[2])
                                           for k, v in sorted(by_shape.items(), key=lambda kv: -kv[1][2])])
             conv_events.clear()
     adapter.engine.timing_events = None
@@ -552,8 +572,46 @@ def run_cpu_baseline(opt):
                        f"{cores} threads")
 
 
+def launch_ranks(opt):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) under torch.distributed.run on
+    this node and hand rank 0's line through.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {opt.gpus} without a launcher: starting {opt.gpus} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.call(cmd, env=env)
+
+
+def rank_report(rank, local, device):
+    """What this rank sees (the driver verifies N ranks on N distinct devices)."""
+    mine = dict(rank=rank, local_rank=local, pid=os.getpid(),
+                dist_world_size=torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                dist_backend=torch.distributed.get_backend() if torch.distributed.is_initialized() else None)
+    if device is not None:
+        props = torch.cuda.get_device_properties(device)
+        mine.update(device_index=device.index, device=props.name, pci_bus_id=getattr(props, "pci_bus_id", None),
+                    uuid=str(getattr(props, "uuid", "")) or None)
+    ranks = [mine]
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        try:
+            gathered = [None] * torch.distributed.get_world_size()
+            torch.distributed.all_gather_object(gathered, mine)
+            ranks = gathered
+        except Exception as e:  # noqa: BLE001  (the report must never cost the benchmark line)
+            log(f"rank report not gathered: {e!r}")
+    return ranks
+
+
 def main():
     opt = parse()
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ and not opt.force_exchanges:
+        raise SystemExit(launch_ranks(opt))
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner through
     # C stdio when a communicator is created, flushed at exit -- after the JSON line): hand file descriptor 1 to stderr
     # for the run and keep the real stdout for the line alone.
@@ -563,6 +621,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(opt.gpus, 1):
+        log(f"WORLD_SIZE={world} but --gpus {opt.gpus}: the line reports the world size the ranks actually form")
+    if opt.rendezvous_only:
+        device = None
+        if torch.cuda.is_available():
+            device = torch.device("cuda", local % torch.cuda.device_count())
+            torch.cuda.set_device(device)
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.distributed.init_process_group(opt.dist_backend if device is not None else "gloo")
+        ranks = rank_report(rank, local, device)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"rendezvous_only": True, "n_gpus": len(ranks), "gpus_requested": opt.gpus,
+                                               "ranks": ranks}) + "\n").encode())
+        os.close(real_stdout)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     device = torch.device("cuda", local % torch.cuda.device_count())
@@ -597,19 +674,8 @@ def main():
     value = videos / elapsed
 
     # what every rank saw (the driver can verify N ranks on N devices)
-    props = torch.cuda.get_device_properties(device)
-    mine = dict(rank=rank, local_rank=local, device_index=device.index, device=props.name,
-                pci_bus_id=getattr(props, "pci_bus_id", None),
-                dist_world_size=torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                dist_backend=torch.distributed.get_backend() if torch.distributed.is_initialized() else None)
-    ranks = [mine]
-    if world > 1:
-        try:
-            gathered = [None] * world
-            torch.distributed.all_gather_object(gathered, mine)
-            ranks = gathered
-        except Exception as e:  # noqa: BLE001  (the report must never cost the benchmark line)
-            log(f"rank report not gathered: {e!r}")
+    ranks = rank_report(rank, local, device)
+    dp_graph = getattr(adapter, "dp_graph", "eager") if "hipGraph" in mode else "eager"
 
     if opt.arch == "swin":
         algo_bytes = 4.0 * sum(o * c * i for o, c, i, _ in adapter.engine.plan.shapes)  # 253.7 MB at 2x16x224^2
@@ -647,6 +713,10 @@ def main():
                                   "bottleneck convolution of the trunk, forward + data gradient + evaluation forward",
                         "bound": "mfma", "achieved": tf, "peak": tf / frac, "unit": "TFLOP/s", "frac": frac,
                         "frac_of_fp32_matrix_peak": tf / MFMA_F32_PEAK_TF,
+                        # composite: every launch against max(flops / its matrix peak, algorithmic bytes / 8 TB/s); time-weighted
+                        "frac_composite": conv["ms_at_roof"] / conv["ms"],
+                        "algorithmic_bytes_per_step": conv["bytes"] / conv["steps"],
+                        "hbm_bound_launches_per_step": conv["hbm_bound_launches"] / conv["steps"],
                         "peaks": {"conv_b3 (v_mfma_f32_32x32x16_bf16, 6 split products per multiply-add)": MFMA_BF16_PEAK_TF / B3_PRODUCTS,
                                   "fp32 kernels (v_mfma_f32_32x32x2_f32)": MFMA_F32_PEAK_TF},
                         "split_bf16_share_of_flops": conv["b3_flops"] / conv["flops"],
@@ -664,7 +734,9 @@ def main():
                                 "x C x K x taps per launch (vitta_conv_flops), whatever the instruction; peak = flops / "
                                 "(sum over launches of flops / the peak of the instruction that launch issues); "
                                 "share_of_step > what a serial schedule would allow where the evaluation stream overlaps "
-                                "the adaptation stream",
+                                "the adaptation stream; frac_composite / by_shape[*].frac_roof = (sum of per-launch "
+                                "max(flops / matrix peak, algorithmic bytes / 8 TB/s)) / (sum of durations), algorithmic bytes "
+                                "= x + fp32 weights + y + the epilogue's input streams, each once",
                         "by_shape": conv["by_shape"][:14], "moments": moments, "streaming": streaming}
         else:
             ov = one_video or {}
@@ -675,7 +747,7 @@ def main():
     line = {
         "metric": f"videos/sec TTA step (TANet-R50, 2x{opt.clip_length}x{opt.size}^2), whole job", "value": value,
         "unit": "videos/s",
-        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
+        "n_gpus": len(ranks) if world > 1 else 1, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if (opt.arch == "swin" or os.environ.get("VITTA_CONV_ARITH", "b3") != "b3") else
                  "f32 (convolutions: operands split into three bf16 terms, six bf16-MFMA products per multiply-add, fp32 accumulation)",
@@ -691,7 +763,7 @@ def main():
                                "overlapped: eval(i-1) on a second stream beside adapt(i), optimizer update after both "
                                "(same weights and results as the sequential order)"},
         "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "launch_mode": mode, "eager_ms_per_step": eager_ms,
-        "roofline": roofline, "ranks": ranks,
+        "roofline": roofline, "ranks": ranks, "dp_graph": dp_graph,
     }
     if opt.arch == "swin":
         n_ln = len(adapter.engine.hooks)

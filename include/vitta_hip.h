@@ -401,7 +401,9 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
  *   forward : raw = acc                                   -> y_raw (optional second output)
  *             z = raw * s_k + t_k  (epi_bn, eval-mode BatchNorm2d: s = gamma / sqrt(var + eps), t = beta - mean * s)
  *             VITTA_CONV_STATS: st_s1[k] += sum(z - shift_k), st_s2[k] += sum (z - shift_k)^2 over the tile's pixels
- *                               (the hooked-layer moments of utils/norm_stats_utils.py:185-253, additive form)
+ *                               (the hooked-layer moments of utils/norm_stats_utils.py:185-253, additive form);
+ *                               with VITTA_CONV_STATS_RAW the same sums of raw - shift_k: moments of the BatchNorm INPUT
+ *                               (before_norm hooks, utils/norm_stats_utils.py:52-53), taken directly -- no division by gamma
  *             o = (VITTA_CONV_EPI_APPLY ? z : raw) (+ res) ; VITTA_CONV_EPI_RELU: max(o, 0)          -> y
  *   backward (VITTA_CONV_BWD_BN; acc = gradient w.r.t. the ACTIVATED input a = relu(bn(bwd_x)) of the forward conv):
  *             g = acc (+ res: the gradient arriving over the identity path)
@@ -424,6 +426,7 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
  * the descriptor qualifies): ostride must be 2, the taps are listed class by class -- class c = 2 a + b writes output
  * pixels (2 i + a, 2 j + b) and owns cls_ntaps[c] >= 1 consecutive entries of the tap table (oa / ob are ignored). */
 #define VITTA_CONV_PARITY4 256
+#define VITTA_CONV_STATS_RAW 512 /* with VITTA_CONV_STATS: the sums are of the raw convolution output, not of z */
 #define VITTA_CONV_MAX_TAPS 9
 
 typedef struct vitta_conv_desc {

@@ -10,7 +10,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(rank, world, port, tmp):
+def run(rank, world, port, tmp, dev_name="cuda:0", steps=3):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import helpers as H
@@ -18,7 +18,9 @@ def run(rank, world, port, tmp):
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda:0")
+    dev = torch.device(dev_name)
+    if dev.type == "cpu":
+        torch.set_num_threads(4)
     g = H.golden("tta3_swin.npz")
     cfg = json.loads(str(g["config"]))
     T, size = cfg["T"], cfg["size"]
@@ -34,11 +36,16 @@ def run(rank, world, port, tmp):
     args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "synthetic", size, size, 0, False
     args.result_dir, args.num_classes, args.batch_size = rdir, 101, 1
     args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp_, vp_
-    args.update_only_bn_affine, args.lr = True, cfg["lr_adam"]
+    sgd_all = os.environ.get("VITTA_TEST_SWIN_SGD_ALL", "0") == "1"  # the reference's default optimizer: 351 MB gradient arena
+    args.update_only_bn_affine, args.lr = (False, cfg["lr_sgd"]) if sgd_all else (True, cfg["lr_adam"])
+    if dev_name != "cuda:0":
+        from oracle.oracle_backend import OracleBackend
+        tta.BACKEND_FACTORY = OracleBackend
     adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model).to(dev), args)
+    tta.BACKEND_FACTORY = None
     tta_set = data.SyntheticVideoDataset(6, 2, T, size, 101, "swin", seed0=cfg["seed0"])
     out = {}
-    for step in range(3):
+    for step in range(steps):
         vids = [2 * step + rank] if world > 1 else [2 * step, 2 * step + 1]
         x = torch.stack([tta_set[v][0] for v in vids]).to(dev)
         adapter.set_adapt_mode()
@@ -47,6 +54,10 @@ def run(rank, world, port, tmp):
         out[f"step{step}_loss_consis"] = float(loss_consis)
         out[f"step{step}_ema"] = adapter.engine.ema_mean.detach().cpu().numpy().copy()
         out[f"step{step}_param_sum"] = float(sum(float(p.double().sum()) for p in adapter.model.parameters()))
+        out[f"step{step}_grad"] = adapter.arena.grad.detach().cpu().numpy()[::997].copy()  # a sample of the reduced arena
+    plan = adapter.bucket_plan()
+    out["n_buckets"] = 0 if plan is None else len(plan["buckets"])
+    out["buckets_from_backward"] = int(adapter.n_from_backward)
     np.savez(os.path.join(tmp, f"w{world}r{rank}.npz"), **out)
     if world > 1:
         torch.distributed.destroy_process_group()

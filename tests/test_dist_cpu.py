@@ -238,3 +238,71 @@ def test_bucketed_gradient_exchange_equals_the_monolithic_all_reduce(tmp_path):
     np.testing.assert_array_equal(r[0]["mono"], r[1]["mono"])
     np.testing.assert_array_equal(r[0]["bucketed"], r[0]["mono"])
     np.testing.assert_array_equal(r[1]["bucketed"], r[1]["mono"])
+
+
+def test_swin_bucket_plan_partitions_the_arena_at_block_boundaries():
+    """Video Swin-B under SGD over all parameters: the gradient arena (351 MB at full size) is cut at transformer-block /
+    patch-merging boundaries; a bucket leaves when the signal of its LOWEST unit fires -- for a block that is not the first of
+    its stage that is the signal of the block before it (its norm1 is differentiated in that block's closing pass).  Built
+    from the model's structure alone, so every rank holds the same plan before any step has run."""
+    from vitta_amd import scripts, tta
+    from vitta_amd.swin import PatchMerging, SwinTransformerBlock3D
+    model = tta.SingleDeviceParallel(H.build_swin(11, 0))
+    args = scripts.swin_ucf101_args([])
+    args.update_only_bn_affine = False
+
+    class A(tta.ViTTAAdapter):  # the exchange plumbing alone: no hooks, no statistics files
+        def __init__(self, model, args):
+            self.model, self.args = model, args
+            self.arena = tta.FlatArena(list(model.parameters()))
+            self.bucket, self.grad_buckets, self._bucket_plan = self.arena, 4, None
+            self._armed = self._armed_runner = None
+            self._launched, self.n_from_backward = set(), 0
+
+    ad = A(model, args)
+    units = ad._bucket_units()
+    kinds = [type(m) for m, _ in units]
+    assert kinds.count(SwinTransformerBlock3D) == 24 and kinds.count(PatchMerging) == 3
+    first_of_stage = {0, 3, 6, 25}  # blocks 2, 2, 18, 2 with a PatchMerging after each of the first three stages
+    for i, (m, rel) in enumerate(units):
+        assert rel == (i if (i in first_of_stage or isinstance(m, PatchMerging)) else i - 1), (i, rel)
+    plan = ad.bucket_plan()
+    n = ad.arena.grad.numel()
+    pieces = sorted([(lo, hi) for _, lo, hi in plan["buckets"]] + [r for r in plan["rest"] if r[1] > r[0]])
+    assert pieces[0][0] == 0 and pieces[-1][1] == n and all(pieces[i][1] == pieces[i + 1][0] for i in range(len(pieces) - 1))
+    assert 2 <= len(plan["buckets"]) <= 5
+    los = [lo for _, lo, _ in plan["buckets"]]
+    sigs = [sig for sig, _, _ in plan["buckets"]]
+    assert los == sorted(los, reverse=True) and sigs == sorted(sigs, reverse=True)  # launch order = backward order
+    for sig, lo, hi in plan["buckets"]:  # the signal's unit starts at or before the bucket's first parameter
+        assert ad.arena.span(list(units[sig][0].parameters()))[0] <= lo
+    assert ad.bucket_plan() is plan
+    # the TANet plan comes from structure too: a rank that never ran the trunk holds it
+    t = A(tta.SingleDeviceParallel(H.build_tanet(11, 8, 0)), H.tanet_args("/tmp", update_only_bn_affine=False))
+    tp = t.bucket_plan()
+    assert tp is not None and len(tp["buckets"]) == 4 and [m for m, _ in t._bucket_units()] == tp["blocks"]
+
+
+def _swin_rank(rank, world, port, tmp, buckets):
+    sys.path.insert(0, HERE)
+    os.environ.update(VITTA_GRAD_BUCKETS=str(buckets), VITTA_TEST_SWIN_SGD_ALL="1")
+    import swin_dp_worker as W
+    W.run(rank, world, port, tmp, dev_name="cpu", steps=1)
+
+
+def test_swin_bucketed_gradient_exchange_equals_the_monolithic_all_reduce(tmp_path):
+    """Two ranks over gloo, Video Swin-B (64^2 clips), SGD over all parameters, one full adaptation step through
+    ViTTAAdapter: with the arena exchanged in four buckets both ranks hold bit-for-bit the reduced gradients, EMA state and
+    weights that ONE all-reduce leaves."""
+    res = {}
+    for nb in (1, 4):
+        sub = tmp_path / f"b{nb}"
+        sub.mkdir()
+        mp.spawn(_swin_rank, args=(2, _free_port(), str(sub), nb), nprocs=2, join=True)
+        res[nb] = [np.load(os.path.join(str(sub), f"w2r{r}.npz")) for r in range(2)]
+    assert int(res[1][0]["n_buckets"]) == 0 and int(res[4][0]["n_buckets"]) >= 2
+    for r in range(2):
+        np.testing.assert_array_equal(res[4][r]["step0_grad"], res[1][r]["step0_grad"])
+        np.testing.assert_array_equal(res[4][r]["step0_ema"], res[1][r]["step0_ema"])
+        assert float(res[4][r]["step0_param_sum"]) == float(res[1][r]["step0_param_sum"])
+    np.testing.assert_array_equal(res[4][0]["step0_grad"], res[4][1]["step0_grad"])

@@ -249,3 +249,30 @@ def test_eval_dispatches_to_epoch_style_when_if_tta_standard_is_falsy(tmp_path, 
     model = tta.SingleDeviceParallel(H.build_tanet(101, 8, 0))
     res, back = main_eval.eval(args=args, model=model)
     assert called and res == [12.5] and back is model
+
+
+def test_bench_gpus_n_starts_n_ranks_that_rendezvous():
+    """`python bench.py --gpus 2` -- the shape of the driver's command when no launcher wraps it -- starts two ranks under
+    torch.distributed.run (127.0.0.1 rendezvous), the ranks form a process group and rank 0 alone prints ONE JSON line whose
+    `n_gpus` is the gathered world size and whose `ranks` lists both processes.  --rendezvous-only stops there (gloo: no GPU
+    needed); the timed path continues from the same point."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["gpus_requested"] == 2 and rec["rendezvous_only"] is True
+    assert sorted(r["rank"] for r in rec["ranks"]) == [0, 1] and len({r["pid"] for r in rec["ranks"]}) == 2
+    assert all(r["dist_world_size"] == 2 and r["dist_backend"] == "gloo" for r in rec["ranks"])
+    # under a launcher (WORLD_SIZE set) the same file is a rank, not a launcher: one rank, no re-exec
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--rendezvous-only"], cwd=root, env=env1,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1

@@ -220,6 +220,114 @@ def test_data_gradient_with_batchnorm_backward_epilogue(n, c, k, h, relu, inject
     _close(CV.from_cm(gm, n, h, h), gref, what="masked gradient")
 
 
+# ---- where a three-term operand split could differ from fp32 arithmetic (and the exact-fp32 kernels are held to the same) ----
+# Bound per OUTPUT ELEMENT, relative to that element's sum of |a b| (not to the tensor's maximum): an fp32 multiply-add chain
+# of R terms is within R 2^-24 sum|a b| worst case, ~sqrt(R) 2^-24 typically; the split drops mid x lo, lo x mid, lo x lo
+# (<= 2^-25 |a b| together) and rounds the third term (2^-27).  4 x 2^-23 x sqrt(R) holds both kernels with a margin of ~10
+# and is 4 000 x below what a dropped `lo` term (2^-16) and 10^6 x below what a dropped `mid` term (2^-9) would produce.
+def _elem_bound(mag, r):
+    return 4.0 * 2.0 ** -23 * (r ** 0.5) * mag + 1e-30
+
+
+def _log_uniform(nn_, lo, hi, g):
+    return 10.0 ** (torch.rand(nn_, generator=g) * (hi - lo) + lo)
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz", [(8, 256, 64, 28, 1), (8, 128, 128, 28, 3), (16, 512, 512, 7, 3), (16, 1024, 256, 14, 1)])
+def test_wide_dynamic_range_inside_one_reduction(n, c, k, h, ksz):
+    """Per-channel scales log-uniform in 1e-4 .. 1e4 on the activations AND on the weights (un-normalised early features look
+    like this): terms of one reduction span 16 decades.  Forward and data gradient, every element against fp64 relative to its
+    own sum of magnitudes."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(77 * c + k + h + ksz)
+    sa, sw_c, sw_k, sg = _log_uniform(c, -4, 4, g), _log_uniform(c, -2, 2, g), _log_uniform(k, -2, 2, g), _log_uniform(k, -4, 4, g)
+    x = torch.randn(n, c, h, h, generator=g) * sa.view(1, -1, 1, 1)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * sw_c.view(1, -1, 1, 1) * sw_k.view(-1, 1, 1, 1) * (c * ksz * ksz) ** -0.5
+    gy = torch.randn(n, k, h, h, generator=g) * sg.view(1, -1, 1, 1)
+    pad = ksz // 2
+    xd, wd, gd = x.double(), w.double(), gy.double()
+    ref, mag = F.conv2d(xd, wd, padding=pad), F.conv2d(xd.abs(), wd.abs(), padding=pad)
+    gref, gmag = F.conv_transpose2d(gd, wd, padding=pad), F.conv_transpose2d(gd.abs(), wd.abs(), padding=pad)
+    d = _dev()
+    y = torch.full((k, n * h * h), float("nan"), device=d)
+    CV.launch(CV.Geometry.forward(n, h, h, ksz, 1, pad), CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k)
+    err = (CV.from_cm(y, n, h, h).cpu().double() - ref).abs()
+    bad = err > _elem_bound(mag, c * ksz * ksz)
+    assert not bool(bad.any()), ("forward", int(bad.sum()), float((err / mag.clamp_min(1e-300)).max()))
+    gx = torch.full((c, n * h * h), float("nan"), device=d)
+    CV.launch(CV.Geometry.dgrad(n, h, h, ksz, 1, pad)[0], CV.to_cm(gy.to(d)), CV.pack_bwd(w.to(d)), gx, k, c)
+    err = (CV.from_cm(gx, n, h, h).cpu().double() - gref).abs()
+    bad = err > _elem_bound(gmag, k * ksz * ksz)
+    assert not bool(bad.any()), ("data gradient", int(bad.sum()), float((err / gmag.clamp_min(1e-300)).max()))
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz", [(8, 256, 64, 28, 1), (8, 128, 128, 28, 3)])
+def test_large_mean_small_variance_input_and_the_epilogue_moments(n, c, k, h, ksz):
+    """x = 1000 + N(0, 1) (mean / sigma = 1e3): every product is ~1000 x the spread of the result, so a lost low-order term of
+    the split shows up in the output's VARIANCE first.  BatchNorm constants as a trained net has them (running statistics =
+    the convolution output's own), hooked moments about a shift near the mean (what the engine passes): output element-wise,
+    sums within the bound that element-wise bound implies."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(5 * c + k + h + ksz)
+    x = 1000.0 + torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    pad = ksz // 2
+    xd, wd = x.double(), w.double()
+    raw, mag = F.conv2d(xd, wd, padding=pad), F.conv2d(xd.abs(), wd.abs(), padding=pad)
+    rm, rv = raw.mean((0, 2, 3)).float(), raw.var((0, 2, 3), unbiased=False).float()
+    gam, bet = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.3
+    shift = bet + torch.randn(k, generator=g) * 0.05
+    es = (gam.double() / torch.sqrt(rv.double() + 1e-5)).view(1, -1, 1, 1)
+    z = (raw - rm.double().view(1, -1, 1, 1)) * es + bet.double().view(1, -1, 1, 1)
+    d = _dev()
+    y = torch.full((k, n * h * h), float("nan"), device=d)
+    s1, s2 = torch.zeros(k, device=d), torch.zeros(k, device=d)
+    CV.launch(CV.Geometry.forward(n, h, h, ksz, 1, pad), CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k,
+              flags=CV.CONV_EPI_APPLY | CV.CONV_STATS, epi_bn=[t.to(d) for t in (gam, bet, rm, rv)], stats=(shift.to(d), s1, s2))
+    # the fp32 epilogue itself rounds raw * s + t once more: (|raw s| + |t|) 2^-23
+    eb = _elem_bound(mag, c * ksz * ksz) * es.abs() + 2.0 ** -22 * ((raw * es).abs() + (rm.double().view(1, -1, 1, 1) * es).abs())
+    err = (CV.from_cm(y, n, h, h).cpu().double() - z).abs()
+    assert not bool((err > eb).any()), float((err / eb).max())
+    assert float((mag.mean((0, 2, 3)) / raw.std((0, 2, 3))).median()) > 50    # the case is what it says it is
+    dz = z - shift.double().view(1, -1, 1, 1)
+    r1, r2 = dz.sum((0, 2, 3)), (dz * dz).sum((0, 2, 3))
+    b1 = eb.sum((0, 2, 3)) + 1e-5 * dz.abs().sum((0, 2, 3))
+    b2 = (2 * dz.abs() * eb + eb * eb).sum((0, 2, 3)) + 1e-5 * r2
+    assert bool(((s1.cpu().double() - r1).abs() <= b1).all()), float(((s1.cpu().double() - r1).abs() / b1).max())
+    assert bool(((s2.cpu().double() - r2).abs() <= b2).all()), float(((s2.cpu().double() - r2).abs() / b2).max())
+    # and the variance those sums give is the fp64 one to 1 %: a bf16-only product would be off by orders of magnitude
+    cnt = n * h * h
+    var = s2.cpu().double() / cnt - (s1.cpu().double() / cnt) ** 2
+    vref = r2 / cnt - (r1 / cnt) ** 2
+    assert float(((var - vref).abs() / vref).max()) <= 1e-2
+
+
+@pytest.mark.parametrize("n,c,k,h,ksz", [(4, 64, 64, 28, 1), (4, 64, 64, 28, 3)])
+def test_non_finite_inputs_stay_where_fp32_arithmetic_puts_them(n, c, k, h, ksz, arith):
+    """One +Inf and one NaN among the activations.  Stated behaviour: an output element is non-finite exactly where fp32
+    arithmetic makes it non-finite (the elements whose reduction contains the value), every other element is unaffected; the
+    KIND is not preserved by the split form -- x - bf16(x) is NaN for x = Inf, so +-Inf outputs of the exact kernels come out
+    as NaN.  Nothing downstream distinguishes them (a non-finite feature poisons the statistics either way)."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(c + k + h + ksz)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, ksz, ksz, generator=g) * (c * ksz * ksz) ** -0.5
+    x[1, 3, 5, 7] = float("inf")
+    x[2, 10, 9, 2] = float("nan")
+    pad = ksz // 2
+    ref = F.conv2d(x.double(), w.double(), padding=pad)
+    d = _dev()
+    y = torch.full((k, n * h * h), 12345.0, device=d)
+    CV.launch(CV.Geometry.forward(n, h, h, ksz, 1, pad), CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k)
+    got = CV.from_cm(y, n, h, h).cpu().double()
+    fin = torch.isfinite(ref)
+    assert int((~fin).sum()) == 2 * k * ksz * ksz                   # the two receptive fields, every output channel
+    assert torch.equal(torch.isfinite(got), fin)
+    assert (got[fin] - ref[fin]).abs().max().item() <= TOL * ref[fin].abs().max().item()
+    if arith == "f32":                                              # the exact kernels also keep the kind
+        assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)])
+
+
 @pytest.mark.parametrize("n,ng,c,k,h,ksz", [(12, 8, 256, 1024, 14, 1), (6, 4, 64, 64, 28, 3), (24, 16, 512, 2048, 7, 1)])
 def test_leading_frames_only_statistics_raw_output_and_pitched_backward_inputs(n, ng, c, k, h, ksz):
     """A forward over n frames of which only the first ng are the adaptation batch (trunk.py: the evaluation clip rides

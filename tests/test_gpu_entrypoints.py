@@ -296,3 +296,35 @@ def test_bucketed_exchange_from_inside_the_backward_equals_the_monolithic_one_on
         for name in map(str, g["sampled_params"]):
             np.testing.assert_array_equal(res["4"][0][f"step{i}_grad::{name}"], res["4"][1][f"step{i}_grad::{name}"])
             np.testing.assert_array_equal(res["4"][0][f"step{i}_param::{name}"], res["4"][1][f"step{i}_param::{name}"])
+
+
+def _swin_sgd_rank(rank, world, port, tmp, buckets):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(VITTA_GRAD_BUCKETS=str(buckets), VITTA_TEST_SWIN_SGD_ALL="1")
+    import swin_dp_worker as W
+    W.run(rank, world, port, tmp)
+
+
+def test_swin_buckets_leave_from_inside_the_backward_on_gpu(tmp_path):
+    """Video Swin-B, SGD over all parameters, 2 ranks over gloo sharing the GPU, three steps: from the second step on (every
+    parameter's gradient is then known to be written straight into the arena by our kernels) the buckets are reduced by the
+    tensor-hook signals WHILE the backward runs (tta.ViTTAAdapter._signal); the ranks hold identical reduced gradients, and
+    the same numbers as with one all-reduce after the backward up to the round-off of the weight-gradient accumulation."""
+    import torch.multiprocessing as mp
+    from test_dist_cpu import _free_port
+    res = {}
+    for nb in (1, 4):
+        sub = tmp_path / f"b{nb}"
+        sub.mkdir()
+        mp.spawn(_swin_sgd_rank, args=(2, _free_port(), str(sub), nb), nprocs=2, join=True)
+        res[nb] = [np.load(os.path.join(str(sub), f"w2r{r}.npz")) for r in range(2)]
+    nbk = int(res[4][0]["n_buckets"])
+    assert nbk >= 2 and int(res[1][0]["n_buckets"]) == 0
+    assert int(res[4][0]["buckets_from_backward"]) == 2 * nbk and int(res[1][0]["buckets_from_backward"]) == 0
+    for i in range(3):
+        np.testing.assert_array_equal(res[4][0][f"step{i}_grad"], res[4][1][f"step{i}_grad"])  # replicas identical
+        assert float(res[4][0][f"step{i}_param_sum"]) == float(res[4][1][f"step{i}_param_sum"])
+        assert float(res[4][0][f"step{i}_loss_reg"]) == pytest.approx(float(res[1][0][f"step{i}_loss_reg"]), rel=1e-4 if i == 0 else 5e-3)
+    a, b = res[4][0]["step0_grad"], res[1][0]["step0_grad"]
+    assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-9

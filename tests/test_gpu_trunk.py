@@ -137,16 +137,24 @@ def test_sgd_all_step_equals_module_path(tmp_path):
     assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
 
 
-@pytest.mark.parametrize("before_norm", [False, True])
-def test_source_statistics_producer_runs_on_the_trunk_node(before_norm, abi_calls):
+@pytest.mark.parametrize("before_norm,dead_gamma", [(False, False), (True, False), (True, True), (False, True)])
+def test_source_statistics_producer_runs_on_the_trunk_node(before_norm, dead_gamma, abi_calls):
     """compute_statistics' hooks (ComputeNormStatsHook on all 53 BatchNorm2d, corpus/basics.py:220-307,
     utils/norm_stats_utils.py:18-101): the node supplies every hook's batch moments from the convolution epilogues (the stem's
-    from its raw output), of the BN output or -- before_norm -- of its input through the inverse affine map; same numbers as
-    the module-by-module path (library convolutions + the stand-alone moments kernel on every materialised feature)."""
+    from its raw output), of the BN output or -- before_norm -- of its INPUT, summed directly from the raw convolution output
+    (VITTA_CONV_STATS_RAW); same numbers as the module-by-module path (library convolutions + the stand-alone moments kernel on
+    every materialised feature).  dead_gamma: trained networks have BatchNorm channels with gamma = 0 or ~ 1e-8; the input
+    moments of such a channel are ordinary numbers (round 3 recovered them by dividing the output moments by gamma)."""
     from vitta_amd import trunk
     from vitta_amd.norm_stats import ComputeNormStatsHook
     dev = torch.device("cuda:0")
     model = H.build_tanet(11, 8, 0).to(dev).eval()
+    if dead_gamma:
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight[::7] = 0.0
+                    m.weight[1::7] = 1e-8
     x = H.seeded_randn((2, 8, 3, 64, 64), 5).to(dev)
     bn2d = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
     res = {}

@@ -172,14 +172,16 @@ def assert_logits_close_abs(got, ref, bound):
         assert a == b or (row_ref[b] - row_ref[a]).item() <= 2 * bound, (a, b)
 
 
-def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=False):
-    """common_floor (GPU suites): the noise floor of a sampled gradient on steps AFTER the first is at least the MEDIAN, over
-    the sampled tensors of that step, of noise / max|g|.  The fixtures hold ONE perturbed re-run of the reference per step:
-    by the third step its deviations are 3-30 % of max|g| for most tensors (the trajectory is chaotic: L1 sign terms, SGD
-    on every weight), but a single sample can come out 10x smaller for one tensor (layer4.2.net.bn3.bias, batch of two:
-    0.6 % where its neighbours show 3-30 %), and any other summation order then lands outside "4 x its own floor" --
-    tools/debug/bz2_step_probe.py prints the table for the arithmetic forms.  The first step (identical weights) keeps the
-    strict per-tensor bounds."""
+def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=None):
+    """common_floor (GPU suites; a fraction of max|g|, None = off): the noise floor of a sampled gradient on steps AFTER the
+    first is at least the MEDIAN, over the sampled tensors of that step, of noise / max|g| -- CAPPED at `common_floor`.  The
+    fixtures hold ONE perturbed re-run of the reference per step: by the third step its deviations are 3-30 % of max|g| for
+    most tensors (the trajectory is chaotic: L1 sign terms, SGD on every weight), but a single sample can come out 10x
+    smaller for one tensor (layer4.2.net.bn3.bias, batch of two: 0.6 % where its neighbours show 3-30 %), and any other
+    summation order then lands outside "4 x its own floor" -- tools/debug/bz2_step_probe.py prints the table for the
+    arithmetic forms.  The cap keeps the check a check: without it 4 x a 30 % median is 120 % of max|g|.  The first step
+    (identical weights) keeps the strict per-tensor bounds, and the exact-fp32 arithmetic is run WITHOUT the common floor
+    wherever it holds (tests/test_gpu_tta.py)."""
     rows = int(g["sample_rows"])
     cfg = json.loads(str(g["config"]))
     lr = cfg["lr_sgd"] if mode == "sgd" else cfg["lr_adam"]
@@ -206,7 +208,7 @@ def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=False
             ref = torch.from_numpy(g[key])
             bound = max(base["grad_frac"] * ref.abs().max().item(), floor_mult * float(g[k + f"noise_grad::{name}"])) + 1e-10
             if i > 0 and common_floor:
-                bound = max(bound, floor_mult * rel_floor * ref.abs().max().item())
+                bound = max(bound, min(floor_mult * rel_floor, float(common_floor)) * ref.abs().max().item())
             err = (gr[:rows] - ref).abs().max().item()
             assert err <= bound, (i, name, err, bound)
             report.append((i, "grad " + name, err, bound))

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_BWD_BN, CONV_BWD_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_PRO_BN_RELU, CONV_RES, CONV_RES_HALF,
-                   CONV_STATS, ConvDesc, check, lib)
+                   CONV_STATS, CONV_STATS_RAW, ConvDesc, check, lib)
 
 
 def to_cm(x):
@@ -251,7 +251,13 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if TIMING is not None:  # bench.py: one event pair per launch, attached to the kernel's dispatch
         if KERNEL_TRACE is not None:
             KERNEL_TRACE.append(int(lib().vitta_conv_kernel(C.byref(d))))
-        ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg))
+        # algorithmic bytes of the launch (SURVEY 8d style: every operand once): x, the fp32 weights, y, and the epilogue's
+        # input streams (residual / BatchNorm-backward input / mask); NOT the optional second output y_raw
+        xp, yp = geom.n * geom.hs * geom.ws, geom.n * geom.hy * geom.wy
+        rp = geom.n * ((geom.hy + 1) // 2) * ((geom.wy + 1) // 2) if (flags & CONV_RES_HALF) else yp
+        abytes = 4 * (int(c) * xp + int(c) * int(k) * len(geom.taps) + int(k) * yp + (int(k) * rp if res is not None else 0)
+                      + (int(k) * yp if bwd_x is not None else 0) + (int(k) * yp if bwd_mask is not None else 0))
+        ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg, abytes))
         check(lib().vitta_conv_timed_f32(C.byref(d), st, ev.start, ev.stop), "vitta_conv_timed_f32")
         return y
     check(lib().vitta_conv_f32(C.byref(d), st), "vitta_conv_f32")
@@ -376,4 +382,4 @@ def stem_conv(x, wp):
 
 
 __all__ = ["Geometry", "launch", "Pack", "pack_b3", "make_pack", "b3_eligible", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
-           "CONV_EPI_RELU", "CONV_STATS", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]
+           "CONV_EPI_RELU", "CONV_STATS", "CONV_STATS_RAW", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

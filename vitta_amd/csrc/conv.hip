@@ -403,6 +403,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
   // register v of tile (x, y): pixel row = 32x + 8 (v / 4) + 4 lk + (v % 4), channel column = 32y + li
   const bool BWD = flags & VITTA_CONV_BWD_BN;
   const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
+  const bool RAWST = flags & VITTA_CONV_STATS_RAW;
   const bool APPLY = flags & VITTA_CONV_EPI_APPLY;
   const bool RELU = flags & VITTA_CONV_EPI_RELU;
   const bool RES = (flags & VITTA_CONV_RES) && d.res;
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
             for (int e = 0; e < 4; ++e) {
               const float z = fmaf(v[e], es, et);
               if (STATS && m < a.statM) {
-                const float dd = z - sh;
+                const float dd = (RAWST ? v[e] : z) - sh;
                 r1 += dd;
                 r2 = fmaf(dd, dd, r2);
               }

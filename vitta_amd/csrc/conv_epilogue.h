@@ -106,6 +106,7 @@ struct TileEpilogue {
     const int flags = d.flags;
     const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
     const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
+    const bool RAWST = flags & VITTA_CONV_STATS_RAW;
     const bool APPLY = flags & VITTA_CONV_EPI_APPLY;
     const bool RELU = flags & VITTA_CONV_EPI_RELU;
     const bool RES = (flags & VITTA_CONV_RES) && d.res;
@@ -178,7 +179,7 @@ struct TileEpilogue {
           for (int e = 0; e < 4; ++e) {
             const float z = fmaf(v[e], es, et);
             if (counted) {
-              const float dd = z - sh;
+              const float dd = (RAWST ? v[e] : z) - sh;
               r1 += dd;
               r2 = fmaf(dd, dd, r2);
             }

@@ -6,6 +6,9 @@
 // As torch modules this is ~14 launches forward and ~25 backward of 3-5 us kernels on KB-sized tensors, 16 TAMs
 // per pass: half of all launches of a TTA step (r1e profile).  Here: two launches forward, two backward, each
 // spread over N x (C/32 .. C/4/8) workgroups with the clip's intermediates in LDS (<= 3 MFLOP per clip).
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 using namespace vitta;
@@ -621,19 +624,31 @@ namespace {
 // schedule may run the evaluation pass's fused launch beside the adaptation pass's on a second stream.
 template <typename Kern>
 int64_t fused_capacity(Kern kernel, size_t lds) {
-  // (one entry per kernel instantiation: the answer for the last LDS size asked, which repeats launch after launch)
-  static size_t last_lds = 0;
-  static int64_t last_cap = -1;
-  if (last_cap >= 0 && last_lds == lds) return last_cap;
-  int dev = 0, cus = 0, per_cu = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
+  // one table per kernel instantiation, keyed by (device, LDS size), under a lock: the entry points are called from the main
+  // thread and from autograd's worker thread, and the answer differs between devices with different CU counts.
+  // ASSUMPTION the halving encodes: at most TWO fused launches of a kernel run side by side (the adaptation stream and the
+  // evaluation stream of tta.ViTTAAdapter.step); a caller that runs the trunk on more streams at once must take the two-launch
+  // form (vitta_tam_branch_{fwd,bwd}_f32), which has no device-side meeting point.
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, int64_t> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(dev, lds);
+  const auto hit = table.find(key);
+  if (hit != table.end()) return hit->second;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, TBW, lds) != hipSuccess || per_cu <= 0) {
     (void)hipGetLastError();
     return 0;
   }
-  last_lds = lds;
-  last_cap = (int64_t)per_cu * cus / 2;
-  return last_cap;
+  const int64_t cap = (int64_t)per_cu * cus / 2;
+  table[key] = cap;
+  return cap;
 }
 
 int fused_geometry(int32_t N, int32_t C, int32_t T, bool bwd, int& nt1, int& nt2, size_t& l1, size_t& lds) {

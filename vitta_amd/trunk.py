@@ -157,9 +157,17 @@ def _noop_hooks_only(module):
     return not module._forward_pre_hooks
 
 
+def _sflags(site):
+    """Statistics flags of a convolution launch that feeds `site` (None: no statistics)."""
+    if site is None:
+        return 0
+    return CV.CONV_STATS | (CV.CONV_STATS_RAW if site.raw else 0)
+
+
 class Site:
     """A hooked BatchNorm2d of this step: where the convolution epilogue deposits the additive statistics and which
     coefficient slices its backward injects."""
+    raw = False
 
     def __init__(self, engine, plan, index):
         sl = plan.channel_slice(index)
@@ -168,29 +176,29 @@ class Site:
 
 
 class ProducerSite:
-    """A BatchNorm2d carrying ComputeNormStatsHook objects: the convolution epilogue deposits sum(z - k), sum (z - k)^2 of
-    z = bn(conv output) with k = the BN's bias; finish() turns them into the hooks' batch_mean / batch_var -- of z, or of
-    the BN INPUT (before_norm) through the inverse of the eval-mode affine map z = gamma (x - rm) / sqrt(rv + eps) + beta."""
+    """A BatchNorm2d carrying ComputeNormStatsHook objects: the convolution epilogue deposits sum(f - k), sum (f - k)^2 of the
+    hooked feature f and finish() turns them into the hooks' batch_mean / batch_var.  f = z = bn(conv output) with k = the
+    BN's bias, or -- before_norm hooks, utils/norm_stats_utils.py:52-53 -- f = the RAW convolution output (the BN's input)
+    with k = its running mean (VITTA_CONV_STATS_RAW): taken directly as the reference does, so a zero / tiny gamma is just
+    another channel (round 3 inverted the affine map and divided by gamma)."""
     inj = None
 
     def __init__(self, bn, hooks, device):
         c = bn.num_features
         self.bn, self.hooks = bn, hooks
+        self.raw = bool(hooks[0].before_norm)
+        if any(bool(h.before_norm) != self.raw for h in hooks):
+            raise RuntimeError("vitta_amd.trunk: one BatchNorm2d carries before_norm and after-norm producer hooks")
         self.s = torch.zeros(2, c, dtype=torch.float32, device=device)
-        self.stats = (bn.bias.detach(), self.s[0], self.s[1])
+        self.shift = (bn.running_mean if self.raw else bn.bias).detach()
+        self.stats = (self.shift, self.s[0], self.s[1])
 
     def finish(self, count):
-        bn = self.bn
         d1 = self.s[0].double() / count
-        mean_z = bn.bias.detach().double() + d1
-        var_z = (self.s[1].double() / count - d1 * d1).clamp_(min=0.0)
+        mean = (self.shift.double() + d1).float()
+        var = (self.s[1].double() / count - d1 * d1).clamp_(min=0.0).float()
         for h in self.hooks:
-            if h.before_norm:
-                inv = torch.sqrt(bn.running_var.double() + bn.eps) / bn.weight.detach().double()
-                h.batch_mean = (bn.running_mean.double() + (mean_z - bn.bias.detach().double()) * inv).float()
-                h.batch_var = (var_z * inv * inv).float()
-            else:
-                h.batch_mean, h.batch_var = mean_z.float(), var_z.float()
+            h.batch_mean, h.batch_var = mean, var
 
 
 class TrunkRunner:
@@ -298,9 +306,8 @@ class TrunkRunner:
         if not ok or hook is not None:  # an ENGINE hook on the stem BN takes the module path (the shipped configuration hooks
             return False                # layer3/4); producer hooks get the stem's moments from its raw output
         for bn in [net.bn1] + [m for b in blocks for m in ([b.net.bn1, b.net.bn2, b.net.bn3] + ([b.net.downsample[1]] if b.net.downsample is not None else []))]:
-            for h in _producer_hooks(bn):
-                if h.before_norm and bool((bn.weight.detach() == 0).any()):
-                    return False  # the inverse affine map needs gamma != 0
+            if len({bool(h.before_norm) for h in _producer_hooks(bn)}) > 1:
+                return False  # one statistics site per BatchNorm2d: its input OR its output
         return len(engines) <= 1
 
     # -- caches ------------------------------------------------------------------------------------------------
@@ -527,7 +534,7 @@ class TrunkRunner:
             wd = self.packed(dconv, "f", keep)
 
             def identity_path():
-                CV.launch(gdn, xin, wd, ident, cin, 4 * p, flags=CV.CONV_EPI_APPLY | (CV.CONV_STATS if sd else 0), y_raw=xd,
+                CV.launch(gdn, xin, wd, ident, cin, 4 * p, flags=CV.CONV_EPI_APPLY | _sflags(sd), y_raw=xd,
                           epi_bn=_bn_t(dbn), eps=dbn.eps, stats=sd.stats if sd else None, stat_m=ng * gdn.hy * gdn.wy if ng != n else 0)
             if SIDE_FWD and keep:  # the evaluation pass already runs beside the adaptation pass (a fork nested in that fork
                 # crashes hipStreamEndCapture on ROCm 7.2)
@@ -540,7 +547,7 @@ class TrunkRunner:
             ident = xin
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
-        CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=CV.CONV_STATS if s1 else 0,
+        CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=_sflags(s1),
                   epi_bn=_bn_t(net.bn1) if s1 else None, eps=net.bn1.eps, stats=s1.stats if s1 else None,
                   stat_m=ng * h * w if ng != n else 0)
         # TAM on relu(bn1(x1))
@@ -574,7 +581,7 @@ class TrunkRunner:
         a2 = torch.empty(p, Po, **f)
         x2 = torch.empty(p, Po, **f) if keep else None
         CV.launch(g2, a1, self.packed(net.conv2, "f", keep), a2, p, p,
-                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | (CV.CONV_STATS if s2 else 0), y_raw=x2,
+                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | _sflags(s2), y_raw=x2,
                   epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None, stat_m=ng * ho * wo if ng != n else 0)
         # conv3 -> x3 raw, out
         if fork is not None:
@@ -582,7 +589,7 @@ class TrunkRunner:
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
         CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f", keep), out, p, 4 * p,
-                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | (CV.CONV_STATS if s3 else 0),
+                  flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | _sflags(s3),
                   y_raw=x3, res=ident, epi_bn=_bn_t(net.bn3), eps=net.bn3.eps, stats=s3.stats if s3 else None,
                   stat_m=ng * ho * wo if ng != n else 0)
         saved = None
@@ -764,7 +771,15 @@ class TrunkRunner:
             helper = _Fork(dev, role=1)  # waits for everything this block has queued
             with helper:  # four launches + ONE reduction of their partial tiles
                 CV.wgrad_reduce([CV.wgrad(*wa, defer=i, **wkw) for i, (wa, wkw) in enumerate(wq)])
-            self._wgrad_pending.append((helper, wq))
+            done = torch.cuda.Event()
+            done.record(helper.side)
+            self._wgrad_pending.append((helper, wq, done))
+            # the operands of a block's weight gradients (its saved activations and gradient tensors) stay alive until the
+            # main stream has waited for THAT block's helper work; two blocks back it has long finished, so the wait is free
+            # and the tensors of at most three blocks are held instead of all sixteen
+            while len(self._wgrad_pending) > 2:
+                h0, _, ev0 = self._wgrad_pending.pop(0)
+                h0.main.wait_event(ev0)
         return gin
 
     def join_wgrads(self):
@@ -778,14 +793,17 @@ class TrunkRunner:
         G = torch.empty(c, n * h * w, dtype=torch.float32, device=gfeat.device)
         check(lib().vitta_avgpool_cm_bwd_f32(_p(gfeat[:n].contiguous()), c, n, h * w, _p(G), _stream()), "vitta_avgpool_cm_bwd_f32")
         blocks = self.blocks()
-        for i in range(len(blocks) - 1, -1, -1):
-            sv = ctxd["tape"][i]
-            G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink)
-            sv.clear()
-            if self.after_block is not None:
-                self.join_wgrads()  # a gradient bucket may leave now
-                self.after_block(i)
-        self.join_wgrads()
+        try:
+            for i in range(len(blocks) - 1, -1, -1):
+                sv = ctxd["tape"][i]
+                G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink)
+                sv.clear()
+                if self.after_block is not None:
+                    self.join_wgrads()  # a gradient bucket may leave now
+                    self.after_block(i)
+            self.join_wgrads()
+        finally:
+            self._wgrad_pending = []  # (a backward that raised leaves nothing behind for the next step)
         h0, w0 = ctxd["pooled_hw"]
         if ctxd["stem"] is None:  # the stem ran outside (trainable 7x7 convolution): hand its output gradient back
             return CV.from_cm(G, n, h0, w0)

@@ -350,7 +350,10 @@ class ViTTAAdapter:
         # stays one all-reduce.  VITTA_GRAD_BUCKETS=1: one monolithic all-reduce after the backward.
         self.grad_buckets = int(os.environ.get("VITTA_GRAD_BUCKETS", "4")) if not getattr(args, "update_only_bn_affine", False) else 1
         self._bucket_plan = None
-        self._armed = None
+        self._armed = None          # {release signal: arena range} while a backward may release buckets
+        self._armed_runner = None   # the trunk runner whose after_block callback is set meanwhile
+        self._launched = set()      # signals whose bucket has left during the running backward
+        self.dp_graph = "eager"     # how the data-parallel step is replayed: "one" graph | "segments" | "eager"
         self.n_from_backward = 0  # bucket reductions launched from inside a backward so far (tests)
 
         self.n_clips = _n_clips(args)
@@ -509,7 +512,7 @@ class ViTTAAdapter:
                 g["seg_fwd"].replay()
                 self.engine.exchange()
                 g["seg_bwd"].replay()
-                self._armed = None
+                self._disarm()
                 self._exchange_end(ran_backward=False)
                 g["seg_opt"].replay()
             return g["adapt_out"], g["eval_out_overlapped"]
@@ -571,49 +574,103 @@ class ViTTAAdapter:
         return out, ev
 
     # -- gradient exchange --------------------------------------------------------------------------------------------
+    def _net(self):
+        return self.model.module if isinstance(self.model, SingleDeviceParallel) else self.model
+
+    def _bucket_units(self):
+        """[(module, release)] in FORWARD order: the modules at whose boundaries the gradient arena may be cut, and for each the
+        index of the unit whose "backward done" signal makes its gradients final.  From the model's STRUCTURE only, so every
+        rank builds the same plan whether or not it has run a step (a rank without a video must issue the same collectives).
+        TANet: the bottleneck blocks of the hand-written trunk, signalled by the trunk node after each block's backward
+        (release = itself).  Video Swin: every SwinTransformerBlock3D and PatchMerging, signalled by a tensor hook on its
+        input (the autograd engine runs every node recorded after a tensor before the node that produced it); a block that is
+        not the first of its stage has its norm1 differentiated inside the PREVIOUS block's closing residual + LayerNorm pass
+        (swin.py, `next_norm`), so it is released one signal later."""
+        net = self._net()
+        if self.args.arch == "tanet":
+            base = getattr(net, "base_model", None)
+            if base is None or not hasattr(base, "layer1"):
+                return None
+            from . import trunk
+            return [(b, i) for i, b in enumerate(trunk.runner_of(base).blocks())]
+        layers = getattr(getattr(net, "backbone", None), "layers", None)
+        if layers is None:
+            return None
+        units = []
+        for layer in layers:
+            for j, blk in enumerate(layer.blocks):
+                units.append((blk, len(units) if j == 0 else len(units) - 1))
+            if layer.downsample is not None:
+                units.append((layer.downsample, len(units)))
+        return units
+
     def bucket_plan(self):
-        """[(first block index, lo, hi)] in LAUNCH order (last blocks first) + the complement ranges reduced after the
-        backward; None when the exchange stays monolithic (one rank, affine-only mode, no hand-written trunk)."""
-        if self.bucket is None or self.grad_buckets <= 1 or self.args.arch != "tanet":
+        """buckets [(release signal, lo, hi)] in LAUNCH order (last units first) + the complement ranges reduced after the
+        backward; None when the exchange stays monolithic (one rank, affine-only mode, a model without bucket units)."""
+        if self.bucket is None or self.grad_buckets <= 1:
             return None
         if self._bucket_plan is not None:
-            return self._bucket_plan
-        runner = getattr(self.model.module.base_model, "_vitta_trunk", None)
-        if runner is None:
+            return self._bucket_plan or None
+        units = self._bucket_units()
+        self._bucket_plan = False  # (decided: do not walk the model again)
+        if not units:
             return None
-        blocks = runner.blocks()
-        spans = [self.arena.span(list(b.parameters())) for b in blocks]
+        spans = [self.arena.span(list(m.parameters())) for m, _ in units]
         if any(sp is None for sp in spans) or any(spans[i][1] != spans[i + 1][0] for i in range(len(spans) - 1)):
             return None
         total = spans[-1][1] - spans[0][0]
         plan, hi, acc = [], spans[-1][1], 0
-        for i in range(len(blocks) - 1, -1, -1):  # walk the blocks the way the backward does
+        for i in range(len(units) - 1, -1, -1):  # walk the units the way the backward does
             acc += spans[i][1] - spans[i][0]
             if acc >= total / self.grad_buckets or i == 0:
-                plan.append((i, spans[i][0], hi))
+                plan.append((units[i][1], spans[i][0], hi))
                 hi, acc = spans[i][0], 0
         n = self.arena.grad.numel()
-        self._bucket_plan = dict(buckets=plan, rest=[(0, spans[0][0]), (spans[-1][1], n)], blocks=blocks)
+        self._bucket_plan = dict(buckets=plan, rest=[(0, spans[0][0]), (spans[-1][1], n)], blocks=[m for m, _ in units])
+        if self.args.arch != "tanet":  # tensor hooks on the inputs of the units whose signal releases a bucket
+            for sig in sorted({sig for sig, _, _ in plan}):
+                units[sig][0].register_forward_pre_hook(self._signal_hook(sig))
         return self._bucket_plan
 
-    def _exchange_begin(self):
-        """Before the backward: arm the trunk so that a bucket is reduced the moment its first block's backward returns."""
-        plan = self.bucket_plan()
+    def _signal_hook(self, index):
+        def pre_hook(module, args):
+            x = args[0] if args else None
+            if torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled():
+                x.register_hook(lambda g: self._signal(index))
+        return pre_hook
+
+    def _signal(self, index):
+        """The backward of unit `index` (and of everything after it) has been issued on the current stream."""
+        if self._armed is None:
+            return
+        hit = self._armed.get(index)
+        if hit is not None and index not in self._launched:
+            self._launched.add(index)
+            self.arena.reduce_range(*hit, async_op=True)
+            self.n_from_backward += 1
+
+    def _disarm(self):
+        """No bucket leaves from inside a backward any more; nothing of an abandoned step (a failed capture) stays pending."""
         self._armed = None
+        if self._armed_runner is not None:
+            self._armed_runner.after_block = None
+            self._armed_runner = None
+
+    def _exchange_begin(self):
+        """Before the backward: arm the signals so that a bucket is reduced the moment its last unit's backward has been issued."""
+        plan = self.bucket_plan()
+        self._disarm()
+        self._launched = set()
         if plan is None:
             return
-        runner = self.model.module.base_model._vitta_trunk
         if not all(self.arena.all_direct(list(b.parameters())) for b in plan["blocks"]):
-            return  # (first step, or a block with an autograd-accumulated parameter): everything after the backward
-        first = {i: (lo, hi) for i, lo, hi in plan["buckets"]}
-
-        def after_block(index):
-            if index in first:
-                self.arena.reduce_range(*first[index], async_op=True)
-                self.n_from_backward += 1
-
-        runner.after_block = after_block
-        self._armed = runner
+            return  # (first step, or a unit with an autograd-accumulated parameter): everything after the backward
+        self._armed = {sig: (lo, hi) for sig, lo, hi in plan["buckets"]}
+        if self.args.arch == "tanet":
+            from . import trunk
+            runner = trunk.runner_of(self._net().base_model)
+            runner.after_block = self._signal
+            self._armed_runner = runner
 
     def _exchange_end(self, ran_backward=True):
         """After the backward (+ the copy of autograd-accumulated gradients into the arena): whatever was not reduced from
@@ -622,18 +679,18 @@ class ViTTAAdapter:
             return
         plan = self.bucket_plan()
         if plan is None:
+            self._disarm()
             self.bucket.all_reduce()
             return
-        armed = self._armed is not None and ran_backward
-        if self._armed is not None:
-            self._armed.after_block = None
-            self._armed = None
-        if not armed:  # same collectives, same order as the armed ranks issue them
-            for _, lo, hi in plan["buckets"]:
+        launched = self._launched if (self._armed is not None and ran_backward) else set()
+        self._disarm()
+        for sig, lo, hi in plan["buckets"]:  # (those launched from inside the backward are a prefix of this order)
+            if sig not in launched:
                 self.arena.reduce_range(lo, hi, async_op=True)
         for lo, hi in plan["rest"]:
             self.arena.reduce_range(lo, hi, async_op=True)
         self.arena.wait_pending()
+        self._launched = set()
 
     def adapt_step(self, input, has_video=True):
         """One gradient step on one (already device-resident, already reshaped) TTA input.
@@ -650,7 +707,7 @@ class ViTTAAdapter:
                 g["seg_fwd"].replay()
                 self.engine.exchange()
                 g["seg_bwd"].replay()
-                self._armed = None
+                self._disarm()
                 self._exchange_end(ran_backward=False)
                 g["seg_opt"].replay()
             return g["adapt_out"]
@@ -671,7 +728,7 @@ class ViTTAAdapter:
             if self.engine is None:
                 raise RuntimeError("ragged data-parallel steps need the batched engine")
             loss_reg = self.engine.finish_empty()
-            self._armed = None
+            self._disarm()
         self._exchange_end(ran_backward=has_video)
         if join is not None:  # an evaluation on a side stream still reads the weights this update overwrites
             torch.cuda.current_stream().wait_stream(join)
@@ -749,14 +806,27 @@ class ViTTAAdapter:
             torch.cuda.synchronize()
             time.sleep(0.35)
             try:
-                return self._capture(tta_input, eval_input, segmented, overlap_eval, True)
+                self._capture(tta_input, eval_input, segmented, overlap_eval, True)
+                self.dp_graph = "one"
+                return
             except Exception as e:  # noqa: BLE001  (a capture the collectives library refuses must not cost the run)
                 import warnings
                 warnings.warn(f"data-parallel step not captured as one graph ({e!r}); using three segments")
                 torch.cuda.synchronize()
-        return self._capture(tta_input, eval_input, segmented, overlap_eval, False)
+        self._capture(tta_input, eval_input, segmented, overlap_eval, False)
+        self.dp_graph = "segments" if "seg_fwd" in self._graph else "one"
+
+    def _abandon_step(self):
+        """Forget everything a step that did not finish (a capture that raised inside the backward) left armed or pending:
+        the trunk's after_block callback, the armed bucket signals, the Work objects of reductions issued into the aborted
+        capture.  Without this the fallback capture would reduce from inside its backward segment AND again eagerly."""
+        self._disarm()
+        self._launched = set()
+        self.arena._pending = []
+        self._graph = None
 
     def _capture(self, tta_input, eval_input, segmented, overlap_eval, collectives_in_graph):
+        self._abandon_step()
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
         self.set_adapt_mode()
