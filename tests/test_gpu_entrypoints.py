@@ -321,7 +321,10 @@ def test_swin_buckets_leave_from_inside_the_backward_on_gpu(tmp_path):
         res[nb] = [np.load(os.path.join(str(sub), f"w2r{r}.npz")) for r in range(2)]
     nbk = int(res[4][0]["n_buckets"])
     assert nbk >= 2 and int(res[1][0]["n_buckets"]) == 0
-    assert int(res[4][0]["buckets_from_backward"]) == 2 * nbk and int(res[1][0]["buckets_from_backward"]) == 0
+    # armed once every unit parameter is known to be written straight into the arena: the hooked LayerNorms take the recording
+    # path in the very first step, so that is known after the second backward -- the third step runs armed
+    fb = int(res[4][0]["buckets_from_backward"])
+    assert fb >= nbk and fb % nbk == 0 and fb == int(res[4][1]["buckets_from_backward"]) and int(res[1][0]["buckets_from_backward"]) == 0
     for i in range(3):
         np.testing.assert_array_equal(res[4][0][f"step{i}_grad"], res[4][1][f"step{i}_grad"])  # replicas identical
         assert float(res[4][0][f"step{i}_param_sum"]) == float(res[4][1][f"step{i}_param_sum"])

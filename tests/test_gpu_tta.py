@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 # TANet convolution is our own fp32-MFMA kernel (round 1 ran them in MIOpen / rocBLAS with their own reduction orders and
 # needed grad_frac 2e-2); later steps are bounded by the reference's own noise floor exactly as on the CPU.
 BASE_GPU = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.1)
-# After the first step a sampled gradient may deviate by the MEDIAN noise of its step's tensors, capped at this fraction of
-# max|g| (tests/test_host_cpu.py::check_tta_records); the exact-fp32 convolution arithmetic runs without it (strict
-# per-tensor floors) so that a path bug cannot hide behind the allowance the split arithmetic's summation order needs.
-COMMON_FLOOR = 0.05
+# After the first step at most ONE sampled gradient tensor per step may exceed its own strict bound, by at most 30 % of max|g|
+# (one sign(ema - source) flip of an L1 term among the sampled channels: tests/test_host_cpu.py::check_tta_records); the
+# exact-fp32 convolution arithmetic runs without the allowance (strict per-tensor floors everywhere) so that a path bug
+# cannot hide behind what the split arithmetic's other summation order needs.
+OUTLIERS = (1, 0.30)
 
 
 @pytest.fixture
@@ -62,17 +63,19 @@ def test_three_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine, arit
     conv_arith(arith)
     g = H.golden("tta3.npz")
     recs = run_product_tta(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
-    report = check_tta_records(g, mode, recs, BASE_GPU, common_floor=COMMON_FLOOR if arith == "b3" else None)
+    report = check_tta_records(g, mode, recs, BASE_GPU, outliers=OUTLIERS if arith == "b3" else None)
     for row in report:
         print("step %d %-60s err %.3e bound %.3e" % row)
     if use_engine:  # the hand-written trunk (stand-alone hooks are foreign to it: that mode checks the module path)
         abi_calls.assert_tanet_trunk()
 
 
-def test_batch_of_two_matches_reference_on_gpu(tmp_path, abi_calls):
+@pytest.mark.parametrize("arith", ["b3", "f32"])
+def test_batch_of_two_matches_reference_on_gpu(tmp_path, arith, abi_calls, conv_arith):
+    conv_arith(arith)
     g = H.golden("tta3_bz2.npz")
     recs = run_product_tta(g, "sgd", tmp_path, _dev(), None, batch_size=2)
-    check_tta_records(g, "sgd", recs, BASE_GPU, common_floor=COMMON_FLOOR)
+    check_tta_records(g, "sgd", recs, BASE_GPU, outliers=OUTLIERS if arith == "b3" else None)
     abi_calls.assert_tanet_trunk()
 
 
@@ -175,7 +178,7 @@ def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine,
     from test_swin_cpu import run_product_tta_swin
     g = H.golden("tta3_swin.npz")
     recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
-    check_tta_records(g, mode, recs, BASE_GPU, common_floor=COMMON_FLOOR)
+    check_tta_records(g, mode, recs, BASE_GPU, outliers=OUTLIERS)
     abi_calls.assert_swin_kernels()
 
 

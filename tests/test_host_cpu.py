@@ -172,16 +172,20 @@ def assert_logits_close_abs(got, ref, bound):
         assert a == b or (row_ref[b] - row_ref[a]).item() <= 2 * bound, (a, b)
 
 
-def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=None):
-    """common_floor (GPU suites; a fraction of max|g|, None = off): the noise floor of a sampled gradient on steps AFTER the
-    first is at least the MEDIAN, over the sampled tensors of that step, of noise / max|g| -- CAPPED at `common_floor`.  The
-    fixtures hold ONE perturbed re-run of the reference per step: by the third step its deviations are 3-30 % of max|g| for
-    most tensors (the trajectory is chaotic: L1 sign terms, SGD on every weight), but a single sample can come out 10x
-    smaller for one tensor (layer4.2.net.bn3.bias, batch of two: 0.6 % where its neighbours show 3-30 %), and any other
-    summation order then lands outside "4 x its own floor" -- tools/debug/bz2_step_probe.py prints the table for the
-    arithmetic forms.  The cap keeps the check a check: without it 4 x a 30 % median is 120 % of max|g|.  The first step
-    (identical weights) keeps the strict per-tensor bounds, and the exact-fp32 arithmetic is run WITHOUT the common floor
-    wherever it holds (tests/test_gpu_tta.py)."""
+def check_tta_records(g, mode, records, base, floor_mult=4.0, outliers=None):
+    """Every sampled quantity within max(BASE bound, floor_mult x the reference's own noise floor).  The floors of the TANet
+    fixtures are the worst of EIGHT perturbed re-runs of the reference per step (inputs, and in every second draw also every
+    parameter, perturbed by 1e-7 relative: tools/refgen/gen_golden.py).
+    outliers = (count, cap) (GPU suites, split-bf16 arithmetic only): on steps AFTER the first, at most `count` sampled
+    gradient tensors of a step may exceed their own bound, by no more than `cap` x max|g| -- every other tensor stays under
+    its strict bound, and the exact-fp32 arithmetic runs with outliers=None.  Why any: the alignment loss is L1, a hooked
+    BatchNorm channel contributes +-momentum / C to its d beta (and the like to d gamma) through sign(ema - source); a channel
+    whose EMA sits within round-off of its source statistic flips with ANY change of summation order, and one flip among the
+    four sampled channels of layer4.2.net.bn3.bias is 14 % of that tensor's max|g| (2 x 0.1 / 2048 against 7e-4) -- a
+    quantum the eight reference re-runs either show for a tensor or do not (tools/debug/bz2_step_probe.py prints the table
+    for both arithmetic forms: the exact-fp32 kernels show 12 % on layer1.0.net.bn1.weight in the same step).  Round 3 covered
+    this with a median-of-others floor (up to 120 % of max|g| on the third step); a counted, capped allowance keeps every
+    other tensor's check strict."""
     rows = int(g["sample_rows"])
     cfg = json.loads(str(g["config"]))
     lr = cfg["lr_sgd"] if mode == "sgd" else cfg["lr_adam"]
@@ -197,9 +201,7 @@ def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=None)
         bound = max(base["logit_frac"] * ref.abs().max().item(), floor_mult * float(g[k + "noise_eval_logits"]))
         assert_logits_close_abs(rec["eval_logits"], ref, bound)
         report.append((i, "eval_logits", (rec["eval_logits"] - ref).abs().max().item(), bound))
-        rel = [float(g[k + f"noise_grad::{n_}"]) / max(float(np.abs(g[k + f"grad::{n_}"]).max()), 1e-30)
-               for n_ in rec["grads"] if k + f"grad::{n_}" in g.files]
-        rel_floor = float(np.median(rel)) if rel else 0.0
+        over = []
         for name, gr in rec["grads"].items():
             key = k + f"grad::{name}"
             if key not in g.files:
@@ -207,11 +209,14 @@ def check_tta_records(g, mode, records, base, floor_mult=4.0, common_floor=None)
                 continue
             ref = torch.from_numpy(g[key])
             bound = max(base["grad_frac"] * ref.abs().max().item(), floor_mult * float(g[k + f"noise_grad::{name}"])) + 1e-10
-            if i > 0 and common_floor:
-                bound = max(bound, min(floor_mult * rel_floor, float(common_floor)) * ref.abs().max().item())
             err = (gr[:rows] - ref).abs().max().item()
-            assert err <= bound, (i, name, err, bound)
+            if err > bound and i > 0 and outliers is not None:
+                assert err <= float(outliers[1]) * ref.abs().max().item(), (i, name, err, bound, "beyond the outlier cap")
+                over.append((name, err, bound))
+            else:
+                assert err <= bound, (i, name, err, bound)
             report.append((i, "grad " + name, err, bound))
+        assert outliers is None or len(over) <= int(outliers[0]), (i, "sampled gradients over their own bound", over)
         for name, p in rec["params"].items():
             ref = torch.from_numpy(g[k + f"param::{name}"])
             gkey = k + f"grad::{name}"
