@@ -616,64 +616,3 @@ def test_parity_merged_stride2_data_gradient_is_one_launch(n, c, k, h, arith):
         CV.KERNEL_COUNTS = None
     assert sum(counts.values()) == 1
     _close(CV.from_cm(gx, n, h, h), x.grad)
-
-
-@pytest.mark.parametrize("variant", ["persistent", "bm64"])
-def test_opt_in_pointwise_variants_of_the_split_kernel(variant, arith):
-    """The two measured-and-not-default forms of conv_b3.hip's pointwise kernel stay correct: persistent workgroups walking a
-    range of tiles (ksplit = -1; 1568 tiles here), and 64 x 64 tiles on two-wave workgroups (tile request) -- with the
-    BatchNorm + ReLU + residual + moments epilogue, against fp64."""
-    from vitta_amd import conv as CV
-    if arith != "b3":
-        pytest.skip("variants of the split-bf16 kernel")
-    n, c, k, h = 16, 64, 256, 56
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(n, c, h, h, generator=g)
-    w = torch.randn(k, c, 1, 1, generator=g) * c ** -0.5
-    res = torch.randn(n, k, h, h, generator=g)
-    bn = _bn(k, g)
-    shift = torch.randn(k, generator=g) * 0.1
-    z = _bn_apply(F.conv2d(x.double(), w.double()), bn)
-    ref = torch.relu(z + res.double())
-    d = _dev()
-    y = torch.full((k, n * h * h), float("nan"), device=d)
-    s1, s2 = torch.zeros(k, device=d), torch.zeros(k, device=d)
-    kw = dict(ksplit=-1) if variant == "persistent" else dict(tile=(64 << 16) | 64)
-    CV.launch(CV.Geometry.forward(n, h, h), CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k,
-              flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | CV.CONV_STATS, res=CV.to_cm(res.to(d)),
-              epi_bn=[t.to(d) for t in bn], stats=(shift.to(d), s1, s2), **kw)
-    _close(CV.from_cm(y, n, h, h), ref)
-    dz = z - shift.double().view(1, -1, 1, 1)
-    assert (s1.cpu().double() - dz.sum((0, 2, 3))).abs().max().item() <= 1e-5 * dz.abs().sum((0, 2, 3)).max().item()
-    _close(s2, (dz * dz).sum((0, 2, 3)), tol=1e-5, what="s2")
-
-
-def test_three_stage_pointwise_pipeline_equals_the_default_in_a_fresh_process():
-    """VITTA_CONV_B3_Q=1 (read once per process): the pointwise split-bf16 form as three 16-channel stages at three workgroups
-    per CU -- same products in the same order, so the SAME bits as the default two-stage form, split-K included."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import torch, sys\n"
-        "sys.path.insert(0, %r)\n"
-        "from vitta_amd import conv as CV\n"
-        "d = torch.device('cuda:0'); g = torch.Generator().manual_seed(5); out = []\n"
-        "for n, c, k, h in ((16, 64, 256, 56), (16, 1024, 256, 14), (8, 2048, 512, 7), (4, 256, 64, 28)):\n"
-        "    x = torch.randn(c, n * h * h, generator=g).to(d); w = (torch.randn(k, c, 1, 1, generator=g) * c ** -0.5).to(d)\n"
-        "    y = torch.empty(k, n * h * h, device=d)\n"
-        "    CV.launch(CV.Geometry.forward(n, h, h), x, CV.make_pack(CV.pack_fwd(w)), y, c, k)\n"
-        "    torch.cuda.synchronize(); out.append(y.cpu())\n"
-        "torch.save(out, sys.argv[1])\n" % root)
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        res = {}
-        for q in ("0", "1"):
-            path = os.path.join(tmp, f"q{q}.pt")
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, VITTA_CONV_B3_Q=q, VITTA_CONV_ARITH="b3"), capture_output=True,
-                               text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-2000:]
-            res[q] = torch.load(path)
-    for a, b in zip(res["0"], res["1"]):
-        assert torch.equal(a, b)

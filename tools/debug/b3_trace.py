@@ -66,6 +66,9 @@ def run(name, n, c, k, h, ksz, stride=1, dgrad=False, flags=0):
         stat("  -> epilogue constants / input stream requested", t[:, 1] - t[:, 13])
     stat("requests issued -> first stage landed", t[:, 2] - t[:, 1])
     stat("main loop", t[:, 3] - t[:, 2])
+    if (t[:, 14] > 0).any():
+        stat("  of it: waiting for the ring + barrier", t[:, 14])
+        stat("  of it: issuing the step's requests", t[:, 15])
     stat("ring drained", t[:, 4] - t[:, 3])
     if ks.max() > 1:
         stat("partial tile stored (write-through, drained)", t[:, 5] - t[:, 4])

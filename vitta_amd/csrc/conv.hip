@@ -660,7 +660,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   if (!h || !h->x || (!h->w && !h->w_b3) || !h->y) return VITTA_ERR_INVALID_ARG;
   a.d = *h;
   a.nfast = 0;
-  a.q = 0;
+  a.hot = B3Hot{};
   const vitta_conv_desc& d = a.d;
   if (d.C <= 0 || d.K <= 0 || d.N <= 0 || d.ntaps < 1 || d.ntaps > VITTA_CONV_MAX_TAPS || d.sstride < 1 || d.ostride < 1 ||
       d.ostride > 2)
@@ -694,8 +694,7 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   // Split-bf16 operands on the bf16 matrix pipe (conv_b3.hip) whenever the caller supplied the split weight image and the
   // shape fits its one configuration: 128 x 64 tiles, 32-channel slabs (VITTA_CONV_B3=0 keeps the exact-fp32 kernels)
   if (d.w_b3 && b3_enabled() && d.C % 32 == 0 && d.K % 64 == 0 && !(d.flags & VITTA_CONV_PRO_BN_RELU) &&
-      (h->tile == 0 || h->tile == ((128 << 16) | 64) || h->tile == ((64 << 16) | 64) || (h->tile == ((128 << 16) | 128) && d.K % 128 == 0)) &&
-      (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
+      (h->tile == 0 || h->tile == ((128 << 16) | 64)) && (int64_t)d.C * a.xP * 4 < (1ll << 31)) {
     // form: pointwise rows, one patch per channel slab (stride-1 taps inside the halo), or gathered (anything else)
     const int form = is_vector_geometry(d) ? 1 : b3_patch_geometry(d, 63) ? 2 : 3;
     static const int gather_on = env_int("VITTA_CONV_B3_GATHER", 1);  // 0: gathered geometries stay on the exact-fp32 kernels (A/B)
@@ -707,22 +706,9 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
         if (d.cls_ntaps[c] < 1) return VITTA_ERR_INVALID_ARG;
         sum += d.cls_ntaps[c];
       }
-      if (sum != d.ntaps || d.ostride != 2 || form != 2 || (h->tile && (h->tile & 0xffff) != 64)) return VITTA_ERR_UNSUPPORTED;
+      if (sum != d.ntaps || d.ostride != 2 || form != 2) return VITTA_ERR_UNSUPPORTED;
     }
-    // 128 x 128 tiles (wave = 32 rows x 128 channels: the activation split feeds twice the MFMAs) on request only (tile
-    // field, or VITTA_CONV_B3_WIDE=1 for A/B measurements): measured slower on the trunk's shapes -- half the tiles means
-    // twice the K split, and the last arriver of a tile then sums up to sixteen 64 KB partial tiles alone (layer3 3x3:
-    // 41.9 vs 33.1 us, layer2 3x3: 38.6 vs 32.0 us)
-    static const int wide_on = env_int("VITTA_CONV_B3_WIDE", 0);
-    const bool wide_ok = d.K % 128 == 0 && (form == 1 || b3_patch_geometry(d, 32));
-    const bool wide = !parity4 && (h->tile ? (h->tile & 0xffff) == 128 && wide_ok : (wide_on && wide_ok));
-    if (h->tile && (h->tile & 0xffff) == 128 && !wide_ok) return VITTA_ERR_UNSUPPORTED;
-    // 64 x 64 tiles (two-wave workgroups, four per CU) for pointwise launches: on request, or (VITTA_CONV_B3_BM64=1) always;
-    // measured 15-40 % SLOWER than 128 x 64 on every pointwise layer of the trunk (the weight image is re-read per 64 rows)
-    static const int bm64_on = env_int("VITTA_CONV_B3_BM64", 0);
-    if (h->tile == ((64 << 16) | 64) && form != 1) goto exact_fp32;  // (64 x 64 tiles of a 3x3: the exact-fp32 kernels)
-    const bool small = form == 1 && !parity4 && (h->tile ? (h->tile >> 16) == 64 : bm64_on != 0);
-    const int bm = small ? 64 : 128, bn = wide ? 128 : 64;
+    const int bm = 128, bn = 64;  // the one tile shape of conv_b3.hip (round 3 measured 128 x 128 and 64 x 64 tiles: slower)
     a.nMt = (int)((M + bm - 1) / bm);
     a.nNt = d.K / bn;
     a.d.tile = (bm << 16) | bn;
@@ -756,29 +742,28 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     a.slabs = ks > 1 ? reinterpret_cast<float*>(static_cast<char*>(d.workspace) + counter_bytes(tiles)) : nullptr;
     a.b3 = form;
     {
-      // opt-in: equal over the trunk's fifteen pointwise shapes (1.43 vs 1.41 ms per 16-frame pass; better by 5-11 % where a
-      // launch has >= 1500 tiles or very short slices, worse by 3-8 % elsewhere)
-      static const int q_on = env_int("VITTA_CONV_B3_Q", 0);
-      a.q = (q_on && form == 1 && !wide && !small && a.sk_G == 0) ? 1 : 0;
-    }
-    {
       // operand bytes one XCD pulls through its L2 under either tile order: its share of one operand, all of the other
       static const int nfast_mode = env_int("VITTA_CONV_B3_NFAST", -1);  // -1: by operand size, 0 / 1: forced
       const double w_bytes = 6.0 * d.C * d.K * d.ntaps, a_bytes = 4.0 * d.C * (double)a.xP;
-      a.nfast = (nfast_mode < 0 ? (w_bytes > 1.5 * a_bytes && a.nNt >= 8) : nfast_mode) && !wide && !small ? 1 : 0;
+      a.nfast = (nfast_mode < 0 ? (w_bytes > 1.5 * a_bytes && a.nNt >= 8) : nfast_mode) ? 1 : 0;
     }
-    // pointwise launches with more tiles than resident workgroups (two per CU) can run the persistent form of conv_b3.hip,
-    // every workgroup a contiguous range of tiles with the request ring running on across tile boundaries -- on request
-    // only (ksplit = -1, or VITTA_CONV_B3_PERSIST=1): measured EQUAL to one tile per workgroup on the trunk's shapes (64 ->
-    // 256 at 56 x 56: 28.9 vs 28.8 us; the per-step request latency, not the per-tile prologue, sets the pace)
-    static const int persist_on = env_int("VITTA_CONV_B3_PERSIST", 0);
-    if ((persist_on || d.ksplit == -1) && form == 1 && !wide && !small && ks == 1 && !parity4 && a.contig && tiles > 2 * resident_slots() / 3)
-      a.sk_G = 2 * resident_slots() / 3;
     static const int pf = env_int("VITTA_CONV_PW_PREFETCH", 1);
     a.pw_prefetch = (pf && a.contig &&
                      ((d.flags & VITTA_CONV_BWD_BN) || ((d.flags & VITTA_CONV_RES) && d.res && !(d.flags & VITTA_CONV_RES_HALF)))) ? 1 : 0;
     for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t)
       a.tap[t] = t < d.ntaps ? ((d.dh[t] & 0xff) | ((d.dw[t] & 0xff) << 8) | ((int)d.wt[t] << 16)) : 0;
+    // the workgroup prologue's launch constants, divisions as reciprocal multiplications (conv_common.h)
+    a.hot.d_ks = make_fastdiv(ks);
+    a.hot.d_nNt = make_fastdiv(a.nNt);
+    a.hot.d_nMt = make_fastdiv(a.nMt);
+    a.hot.d_hw = make_fastdiv((int64_t)d.Hg * d.Wg);
+    a.hot.d_w = make_fastdiv(d.Wg);
+    a.hot.nwg = tiles * ks;
+    a.hot.ksplit = ks;
+    a.hot.nNt = a.nNt;
+    a.hot.nMt = a.nMt;
+    a.hot.ncs = ncs;
+    a.hot.flags = (a.nfast ? 1 : 0) | (parity4 ? 2 : 0);
     return VITTA_OK;
   }
 exact_fp32:

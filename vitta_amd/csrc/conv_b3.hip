@@ -5,22 +5,36 @@
 // each a v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Six bf16 MFMAs do 16 k of a 32 x 32 block in 6 x 32 cycles where
 // the exact-fp32 instruction (v_mfma_f32_32x32x2_f32, conv_sk.hip / conv_pw.hip) needs 8 x 64: 2.67x the matrix rate
 // (2.5 PF / 6 = 417 TF of fp32-grade multiply-adds), error of the fp32-roundoff class (tests/test_gpu_conv.py holds both
-// arithmetic forms to the same 2e-5-of-max bound against fp64).
+// arithmetic forms to the same bounds against fp64: 2e-5 of the tensor's maximum, and element-wise 4 x 2^-23 x sqrt(R) x sum|a b|
+// under 16 decades of per-channel dynamic range; an Inf / NaN operand makes exactly the elements non-finite that fp32
+// arithmetic makes non-finite, as NaN -- x - bf16(x) is NaN for x = Inf).
 // Reference call sites: models/tanet_models/temporal_module.py:85-106, tanet.py:125-150 (as conv.hip).
 //
-// Same implicit GEMM as conv.hip -- D[p][k] = sum_{tap, c} X[c][src(p, tap)] W[tap][c][k], pixels of all frames on the MFMA row
-// axis, output channels on the column axis, the epilogues of conv_epilogue.h -- with a 128 x 64 output tile per workgroup
-// (2 x 2 waves of 64 x 32: two 32 x 32 accumulators per wave), K walked tap OUTER in slabs of 32 channels:
-//   * the activations are split WHILE THEY ARE STAGED (global -> registers -> three bf16 planes in LDS): a lane owns four
-//     consecutive pixels x four channels (pointwise: four 16-byte loads) or one pixel x eight channels (gathered taps), so a
-//     pixel's channel group is 8 bytes of a plane and the LDS image is [plane][channel group of 4][pixel row][4 bf16]: the
-//     stores are 16 / 8 contiguous bytes per lane, an MFMA operand (8 k of one row) is two conflict-free ds_read_b64;
-//   * the weights are split ONCE per weight version into exactly that image ([tap][slab][plane][group][K][4] bf16,
-//     vitta_conv_pack_b3): a tile's slab piece is 24 runs of 512 bytes, copied 16 bytes per lane;
-//   * two LDS stages (72 KB: two workgroups per CU), the next slab's split + stores and the loads of the slab after next
-//     ride between the MFMAs of the current one; one barrier per slab;
-//   * launches with few tiles split K over workgroups (partial tiles through the write-through workspace, last arriver
-//     reduces, as conv.hip).
+// What ships (round 4; the round-3 variants that measured equal or slower -- 128 x 128 tiles, a persistent pointwise form, 64 x 64
+// two-wave tiles, three 16-channel stages -- are gone, their measurements are in DESIGN.md section 4a'):
+//   * same implicit GEMM as conv.hip -- D[p][k] = sum_{tap, c} X[c][src(p, tap)] W[tap][c][k], pixels of all frames on the MFMA row
+//     axis, output channels on the column axis, the epilogues of conv_epilogue.h -- with a 128 x 64 output tile per workgroup: four
+//     waves stacked along the pixels (32 rows x 64 columns each: one A fragment feeds twelve MFMAs), K walked tap OUTER in steps of
+//     32 channels x 1 tap;
+//   * the activations stay fp32 in memory AND in LDS and are split in registers per MFMA fragment (44 vector instructions per
+//     32 rows x 16 channels); the weights are split ONCE per weight version into [tap][C / 32][3 planes][4 channel octets][K][8] bf16
+//     (vitta_conv_pack_b3): a B fragment is one 16-byte LDS read;
+//   * both operands reach LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane: no registers, no vector ALU) into a ring of
+//     stages; a step = counted s_waitcnt vmcnt for its stage, ONE s_barrier in its middle, the requests of the step after next,
+//     then reads -> split -> MFMA software-pipelined across the two 16-channel halves;
+//   * MODE 0 pointwise: the A stage is the tile's 128 pixels x 32 channels, two stages.  MODE 1 "patch" (3x3, stride 1): the A
+//     image of a channel slab is the flat pixel range [m0 - 64, m0 + 192) of each channel row, loaded ONCE per slab; a tap is an
+//     address shift of the operand reads (a lane whose tap falls outside the plane reads a position the DMA keeps at zero).
+//     MODE 2 gathered (stride 2, planes wider than the halo): four bytes per lane, out-of-plane taps requested out of range;
+//   * launches with few tiles split K over channel slabs (partial tiles through the write-through workspace, the last arriver of a
+//     tile sums them in slice order and runs the epilogue); the stride-2 data gradient's four parity classes are ONE launch;
+//   * XCD-aware tile order (an XCD owns a contiguous range of logical workgroup ids; pixel tiles fastest where the weight image is
+//     the larger operand).
+// Round 4, the workgroup prologue: a workgroup used to need 2.3 (pointwise) to 3.8 us (3x3) from its first instruction to its
+// first stage in LDS (tools/debug/b3_trace.py) -- ~500 instructions with 23 serialised scalar-memory waits and nine integer
+// divisions by launch constants.  The launch constants now arrive as one 64-byte block (ConvK::hot), every division is a multiply
+// by a host-made reciprocal (FastDiv), the tap table is read by independent loads, the tap word of a request is fetched one step
+// ahead of its use, and the epilogue gets the tile origin handed over instead of dividing again.
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -47,17 +61,7 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
 }
 
-// PATCH: 3x3 (any stride-1 tap set on a source grid equal to the output grid): the A image of a channel slab is the flat
-// pixel range [m0 - 64, m0 + 192) of each channel row (the tile's 128 pixels + a halo that covers every tap shift
-// dh * W + dw for W <= 62), loaded ONCE per channel slab; a tap is an address shift of the operand reads, and a lane whose
-// tap falls outside the plane reads position 0 of the row instead, which the DMA keeps at zero.
-// MODE 0: pointwise, the A image is the tile's 128 pixels, two stages.  MODE 2: any other tap set (strided 3x3, strided
-// pointwise, planes wider than the halo): the A image of a (channel slab, tap) step is GATHERED, four bytes per lane
-// (one instruction = 64 pixels of one channel row; a pixel whose tap falls outside the plane requests out of range and
-// lands as zero), two stages like the pointwise form.
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-// NW = waves per workgroup = 32-row blocks of the tile: 4 (128 x 64 tiles, two workgroups per CU) or, pointwise only, 2
-// (64 x 64 tiles, 40 KB of LDS: FOUR workgroups per CU -- twice the independent request chains for the same wave count)
 #ifdef B3_TRACE
 // tools/debug/b3_trace.py: shader-clock stamps of wave 0 at the phase boundaries of a workgroup, 16 words per workgroup
 __device__ unsigned long long b3_trace_buf[16 * 8192];
@@ -65,27 +69,23 @@ __device__ unsigned long long b3_trace_buf[16 * 8192];
   do {                                                                                                   \
     if (threadIdx.x == 0 && blockIdx.x < 8192) b3_trace_buf[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+#define B3_CLK() __builtin_readcyclecounter()
 #else
 #define B3_STAMP(i) \
   do {              \
   } while (0)
 #endif
 
-// Q (pointwise, four waves): THREE stages of SIXTEEN channels (14 KB each, 44 KB with the epilogue scratch: three workgroups per
-// CU) and one barrier per 16-channel step -- behind it every wave has the step's images and has finished reading the stage of
-// the step before, which takes the request of the step after next: two steps of requests in flight.  The pipeline of
-// gemm_bf16x.hip, where it was worth 14 % against two 64-wide stages at two workgroups per CU.
-template <int MODE, bool PRE, int NB, int NW = 4, bool Q = false>
-__global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK a) {
+template <int MODE, bool PRE>
+__global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
-  static_assert(NW == 4 || (NW == 2 && MODE == 0), "two-wave workgroups: pointwise form only");
-  static_assert(!Q || (MODE == 0 && NW == 4 && NB == 3), "Q: the pointwise form with three stages");
-  constexpr int BM = 32 * NW, BN = 64, BK = 32, HALO = 64, NTHR = 64 * NW;
+  constexpr int NB = PATCH ? 3 : 2;       // B stages (A: NA)
+  constexpr int NW = 4, BM = 128, BN = 64, BK = 32, HALO = 64, NTHR = 256;
   constexpr int PL = PATCH ? 256 : BM;    // pixels per channel row of the A image
-  constexpr int NA = PATCH ? 1 : NB;      // A stages (B: NB)
-  constexpr int PER_STEP = Q ? 4 : PATCH ? 12 / NW : GATHER ? 16 + 12 / NW : 4 + 12 / NW;  // LDS-DMA instructions of a wave per step
-  constexpr int RPW = (Q ? 16 : BK) / NW;  // channel rows of an A stage a wave requests
-  constexpr int A_BYTES = (Q ? 16 : BK) * PL * 4, B_BYTES = (Q ? 6 : 12) * BN * 16;
+  constexpr int NA = PATCH ? 1 : NB;
+  constexpr int PER_STEP = PATCH ? 3 : GATHER ? 19 : 7;  // LDS-DMA instructions of a wave per step
+  constexpr int RPW = BK / NW;            // channel rows of an A stage a wave requests
+  constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const Ab = lds;                        // [NA][BK][PL] fp32
   unsigned char* const Bb = lds + NA * A_BYTES;         // [NB][3 planes][4 channel octets][BN][8] bf16
@@ -95,62 +95,75 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   const vitta_conv_desc& d = a.d;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int li = lane & 31, lk = lane >> 5;
-  const int C = d.C, K = d.K;
   B3_STAMP(0);
-  const int Lz = xcd_remap(blockIdx.x, gridDim.x);
-  const int Lg = Lz / a.ksplit, kz = Lz - Lg * a.ksplit;  // tile of the launch (arrival counter, partial tiles)
-  // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table
-  // (class fastest: the classes have 1, 2, 2 and 4 taps -- as four contiguous blocks of ids the XCDs, which own contiguous id
-  // ranges, would get one class each: a 4x imbalance between them; interleaved, every XCD holds all four classes of its
-  // tiles, which also read the same input pixels)
-  const int cls = a.cls_tiles ? (Lg & 3) : 0, Lc = a.cls_tiles ? (Lg >> 2) : Lg;
-  // which tile: an XCD owns a contiguous range of logical ids (xcd_remap).  With column tiles fastest (default) that range is a
-  // few pixel tiles x ALL output channels -- every XCD pulls the whole weight image through its own L2; where the image is the
-  // larger operand (layer 4: 14 MB against 1.6 MB of activations) the host asks for pixel tiles fastest instead (a.nfast):
-  // an XCD then covers all pixels of a few column tiles and reads only their share of the weights
-  const int L = a.nfast ? (Lc % a.nMt) * a.nNt + Lc / a.nMt : Lc;
-  const int tap0 = a.cls_tiles ? a.cls_tap0[cls] : 0, ntaps = a.cls_tiles ? a.cls_tap0[cls + 1] - tap0 : d.ntaps;
-  const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
-  const int ncs = C / BK;
-  const int cs0 = (int)(((int64_t)ncs * kz) / a.ksplit), cs1 = (int)(((int64_t)ncs * (kz + 1)) / a.ksplit);
-  const int S = (cs1 - cs0) * ntaps * (Q ? 2 : 1);  // steps = (channel slab, tap) pairs (Q: 16-channel halves of a slab)
+  // ---- which tile, which slice of K: launch constants in one block, divisions as multiplications -------------------------------
+  const B3Hot h = a.hot;
+  const int C = d.C, K = d.K, Mtot = a.Mtot;
+  const int Lz = xcd_remap(blockIdx.x, h.nwg);
+  const int Lg = fdiv(Lz, h.d_ks), kz = Lz - Lg * h.ksplit;  // tile of the launch (arrival counter, partial tiles), slice
+  // parity-merged data gradient: the launch holds four classes of tiles, each with its own run of the tap table (class fastest:
+  // the classes have 1, 2, 2 and 4 taps -- as four contiguous blocks of ids the XCDs, which own contiguous id ranges, would get
+  // one class each: a 4x imbalance; interleaved, every XCD holds all four classes of its tiles, which read the same input pixels)
+  const bool par = h.flags & 2;
+  const int cls = par ? (Lg & 3) : 0, Lc = par ? (Lg >> 2) : Lg;
+  // an XCD owns a contiguous range of logical ids.  With column tiles fastest (default) that is a few pixel tiles x ALL output
+  // channels -- every XCD pulls the whole weight image through its own L2; where the image is the larger operand (layer 4: 14 MB
+  // against 1.6 MB of activations) the host asks for pixel tiles fastest instead: an XCD then covers all pixels of a few column
+  // tiles and reads only their share of the weights
+  int L = Lc;
+  if (h.flags & 1) {
+    const int qn = fdiv(Lc, h.d_nMt);
+    L = (Lc - qn * h.nMt) * h.nNt + qn;
+  }
+  const int mt = fdiv(L, h.d_nNt), m0 = mt * BM, k0 = (L - mt * h.nNt) * BN;
+  const int tap0 = par ? a.cls_tap0[cls] : 0, ntaps = par ? a.cls_tap0[cls + 1] - tap0 : d.ntaps;
+  const int ncs = h.ncs;
+  const int cs0 = fdiv(ncs * kz, h.d_ks), cs1 = fdiv(ncs * (kz + 1), h.d_ks);
+  const int S = (cs1 - cs0) * ntaps;  // steps = (channel slab, tap) pairs
   B3_STAMP(9);
 
   // wave w owns pixel rows 32 w .. 32 w + 31 and all 64 output channels (two 32 x 32 accumulators)
-  TileEpilogue epi0(a, red, NW == 4 ? wave >> 1 : wave, 0, li, lk, BM), epi1(a, red, NW == 4 ? wave >> 1 : wave, 1, li, lk, BM);
-  const int xb = NW == 4 ? wave & 1 : 0;
-  if (a.cls_tiles) {
+  TileEpilogue epi0(a, red, wave >> 1, 0, li, lk, BM), epi1(a, red, wave >> 1, 1, li, lk, BM);
+  epi0.set_tile(m0, k0);
+  epi1.set_tile(m0, k0);
+  const int xb = wave & 1;
+  if (par) {
     epi0.oa = epi1.oa = cls >> 1;
     epi0.ob = epi1.ob = cls & 1;
   }
 
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)((int64_t)C * a.xP * 4), 0x00020000);
+  const int row_bytes = (int)(a.xP * 4);
+  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, C * row_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_b3), 0, 0x7fffffff, 0x00020000);
   constexpr int OOB = (int)0x80000000u;
-  const int row_bytes = (int)(a.xP * 4);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   B3_STAMP(10);
 
   // ---- LDS-DMA side ----------------------------------------------------------------------------------------------------
   // A, patch: one instruction = one channel row (256 pixels; lane 0 out of range: positions 0..3 stay zero); wave w loads
   // rows 8 w .. 8 w + 7.  A, pointwise: one instruction = two channel rows (2 x 128 pixels), four per wave.
-  // (pointwise: one instruction = 256 / PL channel rows of PL pixels)
   const int voff_a = PATCH ? (lane == 0 ? OOB : (m0 - HALO + 4 * lane) * 4)
-                           : (lane / (PL / 4)) * row_bytes + min(m0 + 4 * (lane % (PL / 4)), a.Mtot - 4) * 4;
+                           : (lane / (PL / 4)) * row_bytes + min(m0 + 4 * (lane % (PL / 4)), Mtot - 4) * 4;
+  // the tap table (nine words at most): independent scalar loads, one wait
+  int tapw[VITTA_CONV_MAX_TAPS];
+#pragma unroll
+  for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t) tapw[t] = (PATCH || GATHER) ? a.tap[min(tap0 + t, VITTA_CONV_MAX_TAPS - 1)] : 0;
   // gathered: the lane's two pixels (lane, lane + 64 of the tile): source offset of tap (0, 0), validity bit per tap
   int g_base[2] = {0, 0};
   unsigned g_valid[2] = {0, 0};
   if constexpr (GATHER) {
+    const int hwg = d.Hg * d.Wg;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int m = m0 + lane + 64 * hh;
-      const int hw = d.Hg * d.Wg, mm = m < a.Mtot ? m : 0;
-      const int n = mm / hw, r = mm - n * hw, gi = r / d.Wg, gj = r - gi * d.Wg;
+      const int mm = m < Mtot ? m : 0;
+      const int n = fdiv(mm, h.d_hw), r = mm - n * hwg, gi = fdiv(r, h.d_w), gj = r - gi * d.Wg;
       g_base[hh] = (n * d.Hs * d.Ws + gi * d.sstride * d.Ws + gj * d.sstride) * 4;
-      for (int t = 0; t < ntaps; ++t) {
-        const int tp = a.tap[tap0 + t];
+#pragma unroll
+      for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t) {
+        const int tp = tapw[t];
         const int sh = gi * d.sstride + (int)(int8_t)(tp & 0xff), sw = gj * d.sstride + (int)(int8_t)((tp >> 8) & 0xff);
-        if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) g_valid[hh] |= 1u << t;
+        if (t < ntaps && m < Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) g_valid[hh] |= 1u << t;
       }
     }
   }
@@ -169,11 +182,6 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c0 + i) * row_bytes, 0, 0);
-    } else if constexpr (Q) {  // cs = 16-channel step: the wave's four channel rows, two per instruction
-      const int c16 = cs * 16 + wave * RPW;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(dst + i * 1024), 16, voff_a, (c16 + 2 * i) * row_bytes, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -182,21 +190,10 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   };
   // B: the slab image of this tile's 64 output channels = 12 runs (plane, channel octet) of 64 x 16 bytes, three per wave
   auto dma_b = [&](int cs, int tp, int stage) __attribute__((always_inline)) {
-    if constexpr (Q) {
-      // cs = 16-channel step: the two octets 2 h, 2 h + 1 of each plane of slab cs / 2 = six runs, LDS order (plane, octet).
-      // Waves 0, 1 bring two runs each, waves 2, 3 one each -- issued TWICE, so that every wave has the same number of
-      // instructions in flight for the counted waits (same bytes to the same place)
-      const int h = cs & 1, r0 = wave < 2 ? 2 * wave : 2 + wave, r1 = wave < 2 ? r0 + 1 : r0;
-      const int base = ((tp >> 16) * ncs + (cs >> 1)) * 12 + 2 * h;
-      unsigned char* dst = Bb + stage * B_BYTES;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + r0 * 1024), 16, lane * 16, ((base + (r0 >> 1) * 4 + (r0 & 1)) * K + k0) * 16, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + r1 * 1024), 16, lane * 16, ((base + (r1 >> 1) * 4 + (r1 & 1)) * K + k0) * 16, 0, 0);
-      return;
-    }
-    unsigned char* dst = Bb + stage * B_BYTES + wave * (12 / NW) * 1024;
-    const int run0 = (((tp >> 16) * ncs + cs) * 12 + wave * (12 / NW));
+    unsigned char* dst = Bb + stage * B_BYTES + wave * 3 * 1024;
+    const int run0 = (((tp >> 16) * ncs + cs) * 12 + wave * 3);
 #pragma unroll
-    for (int u = 0; u < 12 / NW; ++u)
+    for (int u = 0; u < 3; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + u * 1024), 16, lane * 16, ((run0 + u) * K + k0) * 16, 0, 0);
   };
 
@@ -206,13 +203,14 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   unsigned valid = 0x1ff;
   if constexpr (PATCH) {
     const int m = m0 + 32 * wave + li;
-    const int hw = d.Hs * d.Ws, mm = m < a.Mtot ? m : 0;
-    const int r = mm % hw, h = r / d.Ws, w = r - h * d.Ws;
+    const int hw = d.Hs * d.Ws, mm = m < Mtot ? m : 0;
+    const int n = fdiv(mm, h.d_hw), r = mm - n * hw, hh = fdiv(r, h.d_w), ww = r - hh * d.Ws;
     valid = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int tp = a.tap[tap0 + t];
-      const int sh = h + (int)(int8_t)(tp & 0xff), sw = w + (int)(int8_t)((tp >> 8) & 0xff);
-      if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) valid |= 1u << t;
+#pragma unroll
+    for (int t = 0; t < VITTA_CONV_MAX_TAPS; ++t) {
+      const int tp = tapw[t];
+      const int sh = hh + (int)(int8_t)(tp & 0xff), sw = ww + (int)(int8_t)((tp >> 8) & 0xff);
+      if (t < ntaps && m < Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) valid |= 1u << t;
     }
   }
   B3_STAMP(11);
@@ -321,61 +319,36 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   };
   float4 pre[2][4] = {};
   // requests run NB steps ahead: (cs_q, t_q) = the step to request next, clamped to the slice's last step (the tail
-  // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits)
-  int cs_q = Q ? 2 * cs0 : cs0, t_q = 0, q = 0;
+  // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits).
+  // tq_w = the table word of that step's tap, fetched when the step BEFORE it was requested (pointwise: one tap, a constant):
+  // its scalar load has a whole step to return instead of sitting between the barrier and the step's first request
+  int cs_q = cs0, t_q = 0, q = 0;
+  int tq_w = a.tap[tap0];
   auto request = [&](int stage, bool with_a) __attribute__((always_inline)) {
 #ifdef B3_ABL_NODMA
     if (q >= NB) return;
 #endif
-    dma_b(cs_q, a.tap[tap0 + t_q], stage);
+    dma_b(cs_q, tq_w, stage);
     if constexpr (!PATCH) {
-      if (with_a) dma_a(cs_q, stage, a.tap[tap0 + t_q], t_q);
+      if (with_a) dma_a(cs_q, stage, tq_w, t_q);
     }
     const bool adv = q + 1 < S;
     q += adv ? 1 : 0;
     const bool wrap = adv && t_q + 1 == ntaps;
     t_q = adv ? (wrap ? 0 : t_q + 1) : t_q;
     cs_q += wrap ? 1 : 0;
+    if constexpr (MODE != 0) tq_w = a.tap[tap0 + t_q];
   };
-  if constexpr (Q) {
-    request(0, true);
-    request(1, true);
-  } else {
-    dma_a(cs0, 0, a.tap[tap0], 0);
+  dma_a(cs0, 0, tq_w, 0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) request(i, i > 0);
-  }
+  for (int i = 0; i < NB; ++i) request(i, i > 0);
   B3_STAMP(13);
   epi0.load_consts(L);
   epi1.load_consts(L);
   if constexpr (PRE) {
 #pragma unroll
-    for (int y = 0; y < 2; ++y) tile_prefetch(a, L, NW == 4 ? wave >> 1 : wave, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
+    for (int y = 0; y < 2; ++y) tile_prefetch_at(a, m0, k0, wave >> 1, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
   }
-  if constexpr (Q) {
-    float raw[8];
-    bf16x8 fa[3], fb[2][3];
-    int st = 0;
-    B3_STAMP(1);
-    for (int s = 0; s < S; ++s) {
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");  // step s has landed (step s + 1 may be in flight)
-      barrier();
-      if (s == 0) B3_STAMP(2);
-      request(st >= 1 ? st - 1 : 2, true);  // step s + 2 into the stage of step s - 1
-      const float* ap = reinterpret_cast<const float*>(Ab + st * A_BYTES + a_lane);
-      const unsigned char* bs_ = Bb + st * B_BYTES;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = ap[j * PL];
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + (p * 2 * BN + 32 * y) * 16);
-      split(raw, fa);
-      mfma12(fa, fb);
-      st = st == 2 ? 0 : st + 1;
-    }
-  } else {
   // step 0 (requested first) has landed; loads the compiler placed behind the requests only make this wait longer
   B3_STAMP(1);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PER_STEP) : "memory");
@@ -383,9 +356,12 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   B3_STAMP(2);
   float raw[8];
   bf16x8 fa0[3], fa1[3], fb0[2][3], fb1[2][3];
-  read_ops(a_addr(a.tap[tap0], 0, 0), Bb, 0, raw, fb0);
+  read_ops(a_addr(tapw[0], 0, 0), Bb, 0, raw, fb0);
   split(raw, fa0);
   int st = 0;  // stage of the current step
+#ifdef B3_TRACE
+  unsigned long long tr_wait = 0, tr_req = 0;  // shader-clock ticks of wave 0 in: wait for the ring + barrier; issuing the requests
+#endif
   // one step whose successor's images are (or will be, after the barrier) in the ring: both k-steps covered
   auto full_step = [&](int tp, int t, int tp1, int t1) __attribute__((always_inline)) {
     const int st1 = st + 1 == NB ? 0 : st + 1;
@@ -393,9 +369,20 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
     split(raw, fa1);
     mfma12(fa0, fb0);
     interleave();
+#ifdef B3_TRACE
+    const unsigned long long c0 = B3_CLK();
+#endif
     wait_ring();
     barrier();
+#ifdef B3_TRACE
+    const unsigned long long c1 = B3_CLK();
+#endif
     request(st, true);
+#ifdef B3_TRACE
+    const unsigned long long c2 = B3_CLK();
+    tr_wait += c1 - c0;
+    tr_req += c2 - c1;
+#endif
     read_ops(a_addr(tp1, t1, PATCH ? 0 : st1), Bb + st1 * B_BYTES, 0, raw, fb0);
     split(raw, fa0);
     mfma12(fa1, fb1);
@@ -439,7 +426,12 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
       }
     }
   }
+#ifdef B3_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    b3_trace_buf[blockIdx.x * 16 + 14] = tr_wait;
+    b3_trace_buf[blockIdx.x * 16 + 15] = tr_req;
   }
+#endif
   B3_STAMP(3);
   wait_all();       // the tail's surplus requests: nothing may land in LDS that the next workgroup of this CU owns
   __syncthreads();
@@ -448,14 +440,14 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
   if (threadIdx.x == 0 && blockIdx.x < 8192) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    b3_trace_buf[blockIdx.x * 16 + 12] = ((unsigned long long)xcc << 32) | (unsigned)(kz | (a.ksplit << 8) | (S << 16));
+    b3_trace_buf[blockIdx.x * 16 + 12] = ((unsigned long long)xcc << 32) | (unsigned)(kz | (h.ksplit << 8) | (S << 16));
   }
 #endif
 
   // ---- split K: partial tiles meet in the last-arriving workgroup (write-through slabs, ticket; as conv.hip) --------
-  if (a.ksplit > 1) {
+  if (h.ksplit > 1) {
     constexpr int tile_bytes = BM * BN * 4;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)Lg * a.ksplit * (BM * BN), 0, a.ksplit * tile_bytes,
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)Lg * h.ksplit * (BM * BN), 0, h.ksplit * tile_bytes,
                                                                   0x00020000);
 #pragma unroll
     for (int y = 0; y < 2; ++y)
@@ -469,7 +461,7 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
     B3_STAMP(5);
     if (tid == 0) {
       const unsigned ticket = __hip_atomic_fetch_add(a.cnt + Lg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = ticket == (unsigned)(a.ksplit - 1);
+      const bool last = ticket == (unsigned)(h.ksplit - 1);
       if (last) __hip_atomic_store(a.cnt + Lg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = last ? 1 : 0;
     }
@@ -481,32 +473,20 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
     // the slices' tiles are added in slice order (the result does not depend on who arrived last).  This re-read takes 2.0 /
-    // 3.9 / 7.6 us for 2 / 4 / 8 slices (tools/debug/b3_trace.py) -- ~1 us per 32 KB slice; B3_RU slices in flight together
-    // change nothing (launch totals 1.427 / 1.421 / 1.448 ms for 1 / 2 / 4): the consumer CU's memory queue, not the
-    // round-trip latency, sets the pace (MI355X_MICROARCH.md "handoff-payload": 47-75 GB/s per block at these sizes)
-#ifndef B3_RU
-#define B3_RU 1
-#endif
-    for (int z0 = 0; z0 < a.ksplit; z0 += B3_RU) {
-      f32x4 pv[B3_RU][8];
+    // 3.9 / 7.6 us for 2 / 4 / 8 slices (tools/debug/b3_trace.py) -- ~1 us per 32 KB slice; several slices in flight together
+    // change nothing (measured in round 3): the consumer CU's memory queue, not the round-trip latency, sets the pace
+    // (MI355X_MICROARCH.md "handoff-payload": 47-75 GB/s per block at these sizes)
+    for (int z = 0; z < h.ksplit; ++z) {
+      f32x4 pv[8];
 #pragma unroll
-      for (int u = 0; u < B3_RU; ++u) {
-        const int z = min(z0 + u, a.ksplit - 1);  // (past the end: a valid address, the value is not added)
+      for (int i = 0; i < 8; ++i)
+        pv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTHR + tid) * 16, z * tile_bytes, 16));
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          pv[u][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * NTHR + tid) * 16, z * tile_bytes, 16));
-      }
-#pragma unroll
-      for (int u = 0; u < B3_RU; ++u) {
-        if (z0 + u < a.ksplit) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            acc[i / 4][4 * (i % 4)] += pv[u][i].x;
-            acc[i / 4][4 * (i % 4) + 1] += pv[u][i].y;
-            acc[i / 4][4 * (i % 4) + 2] += pv[u][i].z;
-            acc[i / 4][4 * (i % 4) + 3] += pv[u][i].w;
-          }
-        }
+      for (int i = 0; i < 8; ++i) {
+        acc[i / 4][4 * (i % 4)] += pv[i].x;
+        acc[i / 4][4 * (i % 4) + 1] += pv[i].y;
+        acc[i / 4][4 * (i % 4) + 2] += pv[i].z;
+        acc[i / 4][4 * (i % 4) + 3] += pv[i].w;
       }
     }
   }
@@ -556,599 +536,23 @@ __global__ __launch_bounds__(64 * NW, Q ? 3 : 2) void conv_b3_kernel(const ConvK
     }
   }
 }
-// ---- pointwise launches with more tiles than resident workgroups: persistent form ----------------------------------------
-// A pointwise tile of a short-K layer is two to eight steps: with one tile per workgroup the launch is a chain of
-// request latency -> a few steps -> epilogue per workgroup, three rounds of it on the 64 -> 256 layer at 56 x 56 (1568 tiles on
-// 512 resident workgroups, 23 us with the output stores removed).  Here a workgroup owns a contiguous range of tiles and the
-// request ring simply runs on across tile boundaries: the next tile's first images are in flight under the current tile's
-// last MFMAs and land during its epilogue; the operand reads never depend on the tile (a wave's rows are rows 32 w .. of
-// whatever the stage holds), only the request addresses and the epilogue do.
-template <bool PRE>
-__global__ __launch_bounds__(256, 2) void conv_b3p_kernel(const ConvK a) {
-  constexpr int BM = 128, BN = 64, BK = 32, PL = 128, NB = 2;
-  constexpr int A_BYTES = BK * PL * 4, B_BYTES = 12 * BN * 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const Ab = lds;
-  unsigned char* const Bb = lds + NB * A_BYTES;
-  float* const red = reinterpret_cast<float*>(Bb + NB * B_BYTES);
-
-  const vitta_conv_desc& d = a.d;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int li = lane & 31, lk = lane >> 5;
-  const int C = d.C, K = d.K, ncs = C / BK;
-  const int tiles = a.nMt * a.nNt, G = (int)gridDim.x;
-  const int g = xcd_remap(blockIdx.x, G);
-  const int T0 = (int)((int64_t)g * tiles / G), T1 = (int)((int64_t)(g + 1) * tiles / G);
-  if (T1 <= T0) return;
-  const int S = (T1 - T0) * ncs;  // steps of this workgroup = (tile, channel slab)
-  const int wslot = a.tap[0] >> 16;
-
-  TileEpilogue epi0(a, red, wave >> 1, 0, li, lk, BM), epi1(a, red, wave >> 1, 1, li, lk, BM);
-  const int xb = wave & 1;
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)((int64_t)C * a.xP * 4), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_b3), 0, 0x7fffffff, 0x00020000);
-  const int row_bytes = (int)(a.xP * 4);
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-
-  // ---- requests: (tile Lq, channel slab csq), clamped to the range's last step --------------------------------------------
-  int q = 0, Lq = T0, csq = 0;
-  auto tile_voff = [&](int Lx) __attribute__((always_inline)) { return lk * row_bytes + min((Lx / a.nNt) * BM + 4 * li, a.Mtot - 4) * 4; };
-  int voff_q = tile_voff(Lq);
-  auto request = [&](int stage) __attribute__((always_inline)) {
-    const int k0q = (Lq % a.nNt) * BN;
-    unsigned char* db = Bb + stage * B_BYTES + wave * 3 * 1024;
-    const int run0 = (wslot * ncs + csq) * 12 + wave * 3;
-#pragma unroll
-    for (int u = 0; u < 3; ++u)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(db + u * 1024), 16, lane * 16, ((run0 + u) * K + k0q) * 16, 0, 0);
-    unsigned char* da = Ab + stage * A_BYTES + wave * 8 * PL * 4;
-    const int c0 = csq * BK + wave * 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(da + i * 1024), 16, voff_q, (c0 + 2 * i) * row_bytes, 0, 0);
-    if (q + 1 < S) {
-      ++q;
-      if (++csq == ncs) {
-        csq = 0;
-        ++Lq;
-        voff_q = tile_voff(Lq);
-      }
-    }
-  };
-
-  // ---- operands (tile independent) ---------------------------------------------------------------------------------------------
-  const int a_lane = (8 * lk * PL + 32 * wave + li) * 4, b_lane = (lk * BN + li) * 16;
-  f32x16 acc[2];
-  auto read_ops = [&](int stage, int ks, float (&raw)[8], bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
-    const float* ap = reinterpret_cast<const float*>(Ab + stage * A_BYTES + a_lane);
-    const unsigned char* bs_ = Bb + stage * B_BYTES;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = ap[(16 * ks + j) * PL];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + ((p * 4 + 2 * ks) * BN + 32 * y) * 16);
-  };
-  auto split = [&](const float (&raw)[8], bf16x8 (&fa)[3]) __attribute__((always_inline)) {
-    u32x4 sp[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      unsigned h_, m_, l_;
-      split2(raw[2 * j], raw[2 * j + 1], h_, m_, l_);
-      sp[0][j] = h_;
-      sp[1][j] = m_;
-      sp[2][j] = l_;
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) fa[p] = __builtin_bit_cast(bf16x8, sp[p]);
-  };
-  auto mfma12 = [&](const bf16x8 (&fa)[3], const bf16x8 (&fb)[2][3]) __attribute__((always_inline)) {
-#define B3_MFMA(PA, PB)                                                                                  \
-  _Pragma("unroll") for (int y = 0; y < 2; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[y][PB], acc[y], 0, 0, 0)
-    B3_MFMA(2, 0);
-    B3_MFMA(0, 2);
-    B3_MFMA(1, 1);
-    B3_MFMA(1, 0);
-    B3_MFMA(0, 1);
-    B3_MFMA(0, 0);
-#undef B3_MFMA
-  };
-  auto interleave = [&]() __attribute__((always_inline)) {
-    SGB(0x100, 10);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      SGB(0x008, 1);
-      SGB(0x002, 4);
-    }
-  };
-  auto barrier_all_landed = [&]() __attribute__((always_inline)) {  // NB = 2: every request of this wave has landed
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  request(0);
-  request(1);
-  barrier_all_landed();
-  float raw[8];
-  bf16x8 fa0[3], fa1[3], fb0[2][3], fb1[2][3];
-  read_ops(0, 0, raw, fb0);
-  split(raw, fa0);
-  int st = 0, s = 0;
-  for (int L = T0; L < T1; ++L) {
-#pragma unroll
-    for (int y = 0; y < 2; ++y)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
-    epi0.load_consts(L);
-    epi1.load_consts(L);
-    float4 pre[2][4] = {};
-    if constexpr (PRE) {
-#pragma unroll
-      for (int y = 0; y < 2; ++y) tile_prefetch(a, L, wave >> 1, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
-    }
-    for (int cs = 0; cs < ncs; ++cs, ++s) {
-      read_ops(st, 1, raw, fb1);
-      split(raw, fa1);
-      mfma12(fa0, fb0);
-      interleave();
-      if (s + 1 < S) {  // the next step (of this tile or the next) is in the other stage once the barrier is passed
-        barrier_all_landed();
-        request(st);
-        read_ops(st ^ 1, 0, raw, fb0);
-        split(raw, fa0);
-        mfma12(fa1, fb1);
-        interleave();
-        st ^= 1;
-      } else {
-        mfma12(fa1, fb1);
-      }
-    }
-    float r1[2] = {0.f, 0.f}, r2[2] = {0.f, 0.f};
-    epi0.template body<PRE>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
-    epi1.template body<PRE>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
-    const bool BWD = d.flags & VITTA_CONV_BWD_BN;
-    if (((d.flags & VITTA_CONV_STATS) && d.st_s1) || BWD) {
-#pragma unroll
-      for (int y = 0; y < 2; ++y) {
-        r1[y] += __shfl_xor(r1[y], 32, 64);
-        r2[y] += __shfl_xor(r2[y], 32, 64);
-      }
-      if (wave > 0 && lk == 0) {
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          red[(((wave - 1) * 2 + y) * 32 + li) * 2] = r1[y];
-          red[(((wave - 1) * 2 + y) * 32 + li) * 2 + 1] = r2[y];
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (wave == 0 && lk == 0) {
-        const int k0 = (L % a.nNt) * BN;
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          float s1 = r1[y], s2 = r2[y];
-#pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            s1 += red[((w * 2 + y) * 32 + li) * 2];
-            s2 += red[((w * 2 + y) * 32 + li) * 2 + 1];
-          }
-          const int k = k0 + 32 * y + li;
-          if (BWD) {
-            if (d.dgamma) atomicAdd(d.dgamma + k, s1);
-            if (d.dbeta) atomicAdd(d.dbeta + k, s2);
-          } else {
-            atomicAdd(d.st_s1 + k, s1);
-            atomicAdd(d.st_s2 + k, s2);
-          }
-        }
-      }
-      // (`red` is written again only after the next tile's barriers)
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-template <bool PRE>
-int launch_persistent(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr size_t lds = (size_t)2 * 32 * 128 * 4 + 2 * 12 * 64 * 16 + 384 * 4 + 16;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3p_kernel<PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      return VITTA_ERR_LAUNCH;
-    raised = true;
-  }
-  const dim3 grid((unsigned)a.sk_G), block(256);
-  (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3p_kernel<PRE>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3p_kernel<PRE>), grid, block, lds, st, a);
-  return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
-}
-
-// ---- 128 x 128 tiles ("wide"): a wave = 32 pixel rows x 128 output channels, four accumulators --------------------------
-// The split of the activations (44 vector instructions per 32 rows x 16 channels) is the same whatever the tile's width:
-// with four column blocks it feeds 24 MFMAs (768 matrix-pipe cycles) instead of 12, and the step overheads (requests,
-// address arithmetic, barrier) halve per MFMA as well.  Step = ONE k-step of 16 channels (x one tap), one barrier per step:
-//   barrier X_s (step s + 1's images have landed, counted vmcnt) -> request step s + NB into the stage step s has left
-//   (its operands sit in registers) -> operand reads of step s + 1 -> the 24 MFMAs of step s with the split of step s + 1
-//   between them.
-// Images: A = the 16 channel rows of the step (pointwise, ring of NB stages) or the 32-row patch of a channel slab
-// (pixels [m0 - 32, m0 + 160): every tap shift |dh W + dw| <= 32, i.e. W <= 31; one stage, rows out of the plane masked
-// per lane); B = [3 planes][2 channel octets][128 output channels][8] bf16 = 12 KB per step, ring of NB stages.
-// The nine per-channel epilogue constants wait in LDS, not in registers.
-template <int PATCH_I>
-__global__ __launch_bounds__(256, 2) void conv_b3w_kernel(const ConvK a) {
-  constexpr bool PATCH = PATCH_I != 0;
-  constexpr int BM = 128, BN = 128, NY = 4, HALO = 32;
-  constexpr int PL = PATCH ? 192 : 128;
-  constexpr int NB = PATCH ? 4 : 3;
-  constexpr int A_STAGE = PATCH ? 32 * PL * 4 : 16 * PL * 4, NA = PATCH ? 1 : NB;
-  constexpr int B_STAGE = 3 * 2 * BN * 16;
-  constexpr int PER_STEP = PATCH ? 3 : 5;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const Ab = lds;
-  unsigned char* const Bb = lds + NA * A_STAGE;
-  float* const cst = reinterpret_cast<float*>(Bb + NB * B_STAGE);  // [9][BN]
-  float* const red = cst + 9 * BN;                                  // [3][NY][32][2]
-  int* const flag = reinterpret_cast<int*>(red + 3 * NY * 64);
-
-  const vitta_conv_desc& d = a.d;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int li = lane & 31, lk = lane >> 5;
-  const int C = d.C, K = d.K;
-  const int Lz = xcd_remap(blockIdx.x, gridDim.x);
-  const int L = Lz / a.ksplit, kz = Lz - L * a.ksplit;
-  const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
-  const int ncs = C / 32, ntaps = d.ntaps;
-  const int cs0 = (int)(((int64_t)ncs * kz) / a.ksplit), cs1 = (int)(((int64_t)ncs * (kz + 1)) / a.ksplit);
-  const int S = (cs1 - cs0) * ntaps * 2;  // steps = (channel slab, tap, k-step)
-
-  __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, (int)((int64_t)C * a.xP * 4), 0x00020000);
-  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_b3), 0, 0x7fffffff, 0x00020000);
-  const int row_bytes = (int)(a.xP * 4);
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-
-  // ---- requests (LDS-DMA) ------------------------------------------------------------------------------------------------
-  // patch: 32 rows x 48 sixteen-byte units = 24 instructions, six per wave; unit u -> row u / 48, pixels 4 (u % 48) ..
-  int voff_p[6] = {};  // (fixed bounds: a bound that depends on the template argument, captured by the lambdas below, makes
-                       // hipcc drop the host stub of the instantiation silently)
-  int row0_p[6] = {};  // first row an instruction touches (wave-uniform): the scalar part of its address
-  if constexpr (PATCH) {
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int u0 = (wave * 6 + i) * 64, u = u0 + lane;
-      row0_p[i] = u0 / 48;
-      voff_p[i] = (u / 48 - row0_p[i]) * row_bytes + (m0 - HALO + 4 * (u % 48)) * 4;
-    }
-  }
-  auto dma_patch = [&](int cs) __attribute__((always_inline)) {
-    if constexpr (PATCH) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(Ab + (wave * 6 + i) * 1024), 16, voff_p[i], (cs * 32 + row0_p[i]) * row_bytes,
-                                                 0, 0);
-    }
-  };
-  // pointwise A: 16 rows x 512 bytes = 8 instructions (two rows each), two per wave
-  const int voff_a = lk * row_bytes + min(m0 + 4 * li, a.Mtot - 4) * 4;
-  // B: 6 runs (plane, octet) of 128 x 16 bytes = 12 instructions, three per wave: instruction 3 w + u -> run, half
-  int b_soff[3], b_dst[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int i = wave * 3 + u, run = i >> 1, half = i & 1;  // run = plane * 2 + j
-    b_soff[u] = (((run >> 1) * 4 + (run & 1)) * K + k0 + 64 * half) * 16;
-    b_dst[u] = run * 2048 + half * 1024;
-  }
-  // step q -> (channel slab, tap, k-step); the request index runs NB ahead and stops at the slice's last step (re-requested)
-  int q = 0, q_cs = cs0, q_t = 0, q_ks = 0;
-  auto request = [&](int stage) __attribute__((always_inline)) {
-    const int base = ((((a.tap[q_t] >> 16) * ncs + q_cs) * 12 + 2 * q_ks) * K) * 16;
-    unsigned char* dst = Bb + stage * B_STAGE;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(dst + b_dst[u]), 16, lane * 16, base + b_soff[u], 0, 0);
-    if constexpr (!PATCH) {
-      unsigned char* da = Ab + stage * A_STAGE + wave * 4 * PL * 4;
-      const int c0 = q_cs * 32 + q_ks * 16 + wave * 4;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr)(da + u * 1024), 16, voff_a, (c0 + 2 * u) * row_bytes, 0, 0);
-    }
-    const bool adv = q + 1 < S;
-    q += adv ? 1 : 0;
-    const bool w1 = adv && q_ks == 1;
-    q_ks = adv ? (q_ks ^ 1) : q_ks;
-    const bool w2 = w1 && q_t + 1 == ntaps;
-    q_t = w1 ? (w2 ? 0 : q_t + 1) : q_t;
-    q_cs += w2 ? 1 : 0;
-  };
-
-  // ---- operands ----------------------------------------------------------------------------------------------------------
-  const int pos = (PATCH ? HALO : 0) + 32 * wave + li;
-  unsigned valid = 0x1ff;
-  if constexpr (PATCH) {
-    const int m = m0 + 32 * wave + li;
-    const int hw = d.Hs * d.Ws, mm = m < a.Mtot ? m : 0;
-    const int r = mm % hw, h = r / d.Ws, w = r - h * d.Ws;
-    valid = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int tp = a.tap[t];
-      const int sh = h + (int)(int8_t)(tp & 0xff), sw = w + (int)(int8_t)((tp >> 8) & 0xff);
-      if (m < a.Mtot && (unsigned)sh < (unsigned)d.Hs && (unsigned)sw < (unsigned)d.Ws) valid |= 1u << t;
-    }
-  }
-  const int a_lane = (8 * lk * PL + pos) * 4;
-  const int b_lane = (lk * BN + li) * 16;
-
-  f32x16 acc[NY];
-#pragma unroll
-  for (int y = 0; y < NY; ++y)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
-
-  // operand reads of the step whose A rows start at `ap` (lane address incl. tap shift) and whose B image is `bs_`
-  auto read_a = [&](const float* ap, bool ok, float (&raw)[8]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = ap[j * PL];
-    if constexpr (PATCH) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = ok ? raw[j] : 0.f;
-    }
-  };
-  auto read_b = [&](const unsigned char* bs_, bf16x8 (&fb)[NY][3]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int y = 0; y < NY; ++y)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) fb[y][p] = *reinterpret_cast<const bf16x8*>(bs_ + b_lane + (p * 2 * BN + 32 * y) * 16);
-  };
-  auto split = [&](const float (&raw)[8], bf16x8 (&fa)[3]) __attribute__((always_inline)) {
-    u32x4 sp[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      unsigned h_, m_, l_;
-      split2(raw[2 * j], raw[2 * j + 1], h_, m_, l_);
-      sp[0][j] = h_;
-      sp[1][j] = m_;
-      sp[2][j] = l_;
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) fa[p] = __builtin_bit_cast(bf16x8, sp[p]);
-  };
-  auto mfma24 = [&](const bf16x8 (&fa)[3], const bf16x8 (&fb)[NY][3]) __attribute__((always_inline)) {
-#define B3_MFMA(PA, PB)                                                                                  \
-  _Pragma("unroll") for (int y = 0; y < NY; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA], fb[y][PB], acc[y], 0, 0, 0)
-    B3_MFMA(2, 0);
-    B3_MFMA(0, 2);
-    B3_MFMA(1, 1);
-    B3_MFMA(1, 0);
-    B3_MFMA(0, 1);
-    B3_MFMA(0, 0);
-#undef B3_MFMA
-  };
-  // A address of the lane for (tap word, k-step) in `stage`
-  auto a_ptr = [&](int tp, int ks, int stage) __attribute__((always_inline)) -> const float* {
-    if constexpr (PATCH) {
-      const int sh = (int)(int8_t)(tp & 0xff) * d.Ws + (int)(int8_t)((tp >> 8) & 0xff);
-      return reinterpret_cast<const float*>(Ab + a_lane + (sh + 16 * ks * PL) * 4);
-    } else {
-      return reinterpret_cast<const float*>(Ab + stage * A_STAGE + a_lane);
-    }
-  };
-  auto wait_ring = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * PER_STEP) : "memory");
-  };
-  auto wait_all = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  auto barrier = [&]() __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // 24 MFMAs with the next step's reads in front and its split between them
-  auto interleave = [&]() __attribute__((always_inline)) {
-    SGB(0x100, 16);
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-      SGB(0x008, 1);
-      SGB(0x002, 3);
-    }
-  };
-
-  // ---- pipeline ----------------------------------------------------------------------------------------------------------
-  dma_patch(cs0);
-#pragma unroll
-  for (int i = 0; i < NB; ++i) request(i);
-  if (tid < BN) TileEpilogue::stage_consts(a, L, BN, cst, tid);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 1) * PER_STEP) : "memory");  // step 0 has landed (later loads only lengthen the wait)
-  barrier();
-  float raw[8];
-  bf16x8 fa0[3], fa1[3], fb0[NY][3], fb1[NY][3];
-  int tp = a.tap[0];
-  read_a(a_ptr(tp, 0, 0), valid & 1, raw);
-  read_b(Bb, fb0);
-  split(raw, fa0);
-  int st = 0, t = 0, ks = 0, cs = cs0;
-  // step s in (fa0, fb0); two steps per trip so that the register sets alternate by name
-  auto step = [&](bf16x8 (&fa_c)[3], bf16x8 (&fb_c)[NY][3], bf16x8 (&fa_n)[3], bf16x8 (&fb_n)[NY][3], bool last) __attribute__((always_inline)) {
-    if (last) {
-      mfma24(fa_c, fb_c);
-      return;
-    }
-    // successor of step (cs, t, ks)
-    int t1 = t, ks1 = ks ^ 1, cs_n = cs;
-    if (ks == 1) {
-      t1 = t + 1;
-      if (t1 == ntaps) {
-        t1 = 0;
-        ++cs_n;
-      }
-    }
-    const int st1 = st + 1 == NB ? 0 : st + 1;
-    const int tp1 = a.tap[t1];
-    const bool new_patch = PATCH && cs_n != cs;
-    wait_ring();
-    barrier();
-    request(st);
-    if (!new_patch) {
-      read_a(a_ptr(tp1, ks1, st1), (valid >> t1) & 1, raw);
-      read_b(Bb + st1 * B_STAGE, fb_n);
-      split(raw, fa_n);
-      mfma24(fa_c, fb_c);
-      interleave();
-    } else {
-      dma_patch(cs_n);
-      mfma24(fa_c, fb_c);
-      wait_all();
-      barrier();
-      read_a(a_ptr(tp1, ks1, st1), (valid >> t1) & 1, raw);
-      read_b(Bb + st1 * B_STAGE, fb_n);
-      split(raw, fa_n);
-    }
-    t = t1;
-    ks = ks1;
-    cs = cs_n;
-    st = st1;
-  };
-  for (int s = 0; s < S; s += 2) {
-    step(fa0, fb0, fa1, fb1, s + 1 >= S);
-    if (s + 1 < S) step(fa1, fb1, fa0, fb0, s + 2 >= S);
-  }
-  wait_all();
-  __syncthreads();
-
-  // ---- split K (as conv.hip: write-through partial tiles, ticket, last arriver reduces) ----------------------------------
-  if (a.ksplit > 1) {
-    constexpr int tile_bytes = BM * BN * 4;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slabs + (int64_t)L * a.ksplit * (BM * BN), 0, a.ksplit * tile_bytes,
-                                                                  0x00020000);
-#pragma unroll
-    for (int y = 0; y < NY; ++y)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 v = {acc[y][4 * qd], acc[y][4 * qd + 1], acc[y][4 * qd + 2], acc[y][4 * qd + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((y * 4 + qd) * 256 + tid) * 16, kz * tile_bytes, 16);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(a.cnt + L, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool lastw = ticket == (unsigned)(a.ksplit - 1);
-      if (lastw) __hip_atomic_store(a.cnt + L, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = lastw ? 1 : 0;
-    }
-    __syncthreads();
-    if (flag[0] == 0) return;
-#pragma unroll
-    for (int y = 0; y < NY; ++y)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[y][v] = 0.f;
-    for (int z = 0; z < a.ksplit; ++z) {
-#pragma unroll
-      for (int i = 0; i < NY * 4; ++i) {
-        const f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (i * 256 + tid) * 16, z * tile_bytes, 16));
-        acc[i / 4][4 * (i % 4)] += pv.x;
-        acc[i / 4][4 * (i % 4) + 1] += pv.y;
-        acc[i / 4][4 * (i % 4) + 2] += pv.z;
-        acc[i / 4][4 * (i % 4) + 3] += pv.w;
-      }
-    }
-  }
-
-  // ---- epilogue: four column blocks, constants from LDS; per-channel sums of the four waves meet in LDS ---------------------
-  float r1[NY], r2[NY];
-#pragma unroll
-  for (int y = 0; y < NY; ++y) {
-    r1[y] = r2[y] = 0.f;
-    TileEpilogue epi(a, red, wave >> 1, y, li, lk, BM, BN);
-    epi.consts_from_lds(cst);
-    epi.template body<false>(L, wave & 1, acc[y], r1[y], r2[y]);
-  }
-  const bool BWD = d.flags & VITTA_CONV_BWD_BN;
-  if (((d.flags & VITTA_CONV_STATS) && d.st_s1) || BWD) {
-#pragma unroll
-    for (int y = 0; y < NY; ++y) {
-      r1[y] += __shfl_xor(r1[y], 32, 64);
-      r2[y] += __shfl_xor(r2[y], 32, 64);
-    }
-    if (wave > 0 && lk == 0) {
-#pragma unroll
-      for (int y = 0; y < NY; ++y) {
-        red[(((wave - 1) * NY + y) * 32 + li) * 2] = r1[y];
-        red[(((wave - 1) * NY + y) * 32 + li) * 2 + 1] = r2[y];
-      }
-    }
-    __syncthreads();
-    if (wave == 0 && lk == 0) {
-#pragma unroll
-      for (int y = 0; y < NY; ++y) {
-        float s1 = r1[y], s2 = r2[y];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          s1 += red[((w * NY + y) * 32 + li) * 2];
-          s2 += red[((w * NY + y) * 32 + li) * 2 + 1];
-        }
-        const int k = k0 + 32 * y + li;
-        if (BWD) {
-          if (d.dgamma) atomicAdd(d.dgamma + k, s1);
-          if (d.dbeta) atomicAdd(d.dbeta + k, s2);
-        } else {
-          atomicAdd(d.st_s1 + k, s1);
-          atomicAdd(d.st_s2 + k, s2);
-        }
-      }
-    }
-  }
-}
-
-int launch_wide(const ConvK& a, bool patch, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  const size_t lds = (size_t)(patch ? 32 * 192 * 4 : 3 * 16 * 128 * 4) + (patch ? 4 : 3) * 3 * 2 * 128 * 16 + 9 * 128 * 4 + 3 * 4 * 64 * 4 + 16;
-  void (*const kp)(ConvK) = conv_b3w_kernel<1>;
-  void (*const kf)(ConvK) = conv_b3w_kernel<0>;
-  static bool raised[2] = {false, false};
-  if (!raised[patch]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(patch ? kp : kf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return VITTA_ERR_LAUNCH;
-    raised[patch] = true;
-  }
-  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit)), block(256);
-  (void)hipGetLastError();
-  if (patch) {
-    if (e0) hipExtLaunchKernelGGL(conv_b3w_kernel<1>, grid, block, lds, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(conv_b3w_kernel<1>, grid, block, lds, st, a);
-  } else {
-    if (e0) hipExtLaunchKernelGGL(conv_b3w_kernel<0>, grid, block, lds, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(conv_b3w_kernel<0>, grid, block, lds, st, a);
-  }
-  return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
-}
-
 #undef SGB
 
-template <int MODE, bool PRE, int NW = 4, bool Q = false>
+template <int MODE, bool PRE>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  constexpr int NB = Q ? 3 : MODE == 1 ? 3 : 2;
-  constexpr size_t lds = Q ? (size_t)3 * (16 * 128 * 4 + 6 * 64 * 16) + 384 * 4 + 16
-                           : (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 32 * NW) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
+  constexpr int NB = MODE == 1 ? 3 : 2;
+  constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 128) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, NB, NW, Q>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return VITTA_ERR_LAUNCH;
     raised = true;
   }
-  const dim3 grid((unsigned)(a.nMt * a.nNt * a.ksplit * (a.cls_tiles ? 4 : 1))), block(64 * NW);
+  const dim3 grid((unsigned)a.hot.nwg), block(256);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW, Q>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, NB, NW, Q>), grid, block, lds, st, a);
+  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE>), grid, block, lds, st, a);
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
@@ -1207,12 +611,8 @@ __global__ __launch_bounds__(256) void pack_b3_table_kernel(const PackB3* __rest
 namespace vitta_conv {
 
 int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-  if (a.sk_G > 0) return a.pw_prefetch ? launch_persistent<true>(a, st, e0, e1) : launch_persistent<false>(a, st, e0, e1);
-  if ((a.d.tile & 0xffff) == 128) return launch_wide(a, a.b3 == 2, st, e0, e1);
   if (a.b3 == 2) return a.pw_prefetch ? launch_one<1, true>(a, st, e0, e1) : launch_one<1, false>(a, st, e0, e1);
   if (a.b3 == 3) return a.pw_prefetch ? launch_one<2, true>(a, st, e0, e1) : launch_one<2, false>(a, st, e0, e1);
-  if ((a.d.tile >> 16) == 64) return a.pw_prefetch ? launch_one<0, true, 2>(a, st, e0, e1) : launch_one<0, false, 2>(a, st, e0, e1);
-  if (a.q) return a.pw_prefetch ? launch_one<0, true, 4, true>(a, st, e0, e1) : launch_one<0, false, 4, true>(a, st, e0, e1);
   return a.pw_prefetch ? launch_one<0, true>(a, st, e0, e1) : launch_one<0, false>(a, st, e0, e1);
 }
 

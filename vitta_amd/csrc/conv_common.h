@@ -10,6 +10,32 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PRO_MAX = 2048;  // input channels whose prologue BatchNorm constants are held in LDS
 
+// n / d for 0 <= n < 2^31 and a launch constant d >= 1, without a division on the device (an integer division is ~30
+// instructions there, a 64-bit one ~150 -- the start of a convolution workgroup had nine of them on its path to the first
+// memory request): mul = ceil(2^(31 + l) / d), l = ceil(log2 d); n / d == (n * mul) >> (31 + l), exact for every n < 2^31
+// (Granlund-Montgomery with a 31-bit dividend).  sh = l - 1 applies to the HIGH word of the product; sh < 0 marks d == 1.
+struct FastDiv {
+  unsigned mul;
+  int sh;
+};
+inline FastDiv make_fastdiv(int64_t d) {
+  if (d <= 1) return FastDiv{0u, -1};
+  int l = 0;
+  while ((1ll << l) < d) ++l;
+  const uint64_t num = 1ull << (31 + l);  // d < 2^31: l <= 31
+  return FastDiv{(unsigned)((num + (uint64_t)d - 1) / (uint64_t)d), l - 1};
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv f) { return f.sh < 0 ? n : (int)(__umulhi((unsigned)n, f.mul) >> f.sh); }
+
+// conv_b3.hip: what a workgroup needs before its first memory request, as ONE 64-byte block (one scalar load)
+struct B3Hot {
+  FastDiv d_ks, d_nNt, d_nMt;  // divisions by ksplit, nNt, nMt
+  FastDiv d_hw, d_w;           // ... by the pixels of a plane of the M grid (Hg * Wg) and its width (patch / gathered forms, scattered output)
+  int nwg;               // workgroups of the launch (the grid)
+  int ksplit, nNt, nMt, ncs;
+  int flags;             // 1: pixel tiles fastest (nfast), 2: four parity classes of tiles (cls_tiles)
+};
+
 struct ConvK {
   vitta_conv_desc d;
   int64_t xP, yP, rP;  // pixels per channel row of x, y, res
@@ -29,9 +55,9 @@ struct ConvK {
   int pw;              // 1: conv_pw.hip (pointwise, one workgroup per tile, four workgroups per CU)
   int cls_tiles;       // VITTA_CONV_PARITY4: tiles (nMt * nNt) per parity class; 0: one class
   int cls_tap0[5];     // ... first tap of class c (and the end of the last)
-  int q;               // conv_b3.hip: the pointwise form as three 16-channel stages, three workgroups per CU
   int nfast;           // conv_b3.hip: logical ids walk pixel tiles fastest (an XCD = all pixels of a few column tiles)
   int b3;              // conv_b3.hip (split-bf16 operands on the bf16 matrix pipe): 1 pointwise, 2 patch (3x3), 3 gathered; 0: not
+  B3Hot hot;           // conv_b3.hip: launch constants of the workgroup prologue (hot.nwg == 0: not filled)
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {

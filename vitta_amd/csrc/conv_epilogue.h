@@ -17,6 +17,14 @@ struct TileEpilogue {
   int BM = 64;  // pixel rows of the workgroup's tile: wave row wm covers [wm * BM / 2, (wm + 1) * BM / 2) in 32-row blocks
   int BN = 64;  // output channels of the tile: column block wn covers [32 wn, 32 wn + 32)
   int oa, ob;   // scattered output (ostride 2): row / column offset of this tile's parity class
+  // tile origin handed over by a kernel that has it already (conv_b3.hip: no divisions by nNt in the epilogue)
+  int tm0 = 0, tk0 = 0;
+  bool has_tile = false;
+  __device__ __forceinline__ void set_tile(int m0, int k0) {
+    tm0 = m0;
+    tk0 = k0;
+    has_tile = true;
+  }
   // constants of the current tile's channel of this lane: loaded at the tile's start, used at its end
   float c_gam = 1.f, c_bet = 0.f, c_mean = 0.f, c_var = 1.f, c_sh = 0.f, c_a = 0.f, c_b = 0.f, c_mu = 0.f, c_gs = 0.f;
 
@@ -66,7 +74,7 @@ struct TileEpilogue {
   }
 
   __device__ __forceinline__ void load_consts(int L) {
-    const int k = (L % a.nNt) * BN + wn * 32 + li;
+    const int k = (has_tile ? tk0 : (L % a.nNt) * BN) + wn * 32 + li;
     if (BWD) {
       c_gam = d.bwd_bn[0][k];
       c_bet = d.bwd_bn[1][k];
@@ -104,7 +112,7 @@ struct TileEpilogue {
   __device__ __forceinline__ void body(int L, int xb, const f32x16& acc, float& r1, float& r2, float4 p0 = float4{}, float4 p1 = float4{},
                                        float4 p2 = float4{}, float4 p3 = float4{}) {
     const int flags = d.flags;
-    const int m0 = (L / a.nNt) * BM, k0 = (L % a.nNt) * BN;
+    const int m0 = has_tile ? tm0 : (L / a.nNt) * BM, k0 = has_tile ? tk0 : (L % a.nNt) * BN;
     const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
     const bool RAWST = flags & VITTA_CONV_STATS_RAW;
     const bool APPLY = flags & VITTA_CONV_EPI_APPLY;
@@ -200,10 +208,11 @@ struct TileEpilogue {
       } else {
         // scattered destination (data gradient of a stride-2 convolution, one parity class per launch): plain values
         const int hwg = d.Hg * d.Wg;
+        const bool fast = a.hot.nwg > 0;  // (conv_b3.hip: hot.hw / hot.w divide by Hs * Ws == Hg * Wg and Ws == Wg there)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int p = m + e;
-          const int n = p / hwg, r = p - n * hwg, gi = r / d.Wg, gj = r - gi * d.Wg;
+          const int n = fast ? fdiv(p, a.hot.d_hw) : p / hwg, r = p - n * hwg, gi = fast ? fdiv(r, a.hot.d_w) : r / d.Wg, gj = r - gi * d.Wg;
           const int h = gi * d.ostride + oa, w = gj * d.ostride + ob;
           if (h < d.Hy && w < d.Wy) d.y[yrow + (int64_t)n * HWy + h * d.Wy + w] = v[e];
         }
@@ -248,16 +257,20 @@ struct TileEpilogue {
 // afford the sixteen registers at three workgroups per CU).  Rows past Mtot read the last valid quad (never used).
 // (Written without conditionals around the loads: the compiler turns `c ? *p : zero` into a select of ADDRESSES with the
 // zero parked in scratch memory.)
-__device__ __forceinline__ void tile_prefetch(const ConvK& a, int L, int wm, int wn, int li, int lk, float4& p0, float4& p1, float4& p2,
-                                              float4& p3, int bm = 64, int xb = 0) {
+__device__ __forceinline__ void tile_prefetch_at(const ConvK& a, int m0, int k0, int wm, int wn, int li, int lk, float4& p0, float4& p1,
+                                                 float4& p2, float4& p3, int bm = 64, int xb = 0) {
   const vitta_conv_desc& d = a.d;
   const bool bwd = d.flags & VITTA_CONV_BWD_BN;
-  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)((L % a.nNt) * 64 + wn * 32 + li) * (bwd ? a.bP : a.rP);
-  const int m = (L / a.nNt) * bm + wm * (bm >> 1) + 32 * xb + 4 * lk, last = a.Mtot - 4;
+  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + wn * 32 + li) * (bwd ? a.bP : a.rP);
+  const int m = m0 + wm * (bm >> 1) + 32 * xb + 4 * lk, last = a.Mtot - 4;
   p0 = *reinterpret_cast<const float4*>(row + min(m, last));
   p1 = *reinterpret_cast<const float4*>(row + min(m + 8, last));
   p2 = *reinterpret_cast<const float4*>(row + min(m + 16, last));
   p3 = *reinterpret_cast<const float4*>(row + min(m + 24, last));
+}
+__device__ __forceinline__ void tile_prefetch(const ConvK& a, int L, int wm, int wn, int li, int lk, float4& p0, float4& p1, float4& p2,
+                                              float4& p3, int bm = 64, int xb = 0) {
+  tile_prefetch_at(a, (L / a.nNt) * bm, (L % a.nNt) * 64, wm, wn, li, lk, p0, p1, p2, p3, bm, xb);
 }
 
 }  // namespace vitta_conv
