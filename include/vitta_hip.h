@@ -634,6 +634,23 @@ int vitta_ln_bwd_f32(const float* d_gy, const float* d_gxnew, const float* d_x, 
                      const float* d_gamma, const float* d_beta, const float* d_scale, const float* d_mu,
                      const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int64_t rows,
                      int64_t rows_per_sample, int32_t C, float* d_gx, float* d_gbranch, float* d_partial, void* stream);
+/* The same passes with bfloat16 on the sides that touch a dense product (the bf16 recipe of BASELINE config 5): the forward reads a
+ * bf16 branch (VITTA_LN_BRANCH_BF16) and / or writes y as bf16 (VITTA_LN_Y_BF16: the LayerNorm output only feeds qkv / fc1); the
+ * backward reads g_y as bf16 (VITTA_LN_GY_BF16: what the product's data gradient wrote) and / or writes d_gbranch as bf16
+ * (VITTA_LN_GBRANCH_BF16: the gradient of a bf16 branch -- then written even without a scale).  Statistics, the residual stream x,
+ * d_gx and every reduction stay fp32. */
+#define VITTA_LN_BRANCH_BF16 1
+#define VITTA_LN_Y_BF16 2
+#define VITTA_LN_GY_BF16 4
+#define VITTA_LN_GBRANCH_BF16 8
+int vitta_ln_fwd_mixed(const float* d_x, const void* d_branch, const float* d_scale, int64_t rows, int64_t rows_per_sample,
+                       int32_t C, const float* d_gamma, const float* d_beta, float eps, float* d_xnew, void* d_y,
+                       float* d_mean, float* d_rstd, const float* d_shift, float* d_partial, int32_t flags, void* stream);
+int vitta_ln_bwd_mixed(const void* d_gy, const float* d_gxnew, const float* d_x, const float* d_mean, const float* d_rstd,
+                       const float* d_gamma, const float* d_beta, const float* d_scale, const float* d_mu,
+                       const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int64_t rows,
+                       int64_t rows_per_sample, int32_t C, float* d_gx, void* d_gbranch, float* d_partial, int32_t flags,
+                       void* stream);
 int vitta_colsum2_f32(const float* d_partial, int64_t n_partials, int32_t C, float* d_out_a, float* d_out_b, float* d_cnt,
                       float cnt_value, void* stream);
 
@@ -710,6 +727,11 @@ int vitta_gemm_nt_bf16w_f32(const float* d_a, const uint16_t* d_b_bf16, const fl
 int vitta_gemm_bf16x_supported(int64_t M, int64_t N, int64_t K);
 int vitta_gemm_nt_bf16x_f32(const void* d_a, const void* d_b, const float* d_bias, float* d_y, int64_t M, int64_t N, int64_t K,
                             void* stream);
+/* The same kernel with the epilogues of vitta_gemm_nt_f32 and 2-byte activations on either side (the bf16 recipe's data flow,
+ * swin_transformer.py:30-35, 144, 165): mode 0 y = acc + bias; mode 1 h = acc + bias -> d_pre (bf16, optional), y = gelu(h);
+ * mode 2 y = acc * gelu'(d_aux) with d_aux the bf16 pre-activation.  out_bf16: d_y is bfloat16 [M][N], else float32. */
+int vitta_gemm_nt_bf16x(const void* d_a, const void* d_b, const float* d_bias, const void* d_aux, void* d_y, void* d_pre, int64_t M,
+                        int64_t N, int64_t K, int32_t mode, int32_t out_bf16, void* stream);
 
 /* The same products at fp32 accuracy on the bf16 matrix pipe (gemm_b3.hip): every fp32 operand split into three bf16
  * terms, six products per multiply-add, fp32 accumulation -- the arithmetic of conv_b3.hip.  d_b_b3 = the split image

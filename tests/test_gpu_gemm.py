@@ -287,3 +287,70 @@ def test_gemm_bf16x_vs_fp64_of_the_rounded_operands(m, n, k, bias):
     ref = a.double().cpu() @ b.double().cpu().t() + (bv.double().cpu() if bias else 0)
     _close(y, ref, rel=2e-5)
     assert not L.vitta_gemm_bf16x_supported(m, n + 64, k) and not L.vitta_gemm_bf16x_supported(m, n, k + 16)
+
+
+@pytest.mark.parametrize("m,n,k", [(3136, 2048, 512), (1000, 512, 128), (12544, 256, 1024), (129, 128, 64)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_gemm_bf16x_epilogues_and_bfloat16_outputs(m, n, k, out_bf16):
+    """vitta_gemm_nt_bf16x: mode 0 (bias), mode 1 (bias + exact GELU, the pre-activation kept as bfloat16), mode 2 (times gelu' of
+    a bfloat16 pre-activation) with the output as fp32 or bfloat16, against fp64 on the same bf16 operands; a bfloat16 output is
+    the fp64 value rounded once."""
+    from vitta_amd import ops
+    dev = _dev()
+    gen = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=gen).to(dev).to(torch.bfloat16)
+    b = (torch.randn(n, k, generator=gen) * k ** -0.5).to(dev).to(torch.bfloat16)
+    bias = torch.randn(n, generator=gen).to(dev)
+    hpre = torch.randn(m, n, generator=gen).to(dev).to(torch.bfloat16)
+    acc = a.double().cpu() @ b.double().cpu().t()
+    rel = 2.0 ** -8 if out_bf16 else 2e-5
+    _close(ops.gemm_bf16x(a, b, bias, out_bf16=out_bf16).float(), acc + bias.double().cpu(), rel=rel)
+    pre = torch.full((m, n), float("nan"), device=dev).to(torch.bfloat16)
+    y1 = ops.gemm_bf16x(a, b, bias, mode=1, pre=pre, out_bf16=out_bf16)
+    h = acc + bias.double().cpu()
+    _close(pre.float(), h, rel=2.0 ** -8)
+    _close(y1.float(), F.gelu(h), rel=rel)
+    hd = hpre.double().cpu().requires_grad_(True)
+    F.gelu(hd).sum().backward()
+    _close(ops.gemm_bf16x(a, b, None, mode=2, aux=hpre, out_bf16=out_bf16).float(), acc * hd.grad, rel=rel)
+    assert y1.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+
+
+@pytest.mark.parametrize("train_weights", [False, True])
+def test_bf16_data_flow_mlp_and_linear_match_the_fp32_path(train_weights):
+    """ops.bf16_flow: LayerNorm -> bfloat16 -> FusedMlp / DenseLinear on gemm_bf16x.hip (h, gelu(h), the MLP output and the
+    gradients between them bfloat16 in memory) against the exact-fp32 kernels on the same modules: outputs and every gradient
+    within the bf16 recipe's error (operands and hand-overs rounded to 8 bits: a few 1e-2 of the tensor's maximum)."""
+    import torch.nn as nn
+    from vitta_amd import fused_ln, ops, swin
+    dev = _dev()
+    torch.manual_seed(5)
+    c, rows = 256, 2 * 4 * 14 * 14
+    norm, mlp, lin = nn.LayerNorm(c).to(dev), swin.Mlp(c, 4 * c).to(dev), nn.Linear(c, 3 * c).to(dev)
+    for p_ in list(mlp.parameters()) + list(lin.parameters()):
+        p_.requires_grad_(train_weights)
+    x = torch.randn(2, 4, 14, 14, c, device=dev)
+    gy1, gy2 = torch.randn(2, 4, 14, 14, c, device=dev), torch.randn(2, 4, 14, 14, 3 * c, device=dev)
+    res = {}
+    keep = (ops.DENSE_BF16,)
+    try:
+        for mode in (False, True):
+            ops.DENSE_BF16 = mode
+            for p_ in list(norm.parameters()) + list(mlp.parameters()) + list(lin.parameters()):
+                p_.grad = None
+            xx = x.clone().requires_grad_(True)
+            y = fused_ln.ln(norm, xx, [mlp.fc1, mlp.fc2] if mode else None)
+            assert y.dtype == (torch.bfloat16 if mode else torch.float32)
+            m_ = mlp(y)
+            y2 = fused_ln.ln(norm, xx, [lin] if mode else None)
+            q = swin.linear(lin, y2)
+            assert m_.dtype == (torch.bfloat16 if mode else torch.float32) and q.dtype == torch.float32
+            torch.autograd.backward([m_, q], [gy1.to(m_.dtype), gy2])
+            res[mode] = (m_.detach().float(), q.detach(), xx.grad.clone(), norm.weight.grad.clone(),
+                         mlp.fc1.weight.grad.clone() if train_weights else None)
+    finally:
+        (ops.DENSE_BF16,) = keep
+    for i, (a_, b_) in enumerate(zip(res[True], res[False])):
+        if a_ is None:
+            continue
+        assert (a_ - b_).abs().max().item() <= 3e-2 * b_.abs().max().item(), (i, (a_ - b_).abs().max().item(), b_.abs().max().item())

@@ -718,6 +718,45 @@ def test_fused_layernorm_matches_torch(c, with_branch):
         assert (a.grad.cpu().double() - ref.grad).abs().max().item() <= 1e-4 * ref.grad.abs().max().item() + 1e-6, i
 
 
+@pytest.mark.parametrize("c", [128, 512, 1024])
+@pytest.mark.parametrize("with_branch", [False, True])
+def test_fused_layernorm_with_bfloat16_sides(c, with_branch):
+    """The bf16 data flow's LayerNorm (vitta_ln_fwd_mixed / _bwd_mixed): y written as bfloat16, a bfloat16 branch, a bfloat16
+    incoming gradient, a bfloat16 branch gradient -- against fp64 F.layer_norm evaluated on the SAME rounded inputs: y is the
+    fp64 result rounded once (half a bf16 ulp), x' and d x, d gamma, d beta are fp32-accurate, d branch is d x' rounded once."""
+    import torch.nn.functional as F
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(c + 7)
+    shape = (3, 2, 5, 7, c)
+    bf = lambda t: t.to(torch.bfloat16)
+    x, br = torch.randn(shape, generator=g), bf(torch.randn(shape, generator=g))
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    scale = torch.tensor([0.0, 1.25, 1.25])
+    gy, gx2 = bf(torch.randn(shape, generator=g)), torch.randn(shape, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (x, br.float(), w, b)]
+    xn = leaves[0] + leaves[1] * scale.double().view(3, 1, 1, 1, 1) if with_branch else leaves[0]
+    y = F.layer_norm(xn, (c,), leaves[2], leaves[3], 1e-5)
+    ((y * gy.double()).sum() + ((xn * gx2.double()).sum() if with_branch else 0.0)).backward()
+    d = _dev()
+    dl = [x.to(d).requires_grad_(True), br.to(d).requires_grad_(True), w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)]
+    if with_branch:
+        xn_d, y_d = ops.FusedLayerNorm.apply(dl[0], dl[1], scale.to(d), dl[2], dl[3], 1e-5, None, True)
+        assert xn_d.dtype == torch.float32
+        torch.autograd.backward([y_d, xn_d], [gy.to(d), gx2.to(d)])
+        torch.testing.assert_close(xn_d.detach().cpu().double(), xn.detach(), rtol=1e-6, atol=1e-6)
+        assert dl[1].grad.dtype == torch.bfloat16
+    else:
+        y_d = ops.FusedLayerNorm.apply(dl[0], None, None, dl[2], dl[3], 1e-5, None, True)
+        y_d.backward(gy.to(d))
+    assert y_d.dtype == torch.bfloat16
+    assert (y_d.detach().cpu().double() - y.detach()).abs().max().item() <= 2.0 ** -8 * y.detach().abs().max().item() + 1e-5
+    for i, (a, ref) in enumerate(zip(dl, leaves)):
+        if i == 1 and not with_branch:
+            continue
+        tol = 2.0 ** -8 if i == 1 else 1e-4   # the branch gradient is bfloat16
+        assert (a.grad.cpu().double() - ref.grad).abs().max().item() <= tol * ref.grad.abs().max().item() + 1e-6, i
+
+
 @pytest.mark.parametrize("shape", [(4, 64, 112, 112), (3, 16, 15, 23), (2, 8, 8, 8)])
 def test_fused_stem_pool_matches_torch(shape):
     """ops.FusedStemPool == max_pool2d(relu(batch_norm_eval(x)), 3, 2, 1): output and the affine gradients (the

@@ -15,7 +15,7 @@ from vitta_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 L = _lib.lib()
 rows = []
-tot = {"bf16x": 0.0, "gemm_bf16": 0.0, "torch": 0.0}
+tot = {"bf16x": 0.0, "bf16x_o16": 0.0, "bf16x_gelu16": 0.0, "gemm_bf16": 0.0, "torch": 0.0}
 flops = 0.0
 for tokens, c in ((200704, 128), (50176, 256), (12544, 512), (3136, 1024)):
     for n, k in ((3 * c, c), (c, c), (4 * c, c), (c, 4 * c)):
@@ -36,7 +36,15 @@ for tokens, c in ((200704, 128), (50176, 256), (12544, 512), (3136, 1024)):
 
         def f_t():
             torch.matmul(a, w.t(), out=yt)
-        us = {"bf16x": time_it(f_x, 10), "gemm_bf16": time_it(f_g, 10), "torch": time_it(f_t, 10)}
+        pre = torch.empty(tokens, n, device=dev, dtype=torch.bfloat16)
+
+        def f_o():
+            ops.gemm_bf16x(a, w, None, out_bf16=True)
+
+        def f_m():
+            ops.gemm_bf16x(a, w, None, mode=1, pre=pre, out_bf16=True)
+        us = {"bf16x": time_it(f_x, 10), "bf16x_o16": time_it(f_o, 10), "bf16x_gelu16": time_it(f_m, 10), "gemm_bf16": time_it(f_g, 10),
+              "torch": time_it(f_t, 10)}
         fl = 2.0 * tokens * n * k
         flops += fl
         for kk in tot:

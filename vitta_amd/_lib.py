@@ -34,6 +34,7 @@ class WgradDesc(C.Structure):
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
 CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW = 16, 32, 64, 128, 256, 512
 WGRAD_DEFER_REDUCE = 1024
+LN_BRANCH_BF16, LN_Y_BF16, LN_GY_BF16, LN_GBRANCH_BF16 = 1, 2, 4, 8
 CONV_KERNEL_TILE, CONV_KERNEL_SK, CONV_KERNEL_PW, CONV_KERNEL_B3 = 0, 1, 2, 3
 
 
@@ -134,6 +135,7 @@ SIGNATURES = {
     "vitta_conv_wgrad_f32": (C.c_int, [C.POINTER(WgradDesc), _p]),
     "vitta_gemm_bf16x_supported": (C.c_int, [_i64, _i64, _i64]),
     "vitta_gemm_nt_bf16x_f32": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _p]),
+    "vitta_gemm_nt_bf16x": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _p]),
     "vitta_conv_wgrad_reduce_f32": (C.c_int, [C.POINTER(C.POINTER(WgradDesc)), _i32, _p]),
     "vitta_conv_repack_f32": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_pack_b3_bytes": (_sz, [_i32, _i32, _i32]),
@@ -169,6 +171,8 @@ SIGNATURES = {
     "vitta_ln_num_partials": (_i64, [_i64]),
     "vitta_ln_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "vitta_ln_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "vitta_ln_fwd_mixed": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "vitta_ln_bwd_mixed": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p]),
     "vitta_colsum2_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p]),
     "vitta_stem_bn_relu_pool_fwd_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p]),
     "vitta_stem_bn_relu_pool_bwd_affine_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p]),

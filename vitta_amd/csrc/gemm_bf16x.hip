@@ -14,8 +14,10 @@
 // Measured (tools/debug/gemm_bf16x_probe.py, config 5's sixteen shapes): 352 TF over the set against 268 TF for gemm.hip's bf16
 // kernel and 529 TF for hipBLASLt writing bf16; 500-610 TF on the K >= 1024 shapes, 165-183 TF on the K = 128 ones, whose fp32
 // output (308 MB at 200 704 tokens x 384) is what the launch waits for: the next step is a bf16 output written in whole lines.
-// Round-3 state: a stand-alone kernel with its test and bench; the model path still runs gemm.hip -- it has no bf16 activations
-// to hand over yet.
+// Round 4: the kernel of the bf16 recipe's dense layers (ops.py: --dense_bf16).  Epilogues as gemm.hip's -- mode 0 bias, mode 1
+// bias + exact-erf GELU with the pre-activation kept, mode 2 times gelu'(aux) -- with the OUTPUT (and pre / aux) in bfloat16 where the
+// consumer is another product or the residual update: fc1 -> fc2 passes 2-byte activations, the K = 128 products stop waiting for
+// a 4-byte-per-element output.
 #include <hip/hip_runtime.h>
 
 #include "conv_common.h"
@@ -27,16 +29,49 @@ using vitta_conv::xcd_remap;
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmX {
   const void* a;      // [M][K] bf16
   const void* b;      // [N][K] bf16
   const float* bias;  // [N] or null
-  float* y;           // [M][N]
+  void* y;            // [M][N] fp32 or bf16 (OUT16)
+  const unsigned short* aux;  // mode 2: [M][N] bf16 pre-activation
+  unsigned short* pre;        // mode 1: [M][N] bf16 pre-activation out (or null)
   int M, N, K;
   int nMt, nNt;
 };
 
+// exact-erf GELU (nn.GELU, approximate = "none") to well below what a bfloat16 hand-over keeps: erf by Abramowitz-Stegun 7.1.26,
+//   erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0,   |error| <= 1.5e-7,
+// with z = |h| / sqrt 2, so exp(-z^2) = exp(-h^2 / 2) is ALSO the density term of gelu' -- one v_exp, one v_rcp and ten multiply-adds
+// per element where erff() is ~40 instructions (the fc1 epilogue at 200 704 tokens x 512 columns was 124 us of 232 with it).
+__device__ __forceinline__ void erf_terms(float h, float& phi_cdf, float& e) {
+  const float z = fabsf(h) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  e = __expf(-0.5f * h * h);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float half_erfc = 0.5f * poly * e;            // 0.5 (1 - erf(z))
+  phi_cdf = h >= 0.f ? 1.f - half_erfc : half_erfc;   // Phi(h) = 0.5 (1 + erf(h / sqrt 2))
+}
+__device__ __forceinline__ float gelu_f(float h) {
+  float cdf, e;
+  erf_terms(h, cdf, e);
+  return h * cdf;
+}
+__device__ __forceinline__ float dgelu_f(float h) {
+  float cdf, e;
+  erf_terms(h, cdf, e);
+  return fmaf(h * 0.3989422804014327f, e, cdf);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+template <int MODE, bool OUT16>
 __global__ __launch_bounds__(256, 3) void gemm_bf16x_kernel(const GemmX g) {
   constexpr int BM = 128, BN = 128, BK = 32, NB = 3;
   constexpr int STAGE = BM * BK * 2;  // bytes per operand per stage (8 KB): three stages of both = 48 KB, three workgroups per CU
@@ -133,20 +168,84 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16x_kernel(const GemmX g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's surplus requests must not land in the next workgroup's LDS
 
-  // epilogue: accumulator v of block (x, y): row 8 (v / 4) + 4 lk + v % 4, column li
+  // epilogue.  Accumulator v of block (x, y) = row 8 (v / 4) + 4 lk + v % 4, column li: written from there a store is 2 or 4 bytes
+  // per lane (and mode 2's gelu' operand a 2-byte load per element: fc2's data gradient at 200 704 tokens took 136 us against 46
+  // for the plain product).  The ring is free now: every wave turns its 32 x 64 half tiles through its own 8.5 KB of LDS so that a
+  // lane owns EIGHT consecutive columns of a row -- bias, pre-activation, gelu' operand and output move as 16-byte vectors, eight
+  // lanes write one full 128-byte line of a bfloat16 row.
+  __syncthreads();  // every wave has left the ring
+  constexpr int TP = 68;  // floats per row of the turn-around tile (the two lane halves of a ds_write_b32 land 16 banks apart)
+  float* const turn = reinterpret_cast<float*>(lds) + wave * (32 * TP);
+  float* const yf = static_cast<float*>(g.y);
+  unsigned short* const yh = static_cast<unsigned short*>(g.y);
+  const int rl = lane >> 3, cg = lane & 7;  // reading side: row rl + 8 it of the half tile, columns 8 cg .. 8 cg + 7
+  const int nb = n0 + 64 * wn + 8 * cg;
+  float bv[8];
 #pragma unroll
-  for (int y = 0; y < 2; ++y) {
-    const int n = n0 + 64 * wn + 32 * y + li;
-    const float bv = g.bias ? g.bias[n] : 0.f;
+  for (int j = 0; j < 8; ++j) bv[j] = (MODE != 2 && g.bias) ? g.bias[nb + j] : 0.f;
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
+  for (int x = 0; x < 2; ++x) {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int m = m0 + 64 * wm + 32 * x + 8 * (v >> 2) + 4 * lk + (v & 3);
-        if (m < M) g.y[(int64_t)m * N + n] = acc[x][y][v] + bv;
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) turn[(8 * (v >> 2) + 4 * lk + (v & 3)) * TP + 32 * y + li] = acc[x][y][v];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = rl + 8 * it;
+      const int m = m0 + 64 * wm + 32 * x + r;
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(turn + r * TP + 8 * cg);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(turn + r * TP + 8 * cg + 4);
+      if (m < M) {
+        const int64_t o = (int64_t)m * N + nb;
+        float h[8] = {lo.x + bv[0], lo.y + bv[1], lo.z + bv[2], lo.w + bv[3], hi.x + bv[4], hi.y + bv[5], hi.z + bv[6], hi.w + bv[7]};
+        if constexpr (MODE == 1) {
+          if (g.pre) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk[j] = (unsigned)f2bf(h[2 * j]) | ((unsigned)f2bf(h[2 * j + 1]) << 16);
+            *reinterpret_cast<u32x4*>(g.pre + o) = pk;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = gelu_f(h[j]);
+        }
+        if constexpr (MODE == 2) {
+          const u32x4 ax = *reinterpret_cast<const u32x4*>(g.aux + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            h[2 * j] *= dgelu_f(__uint_as_float(ax[j] << 16));
+            h[2 * j + 1] *= dgelu_f(__uint_as_float(ax[j] & 0xffff0000u));
+          }
+        }
+        if constexpr (OUT16) {
+          u32x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pk[j] = (unsigned)f2bf(h[2 * j]) | ((unsigned)f2bf(h[2 * j + 1]) << 16);
+          *reinterpret_cast<u32x4*>(yh + o) = pk;
+        } else {
+          *reinterpret_cast<f32x4*>(yf + o) = f32x4{h[0], h[1], h[2], h[3]};
+          *reinterpret_cast<f32x4*>(yf + o + 4) = f32x4{h[4], h[5], h[6], h[7]};
+        }
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads of this half tile are done before the next one overwrites it
   }
+}
+
+template <int MODE, bool OUT16>
+int launch(const GemmX& g, hipStream_t st) {
+  constexpr size_t lds = 2 * 3 * 128 * 32 * 2;
+  static bool raised = false;
+  if (!raised) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x_kernel<MODE, OUT16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return VITTA_ERR_LAUNCH;
+    raised = true;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((gemm_bf16x_kernel<MODE, OUT16>), dim3((unsigned)(g.nMt * g.nNt)), dim3(256), lds, st, g);
+  return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -157,22 +256,21 @@ int vitta_gemm_bf16x_supported(int64_t M, int64_t N, int64_t K) {
   return M > 0 && N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0 && M * K * 2 < (1ll << 31) && N * K * 2 < (1ll << 31) && M * N < (1ll << 40);
 }
 
+int vitta_gemm_nt_bf16x(const void* d_a, const void* d_b, const float* d_bias, const void* d_aux, void* d_y, void* d_pre, int64_t M,
+                        int64_t N, int64_t K, int32_t mode, int32_t out_bf16, void* stream) {
+  if (!d_a || !d_b || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux)) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_gemm_bf16x_supported(M, N, K)) return VITTA_ERR_UNSUPPORTED;
+  GemmX g{d_a, d_b, d_bias, d_y, static_cast<const unsigned short*>(d_aux), static_cast<unsigned short*>(d_pre), (int)M, (int)N, (int)K,
+          (int)((M + 127) / 128), (int)(N / 128)};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 0) return out_bf16 ? launch<0, true>(g, st) : launch<0, false>(g, st);
+  if (mode == 1) return out_bf16 ? launch<1, true>(g, st) : launch<1, false>(g, st);
+  return out_bf16 ? launch<2, true>(g, st) : launch<2, false>(g, st);
+}
+
 int vitta_gemm_nt_bf16x_f32(const void* d_a, const void* d_b, const float* d_bias, float* d_y, int64_t M, int64_t N, int64_t K,
                             void* stream) {
-  if (!d_a || !d_b || !d_y) return VITTA_ERR_INVALID_ARG;
-  if (!vitta_gemm_bf16x_supported(M, N, K)) return VITTA_ERR_UNSUPPORTED;
-  GemmX g{d_a, d_b, d_bias, d_y, (int)M, (int)N, (int)K, (int)((M + 127) / 128), (int)(N / 128)};
-  constexpr size_t lds = 2 * 3 * 128 * 32 * 2;
-  static bool raised = false;
-  if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      return VITTA_ERR_LAUNCH;
-    raised = true;
-  }
-  (void)hipGetLastError();
-  hipLaunchKernelGGL(gemm_bf16x_kernel, dim3((unsigned)(g.nMt * g.nNt)), dim3(256), lds, static_cast<hipStream_t>(stream), g);
-  return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
+  return vitta_gemm_nt_bf16x(d_a, d_b, d_bias, nullptr, d_y, nullptr, M, N, K, 0, 0, stream);
 }
 
 }  // extern "C"

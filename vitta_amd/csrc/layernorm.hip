@@ -53,15 +53,47 @@ __device__ __forceinline__ void stv(float* dst, const float* src) {
   else *reinterpret_cast<float2*>(dst) = make_float2(src[0], src[1]);
 }
 
+// element i .. i + VEC - 1 of a row held as fp32 or as bfloat16 (the 2-byte activations of the bf16 recipe: a LayerNorm output that
+// only feeds a dense product, a branch that a dense product wrote, a gradient a dense product returns)
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <int VEC>
+__device__ __forceinline__ void ldv_any(float* dst, const void* base, int64_t idx, bool bf16) {
+  if (!bf16) {
+    ldv<VEC>(dst, static_cast<const float*>(base) + idx);
+  } else if constexpr (VEC == 4) {
+    const ushort4 v = *reinterpret_cast<const ushort4*>(static_cast<const unsigned short*>(base) + idx);
+    dst[0] = bf2f(v.x); dst[1] = bf2f(v.y); dst[2] = bf2f(v.z); dst[3] = bf2f(v.w);
+  } else {
+    const ushort2 v = *reinterpret_cast<const ushort2*>(static_cast<const unsigned short*>(base) + idx);
+    dst[0] = bf2f(v.x); dst[1] = bf2f(v.y);
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv_any(void* base, int64_t idx, const float* src, bool bf16) {
+  if (!bf16) {
+    stv<VEC>(static_cast<float*>(base) + idx, src);
+  } else if constexpr (VEC == 4) {
+    *reinterpret_cast<ushort4*>(static_cast<unsigned short*>(base) + idx) = make_ushort4(f2bf(src[0]), f2bf(src[1]), f2bf(src[2]), f2bf(src[3]));
+  } else {
+    *reinterpret_cast<ushort2*>(static_cast<unsigned short*>(base) + idx) = make_ushort2(f2bf(src[0]), f2bf(src[1]));
+  }
+}
+
 struct LnFwdArgs {
-  const float* x; const float* branch; const float* scale;  // branch / scale may be null
+  const float* x; const void* branch; const float* scale;  // branch / scale may be null
   const float* gamma; const float* beta; float eps;
   float* xnew;   // x + s*branch (written only with a branch)
-  float* y; float* mean; float* rstd;
+  void* y; float* mean; float* rstd;
   const float* shift;  // hooked: k_c (source mean); null -> no statistics
   float* partial;      // [gridDim.x][2][C]
   int64_t rows, rows_per_sample;
   int C, rpw;
+  int branch16, y16;   // branch / y are bfloat16
 };
 
 template <int NV, int VEC, bool RES, bool STATS>
@@ -90,12 +122,11 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_fwd_kernel(LnFwdArgs a) {
     for (int j = 0; j < NV; ++j) ldv<VEC>(v + j * VEC, xr + (lane + 64 * j) * VEC);
     if (RES) {
       const float s = a.scale ? a.scale[r / a.rows_per_sample] : 1.f;
-      const float* br = a.branch + r * C;
       float* xo = a.xnew + r * C;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         float b[VEC];
-        ldv<VEC>(b, br + (lane + 64 * j) * VEC);
+        ldv_any<VEC>(b, a.branch, r * C + (lane + 64 * j) * VEC, a.branch16);
 #pragma unroll
         for (int u = 0; u < VEC; ++u) v[j * VEC + u] = fmaf(s, b[u], v[j * VEC + u]);
         stv<VEC>(xo + (lane + 64 * j) * VEC, v + j * VEC);
@@ -112,7 +143,6 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_fwd_kernel(LnFwdArgs a) {
       sq = fmaf(d, d, sq);
     }
     const float rstd = rsqrtf(wave_sum(sq) * inv_c + a.eps);
-    float* yr = a.y + r * C;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       float o[VEC];
@@ -126,7 +156,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_fwd_kernel(LnFwdArgs a) {
           s2[j * VEC + u] = fmaf(d, d, s2[j * VEC + u]);
         }
       }
-      stv<VEC>(yr + (lane + 64 * j) * VEC, o);
+      stv_any<VEC>(a.y, r * C + (lane + 64 * j) * VEC, o, a.y16);
     }
     if (lane == 0) {
       a.mean[r] = mean;
@@ -151,15 +181,16 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_fwd_kernel(LnFwdArgs a) {
 }
 
 struct LnBwdArgs {
-  const float* gy; const float* gxnew;  // gxnew: gradient arriving at x' from the residual path, or null
+  const void* gy; const float* gxnew;  // gxnew: gradient arriving at x' from the residual path, or null
   const float* x;                       // the normalised tensor (x' of the forward)
   const float* mean; const float* rstd; const float* gamma; const float* beta;
   const float* scale;                   // per-sample branch scale or null
   const float* mu; const float* ca; const float* cb; const float* gscale;  // injection (null: none)
-  float* gx; float* gbranch;            // gbranch written only with a scale
+  float* gx; void* gbranch;             // gbranch written only with a scale (or as the bf16 gradient of a bf16 branch)
   float* partial;                       // [gridDim.x][2][C]: d gamma | d beta
   int64_t rows, rows_per_sample;
   int C, rpw;
+  int gy16, gbranch16;                  // gy / gbranch are bfloat16
 };
 
 template <int NV, int VEC, bool INJ>
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       ldv<VEC>(xh + j * VEC, a.x + r * C + (lane + 64 * j) * VEC);
-      ldv<VEC>(g + j * VEC, a.gy + r * C + (lane + 64 * j) * VEC);
+      ldv_any<VEC>(g + j * VEC, a.gy, r * C + (lane + 64 * j) * VEC, a.gy16);
     }
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void ln_bwd_kernel(LnBwdArgs a) {
         ob[u] = s * o[u];
       }
       stv<VEC>(a.gx + r * C + (lane + 64 * j) * VEC, o);
-      if (a.gbranch) stv<VEC>(a.gbranch + r * C + (lane + 64 * j) * VEC, ob);
+      if (a.gbranch) stv_any<VEC>(a.gbranch, r * C + (lane + 64 * j) * VEC, ob, a.gbranch16);
     }
   }
 #pragma unroll
@@ -307,6 +338,13 @@ int64_t vitta_ln_num_partials(int64_t rows) {
 int vitta_ln_fwd_f32(const float* d_x, const float* d_branch, const float* d_scale, int64_t rows, int64_t rows_per_sample,
                      int32_t C, const float* d_gamma, const float* d_beta, float eps, float* d_xnew, float* d_y,
                      float* d_mean, float* d_rstd, const float* d_shift, float* d_partial, void* stream) {
+  return vitta_ln_fwd_mixed(d_x, d_branch, d_scale, rows, rows_per_sample, C, d_gamma, d_beta, eps, d_xnew, d_y, d_mean, d_rstd,
+                            d_shift, d_partial, 0, stream);
+}
+
+int vitta_ln_fwd_mixed(const float* d_x, const void* d_branch, const float* d_scale, int64_t rows, int64_t rows_per_sample,
+                       int32_t C, const float* d_gamma, const float* d_beta, float eps, float* d_xnew, void* d_y,
+                       float* d_mean, float* d_rstd, const float* d_shift, float* d_partial, int32_t flags, void* stream) {
   int nv, vec;
   if (!ln_shape(C, &nv, &vec)) return VITTA_ERR_UNSUPPORTED;
   if (!d_x || !d_gamma || !d_beta || !d_y || !d_mean || !d_rstd || rows <= 0 || rows_per_sample <= 0)
@@ -315,7 +353,7 @@ int vitta_ln_fwd_f32(const float* d_x, const float* d_branch, const float* d_sca
     return VITTA_ERR_INVALID_ARG;
   if (mis16(d_x) || mis16(d_branch) || mis16(d_xnew) || mis16(d_y)) return VITTA_ERR_INVALID_ARG;
   const LnFwdArgs a{d_x, d_branch, d_scale, d_gamma, d_beta, eps, d_xnew, d_y, d_mean, d_rstd, d_shift, d_partial,
-                    rows, rows_per_sample, C, ln_rows_per_wg(rows)};
+                    rows, rows_per_sample, C, ln_rows_per_wg(rows), (flags & VITTA_LN_BRANCH_BF16) ? 1 : 0, (flags & VITTA_LN_Y_BF16) ? 1 : 0};
   const dim3 grid((unsigned)vitta_ln_num_partials(rows));
   const size_t lds = sizeof(float) * (size_t)C * (3 + (d_shift ? 8 : 0));
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -333,6 +371,15 @@ int vitta_ln_bwd_f32(const float* d_gy, const float* d_gxnew, const float* d_x, 
                      const float* d_gamma, const float* d_beta, const float* d_scale, const float* d_mu,
                      const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int64_t rows,
                      int64_t rows_per_sample, int32_t C, float* d_gx, float* d_gbranch, float* d_partial, void* stream) {
+  return vitta_ln_bwd_mixed(d_gy, d_gxnew, d_x, d_mean, d_rstd, d_gamma, d_beta, d_scale, d_mu, d_coef_a, d_coef_b, d_gscale, rows,
+                            rows_per_sample, C, d_gx, d_gbranch, d_partial, 0, stream);
+}
+
+int vitta_ln_bwd_mixed(const void* d_gy, const float* d_gxnew, const float* d_x, const float* d_mean, const float* d_rstd,
+                       const float* d_gamma, const float* d_beta, const float* d_scale, const float* d_mu,
+                       const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int64_t rows,
+                       int64_t rows_per_sample, int32_t C, float* d_gx, void* d_gbranch, float* d_partial, int32_t flags,
+                       void* stream) {
   int nv, vec;
   if (!ln_shape(C, &nv, &vec)) return VITTA_ERR_UNSUPPORTED;
   if (!d_gy || !d_x || !d_mean || !d_rstd || !d_gamma || !d_gx || !d_partial || rows <= 0 || rows_per_sample <= 0)
@@ -341,7 +388,8 @@ int vitta_ln_bwd_f32(const float* d_gy, const float* d_gxnew, const float* d_x, 
   if (I && (!d_coef_a || !d_coef_b || !d_beta)) return VITTA_ERR_INVALID_ARG;
   if (mis16(d_gy) || mis16(d_gxnew) || mis16(d_x) || mis16(d_gx) || mis16(d_gbranch)) return VITTA_ERR_INVALID_ARG;
   const LnBwdArgs a{d_gy, d_gxnew, d_x, d_mean, d_rstd, d_gamma, d_beta, d_scale, d_mu, d_coef_a, d_coef_b, d_gscale,
-                    d_gx, d_gbranch, d_partial, rows, rows_per_sample, C, ln_rows_per_wg(rows)};
+                    d_gx, d_gbranch, d_partial, rows, rows_per_sample, C, ln_rows_per_wg(rows), (flags & VITTA_LN_GY_BF16) ? 1 : 0,
+                    (flags & VITTA_LN_GBRANCH_BF16) ? 1 : 0};
   const dim3 grid((unsigned)vitta_ln_num_partials(rows));
   const size_t lds = sizeof(float) * (size_t)C * 12;
   hipStream_t st = static_cast<hipStream_t>(stream);

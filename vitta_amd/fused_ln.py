@@ -37,26 +37,37 @@ def _site_for(norm, x):
     return site is not None, site
 
 
-def ln(norm, x):
+def _y16(x, consumers):
+    """The fused pass may write its output as bfloat16: the bf16 data flow is on and every module of `consumers` (the dense layers
+    the output feeds, in a chain) runs on gemm_bf16x.hip for this row count."""
+    if not consumers:
+        return False
+    from . import ops
+    return ops.bf16_dense_ok(x.numel() // x.shape[-1], *consumers)
+
+
+def ln(norm, x, consumers=None):
+    """consumers: the nn.Linear chain that is the ONLY reader of the output (qkv; fc1, fc2; a PatchMerging reduction)."""
     fusable, site = _site_for(norm, x)
     if fusable:
         from . import ops
-        return ops.FusedLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, site)
+        return ops.FusedLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, site, _y16(x, consumers))
     return norm(x)
 
 
-def ln_residual(norm, x, branch, drop_path):
+def ln_residual(norm, x, branch, drop_path, consumers=None):
     """(x', norm(x')) with x' = x + drop_path(branch)."""
     from .swin import DropPath, residual
     fusable, site = _site_for(norm, x)
     if fusable:
         from . import ops
+        y16 = _y16(x, consumers)
         if isinstance(drop_path, (DropPath, nn.Identity)):
             scale = drop_path.sample(x.shape[0], x.device) if isinstance(drop_path, DropPath) and drop_path.active() else None
-            return ops.FusedLayerNorm.apply(x, branch, scale, norm.weight, norm.bias, norm.eps, site)
+            return ops.FusedLayerNorm.apply(x, branch, scale, norm.weight, norm.bias, norm.eps, site, y16)
         # a foreign stochastic-depth module (e.g. a test's mask replay): its own call, then the fused norm -- a step is
         # all-fused or all-recorded, so the LayerNorm must not drop back to the module call here
-        x = x + drop_path(branch)
-        return x, ops.FusedLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, site)
+        x = x + drop_path(branch).to(x.dtype)
+        return x, ops.FusedLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, site, y16)
     x = residual(x, branch, drop_path)
     return x, norm(x)

@@ -712,7 +712,10 @@ class FusedLayerNorm(torch.autograd.Function):
     per-workgroup d gamma / d beta partials, then one column sum."""
 
     @staticmethod
-    def forward(ctx, x, branch, scale, weight, bias, eps, site):
+    def forward(ctx, x, branch, scale, weight, bias, eps, site, y_bf16=False):
+        """y_bf16: the normalised output only feeds a dense product of the bf16 recipe -- written as bfloat16 (the statistics of a
+        hooked layer are taken from the fp32 values in registers; x' stays fp32).  A bfloat16 `branch` (what such a product wrote)
+        is read as it is; its gradient leaves the backward as bfloat16."""
         ctx.set_materialize_grads(False)
         _require_cuda_f32(x, "x")
         x = x.contiguous()
@@ -720,48 +723,56 @@ class FusedLayerNorm(torch.autograd.Function):
         rows = x.numel() // c
         rps = rows // x.shape[0]
         f = dict(dtype=torch.float32, device=x.device)
-        y = torch.empty_like(x)
+        y = torch.empty_like(x, dtype=torch.bfloat16 if y_bf16 else torch.float32)
         mean, rstd = torch.empty(rows, **f), torch.empty(rows, **f)
         xnew = None
+        flags = _lib.LN_Y_BF16 if y_bf16 else 0
         if branch is not None:
+            if branch.dtype not in (torch.float32, torch.bfloat16) or not branch.is_cuda:
+                raise _lib.VittaHipError(f"branch must be a float32 or bfloat16 device tensor (got {branch.dtype})")
             branch = branch.contiguous()
             xnew = torch.empty_like(x)
+            flags |= _lib.LN_BRANCH_BF16 if branch.dtype == torch.bfloat16 else 0
         shift = partial = None
         nb = int(lib().vitta_ln_num_partials(rows))
         if site is not None:
             shift, s1, s2, cnt = site.begin(rows, c)
             partial = torch.empty(nb * 2 * c, **f)
-        check(lib().vitta_ln_fwd_f32(_p(x), _p(branch), _p(scale), rows, rps, c, _p(weight), _p(bias), float(eps), _p(xnew),
-                                     _p(y), _p(mean), _p(rstd), _p(shift), _p(partial), _stream()), "vitta_ln_fwd_f32")
+        check(lib().vitta_ln_fwd_mixed(_p(x), _p(branch), _p(scale), rows, rps, c, _p(weight), _p(bias), float(eps), _p(xnew),
+                                       _p(y), _p(mean), _p(rstd), _p(shift), _p(partial), flags, _stream()), "vitta_ln_fwd_mixed")
         if site is not None:
             check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(s1), _p(s2), _p(cnt), float(rows), _stream()),
                   "vitta_colsum2_f32")
         ctx.save_for_backward(xnew if xnew is not None else x, mean, rstd, weight, bias, scale)
-        ctx.meta = (rows, rps, c, site, nb, branch is not None)
+        ctx.meta = (rows, rps, c, site, nb, branch is not None, branch is not None and branch.dtype == torch.bfloat16)
         return (xnew, y) if branch is not None else y
 
     @staticmethod
     def backward(ctx, *grads):
         xn, mean, rstd, weight, bias, scale = ctx.saved_tensors
-        rows, rps, c, site, nb, has_branch = ctx.meta
+        rows, rps, c, site, nb, has_branch, branch16 = ctx.meta
         g_xnew, gy = (grads[0], grads[1]) if has_branch else (None, grads[0])
         if gy is None:  # the normalised output took no part in the loss: only the residual path carries a gradient
             gb = None
             if has_branch and g_xnew is not None:
                 gb = g_xnew if scale is None else g_xnew * scale.view((-1,) + (1,) * (g_xnew.dim() - 1))
-            return g_xnew, gb, None, None, None, None, None
+                gb = gb.to(torch.bfloat16) if branch16 else gb
+            return g_xnew, gb, None, None, None, None, None, None
         f = dict(dtype=torch.float32, device=xn.device)
         gy = gy.contiguous()
         g_xnew = g_xnew.contiguous() if g_xnew is not None else None
         gx = torch.empty_like(xn)
-        gbranch = torch.empty_like(xn) if (has_branch and scale is not None) else None
+        # the branch gradient is its own tensor when it is scaled (stochastic depth) or leaves as bfloat16
+        gbranch = torch.empty_like(xn, dtype=torch.bfloat16 if branch16 else torch.float32) \
+            if (has_branch and (scale is not None or branch16)) else None
         partial = torch.empty(nb * 2 * c, **f)
         mu = ca = cb = gs = None
         if site is not None:
             mu, ca, cb, gs = site.coefficients()
-        check(lib().vitta_ln_bwd_f32(_p(gy), _p(g_xnew), _p(xn), _p(mean), _p(rstd), _p(weight), _p(bias), _p(scale), _p(mu),
-                                     _p(ca), _p(cb), _p(gs), rows, rps, c, _p(gx), _p(gbranch), _p(partial), _stream()),
-              "vitta_ln_bwd_f32")
+        flags = (_lib.LN_GY_BF16 if gy.dtype == torch.bfloat16 else 0) | (_lib.LN_GBRANCH_BF16 if branch16 else 0)
+        check(lib().vitta_ln_bwd_mixed(_p(gy), _p(g_xnew), _p(xn), _p(mean), _p(rstd), _p(weight), _p(bias), _p(scale), _p(mu),
+                                       _p(ca), _p(cb), _p(gs), rows, rps, c, _p(gx), _p(gbranch), _p(partial), flags, _stream()),
+              "vitta_ln_bwd_mixed")
         r_w = r_b = None
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             dw, r_w = _grad_sink(weight, True)   # live .grad storage, or a zeroed buffer: the column sum adds into it
@@ -772,7 +783,7 @@ class FusedLayerNorm(torch.autograd.Function):
             if not ctx.needs_input_grad[4]:
                 r_b = None
         g_branch = (gbranch if gbranch is not None else gx) if has_branch else None
-        return gx, g_branch, None, r_w, r_b, None, None
+        return gx, g_branch, None, r_w, r_b, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -878,6 +889,39 @@ _W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, opera
 
 def gemm_nt_supported(m, n, k):
     return bool(lib().vitta_gemm_nt_supported(m, n, k))
+
+
+def bf16_flow():
+    """The bf16 recipe's DATA FLOW (round 4; BASELINE config 5, recognizer3d.py:36-40): with --dense_bf16 the activations between a
+    LayerNorm and the product it feeds, inside the MLP (fc1 -> GELU -> fc2, pre-activation included) and the MLP's branch into the
+    residual update are bfloat16 in memory, and those products run on gemm_bf16x.hip (both operands by LDS-DMA).  The residual
+    stream, every statistic, softmax and accumulator stay fp32.  VITTA_BF16_FLOW=0: bf16 operands only (the round-3 form: fp32
+    activations rounded while staged)."""
+    return DENSE_BF16 and BF16_FLOW
+
+
+BF16_FLOW = __import__("os").environ.get("VITTA_BF16_FLOW", "1") != "0"
+
+
+def gemm_bf16x_supported(m, n, k):
+    return bool(lib().vitta_gemm_bf16x_supported(int(m), int(n), int(k)))
+
+
+def gemm_bf16x(a, b, bias=None, mode=0, aux=None, pre=None, out_bf16=False):
+    """The same product on bfloat16 operands IN MEMORY (gemm_bf16x.hip): a [M][K], b [N][K] bf16; y fp32 or bf16; mode 1 keeps the
+    pre-activation in `pre` (bf16), mode 2 multiplies by gelu'(aux) with aux the bf16 pre-activation."""
+    if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.is_contiguous() and b.is_contiguous()):
+        raise _lib.VittaHipError("gemm_bf16x: contiguous bfloat16 device operands")
+    m, k = a.shape
+    n = b.shape[0]
+    assert b.shape[1] == k
+    y = torch.empty(m, n, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=a.device)
+    tm = KTIMING("gemm_bf16", 2.0 * m * n * k) if KTIMING is not None else None
+    check(lib().vitta_gemm_nt_bf16x(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, int(mode), int(bool(out_bf16)), _stream()),
+          "vitta_gemm_nt_bf16x")
+    if tm is not None:
+        tm.stop()
+    return y
 
 
 def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
@@ -1004,17 +1048,42 @@ def _bias_grad(bias, needed, g2):
     return torch.sum(g2, 0, out=ret)
 
 
+def _bf16_weight(weight, transposed):
+    """bfloat16 [out][in] (or [in][out]) copy of a dense weight for gemm_bf16x (cached per version while frozen)."""
+    global DENSE_BF16
+    keep, DENSE_BF16 = DENSE_BF16, True
+    try:
+        return _operand(weight, transposed)
+    finally:
+        DENSE_BF16 = keep
+
+
+def _x_dtype_grad(dx, like_bf16):
+    if dx is None:
+        return None
+    return dx if (dx.dtype == torch.bfloat16) == like_bf16 else dx.to(torch.bfloat16 if like_bf16 else torch.float32)
+
+
 class DenseLinear(torch.autograd.Function):
     """F.linear(x, weight, bias) on the hand-written GEMM: forward y = x W^T + b, backward dx = dy W (the same kernel
-    against the transposed weight); weight / bias gradients (SGD over all parameters only) as library products."""
+    against the transposed weight); weight / bias gradients (SGD over all parameters only) on the convolution kernel.
+    bfloat16 activations (the bf16 data flow, ops.bf16_flow): a bfloat16 x goes to gemm_bf16x.hip as it is; `out_bf16` writes
+    the output as bfloat16; the data gradient runs on the same kernel whenever the incoming gradient is bfloat16 (else the
+    fp32-activation kernel, rounded while staged) and leaves in x's dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_bf16=False):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        y = gemm_nt(x2, _operand(weight, False, x2.shape[0]), bias)
+        ctx.x16 = x2.dtype == torch.bfloat16
+        if ctx.x16:
+            y = gemm_bf16x(x2, _bf16_weight(weight, False), bias, out_bf16=out_bf16)
+        else:
+            y = gemm_nt(x2, _operand(weight, False, x2.shape[0]), bias)
+            if out_bf16:
+                y = y.to(torch.bfloat16)
         ctx.save_for_backward(x2 if weight.requires_grad else None, weight, bias)
         ctx.xshape = shape
         return y.view(shape[:-1] + (weight.shape[0],))  # (weight may be a Conv3d kernel [out, ...]: its flattened form is used)
@@ -1025,16 +1094,29 @@ class DenseLinear(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        dx = gemm_nt(g2, _operand(weight, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = _weight_grad(weight, ctx.needs_input_grad[1], g2, x2)
-        db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g2)
-        return dx, dw, db
+        dx = None
+        if ctx.needs_input_grad[0]:
+            kin = weight.numel() // weight.shape[0]
+            if g2.dtype == torch.bfloat16 and gemm_bf16x_supported(g2.shape[0], kin, g2.shape[1]):
+                dx = gemm_bf16x(g2, _bf16_weight(weight, True), out_bf16=ctx.x16)
+            else:
+                dx = _x_dtype_grad(gemm_nt(g2.float() if g2.dtype != torch.float32 else g2, _operand(weight, True, g2.shape[0])), ctx.x16)
+            dx = dx.view(ctx.xshape)
+        if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
+            g32 = g2 if g2.dtype == torch.float32 else g2.float()
+            x32 = x2 if (x2 is None or x2.dtype == torch.float32) else x2.float()
+            dw = _weight_grad(weight, ctx.needs_input_grad[1], g32, x32)
+            db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g32)
+        else:
+            dw = db = None
+        return dx, dw, db, None
 
 
 class FusedMlp(torch.autograd.Function):
     """fc2(gelu(fc1(x))) (swin_transformer.py:30-35 with drop = 0): bias + GELU in fc1's epilogue (the pre-activation h is
     kept for the backward), gelu'(h) in the epilogue of fc2's data gradient -- no stand-alone activation pass in either
-    direction."""
+    direction.  bfloat16 x (ops.bf16_flow): the four products run on gemm_bf16x.hip, h, gelu(h), the output and every
+    gradient between them are bfloat16 in memory."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
@@ -1043,10 +1125,16 @@ class FusedMlp(torch.autograd.Function):
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         need = any(ctx.needs_input_grad)
-        h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
-        a = gemm_nt(x2, _operand(w1, False, x2.shape[0]), b1, mode=1, pre=h)
-        y = gemm_nt(a, _operand(w2, False, x2.shape[0]), b2)
+        ctx.x16 = x2.dtype == torch.bfloat16
         train_w = w1.requires_grad or w2.requires_grad
+        if ctx.x16:
+            h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device) if need else None
+            a = gemm_bf16x(x2, _bf16_weight(w1, False), b1, mode=1, pre=h, out_bf16=True)
+            y = gemm_bf16x(a, _bf16_weight(w2, False), b2, out_bf16=True)
+        else:
+            h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
+            a = gemm_nt(x2, _operand(w1, False, x2.shape[0]), b1, mode=1, pre=h)
+            y = gemm_nt(a, _operand(w2, False, x2.shape[0]), b2)
         ctx.save_for_backward(x2 if train_w else None, h, a if train_w else None, w1, b1, w2, b2)
         ctx.xshape = shape
         return y.view(shape[:-1] + (w2.shape[0],))
@@ -1057,8 +1145,16 @@ class FusedMlp(torch.autograd.Function):
         g2 = gy.reshape(-1, gy.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        gh = gemm_nt(g2, _operand(w2, True, g2.shape[0]), mode=2, aux=h)
-        dx = gemm_nt(gh, _operand(w1, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if ctx.x16:
+            if g2.dtype != torch.bfloat16:
+                g2 = g2.to(torch.bfloat16)
+            gh = gemm_bf16x(g2, _bf16_weight(w2, True), mode=2, aux=h, out_bf16=True)
+            dx = gemm_bf16x(gh, _bf16_weight(w1, True), out_bf16=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+            if any(ctx.needs_input_grad[1:]):  # SGD over all parameters: the weight-gradient products take fp32 operands
+                g2, gh, x2, a = g2.float(), gh.float(), (x2.float() if x2 is not None else None), (a.float() if a is not None else None)
+        else:
+            gh = gemm_nt(g2, _operand(w2, True, g2.shape[0]), mode=2, aux=h)
+            dx = gemm_nt(gh, _operand(w1, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         dw1 = _weight_grad(w1, ctx.needs_input_grad[1], gh, x2)
         db1 = _bias_grad(b1, b1 is not None and ctx.needs_input_grad[2], gh)
         dw2 = _weight_grad(w2, ctx.needs_input_grad[3], g2, a)
@@ -1067,14 +1163,34 @@ class FusedMlp(torch.autograd.Function):
 
 
 def dense_supported(x, *linears):
-    """The hand-written dense path takes fp32 device activations through hook-free nn.Linear modules with K % 32 == 0."""
-    if not (x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+    """The hand-written dense path takes fp32 device activations through hook-free nn.Linear modules with K % 32 == 0 -- or, in
+    the bf16 data flow, bfloat16 activations where gemm_bf16x.hip covers the shapes (N % 128 == 0)."""
+    if not (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0):
         return False
     m = x.numel() // x.shape[-1]
     k = x.shape[-1]
+    x16 = x.dtype == torch.bfloat16
     for lin in linears:
-        if (lin.weight.dtype != torch.float32 or lin._forward_hooks or lin._forward_pre_hooks or lin.weight.shape[1] != k
-                or not gemm_nt_supported(m, lin.weight.shape[0], k)):
+        if lin.weight.dtype != torch.float32 or lin._forward_hooks or lin._forward_pre_hooks or lin.weight.shape[1] != k:
             return False
-        k = lin.weight.shape[0]
+        n = lin.weight.shape[0]
+        if x16 and not (gemm_bf16x_supported(m, n, k) and gemm_bf16x_supported(m, k, n)):  # forward and data gradient
+            return False
+        if not x16 and not gemm_nt_supported(m, n, k):
+            return False
+        k = n
+    return True
+
+
+def bf16_dense_ok(rows, *linears):
+    """True when `linears` (applied in a chain to `rows` rows) can take a bfloat16 input on gemm_bf16x.hip, forward and backward."""
+    if not bf16_flow():
+        return False
+    k = linears[0].weight.shape[1]
+    for lin in linears:
+        n = lin.weight.shape[0]
+        if (lin.weight.dtype != torch.float32 or lin._forward_hooks or lin._forward_pre_hooks or lin.weight.shape[1] != k
+                or not (gemm_bf16x_supported(rows, n, k) and gemm_bf16x_supported(rows, k, n))):
+            return False
+        k = n
     return True

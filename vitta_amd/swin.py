@@ -80,6 +80,8 @@ def draw_drop_path_masks(modules, batch, device, uses=2):
 
 def residual(x, branch, drop_path):
     """x + drop_path(branch); on the GPU one pass (vitta_scale_add_f32) for this module's own DropPath / Identity."""
+    if branch.dtype != x.dtype:  # a bfloat16 branch of the bf16 data flow meeting the fp32 residual stream outside a fused pass
+        branch = branch.to(x.dtype)
     if x.is_cuda and FUSED_RESIDUAL and x.dtype == torch.float32 and (x.numel() // x.shape[0]) % 4 == 0:
         from . import ops
         if isinstance(drop_path, DropPath):
@@ -313,16 +315,16 @@ class SwinTransformerBlock3D(nn.Module):
             x = x[:, :D, :H, :W, :].contiguous()
         return x
 
-    def forward(self, x, mask_matrix, region=None, normed=None, next_norm=None):
+    def forward(self, x, mask_matrix, region=None, normed=None, next_norm=None, next_qkv=None):
         """`normed`: norm1(x) if the caller already has it; `next_norm`: the LayerNorm that consumes this block's
         output (the next block's norm1) -- then the closing residual update and that normalisation are one pass and
         the block returns (x_out, next_norm(x_out)) instead of x_out."""
         from .fused_ln import ln, ln_residual
-        a = self.attention_branch(ln(self.norm1, x) if normed is None else normed, mask_matrix, region)
-        x, y = ln_residual(self.norm2, x, a, self.drop_path)  # x = x + drop_path(a); y = norm2(x): one pass
+        a = self.attention_branch(ln(self.norm1, x, [self.attn.qkv]) if normed is None else normed, mask_matrix, region)
+        x, y = ln_residual(self.norm2, x, a, self.drop_path, [self.mlp.fc1, self.mlp.fc2])  # x = x + drop_path(a); y = norm2(x): one pass
         m = self.mlp(y)
         if next_norm is not None:
-            return ln_residual(next_norm, x, m, self.drop_path)
+            return ln_residual(next_norm, x, m, self.drop_path, next_qkv)
         return residual(x, m, self.drop_path)
 
 
@@ -339,7 +341,7 @@ class PatchMerging(nn.Module):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
         x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
         from .fused_ln import ln
-        return linear(self.reduction, ln(self.norm, x))
+        return linear(self.reduction, ln(self.norm, x, [self.reduction]))
 
 
 class BasicLayer(nn.Module):
@@ -369,7 +371,8 @@ class BasicLayer(nn.Module):
         normed = None
         for i, blk in enumerate(self.blocks):
             nxt = self.blocks[i + 1].norm1 if i + 1 < len(self.blocks) else None
-            out = blk(x, attn_mask, region, normed=normed, next_norm=nxt)
+            out = blk(x, attn_mask, region, normed=normed, next_norm=nxt,
+                      next_qkv=[self.blocks[i + 1].attn.qkv] if nxt is not None else None)
             x, normed = out if nxt is not None else (out, None)
         return self.downsample(x) if self.downsample is not None else x
 
