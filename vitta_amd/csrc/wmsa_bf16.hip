@@ -27,20 +27,23 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int HD = 32;
 constexpr int RP = 40;        // row pitch of a [token][32] bf16 tile in elements (80 bytes: conflict-free 16-byte reads)
 constexpr int NTB = 50;       // 16-token tiles per window: N <= 800
-constexpr int TH_FWD = 256;   // forward, 401..800 tokens: 4 waves (all 50 score tiles of 16 queries live in registers: 256 VGPRs)
-constexpr int TH_FWD_S = 512; // forward, <= 400 tokens: 8 waves (25 tiles: 176 VGPRs)
+constexpr int TH_FWD_S = 512; // forward: 8 waves, 25 score tiles of 16 queries in registers at a time (one or two key chunks)
 constexpr int TH_BWD = 1024;  // backward: 16 waves (the tile loops are rolled: ~56 registers per lane)
 constexpr int T_MAX = 8192;
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// fp32 -> bf16, round to nearest even, on the hardware conversion (v_cvt_pk_bf16_f32: one instruction per two values; the integer
+// form used until round 3 was five per value, ~20 of the ~60 vector instructions a 16 x 16 score tile costs)
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int hu32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  const hf32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
 }
+__device__ __forceinline__ unsigned short f2bf(float f) { return (unsigned short)(pack2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
-  bf16x4 r;
-  r[0] = (short)f2bf(a); r[1] = (short)f2bf(b); r[2] = (short)f2bf(c); r[3] = (short)f2bf(d);
-  return r;
+  const hu32x2 r = {pack2(a, b), pack2(c, d)};
+  return __builtin_bit_cast(bf16x4, r);
 }
 __device__ __forceinline__ f32x4 mfma(bf16x4 a, bf16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
@@ -193,7 +196,11 @@ __device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int
 // ------------------------------------------------------------------------------------------------
 // forward: K row-major, V transposed; a wave keeps all score tiles of its 16 queries in registers
 // ------------------------------------------------------------------------------------------------
-template <int NTM, int THREADS>
+// CH key chunks of NTM tiles each, online softmax across them (running maximum m, running sum l, the output rescaled by
+// exp(m_old - m_new) when a chunk raises the maximum): a 784-token window is two chunks of 25 tiles = 100 score registers per lane
+// and EIGHT waves per workgroup, where holding all 50 tiles (200 registers, round 2-3) left one wave per SIMD with nothing to
+// overlap its LDS gathers and MFMA latencies with (config-5 forward: 206 us per launch).
+template <int NTM, int THREADS, int CH>
 __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16, TP = tpitch(nt);
@@ -216,38 +223,55 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
     bf16x4 qa, qb;
     load_frag(q_base + (int64_t)cv.rows[q] * rs + 8 * g, a.scale, qa, qb);
     const int pq = cv.cr[q];
-    f32x4 acc[NTM];
-    float m = -INFINITY;
+    float m = -INFINITY, l = 0.f;  // of query i (this lane's column of the S^T tiles); l: the lane's share (keys 4 g + r)
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // rows = queries 4 g + r, column d = i (| 16 + i)
 #pragma unroll
-    for (int t = 0; t < NTM; ++t) {
-      if (t < nt) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * t + i) * RP + 8 * g);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
-        s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
-        add_terms_t(s, cv.tab, cv.cr, a.off, t, g, pq, N);
-        acc[t] = s;
-        m = fmaxf(m, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+    for (int c = 0; c < CH; ++c) {
+      const int tb = c * NTM;
+      if (tb >= nt) break;
+      f32x4 acc[NTM];
+      float mc = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) {
+        if (tb + t < nt) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * (tb + t) + i) * RP + 8 * g);
+          f32x4 s = {0.f, 0.f, 0.f, 0.f};
+          s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
+          s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
+          add_terms_t(s, cv.tab, cv.cr, a.off, tb + t, g, pq, N);
+          acc[t] = s;
+          mc = fmaxf(mc, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        }
       }
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NTM; ++t) {
-      if (t < nt) {
-        float p[4];
+      mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+      mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+      const float mn = fmaxf(m, mc);
+      if (CH > 1) {
+        const float corr = __expf(m - mn);  // (first chunk: exp(-inf) = 0 on zero sums)
+        l *= corr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[r] = __expf(acc[t][r] - m);
-          l += p[r];
+          const float cr_ = __shfl(corr, 4 * g + r, 64);  // the factor of query 4 g + r lives in the lanes whose column it is
+          o0[r] *= cr_;
+          o1[r] *= cr_;
         }
-        const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]);
-        const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vt + i * TP + 16 * t + 4 * g);
-        const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vt + (16 + i) * TP + 16 * t + 4 * g);
-        o0 = mfma(pa, v0, o0);
-        o1 = mfma(pa, v1, o1);
+      }
+      m = mn;
+#pragma unroll
+      for (int t = 0; t < NTM; ++t) {
+        if (tb + t < nt) {
+          float p[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[r] = __expf(acc[t][r] - m);
+            l += p[r];
+          }
+          const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]);
+          const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vt + i * TP + 16 * (tb + t) + 4 * g);
+          const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vt + (16 + i) * TP + 16 * (tb + t) + 4 * g);
+          o0 = mfma(pa, v0, o0);
+          o1 = mfma(pa, v1, o1);
+        }
       }
     }
     l += __shfl_xor(l, 16, 64);
@@ -463,15 +487,15 @@ int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
   const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
   if (rc != VITTA_OK) return rc;
   if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
-  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, (nt <= 25 ? TH_FWD_S : TH_FWD) / 64);
+  const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, TH_FWD_S / 64);
   const size_t lds = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nt <= 25) {
-    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
-  } else {
-    if (!set_lds(wmsa_bf16_fwd_kernel<NTB, TH_FWD>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<NTB, TH_FWD>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD), lds, st, a, d_out, d_lse);
+    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, 1>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, 1>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
+  } else {  // 401 .. 800 tokens: two key chunks of 25 tiles, online softmax, eight waves
+    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, 2>, lds)) return VITTA_ERR_LAUNCH;
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, 2>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
   }
   return VITTA_OK;
 }
