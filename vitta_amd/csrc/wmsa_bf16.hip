@@ -185,12 +185,14 @@ __device__ __forceinline__ void add_terms_t(f32x4& acc, const float* tab, const 
   }
 }
 
-// B operand of a contraction over tokens from a ROW-major tile: the four tokens 16 t + 4 g + e of column d
-__device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int g, int d) {
-  const unsigned short* p = tile + (16 * t + 4 * g) * RP + d;
-  bf16x4 r;
-  r[0] = (short)p[0]; r[1] = (short)p[RP]; r[2] = (short)p[2 * RP]; r[3] = (short)p[3 * RP];
-  return r;
+// B operand of a contraction over tokens from a ROW-major tile: the four tokens 16 t + 4 g + e of column d = 16 half + i, by the
+// LDS transpose read of gfx950 (ds_read_b64_tr_b16): lane k of a 16-lane group hands in the address of a quarter row -- token
+// 4 g + k / 4, columns 4 (k % 4) .. + 3 of the [4 tokens][16 columns] block -- and receives column k of the block (verified element
+// by element: tools/ubench/tr16_probe.hip).  ONE instruction where rounds 2-3 issued four 2-byte reads per operand (16 per score
+// tile in the dK / dV kernel).
+__device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int g, int i, int half) {
+  const unsigned short* p = tile + (16 * t + 4 * g + (i >> 2)) * RP + 16 * half + 4 * (i & 3);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,18 +205,18 @@ __device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int
 template <int NTM, int THREADS, int CH>
 __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int N = a.N, nH = a.nH, nt = (N + 15) / 16, TP = tpitch(nt);
-  const Carve cv = carve(smem, nt, (size_t)32 * TP, 0, a.T);
+  const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
+  const Carve cv = carve(smem, nt, (size_t)16 * nt * RP, 0, a.T);
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int64_t rs = 3 * (int64_t)nH * HD;
   fill_rows(cv.rows, a.rm, b, N, nt);
   stage_rows(cv.a0, a.qkv + (int64_t)(nH + h) * HD, rs, N, nt, cv.rows, 1.f);
-  stage_rows_t(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, TP);
+  stage_rows(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, 1.f);  // V row-major: the PV operand comes by transpose read
   setup_terms(cv, a, h, b, nt);
   __syncthreads();
   const unsigned short* krow = cv.a0;
-  const unsigned short* vt = cv.a1;
+  const unsigned short* vrow = cv.a1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   const float* q_base = a.qkv + (int64_t)h * HD;
@@ -267,8 +269,8 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
             l += p[r];
           }
           const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]);
-          const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vt + i * TP + 16 * (tb + t) + 4 * g);
-          const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vt + (16 + i) * TP + 16 * (tb + t) + 4 * g);
+          const bf16x4 v0 = gather4(vrow, tb + t, g, i, 0);
+          const bf16x4 v1 = gather4(vrow, tb + t, g, i, 1);
           o0 = mfma(pa, v0, o0);
           o1 = mfma(pa, v1, o1);
         }
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[r] = __expf(s[r] - L) * (dp[r] - dl);  // exp(-inf) = 0 for padded keys
       const bf16x4 da = pack4(ds[0], ds[1], ds[2], ds[3]);
-      dq0 = mfma(da, gather4(krow, t, g, i), dq0);
-      dq1 = mfma(da, gather4(krow, t, g, 16 + i), dq1);
+      dq0 = mfma(da, gather4(krow, t, g, i, 0), dq0);
+      dq1 = mfma(da, gather4(krow, t, g, i, 1), dq1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -422,10 +424,10 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
         ds[r] = p[r] * (dp[r] - dv[r]);
       }
       const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
-      dv0 = mfma(pa, gather4(grow_l, qt, g, i), dv0);
-      dv1 = mfma(pa, gather4(grow_l, qt, g, 16 + i), dv1);
-      dk0 = mfma(da, gather4(qrow_l, qt, g, i), dk0);
-      dk1 = mfma(da, gather4(qrow_l, qt, g, 16 + i), dk1);
+      dv0 = mfma(pa, gather4(grow_l, qt, g, i, 0), dv0);
+      dv1 = mfma(pa, gather4(grow_l, qt, g, i, 1), dv1);
+      dk0 = mfma(da, gather4(qrow_l, qt, g, i, 0), dk0);
+      dk1 = mfma(da, gather4(qrow_l, qt, g, i, 1), dk1);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -472,7 +474,7 @@ extern "C" {
 int vitta_wmsa_bf16_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
   if (head_dim != HD || N < 1 || N > 16 * NTB || table_rows < 1 || table_rows > T_MAX) return 0;
   const int nt = (N + 15) / 16;
-  const size_t f = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, table_rows), b1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows),
+  const size_t f = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows), b1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows),
                b2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, table_rows);
   return (f <= 160 * 1024 && b1 <= 160 * 1024 && b2 <= 160 * 1024) ? 1 : 0;
 }
@@ -488,7 +490,7 @@ int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
   if (rc != VITTA_OK) return rc;
   if (misaligned(d_qkv, d_out)) return VITTA_ERR_INVALID_ARG;
   const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, TH_FWD_S / 64);
-  const size_t lds = lds_bytes(nt, (size_t)32 * tpitch(nt), 0, T);
+  const size_t lds = lds_bytes(nt, (size_t)16 * nt * RP, 0, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nt <= 25) {
     if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, 1>, lds)) return VITTA_ERR_LAUNCH;
