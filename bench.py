@@ -453,7 +453,7 @@ class _StreamTimer:
         _StreamTimer.records.append(self)
 
 
-def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3):
+def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3, sgd_all=False):
     """One Video Swin-B configuration: per-video iteration (adapt step + evaluation forward, overlapped schedule, hipGraph
     replay) timed over `steps` videos, then two eager steps with every dense (gemm.hip) and window attention launch
     bracketed by stream events."""
@@ -479,7 +479,7 @@ def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3
         args.datatype, args.input_size, args.scale_size, args.workers, args.verbose = "synthetic", size, size, 0, False
         args.clip_length, args.result_dir, args.num_classes = frames, tmp, classes
         args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
-        args.update_only_bn_affine = True
+        args.update_only_bn_affine = not sgd_all
         args.n_augmented_views, args.window_size = views, (window_depth, 7, 7)
         n_videos = 4
         args.synthetic_n_videos, args.synthetic_device = n_videos, device
@@ -528,10 +528,12 @@ def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3
                           "unit": "TFLOP/s", "frac": tf / peak}
         out = {"value": 1.0 / dt, "unit": "videos/s", "ms_per_step": 1e3 * dt, "steps": steps, "blocks_ms": [round(1e3 * b, 3) for b in blocks],
                "launch_mode": "hipGraph replay",
-               "dtype": "f32 (bf16 MFMA operands: window attention + dense layers; fp32 softmax / accumulation / epilogues)" if bf16 else "f32",
+               "dtype": "f32 residual stream / statistics / softmax / accumulation; bf16 MFMA operands AND bf16 activations between the "
+                        "LayerNorms, dense layers and window attention (the bf16 recipe's data flow)" if bf16 else "f32",
+               "optimizer": "SGD all parameters (reference default)" if sgd_all else "Adam on LN affine (update_only_bn_affine)",
                "config": {"workload": f"Video Swin-B ViTTA online TTA, per-video iteration = adapt step ({views} views x {frames} frames x "
                                       f"224^2, window ({window_depth},7,7), {len(adapter.engine.hooks)} hooked LayerNorm layers, l1 stat "
-                                      f"alignment + prediction consistency, backward, Adam on LN affine) + eval forward (1 view), "
+                                      f"alignment + prediction consistency, backward, optimizer) + eval forward (1 view), "
                                       f"{classes} classes",
                           "schedule": "overlapped"},
                "roofline": roof,
@@ -800,7 +802,8 @@ def main():
             and opt.size == 224:
         # the other half of north_star: Video Swin-B at BASELINE config 3's and config 5's shapes, in the same run
         for key, cfg in (("swin", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=8)),
-                         ("swin_c5_bf16", dict(views=4, frames=32, window_depth=16, classes=174, bf16=True, steps=4))):
+                         ("swin_c5_bf16", dict(views=4, frames=32, window_depth=16, classes=174, bf16=True, steps=4)),
+                         ("swin_sgd_all", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=6, sgd_all=True))):
             try:
                 log(f"Video Swin-B leg {key} ...")
                 line[key] = swin_leg(device, **cfg)

@@ -356,6 +356,17 @@ int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
                             float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                             const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
                             void* stream);
+/* The same kernels with 2-byte activations on both sides (io_bf16 != 0: d_qkv, d_out, d_dout, d_dqkv are bfloat16 tensors of the same
+ * shapes; lse / delta stay fp32) -- the attention of the bf16 data flow sits between two dense products that hand over bfloat16. */
+int vitta_wmsa_rel_fwd_bf16_io(const void* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                               const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                               float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                               void* d_out, float* d_lse, int32_t io_bf16, void* stream);
+int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                               const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                               float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                               const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dqkv,
+                               int32_t io_bf16, void* stream);
 
 /* --------------------------------------------------------------------------
  * A7 -- optimizer update on the flat parameter arena, one launch.

@@ -270,7 +270,8 @@ def test_config5_swin_at_full_size_bf16_recipe_agrees_with_fp32(tmp_path, abi_ca
     finally:
         ops.WMSA_BF16, ops.DENSE_BF16 = old
     abi_calls.assert_swin_kernels()
-    assert abi_calls.abi.get("vitta_gemm_nt_bf16w_f32", 0) > 0 and abi_calls.abi.get("vitta_wmsa_rel_fwd_bf16", 0) > 0, abi_calls.abi
+    # the bf16 data flow: dense layers on gemm_bf16x.hip (2-byte activations on both sides), attention on the bf16-operand kernels
+    assert abi_calls.abi.get("vitta_gemm_nt_bf16x", 0) > 0 and abi_calls.abi.get("vitta_wmsa_rel_fwd_bf16", 0) > 0, abi_calls.abi
     f, b = res["fp32"], res["bf16"]
     keys = sorted(f[2])
     va = torch.cat([b[2][k].flatten() for k in keys])

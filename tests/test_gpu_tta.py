@@ -286,7 +286,7 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     res = {}
     from vitta_amd import _lib, ops
     L = _lib.lib()
-    entry = "vitta_wmsa_rel_fwd_bf16" if bf16 else "vitta_wmsa_rel_fwd_f32"
+    entry = "vitta_wmsa_rel_fwd_bf16_io" if bf16 else "vitta_wmsa_rel_fwd_f32"
     orig, seen = getattr(L, entry), []
 
     def spy(*a):

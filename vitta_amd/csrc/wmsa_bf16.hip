@@ -59,7 +59,12 @@ struct Args {
   const float* qkv; const float* table; const int* code; const int* region;
   int T, off, nW; int64_t B_; int N, nH; float scale;
   RowMap rm;
+  int io16;  // qkv, out, d out, d qkv are bfloat16 in memory (the bf16 data flow: a dense product on either side), else float32
 };
+
+// element e of a tensor that is fp32 or (io16) bfloat16: address and converting accessors
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
 
 __device__ __forceinline__ int pk_code(int p) { return p & 0xffff; }
 __device__ __forceinline__ int pk_region(int p) { return p >> 16; }
@@ -112,11 +117,37 @@ __device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h
   }
 }
 
-// rows [0, N) of a [rows, row_stride] fp32 slice (32 floats per row) -> bf16 [16 nt][RP] (x mul); rows >= N are zero
+// rows [0, N) of a [rows, row_stride] slice (32 elements per row; fp32, or bfloat16 with io16) -> bf16 [16 nt][RP] (x mul); rows
+// >= N are zero
 __device__ __forceinline__ void stage_rows(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
-                                           const int* rows, float mul) {
+                                           const int* rows, float mul, int io16) {
   const int TH = blockDim.x;
   const int total = 16 * nt * 8;
+  if (io16) {
+    for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
+      ushort4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * TH, row = i >> 3, c4 = i & 7;
+        v[u] = make_ushort4(0, 0, 0, 0);
+        if (i < total && row < N) v[u] = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(src) + (int64_t)rows[row] * row_stride + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * TH;
+        if (i < total) {
+          bf16x4 o;
+          if (mul == 1.f) {
+            o[0] = (short)v[u].x; o[1] = (short)v[u].y; o[2] = (short)v[u].z; o[3] = (short)v[u].w;
+          } else {
+            o = pack4(bf2f(v[u].x) * mul, bf2f(v[u].y) * mul, bf2f(v[u].z) * mul, bf2f(v[u].w) * mul);
+          }
+          *reinterpret_cast<bf16x4*>(dst + (i >> 3) * RP + 4 * (i & 7)) = o;
+        }
+      }
+    }
+    return;
+  }
   for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
     float4 v[4];
 #pragma unroll
@@ -134,39 +165,31 @@ __device__ __forceinline__ void stage_rows(unsigned short* dst, const float* src
   }
 }
 
-// the same rows transposed: bf16 [32][TP], columns >= N zero
-__device__ __forceinline__ void stage_rows_t(unsigned short* dst, const float* src, int64_t row_stride, int N, int nt,
-                                             const int* rows, int TP) {
-  const int TH = blockDim.x;
-  const int total = 16 * nt * 8;
-  for (int i0 = threadIdx.x; i0 < total; i0 += 4 * TH) {
-    float4 v[4];
+// 8 contiguous elements (element offset e of an fp32 / bfloat16 tensor) -> two bf16x4 (d = 8 g .. 8 g + 3 | 8 g + 4 .. 8 g + 7),
+// scaled; f[8]: the values as floats
+__device__ __forceinline__ void load_frag(const float* base, int64_t e, int io16, float mul, bf16x4& lo, bf16x4& hi, float (&f)[8]) {
+  if (io16) {
+    const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(base) + e);
+    const unsigned w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * TH, row = i >> 3, c4 = i & 7;
-      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < total && row < N) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)rows[row] * row_stride + 4 * c4);
+    for (int j = 0; j < 4; ++j) {
+      f[2 * j] = __uint_as_float(w[j] << 16);
+      f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * TH;
-      if (i < total) {
-        const int row = i >> 3, d0 = 4 * (i & 7);
-        dst[(d0 + 0) * TP + row] = f2bf(v[u].x);
-        dst[(d0 + 1) * TP + row] = f2bf(v[u].y);
-        dst[(d0 + 2) * TP + row] = f2bf(v[u].z);
-        dst[(d0 + 3) * TP + row] = f2bf(v[u].w);
-      }
-    }
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(base + e);
+    const float4 b = *reinterpret_cast<const float4*>(base + e + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
   }
+  lo = pack4(f[0] * mul, f[1] * mul, f[2] * mul, f[3] * mul);
+  hi = pack4(f[4] * mul, f[5] * mul, f[6] * mul, f[7] * mul);
 }
-
-// 8 contiguous floats of a global row -> two bf16x4 (d = 8 g .. 8 g + 3 | 8 g + 4 .. 8 g + 7), scaled
-__device__ __forceinline__ void load_frag(const float* p, float mul, bf16x4& lo, bf16x4& hi) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
-  const float4 b = *reinterpret_cast<const float4*>(p + 4);
-  lo = pack4(a.x * mul, a.y * mul, a.z * mul, a.w * mul);
-  hi = pack4(b.x * mul, b.y * mul, b.z * mul, b.w * mul);
+__device__ __forceinline__ const float* qkv_at(const Args& a, int64_t e) {
+  return a.io16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(a.qkv) + e) : a.qkv + e;
+}
+__device__ __forceinline__ void store_el(float* base, int64_t e, int io16, float v) {
+  if (io16) reinterpret_cast<unsigned short*>(base)[e] = f2bf(v);
+  else base[e] = v;
 }
 
 // additive terms of the S^T tile t (rows = keys 16 t + 4 g + r, column = query q): bias + shift mask, -inf past N
@@ -211,19 +234,19 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
   const int64_t b = blockIdx.z;
   const int64_t rs = 3 * (int64_t)nH * HD;
   fill_rows(cv.rows, a.rm, b, N, nt);
-  stage_rows(cv.a0, a.qkv + (int64_t)(nH + h) * HD, rs, N, nt, cv.rows, 1.f);
-  stage_rows(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, 1.f);  // V row-major: the PV operand comes by transpose read
+  stage_rows(cv.a0, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);
+  stage_rows(cv.a1, qkv_at(a, (int64_t)(2 * nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);  // V row-major: the PV operand comes by transpose read
   setup_terms(cv, a, h, b, nt);
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
-  const float* q_base = a.qkv + (int64_t)h * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
     const int q = min(16 * rt + i, N - 1);
     bf16x4 qa, qb;
-    load_frag(q_base + (int64_t)cv.rows[q] * rs + 8 * g, a.scale, qa, qb);
+    float qf_[8];
+    load_frag(a.qkv, (int64_t)h * HD + (int64_t)cv.rows[q] * rs + 8 * g, a.io16, a.scale, qa, qb, qf_);
     const int pq = cv.cr[q];
     float m = -INFINITY, l = 0.f;  // of query i (this lane's column of the S^T tiles); l: the lane's share (keys 4 g + r)
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // rows = queries 4 g + r, column d = i (| 16 + i)
@@ -285,9 +308,9 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
       const int qrow = 16 * rt + 4 * g + r;
       const float il = __shfl(inv_l, 4 * g + r, 64);
       if (qrow < N) {
-        float* o = out + (int64_t)cv.rows[qrow] * C + h * HD;
-        o[i] = o0[r] * il;
-        o[16 + i] = o1[r] * il;
+        const int64_t o = (int64_t)cv.rows[qrow] * C + h * HD;
+        store_el(out, o + i, a.io16, o0[r] * il);
+        store_el(out, o + 16 + i, a.io16, o1[r] * il);
       }
     }
     if (g == 0 && 16 * rt + i < N) lse[(b * nH + h) * N + 16 * rt + i] = m + __logf(l);
@@ -308,26 +331,25 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
   const int64_t b = blockIdx.z;
   const int64_t rs = 3 * (int64_t)nH * HD;
   fill_rows(cv.rows, a.rm, b, N, nt);
-  stage_rows(cv.a0, a.qkv + (int64_t)(nH + h) * HD, rs, N, nt, cv.rows, 1.f);
-  stage_rows(cv.a1, a.qkv + (int64_t)(2 * nH + h) * HD, rs, N, nt, cv.rows, 1.f);
+  stage_rows(cv.a0, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);
+  stage_rows(cv.a1, qkv_at(a, (int64_t)(2 * nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);
   setup_terms(cv, a, h, b, nt);
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
-  const float* q_base = a.qkv + (int64_t)h * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
     const bool qvalid = 16 * rt + i < N;
     const int q = min(16 * rt + i, N - 1);
-    bf16x4 qa, qb, ga, gb;
-    load_frag(q_base + (int64_t)cv.rows[q] * rs + 8 * g, a.scale, qa, qb);
-    const float* gp = dout + (int64_t)cv.rows[q] * C + h * HD + 8 * g;
-    const float* op = out + (int64_t)cv.rows[q] * C + h * HD + 8 * g;
-    load_frag(gp, 1.f, ga, gb);
+    bf16x4 qa, qb, ga, gb, oa_, ob_;
+    float qf_[8], gf_[8], of_[8];
+    load_frag(a.qkv, (int64_t)h * HD + (int64_t)cv.rows[q] * rs + 8 * g, a.io16, a.scale, qa, qb, qf_);
+    load_frag(dout, (int64_t)cv.rows[q] * C + h * HD + 8 * g, a.io16, 1.f, ga, gb, gf_);
+    load_frag(out, (int64_t)cv.rows[q] * C + h * HD + 8 * g, a.io16, 1.f, oa_, ob_, of_);
     float dl = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) dl = fmaf(gp[s], op[s], dl);
+    for (int s = 0; s < 8; ++s) dl = fmaf(gf_[s], of_[s], dl);
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
     const float L = lse[(b * nH + h) * N + q];
@@ -354,9 +376,9 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
     for (int r = 0; r < 4; ++r) {
       const int qrow = 16 * rt + 4 * g + r;
       if (qrow < N) {
-        float* o = dqkv + (int64_t)cv.rows[qrow] * rs + (int64_t)h * HD;
-        o[i] = dq0[r] * a.scale;
-        o[16 + i] = dq1[r] * a.scale;
+        const int64_t o = (int64_t)cv.rows[qrow] * rs + (int64_t)h * HD;
+        store_el(dqkv, o + i, a.io16, dq0[r] * a.scale);
+        store_el(dqkv, o + 16 + i, a.io16, dq1[r] * a.scale);
       }
     }
   }
@@ -379,8 +401,9 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
   const int64_t rs = 3 * (int64_t)nH * HD;
   const int C = nH * HD;
   fill_rows(cv.rows, a.rm, b, N, nt);
-  stage_rows(cv.a0, a.qkv + (int64_t)h * HD, rs, N, nt, cv.rows, a.scale);
-  stage_rows(cv.a1, dout + h * HD, C, N, nt, cv.rows, 1.f);
+  stage_rows(cv.a0, qkv_at(a, (int64_t)h * HD), rs, N, nt, cv.rows, a.scale, a.io16);
+  stage_rows(cv.a1, a.io16 ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(dout) + h * HD) : dout + h * HD, C, N, nt,
+             cv.rows, 1.f, a.io16);
   setup_terms(cv, a, h, b, nt);
   for (int r = threadIdx.x; r < 16 * nt; r += blockDim.x) {
     l_lds[r] = r < N ? lse[(b * nH + h) * N + r] : INFINITY;  // exp(s - inf) = 0 for padded queries
@@ -394,8 +417,9 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
     const int key = min(16 * kt + i, N - 1);
     const bool kvalid = 16 * kt + i < N;
     bf16x4 ka, kb, va, vb;
-    load_frag(a.qkv + (int64_t)cv.rows[key] * rs + (int64_t)(nH + h) * HD + 8 * g, 1.f, ka, kb);
-    load_frag(a.qkv + (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, 1.f, va, vb);
+    float kf_[8], vf_[8];
+    load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(nH + h) * HD + 8 * g, a.io16, 1.f, ka, kb, kf_);
+    load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va, vb, vf_);
     const int pkey = cv.cr[key];
     const int ckey = pk_code(pkey), rkey = pk_region(pkey);
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
@@ -433,12 +457,11 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
     for (int r = 0; r < 4; ++r) {
       const int krow = 16 * kt + 4 * g + r;
       if (krow < N) {
-        float* ok = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(nH + h) * HD;
-        float* ov = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
-        ok[i] = dk0[r];
-        ok[16 + i] = dk1[r];
-        ov[i] = dv0[r];
-        ov[16 + i] = dv1[r];
+        const int64_t ok = (int64_t)cv.rows[krow] * rs + (int64_t)(nH + h) * HD, ov = (int64_t)cv.rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
+        store_el(dqkv, ok + i, a.io16, dk0[r]);
+        store_el(dqkv, ok + 16 + i, a.io16, dk1[r]);
+        store_el(dqkv, ov + i, a.io16, dv0[r]);
+        store_el(dqkv, ov + 16 + i, a.io16, dv1[r]);
       }
     }
   }
@@ -483,8 +506,18 @@ int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
                             const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                             float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                             float* d_out, float* d_lse, void* stream) {
+  return vitta_wmsa_rel_fwd_bf16_io(d_qkv, d_table, T, d_code, code_off, d_region, nW, B_, N, nH, head_dim, scale, d_rowmap, map_windows,
+                                    tokens_per_sample, d_out, d_lse, 0, stream);
+}
+
+int vitta_wmsa_rel_fwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                               const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                               float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                               void* d_out_, float* d_lse, int32_t io_bf16, void* stream) {
+  const float* d_qkv = static_cast<const float*>(d_qkv_);
+  float* d_out = static_cast<float*>(d_out_);
   const Args a{d_qkv, d_table, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
-               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}, io_bf16 ? 1 : 0};
   if (!d_out || !d_lse) return VITTA_ERR_INVALID_ARG;
   const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
   if (rc != VITTA_OK) return rc;
@@ -507,8 +540,21 @@ int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
                             float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                             const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
                             void* stream) {
+  return vitta_wmsa_rel_bwd_bf16_io(d_qkv, d_table, T, d_code, code_off, d_region, nW, B_, N, nH, head_dim, scale, d_rowmap, map_windows,
+                                    tokens_per_sample, d_out, d_dout, d_lse, d_delta, d_dqkv, 0, stream);
+}
+
+int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
+                               const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
+                               float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
+                               const void* d_out_, const void* d_dout_, const float* d_lse, float* d_delta, void* d_dqkv_,
+                               int32_t io_bf16, void* stream) {
+  const float* d_qkv = static_cast<const float*>(d_qkv_);
+  const float* d_out = static_cast<const float*>(d_out_);
+  const float* d_dout = static_cast<const float*>(d_dout_);
+  float* d_dqkv = static_cast<float*>(d_dqkv_);
   const Args a{d_qkv, d_table, d_code, d_region, T, code_off, d_region ? nW : 1, B_, N, nH, scale,
-               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}};
+               RowMap{d_rowmap, d_rowmap ? map_windows : 1, tokens_per_sample}, io_bf16 ? 1 : 0};
   if (!d_out || !d_dout || !d_lse || !d_delta || !d_dqkv) return VITTA_ERR_INVALID_ARG;
   const int rc = check(a, head_dim, d_rowmap, map_windows, tokens_per_sample);
   if (rc != VITTA_OK) return rc;

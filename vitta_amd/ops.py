@@ -447,29 +447,39 @@ class WindowAttentionRel(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, table, code, code_off, region, scale, num_heads, rowmap=None):
-        _require_cuda_f32(qkv, "qkv")
+        """A bfloat16 qkv (the bf16 data flow: ops.wmsa_io16_ok said the bf16-operand kernels take this shape) is read as it is
+        and the context comes back as bfloat16 -- the dense products on either side hand over 2-byte activations."""
+        io16 = qkv.dtype == torch.bfloat16
+        if not io16:
+            _require_cuda_f32(qkv, "qkv")
         qkv, table = qkv.contiguous(), table.contiguous()
         c = qkv.shape[-1] // 3
         hd = c // num_heads
         if rowmap is None:
             b_, n, _ = qkv.shape
             nwm, tokens = 1, 0
-            out = torch.empty(b_, n, c, dtype=torch.float32, device=qkv.device)
+            out = torch.empty(b_, n, c, dtype=qkv.dtype, device=qkv.device)
         else:
             bsz, tokens, _ = qkv.shape
             nwm, n = rowmap.shape
             if tokens != nwm * n or rowmap.dtype != torch.int32 or not rowmap.is_contiguous():
                 raise ValueError("rowmap must be a contiguous int32 [nW, N] with nW * N tokens per sample")
             b_ = bsz * nwm
-            out = torch.empty(bsz, tokens, c, dtype=torch.float32, device=qkv.device)
+            out = torch.empty(bsz, tokens, c, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
         nw = region.shape[0] if region is not None else 1
         bf16 = bool(WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0]))
-        fwd = lib().vitta_wmsa_rel_fwd_bf16 if bf16 else lib().vitta_wmsa_rel_fwd_f32
+        if io16 and not bf16:
+            raise _lib.VittaHipError("a bfloat16 qkv needs the bf16-operand attention kernels (ops.wmsa_io16_ok)")
         tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 4.0 * n * n * hd * b_ * num_heads) if KTIMING is not None else None
-        check(fwd(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
-                  b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
-                  _stream()), "vitta_wmsa_rel_fwd_bf16" if bf16 else "vitta_wmsa_rel_fwd_f32")
+        if bf16:
+            check(lib().vitta_wmsa_rel_fwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
+                                                   b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
+                                                   int(io16), _stream()), "vitta_wmsa_rel_fwd_bf16")
+        else:
+            check(lib().vitta_wmsa_rel_fwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
+                                               b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
+                                               _stream()), "vitta_wmsa_rel_fwd_f32")
         if tm is not None:
             tm.stop()
         ctx.save_for_backward(qkv, table, code, region, rowmap, out, lse)
@@ -481,13 +491,15 @@ class WindowAttentionRel(torch.autograd.Function):
         qkv, table, code, region, rowmap, out, lse = ctx.saved_tensors
         off, scale, nh, hd, nw, b_, n, nwm, tokens, bf16 = ctx.meta
         dout = dout.contiguous()
+        if dout.dtype != qkv.dtype:
+            dout = dout.to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
         tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 14.0 * n * n * hd * b_ * nh) if KTIMING is not None else None
         if bf16:
-            check(lib().vitta_wmsa_rel_bwd_bf16(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
-                                                hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
-                                                _p(dqkv), _stream()), "vitta_wmsa_rel_bwd_bf16")
+            check(lib().vitta_wmsa_rel_bwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
+                                                   hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
+                                                   _p(dqkv), int(qkv.dtype == torch.bfloat16), _stream()), "vitta_wmsa_rel_bwd_bf16")
             if tm is not None:
                 tm.stop()
             return dqkv, None, None, None, None, None, None, None
@@ -1180,6 +1192,12 @@ def dense_supported(x, *linears):
             return False
         k = n
     return True
+
+
+def wmsa_io16_ok(n_tok, head_dim, table):
+    """True when the window attention takes a bfloat16 qkv and returns a bfloat16 context (bf16 data flow on, the bf16-operand
+    kernels enabled and covering the window, the bias table frozen)."""
+    return bool(bf16_flow() and WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(int(n_tok), int(head_dim), table.shape[0]))
 
 
 def bf16_dense_ok(rows, *linears):

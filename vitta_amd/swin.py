@@ -92,12 +92,15 @@ def residual(x, branch, drop_path):
     return x + drop_path(branch)
 
 
-def linear(mod, x):
-    """nn.Linear on the hand-written GEMM (csrc/gemm.hip) for fp32 device activations; the module itself elsewhere."""
+def linear(mod, x, out_bf16=False):
+    """nn.Linear on the hand-written GEMM (csrc/gemm.hip; gemm_bf16x.hip for bfloat16 activations of the bf16 data flow) for device
+    activations; the module itself elsewhere.  out_bf16: the output is handed on as bfloat16 (honoured only for a bfloat16 x)."""
     if FUSED_DENSE and x.is_cuda:
         from . import ops
         if ops.dense_supported(x, mod):
-            return ops.DenseLinear.apply(x, mod.weight, mod.bias)
+            return ops.DenseLinear.apply(x, mod.weight, mod.bias, bool(out_bf16 and x.dtype == torch.bfloat16))
+    if x.dtype != mod.weight.dtype:
+        x = x.to(mod.weight.dtype)
     return mod(x)
 
 
@@ -300,10 +303,13 @@ class SwinTransformerBlock3D(nn.Module):
             if ops.wmsa_rel_supported(n_tok, C // attn.num_heads, attn.relative_position_bias_table.shape[0]):
                 # shift + partition + reverse + inverse shift as address arithmetic inside the attention kernel
                 rowmap = compute_rowmap(D, H, W, ws, ss, x.device)
-                out = ops.WindowAttentionRel.apply(linear(attn.qkv, x.view(B, D * H * W, C)), attn.relative_position_bias_table,
+                # bf16 data flow: qkv, the context and the branch leave their producers as bfloat16
+                io16 = x.dtype == torch.bfloat16 and ops.wmsa_io16_ok(n_tok, C // attn.num_heads, attn.relative_position_bias_table) \
+                    and ops.bf16_dense_ok(B * D * H * W, attn.proj)
+                out = ops.WindowAttentionRel.apply(linear(attn.qkv, x.view(B, D * H * W, C), io16), attn.relative_position_bias_table,
                                                    attn.relative_position_code[:n_tok], attn.code_offset,
                                                    region if shifted else None, attn.scale, attn.num_heads, rowmap)
-                return attn.proj_drop(linear(attn.proj, out)).view(B, D, H, W, C)
+                return attn.proj_drop(linear(attn.proj, out, io16)).view(B, D, H, W, C)
         if shifted:
             x = torch.roll(x, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
         windows = self.attn(window_partition(x, ws), mask=mask_matrix if shifted else None,
