@@ -707,7 +707,7 @@ def main():
         if conv:
             tf = conv["flops"] / conv["ms"] / 1e9
             conv_pmc = None
-            cpf = os.path.join(ROOT, "profiles", "r3_conv_traffic_pmc.json")
+            cpf = os.path.join(ROOT, "profiles", "r4_conv_traffic_pmc.json")
             if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
                 conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
             frac = conv["ms_at_peak"] / conv["ms"]
@@ -723,7 +723,7 @@ def main():
                                   "fp32 kernels (v_mfma_f32_32x32x2_f32)": MFMA_F32_PEAK_TF},
                         "split_bf16_share_of_flops": conv["b3_flops"] / conv["flops"],
                         "traffic": conv_pmc,
-                        "traffic_source": "profiles/r3_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                        "traffic_source": "profiles/r4_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                           "passes, FETCH x2 per the gfx950 note; per launch)" if conv_pmc else None,
                         "launches_per_step": conv["launches"] / conv["steps"],
                         "algorithmic_flops_per_launch": conv["flops"] / conv["launches"],

@@ -15,6 +15,12 @@ def total(db_path, counter):
     return int(rows[0] or 0), float(rows[1] or 0.0)
 
 
+# algorithmic bytes of the step's 156 convolution launches as bench.py counts them per launch (roofline.algorithmic_bytes_per_step):
+# x + the fp32 weights + y + the epilogue's INPUT streams (residual, BatchNorm-backward input, mask), each once; the optional second
+# output y_raw is not algorithmic.  (Rounds 2-3 quoted 3.61 GB: x + w + y only.)
+ALGO = 4455989248.0
+
+
 def main(fetch_db, write_db, out, launches_per_step=156, flops_per_step=317529784320.0):
     nf, f = total(fetch_db, "FETCH_SIZE")
     nw, w = total(write_db, "WRITE_SIZE")
@@ -27,8 +33,8 @@ def main(fetch_db, write_db, out, launches_per_step=156, flops_per_step=31752978
            "hbm_read_bytes_per_launch_as_counted": rd_raw, "hbm_read_bytes_per_launch_corrected": rd,
            "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
            "hbm_bytes_per_step": (rd + wr) * launches_per_step,
-           "algorithmic_bytes_per_step": 3.61e9,
-           "traffic_over_algorithmic": (rd + wr) * launches_per_step / 3.61e9,
+           "algorithmic_bytes_per_step": ALGO,
+           "traffic_over_algorithmic": (rd + wr) * launches_per_step / ALGO,
            "flop_per_hbm_byte": flops_per_step / ((rd + wr) * launches_per_step)}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
