@@ -192,19 +192,23 @@ __device__ __forceinline__ void store_el(float* base, int64_t e, int io16, float
   else base[e] = v;
 }
 
-// additive terms of the S^T tile t (rows = keys 16 t + 4 g + r, column = query q): bias + shift mask, -inf past N
+// additive terms of the S^T tile t (rows = keys 16 t + 4 g + r, column = query q): bias + shift mask, -inf past N.
+// REG: the launch has region ids (shifted windows); TAIL: N is not a multiple of 16.  Without them (every unshifted block of a
+// 784-token window) the tile costs four table reads, four subtractions and four additions -- the score tiles are VECTOR-ALU bound
+// (head dim 32: 128 matrix flops per element against ~8 vector instructions), so every instruction here is forward time.
+template <bool REG, bool TAIL>
 __device__ __forceinline__ void add_terms_t(f32x4& acc, const float* tab, const int* cr, int off, int t, int g, int pq, int N) {
   const int key0 = 16 * t + 4 * g;
   const int4 ck = *reinterpret_cast<const int4*>(cr + key0);
-  const int cq = pk_code(pq) + off, rq = pk_region(pq);
+  const int cq = (REG ? pk_code(pq) : pq) + off, rq = pk_region(pq);
   const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
   float tv[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tv[r] = tab[cq - pk_code(kc[r])];
+  for (int r = 0; r < 4; ++r) tv[r] = tab[cq - (REG ? pk_code(kc[r]) : kc[r])];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const float v = pk_region(kc[r]) != rq ? tv[r] - 100.f : tv[r];
-    acc[r] = key0 + r < N ? acc[r] + v : -INFINITY;
+    const float v = (REG && pk_region(kc[r]) != rq) ? tv[r] - 100.f : tv[r];
+    acc[r] = (!TAIL || key0 + r < N) ? acc[r] + v : -INFINITY;
   }
 }
 
@@ -225,7 +229,7 @@ __device__ __forceinline__ bf16x4 gather4(const unsigned short* tile, int t, int
 // exp(m_old - m_new) when a chunk raises the maximum): a 784-token window is two chunks of 25 tiles = 100 score registers per lane
 // and EIGHT waves per workgroup, where holding all 50 tiles (200 registers, round 2-3) left one wave per SIMD with nothing to
 // overlap its LDS gathers and MFMA latencies with (config-5 forward: 206 us per launch).
-template <int NTM, int THREADS, int CH>
+template <int NTM, int THREADS, int CH, bool REG, bool TAIL>
 __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, float* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
           f32x4 s = {0.f, 0.f, 0.f, 0.f};
           s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
           s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
-          add_terms_t(s, cv.tab, cv.cr, a.off, tb + t, g, pq, N);
+          add_terms_t<REG, TAIL>(s, cv.tab, cv.cr, a.off, tb + t, g, pq, N);
           acc[t] = s;
           mc = fmaxf(mc, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
         }
@@ -321,6 +325,7 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
 // backward 1: dQ (query-tile major; K and V row-major); also writes delta[q] = sum_d dO O
 //   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
 // ------------------------------------------------------------------------------------------------
+template <bool REG, bool TAIL>
 __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, float* __restrict__ dqkv) {
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
       s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
       dp = mfma(__builtin_shufflevector(vf, vf, 0, 1, 2, 3), ga, dp);
       dp = mfma(__builtin_shufflevector(vf, vf, 4, 5, 6, 7), gb, dp);
-      add_terms_t(s, cv.tab, cv.cr, a.off, t, g, pq, N);
+      add_terms_t<REG, TAIL>(s, cv.tab, cv.cr, a.off, t, g, pq, N);
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[r] = __expf(s[r] - L) * (dp[r] - dl);  // exp(-inf) = 0 for padded keys
@@ -388,6 +393,7 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
 // backward 2: dK, dV (key-tile major; Q (pre-scaled) and dO row-major, lse / delta in LDS)
 //   dV = P^T dO ; dK = dS^T (scale Q)
 // ------------------------------------------------------------------------------------------------
+template <bool REG, bool TAIL>
 __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a, const float* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                float* __restrict__ dqkv) {
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
     load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(nH + h) * HD + 8 * g, a.io16, 1.f, ka, kb, kf_);
     load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va, vb, vf_);
     const int pkey = cv.cr[key];
-    const int ckey = pk_code(pkey), rkey = pk_region(pkey);
+    const int ckey = REG ? pk_code(pkey) : pkey, rkey = pk_region(pkey);
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f}, dv1 = {0.f, 0.f, 0.f, 0.f};
     for (int qt = 0; qt < nt; ++qt) {
       // S tile [query][key]: A = Q rows (LDS), B = K (registers); C layout: column = key i, row = query 4 g + r
@@ -441,9 +447,9 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
       float p[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float term = cv.tab[pk_code(qc[r]) - ckey + a.off];
-        if (pk_region(qc[r]) != rkey) term -= 100.f;
-        const float sv = (q0 + r < N && kvalid) ? s[r] + term : -INFINITY;
+        float term = cv.tab[(REG ? pk_code(qc[r]) : qc[r]) - ckey + a.off];
+        if (REG && pk_region(qc[r]) != rkey) term -= 100.f;
+        const float sv = (!TAIL || (q0 + r < N && kvalid)) ? s[r] + term : -INFINITY;
         p[r] = __expf(sv - lv[r]);
         ds[r] = p[r] * (dp[r] - dv[r]);
       }
@@ -525,13 +531,21 @@ int vitta_wmsa_rel_fwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, TH_FWD_S / 64);
   const size_t lds = lds_bytes(nt, (size_t)16 * nt * RP, 0, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool reg = a.region != nullptr, tail = (N % 16) != 0;
+#define WMSA_FWD(CHV, R, TL)                                                                                                          \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, CHV, R, TL>, lds)) return VITTA_ERR_LAUNCH;                                         \
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, CHV, R, TL>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse); \
+  } while (0)
+  // <= 400 tokens: one key chunk; 401 .. 800: two chunks of 25 tiles, online softmax; eight waves either way
   if (nt <= 25) {
-    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, 1>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, 1>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
-  } else {  // 401 .. 800 tokens: two key chunks of 25 tiles, online softmax, eight waves
-    if (!set_lds(wmsa_bf16_fwd_kernel<25, TH_FWD_S, 2>, lds)) return VITTA_ERR_LAUNCH;
-    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, 2>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse);
+    if (reg) { if (tail) WMSA_FWD(1, true, true); else WMSA_FWD(1, true, false); }
+    else { if (tail) WMSA_FWD(1, false, true); else WMSA_FWD(1, false, false); }
+  } else {
+    if (reg) { if (tail) WMSA_FWD(2, true, true); else WMSA_FWD(2, true, false); }
+    else { if (tail) WMSA_FWD(2, false, true); else WMSA_FWD(2, false, false); }
   }
+#undef WMSA_FWD
   return VITTA_OK;
 }
 
@@ -561,10 +575,18 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   if (misaligned(d_qkv, d_out, d_dout, d_dqkv)) return VITTA_ERR_INVALID_ARG;
   const int nt = (N + 15) / 16, qs = pick_split(B_ * nH, nt, TH_BWD / 64);
   const size_t l1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, T), l2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, T);
-  if (!set_lds(wmsa_bf16_bwd_dq_kernel, l1) || !set_lds(wmsa_bf16_bwd_dkv_kernel, l2)) return VITTA_ERR_LAUNCH;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  VITTA_LAUNCH(wmsa_bf16_bwd_dq_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l1, st, a, d_out, d_dout, d_lse, d_delta, d_dqkv);
-  VITTA_LAUNCH(wmsa_bf16_bwd_dkv_kernel, dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l2, st, a, d_dout, d_lse, d_delta, d_dqkv);
+  const bool reg = a.region != nullptr, tail = (N % 16) != 0;
+#define WMSA_BWD(R, TL)                                                                                                               \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_bwd_dq_kernel<R, TL>, l1) || !set_lds(wmsa_bf16_bwd_dkv_kernel<R, TL>, l2)) return VITTA_ERR_LAUNCH;         \
+    VITTA_LAUNCH((wmsa_bf16_bwd_dq_kernel<R, TL>), dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l1, st, a, d_out, d_dout, d_lse, d_delta,  \
+                 d_dqkv);                                                                                                             \
+    VITTA_LAUNCH((wmsa_bf16_bwd_dkv_kernel<R, TL>), dim3(qs, nH, (unsigned)B_), dim3(TH_BWD), l2, st, a, d_dout, d_lse, d_delta, d_dqkv); \
+  } while (0)
+  if (reg) { if (tail) WMSA_BWD(true, true); else WMSA_BWD(true, false); }
+  else { if (tail) WMSA_BWD(false, true); else WMSA_BWD(false, false); }
+#undef WMSA_BWD
   return VITTA_OK;
 }
 
