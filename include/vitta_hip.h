@@ -509,6 +509,9 @@ size_t vitta_conv_workspace_bytes(const vitta_conv_desc* h_desc);
 #define VITTA_CONV_KERNEL_PW 2   /* conv_pw.hip: exact fp32 MFMA, pointwise tile per workgroup */
 #define VITTA_CONV_KERNEL_B3 3   /* conv_b3.hip: split-bf16 operands on the bf16 matrix pipe */
 int vitta_conv_kernel(const vitta_conv_desc* h_desc);
+/* Host only: n / d as the convolution kernels compute it on the device (multiply-high by the host-made reciprocal of a launch
+ * constant, conv_common.h FastDiv), for 0 <= n < 2^31, 1 <= d < 2^31; -1 outside that range.  The CPU suite holds it to n // d. */
+int64_t vitta_conv_fastdiv_host(int64_t n, int64_t d);
 /* Workgroups the launch of this descriptor would use (for tile selection / tests). */
 int64_t vitta_conv_num_blocks(const vitta_conv_desc* h_desc);
 

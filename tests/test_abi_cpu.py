@@ -63,6 +63,26 @@ def test_host_only_entry_points_answer_without_a_gpu():
     assert L.vitta_wmsa_supported(392, 32) == 1 and L.vitta_ln_supported(1024) == 1
 
 
+def test_reciprocal_division_of_the_convolution_kernels_equals_floor_division():
+    """conv_common.h FastDiv: every index division of a conv_b3 workgroup is a multiply-high by a host-made reciprocal -- exact for
+    every dividend below 2^31 (edge divisors, powers of two and their neighbours, the largest dividends, 10^5 random pairs)."""
+    import numpy as np
+    f = _lib.lib().vitta_conv_fastdiv_host
+    rng = np.random.default_rng(0)
+    ds = [1, 2, 3, 5, 7, 9, 49, 196, 784, 3136, 12544, 50176, 2 ** 16 - 1, 2 ** 16, 2 ** 16 + 1, 2 ** 30, 2 ** 31 - 1]
+    ds += [2 ** k + e for k in range(1, 30) for e in (-1, 0, 1) if 2 ** k + e >= 1]
+    for d in ds:
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31 - 2, (2 ** 31 - 1) // d * d, (2 ** 31 - 1) // d * d - 1]
+        for n in ns:
+            if 0 <= n < 2 ** 31:
+                assert f(n, d) == n // d, (n, d)
+    n = rng.integers(0, 2 ** 31, 100000)
+    d = np.where(rng.random(100000) < 0.5, rng.integers(1, 2 ** 31, 100000), rng.integers(1, 70000, 100000))
+    for a, b in zip(n.tolist(), d.tolist()):
+        assert f(a, b) == a // b, (a, b)
+    assert f(-1, 3) == -1 and f(5, 0) == -1 and f(2 ** 31, 3) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", None)
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "vitta_amd", "csrc", "no_such_lib.so"))

@@ -145,6 +145,7 @@ SIGNATURES = {
     "vitta_conv_pack_b3_table": (C.c_int, [_p, _i32, _i64, _p]),
     "vitta_conv_timed_f32": (C.c_int, [C.POINTER(ConvDesc), _p, _p, _p]),
     "vitta_conv_flops": (_i64, [C.POINTER(ConvDesc)]),
+    "vitta_conv_fastdiv_host": (_i64, [_i64, _i64]),
     "vitta_conv_kernel": (C.c_int, [C.POINTER(ConvDesc)]),
     "vitta_stem_conv7_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "vitta_stem_conv7_wgrad_workspace_bytes": (_sz, []),

@@ -866,6 +866,12 @@ int vitta_conv_kernel(const vitta_conv_desc* h_desc) {
   return a.b3 ? VITTA_CONV_KERNEL_B3 : a.pw ? VITTA_CONV_KERNEL_PW : a.sk_G ? VITTA_CONV_KERNEL_SK : VITTA_CONV_KERNEL_TILE;
 }
 
+int64_t vitta_conv_fastdiv_host(int64_t n, int64_t d) {
+  if (n < 0 || n >= (1ll << 31) || d < 1 || d >= (1ll << 31)) return -1;
+  const FastDiv f = make_fastdiv(d);  // the device's fdiv(): __umulhi(n, mul) >> sh
+  return f.sh < 0 ? n : (int64_t)((((uint64_t)(unsigned)n * f.mul) >> 32) >> f.sh);
+}
+
 int64_t vitta_conv_flops(const vitta_conv_desc* h_desc) {
   ConvK a;
   if (fill(h_desc, a) != VITTA_OK) return -1;
