@@ -352,11 +352,14 @@ def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
 @pytest.mark.parametrize("ws,clamp,B,nh,shift,rowmap", [((8, 7, 7), (8, 7, 7), 1, 4, False, False), ((8, 7, 7), (8, 7, 7), 2, 4, True, False),
                                                         ((16, 7, 7), (16, 7, 7), 1, 4, True, False), ((16, 7, 7), (16, 7, 7), 1, 8, True, True),
                                                         ((16, 7, 7), (9, 7, 7), 1, 4, True, False), ((8, 7, 7), (4, 7, 7), 1, 8, False, True)])
-def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap):
-    """vitta_wmsa_rel_{fwd,bwd}_bf16 (BASELINE config 5: bf16 MFMA W-MSA, window (16,7,7) = 784 tokens in ONE pass) against the
+@pytest.mark.parametrize("io16", [False, True])
+def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap, io16):
+    """vitta_wmsa_rel_{fwd,bwd}_bf16_io (BASELINE config 5: bf16 MFMA W-MSA, window (16,7,7) = 784 tokens in ONE pass) against the
     fp64 composed reference evaluated on bf16-ROUNDED q (x scale), k, v.  Tolerances (bf16 operands, fp32 accumulation: the
     probabilities and dS are rounded to 8 bits of mantissa before their GEMMs): output 1e-2, gradients 3e-2 of the tensor's
-    maximum; the fp32 kernels on the same inputs are held to 1e-4."""
+    maximum; the fp32 kernels on the same inputs are held to 1e-4.  io16: the bf16 data flow's form -- qkv and the upstream
+    gradient ARE bfloat16 tensors, the context and the qkv gradient come back as bfloat16 (one more rounding each, inside the
+    same bounds)."""
     from vitta_amd import ops, swin
     g = torch.Generator().manual_seed(29)
     N = clamp[0] * clamp[1] * clamp[2]
@@ -373,6 +376,8 @@ def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap):
     qkv = torch.randn(B_, N, 3 * C, generator=g)
     gout = torch.randn(B_, N, C, generator=g)
     rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    if io16:  # what the kernels are handed is already 2 bytes wide
+        qkv, gout = rb(qkv), rb(gout)
     # reference on the values the kernel multiplies: q is scaled in fp32 and then rounded
     q, k, v = qkv.view(B_, N, 3, C).unbind(2)
     qkv_r = torch.stack([rb(q * scale) / scale, rb(k), rb(v)], 2).reshape(B_, N, 3 * C)
@@ -396,12 +401,14 @@ def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap):
     old = ops.WMSA_BF16
     ops.WMSA_BF16 = True
     try:
-        qd = qd_in.to(d).requires_grad_(True)
+        io_t = torch.bfloat16 if io16 else torch.float32
+        qd = qd_in.to(d, io_t).requires_grad_(True)
         out = ops.WindowAttentionRel.apply(qd, table.to(d), code[:N].to(d), off, region.to(d) if shift else None, scale, nh, rm)
-        out.backward(gd_in.to(d))
+        out.backward(gd_in.to(d, io_t))
     finally:
         ops.WMSA_BF16 = old
-    o, gq = out.detach().cpu(), qd.grad.cpu()
+    assert out.dtype == io_t and qd.grad.dtype == io_t
+    o, gq = out.detach().float().cpu(), qd.grad.float().cpu()
     if rowmap:
         o = torch.stack([o[bb, perm[w].long()] for bb in range(B) for w in range(nW)])
         gq = torch.stack([gq[bb, perm[w].long()] for bb in range(B) for w in range(nW)])
