@@ -726,6 +726,35 @@ def test_fused_layernorm_matches_torch(c, with_branch):
 
 
 @pytest.mark.parametrize("c", [128, 512, 1024])
+def test_fused_layernorm_passthrough_joins_the_two_gradients_of_its_input(c):
+    """FusedLayerNorm(..., passthrough=True) -> (x, y): the returned x stands for the block input's second reader (the residual
+    update), so the gradient of x is gx(LayerNorm) + g(second reader) produced inside the backward pass -- equal to autograd's own
+    accumulation over the two consumers; with y unused only the second reader's gradient comes back."""
+    import torch.nn.functional as F
+    from vitta_amd import ops
+    g = torch.Generator().manual_seed(c + 1)
+    shape = (2, 3, 5, 7, c)
+    x = torch.randn(shape, generator=g)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    gy, gx2 = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (x, w, b)]
+    y = F.layer_norm(leaves[0], (c,), leaves[1], leaves[2], 1e-5)
+    ((y * gy.double()).sum() + (leaves[0] * gx2.double()).sum()).backward()
+    d = _dev()
+    dl = [t.to(d).requires_grad_(True) for t in (x, w, b)]
+    xa, y_d = ops.FusedLayerNorm.apply(dl[0], None, None, dl[1], dl[2], 1e-5, None, False, True)
+    assert xa.data_ptr() == dl[0].data_ptr() and torch.equal(xa, dl[0])
+    ((y_d * gy.to(d)).sum() + (xa * gx2.to(d)).sum()).backward()
+    torch.testing.assert_close(y_d.detach().cpu().double(), y.detach(), rtol=1e-5, atol=1e-5)
+    for i, (a_, ref) in enumerate(zip(dl, leaves)):
+        assert (a_.grad.cpu().double() - ref.grad).abs().max().item() <= 1e-4 * ref.grad.abs().max().item() + 1e-6, i
+    x2 = x.to(d).requires_grad_(True)
+    xa, _ = ops.FusedLayerNorm.apply(x2, None, None, dl[1], dl[2], 1e-5, None, False, True)
+    (xa * gx2.to(d)).sum().backward()
+    assert torch.equal(x2.grad.cpu(), gx2)
+
+
+@pytest.mark.parametrize("c", [128, 512, 1024])
 @pytest.mark.parametrize("with_branch", [False, True])
 def test_fused_layernorm_with_bfloat16_sides(c, with_branch):
     """The bf16 data flow's LayerNorm (vitta_ln_fwd_mixed / _bwd_mixed): y written as bfloat16, a bfloat16 branch, a bfloat16

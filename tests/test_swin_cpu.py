@@ -38,6 +38,22 @@ def test_swin_layer_selection_matches_reference(swin11):
     assert sum(p.numel() for p in params) == 57600
 
 
+def test_patch_gather_equals_the_composed_slices_forward_and_backward():
+    """swin.PatchGather (PatchMerging's cat of the four pixel parities, swin_transformer.py:281-286, as one autograd node) ==
+    the slices + cat it replaces, values and gradient bit for bit."""
+    import torch
+    from vitta_amd.swin import PatchGather
+    for shape in [(2, 4, 8, 6, 16), (1, 2, 2, 2, 4), (3, 1, 14, 14, 8)]:
+        x = torch.randn(*shape, dtype=torch.float64, requires_grad=True)
+        ref = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+        w = torch.randn_like(ref)
+        (gr,) = torch.autograd.grad((ref * w).sum(), x)
+        x2 = x.detach().clone().requires_grad_(True)
+        out = PatchGather.apply(x2)
+        (g2,) = torch.autograd.grad((out * w).sum(), x2)
+        assert torch.equal(out, ref) and torch.equal(g2, gr)
+
+
 def test_swin_forward_matches_reference(swin11):
     g = H.golden("swin_fwd.npz")
     from vitta_amd.norm_stats import ComputeNormStatsHook

@@ -25,6 +25,7 @@ p.add_argument("--blas", default=None, choices=["hipblaslt", "hipblas", "default
 p.add_argument("--wmsa-bf16", action="store_true", help="bf16-operand window attention (vitta_wmsa_rel_*_bf16, BASELINE config 5)")
 p.add_argument("--library-dense", action="store_true", help="qkv / proj / MLP on torch's library GEMMs + ATen GELU instead of csrc/gemm.hip")
 p.add_argument("--dense-bf16", action="store_true", help="bf16-operand dense layers (vitta_gemm_nt_bf16w_f32)")
+p.add_argument("--aten-sites", action="store_true", help="instead of timing: one eager step under torch.profiler, ATen kernels grouped by the vitta_amd line that launched them")
 p.add_argument("--sequential", action="store_true", help="adapt(i); eval(i) on one stream (default: overlapped schedule)")
 opt = p.parse_args()
 if opt.blas:
@@ -82,6 +83,31 @@ def one(i):
 for i in range(opt.warmup):
     one(i)
 torch.cuda.synchronize()
+if opt.aten_sites:
+    import collections
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    sites = collections.defaultdict(lambda: [0, 0])
+    WATCH = ("copy_", "clone", "_to_copy", "add", "add_", "zeros", "zero_", "fill_", "mul", "mul_", "cat", "zeros_like", "empty_like", "sum", "mean", "div")
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.__name__.split(".")[0]
+            if name in WATCH and isinstance(out, torch.Tensor) and out.is_cuda:
+                st = traceback.extract_stack()
+                fr = next((f for f in reversed(st) if "vitta_amd" in f.filename), None)
+                where = f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.line[:70]}" if fr else "(autograd engine / outside vitta_amd)"
+                key = (func.__name__, str(out.dtype).replace("torch.", ""), where)
+                sites[key][0] += 1
+                sites[key][1] += out.numel() * out.element_size()
+            return out
+    with Log():
+        one(0)
+        torch.cuda.synchronize()
+    for (name, dt, where), (n, by) in sorted(sites.items(), key=lambda kv: -kv[1][1])[:45]:
+        print(f"{n:5d} x {by / n / 1e6:8.2f} MB  {name:22s} {dt:9s} {where}")
+    sys.exit(0)
 if not opt.no_graph:
     adapter.capture_graphs(tta_set[0][0].unsqueeze(0), eval_set[0][0].unsqueeze(0), overlap_eval=not opt.sequential)
     one(0)

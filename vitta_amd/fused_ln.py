@@ -55,6 +55,16 @@ def ln(norm, x, consumers=None):
     return norm(x)
 
 
+def ln_pass(norm, x, consumers=None):
+    """(x, norm(x)) where the returned x is the handle the caller's OTHER reader of x must use (ops.FusedLayerNorm passthrough):
+    the block's input then has one consumer in the autograd graph."""
+    fusable, site = _site_for(norm, x)
+    if fusable and x.requires_grad and torch.is_grad_enabled():
+        from . import ops
+        return ops.FusedLayerNorm.apply(x, None, None, norm.weight, norm.bias, norm.eps, site, _y16(x, consumers), True)
+    return x, ln(norm, x, consumers)
+
+
 def ln_residual(norm, x, branch, drop_path, consumers=None):
     """(x', norm(x')) with x' = x + drop_path(branch)."""
     from .swin import DropPath, residual

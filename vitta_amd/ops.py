@@ -721,10 +721,13 @@ class FusedLayerNorm(torch.autograd.Function):
     """y = LayerNorm_C(x') with x' = x + scale_b * branch (branch optional), one pass; a hooked layer (`site`) leaves the
     shifted channel sums of y in the engine's statistics buffer, and its backward adds the statistics-loss gradient.
     Returns y, or (x', y) with a branch.  Backward: one pass for dx (+ the gradient arriving at x'), d branch, and
-    per-workgroup d gamma / d beta partials, then one column sum."""
+    per-workgroup d gamma / d beta partials, then one column sum.
+    passthrough (no branch): returns (x, y) -- the caller hands the returned x to the block's second reader (the residual
+    update), so that x has ONE consumer in the autograd graph and the two gradients meet inside the backward pass instead of in
+    an accumulation launch over the whole residual stream (the first block of a stage, whose norm1 no previous pass has fused)."""
 
     @staticmethod
-    def forward(ctx, x, branch, scale, weight, bias, eps, site, y_bf16=False):
+    def forward(ctx, x, branch, scale, weight, bias, eps, site, y_bf16=False, passthrough=False):
         """y_bf16: the normalised output only feeds a dense product of the bf16 recipe -- written as bfloat16 (the statistics of a
         hooked layer are taken from the fp32 values in registers; x' stays fp32).  A bfloat16 `branch` (what such a product wrote)
         is read as it is; its gradient leaves the backward as bfloat16."""
@@ -756,20 +759,23 @@ class FusedLayerNorm(torch.autograd.Function):
             check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(s1), _p(s2), _p(cnt), float(rows), _stream()),
                   "vitta_colsum2_f32")
         ctx.save_for_backward(xnew if xnew is not None else x, mean, rstd, weight, bias, scale)
-        ctx.meta = (rows, rps, c, site, nb, branch is not None, branch is not None and branch.dtype == torch.bfloat16)
-        return (xnew, y) if branch is not None else y
+        ctx.meta = (rows, rps, c, site, nb, branch is not None, branch is not None and branch.dtype == torch.bfloat16,
+                    passthrough and branch is None)
+        if branch is not None:
+            return xnew, y
+        return (x.view(x.shape), y) if passthrough else y
 
     @staticmethod
     def backward(ctx, *grads):
         xn, mean, rstd, weight, bias, scale = ctx.saved_tensors
-        rows, rps, c, site, nb, has_branch, branch16 = ctx.meta
-        g_xnew, gy = (grads[0], grads[1]) if has_branch else (None, grads[0])
+        rows, rps, c, site, nb, has_branch, branch16, passthrough = ctx.meta
+        g_xnew, gy = (grads[0], grads[1]) if (has_branch or passthrough) else (None, grads[0])
         if gy is None:  # the normalised output took no part in the loss: only the residual path carries a gradient
             gb = None
             if has_branch and g_xnew is not None:
                 gb = g_xnew if scale is None else g_xnew * scale.view((-1,) + (1,) * (g_xnew.dim() - 1))
                 gb = gb.to(torch.bfloat16) if branch16 else gb
-            return g_xnew, gb, None, None, None, None, None, None
+            return g_xnew, gb, None, None, None, None, None, None, None
         f = dict(dtype=torch.float32, device=xn.device)
         gy = gy.contiguous()
         g_xnew = g_xnew.contiguous() if g_xnew is not None else None
@@ -795,7 +801,7 @@ class FusedLayerNorm(torch.autograd.Function):
             if not ctx.needs_input_grad[4]:
                 r_b = None
         g_branch = (gbranch if gbranch is not None else gx) if has_branch else None
-        return gx, g_branch, None, r_w, r_b, None, None, None
+        return gx, g_branch, None, r_w, r_b, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1128,10 +1134,11 @@ class FusedMlp(torch.autograd.Function):
     """fc2(gelu(fc1(x))) (swin_transformer.py:30-35 with drop = 0): bias + GELU in fc1's epilogue (the pre-activation h is
     kept for the backward), gelu'(h) in the epilogue of fc2's data gradient -- no stand-alone activation pass in either
     direction.  bfloat16 x (ops.bf16_flow): the four products run on gemm_bf16x.hip, h, gelu(h), the output and every
-    gradient between them are bfloat16 in memory."""
+    gradient between them are bfloat16 in memory.  out_f32 (bfloat16 x only): the output is written as float32 -- what a reader
+    outside the fused LayerNorm passes takes (the residual update that closes a stage)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, out_f32=False):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         if not x2.is_contiguous():
@@ -1142,7 +1149,7 @@ class FusedMlp(torch.autograd.Function):
         if ctx.x16:
             h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device) if need else None
             a = gemm_bf16x(x2, _bf16_weight(w1, False), b1, mode=1, pre=h, out_bf16=True)
-            y = gemm_bf16x(a, _bf16_weight(w2, False), b2, out_bf16=True)
+            y = gemm_bf16x(a, _bf16_weight(w2, False), b2, out_bf16=not out_f32)
         else:
             h = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device) if need else None
             a = gemm_nt(x2, _operand(w1, False, x2.shape[0]), b1, mode=1, pre=h)
@@ -1171,7 +1178,7 @@ class FusedMlp(torch.autograd.Function):
         db1 = _bias_grad(b1, b1 is not None and ctx.needs_input_grad[2], gh)
         dw2 = _weight_grad(w2, ctx.needs_input_grad[3], g2, a)
         db2 = _bias_grad(b2, b2 is not None and ctx.needs_input_grad[4], g2)
-        return dx, dw1, db1, dw2, db2
+        return dx, dw1, db1, dw2, db2, None
 
 
 def dense_supported(x, *linears):

@@ -114,13 +114,14 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x):
+    def forward(self, x, out_f32=False):
+        """out_f32: a bfloat16 x (bf16 data flow) still gets a float32 result -- for a reader other than a fused LayerNorm pass"""
         if (FUSED_DENSE and x.is_cuda and (self.drop.p == 0.0 or not self.training) and isinstance(self.act, nn.GELU)
                 and getattr(self.act, "approximate", "none") == "none"):
             from . import ops
             if ops.dense_supported(x, self.fc1, self.fc2):
                 # bias + GELU in fc1's epilogue, gelu' in the epilogue of fc2's data gradient
-                return ops.FusedMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+                return ops.FusedMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, out_f32)
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -325,13 +326,38 @@ class SwinTransformerBlock3D(nn.Module):
         """`normed`: norm1(x) if the caller already has it; `next_norm`: the LayerNorm that consumes this block's
         output (the next block's norm1) -- then the closing residual update and that normalisation are one pass and
         the block returns (x_out, next_norm(x_out)) instead of x_out."""
-        from .fused_ln import ln, ln_residual
-        a = self.attention_branch(ln(self.norm1, x, [self.attn.qkv]) if normed is None else normed, mask_matrix, region)
+        from .fused_ln import ln_pass, ln_residual
+        if normed is None:  # (x comes back as the handle for the residual update below: one consumer of the block input)
+            x, normed = ln_pass(self.norm1, x, [self.attn.qkv])
+        a = self.attention_branch(normed, mask_matrix, region)
         x, y = ln_residual(self.norm2, x, a, self.drop_path, [self.mlp.fc1, self.mlp.fc2])  # x = x + drop_path(a); y = norm2(x): one pass
-        m = self.mlp(y)
+        m = self.mlp(y, out_f32=next_norm is None) if y.dtype == torch.bfloat16 else self.mlp(y)
         if next_norm is not None:
             return ln_residual(next_norm, x, m, self.drop_path, next_qkv)
         return residual(x, m, self.drop_path)
+
+
+class PatchGather(torch.autograd.Function):
+    """cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1) of PatchMerging
+    (swin_transformer.py:281-286) for even H, W as ONE autograd node.  Composed of slices, autograd differentiates it as eight
+    slice_backward nodes (a zero fill + a strided copy of half- and full-size tensors each) and three accumulation adds over the
+    stage's whole output -- 2.1 GB of traffic behind the first PatchMerging of the 4 x 32-frame step, 0.8 ms per video over the three;
+    the gradient is simply the four channel groups written back to their pixel parities: four strided copies, every byte once."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, D, H2, W2, C4 = g.shape
+        C = C4 // 4
+        gx = torch.empty(B, D, 2 * H2, 2 * W2, C, dtype=g.dtype, device=g.device)
+        gx[:, :, 0::2, 0::2] = g[..., 0:C]
+        gx[:, :, 1::2, 0::2] = g[..., C:2 * C]
+        gx[:, :, 0::2, 1::2] = g[..., 2 * C:3 * C]
+        gx[:, :, 1::2, 1::2] = g[..., 3 * C:]
+        return gx
 
 
 class PatchMerging(nn.Module):
@@ -345,7 +371,7 @@ class PatchMerging(nn.Module):
         B, D, H, W, C = x.shape
         if H % 2 or W % 2:
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x = torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
+        x = PatchGather.apply(x)
         from .fused_ln import ln
         return linear(self.reduction, ln(self.norm, x, [self.reduction]))
 
