@@ -438,6 +438,9 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
  * pixels (2 i + a, 2 j + b) and owns cls_ntaps[c] >= 1 consecutive entries of the tap table (oa / ob are ignored). */
 #define VITTA_CONV_PARITY4 256
 #define VITTA_CONV_STATS_RAW 512 /* with VITTA_CONV_STATS: the sums are of the raw convolution output, not of z */
+/* With VITTA_CONV_BWD_BN and inj_*: the hooked feature is the RAW input of the BatchNorm (before_norm hooks,
+ * utils/norm_stats_utils.py:185): gscale (a_k + b_k (x - mu_k)) is added to the output gradient itself, d gamma / d beta do not see it. */
+#define VITTA_CONV_INJ_RAW 1024
 #define VITTA_CONV_MAX_TAPS 9
 
 typedef struct vitta_conv_desc {
@@ -597,8 +600,11 @@ int vitta_conv_repack_f32(const vitta_repack_entry* d_table, int32_t n_entries, 
  * convolutions:  g = d_g (+ d_g2) (+ rowadd_scale * d_rowadd[n, c, t], the TAM pooling gradient with scale 1 / HW);
  *   m = relu ? (d_mask ? d_mask > 0 : z > 0) : 1 ;  dz = g m + gscale (a_c + b_c (z - mu_c)) (statistics-loss gradient, A6);
  *   d_dgamma[c] += sum dz x_hat ; d_dbeta[c] += sum dz (atomics) ; d_dx = dz s_c ; d_gm (optional) = g m.
+ *   relu: bit 0 = the ReLU mask; bit 1 (VITTA_BN_BWD_INJ_RAW) = the hooked feature is the raw input x (before_norm hooks,
+ *   utils/norm_stats_utils.py:185): dz = g m, d_dx = dz s_c + gscale (a_c + b_c (x - mu_c)).
  * vitta_avgpool_cm(_bwd): the trunk's AdaptiveAvgPool2d(1) (tanet.py:147) from planes [C][F*HW] to features [F, C].
  * -------------------------------------------------------------------------- */
+#define VITTA_BN_BWD_INJ_RAW 2
 int vitta_tam_pool_cm_f32(const float* d_x, const float* const* h_bn, float eps, int32_t C, int32_t N, int32_t T, int32_t HW,
                           float* d_pool, void* stream);
 int vitta_tam_agg_fwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,

@@ -170,12 +170,14 @@ def test_bottleneck_tail_epilogue(n, c, k, h, hooked):
 
 
 @pytest.mark.parametrize("n,c,k,h,relu,inject,mask", [(8, 1024, 256, 14, True, True, False), (8, 256, 256, 14, True, False, False),
-                                                       (4, 256, 64, 28, True, True, True), (8, 2048, 512, 7, False, True, False)])
+                                                       (4, 256, 64, 28, True, True, True), (8, 2048, 512, 7, False, True, False),
+                                                       (8, 1024, 256, 14, True, "raw", False), (4, 256, 64, 28, True, "raw", True)])
 def test_data_gradient_with_batchnorm_backward_epilogue(n, c, k, h, relu, inject, mask):
     """conv dgrad whose epilogue differentiates the BatchNorm (+ReLU) that FED the forward convolution:
         a = relu(bn(xr)), y = conv1x1(a);  given gy (+ a second gradient g2 arriving at a):
         g = W^T gy + g2 ; dz = g * [mask] + gscale (a_k + b_k (z - mu_k)) ; d gamma, d beta ; d xr = dz * s
-    against fp64 autograd of the same composition."""
+    against fp64 autograd of the same composition.  inject == "raw" (VITTA_CONV_INJ_RAW, before_norm hooks): the statistics loss
+    is a function of the RAW input xr -- its gradient joins d xr, d gamma / d beta do not see it."""
     from vitta_amd import conv as CV
     g = torch.Generator().manual_seed(c + k + h)
     xr = torch.randn(n, k, h, h, generator=g)
@@ -199,14 +201,15 @@ def test_data_gradient_with_batchnorm_backward_epilogue(n, c, k, h, relu, inject
     loss = (y * gy.double()).sum() + (a * g2.double()).sum()
     if inject:
         v = lambda t: t.double().view(1, -1, 1, 1)
-        loss = loss + gscale * ((v(ca) - v(cb) * v(mu)) * z + 0.5 * v(cb) * z * z).sum()
+        f = xr if inject == "raw" else z
+        loss = loss + gscale * ((v(ca) - v(cb) * v(mu)) * f + 0.5 * v(cb) * f * f).sum()
     loss.backward()
     d = _dev()
     P = n * h * h
     gx = torch.full((k, P), float("nan"), device=d)
     gm = torch.full((k, P), float("nan"), device=d)
     dgam, dbet = torch.full((k,), 0.25, device=d), torch.full((k,), -0.5, device=d)
-    flags = CV.CONV_BWD_BN | CV.CONV_RES | (CV.CONV_BWD_RELU if relu else 0)
+    flags = CV.CONV_BWD_BN | CV.CONV_RES | (CV.CONV_BWD_RELU if relu else 0) | (CV.CONV_INJ_RAW if inject == "raw" else 0)
     CV.launch(CV.Geometry.dgrad(n, h, h)[0], CV.to_cm(gy.to(d)), CV.pack_bwd(w.to(d)), gx, c, k, flags=flags, y_raw=gm,
               res=CV.to_cm(g2.to(d)), bwd_bn=[t.to(d) for t in bn], bwd_x=CV.to_cm(xr.detach().float().to(d)),
               bwd_mask=CV.to_cm(other.to(d)) if mask else None,

@@ -725,6 +725,62 @@ def test_fused_layernorm_matches_torch(c, with_branch):
         assert (a.grad.cpu().double() - ref.grad).abs().max().item() <= 1e-4 * ref.grad.abs().max().item() + 1e-6, i
 
 
+@pytest.mark.parametrize("c,nb,t,hw", [(64, 2, 8, 196), (256, 1, 8, 49), (32, 2, 4, 36)])
+@pytest.mark.parametrize("relu,mask,rowadd,inject", [(True, False, True, "z"), (True, True, False, "raw"), (False, False, False, "raw"),
+                                                      (True, False, True, "raw"), (True, False, False, None)])
+def test_batchnorm_backward_on_channel_major_planes(c, nb, t, hw, relu, mask, rowadd, inject):
+    """vitta_bn_bwd_cm_f32 (the element-wise piece between two data-gradient convolutions of the trunk: BatchNorm (+ReLU)
+    backward with the TAM pooling gradient per (clip, channel, frame) row, the statistics-loss injection of a hooked layer --
+    after the norm, or VITTA_BN_BWD_INJ_RAW for before_norm hooks (utils/norm_stats_utils.py:185) on its raw input -- and
+    d gamma / d beta) against fp64 autograd of the composition it differentiates."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from vitta_amd import _lib
+    from vitta_amd.ops import _ptr4
+    g = torch.Generator().manual_seed(c + hw + t)
+    n = nb * t
+    P = n * hw
+    x = torch.randn(c, P, generator=g)
+    gam, bet = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    rm, rv = torch.randn(c, generator=g) * 0.2, torch.rand(c, generator=g) + 0.5
+    z0 = (x - rm[:, None]) * (gam * (rv + 1e-5).rsqrt())[:, None] + bet[:, None]
+    x = torch.where(z0.abs() < 1e-3, x + 0.01, x)  # away from the ReLU kink
+    other = torch.randn(c, P, generator=g)
+    gy, g2 = torch.randn(c, P, generator=g), torch.randn(c, P, generator=g)
+    radd = torch.randn(nb, c, t, generator=g)
+    mu, ca, cb = torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 1e-2, torch.randn(c, generator=g) * 1e-2
+    gscale = 0.6
+    xd = x.double().requires_grad_(True)
+    gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    z = (xd - rm.double()[:, None]) * (gd * (rv.double() + 1e-5).rsqrt())[:, None] + bd[:, None]
+    a = (z * (other.double() > 0) if mask else torch.relu(z)) if relu else z
+    gtot = gy.double() + g2.double()
+    if rowadd:  # per (clip, channel, frame) constant / HW, the pooling path of TAM
+        gtot = gtot + (radd.double() / hw).permute(1, 0, 2).reshape(c, n).repeat_interleave(hw, dim=1)
+    loss = (a * gtot).sum()
+    if inject:
+        f = xd if inject == "raw" else z
+        loss = loss + gscale * ((ca.double() - cb.double() * mu.double())[:, None] * f + 0.5 * cb.double()[:, None] * f * f).sum()
+    loss.backward()
+    d = _dev()
+    dv = lambda v: v.to(d).contiguous()
+    dx, gm = torch.full((c, P), float("nan"), device=d), torch.full((c, P), float("nan"), device=d)
+    dgam, dbet = torch.full((c,), 0.5, device=d), torch.full((c,), -1.0, device=d)
+    keep = [dv(v) for v in (gy, g2, x, other, radd, gam, bet, rm, rv, mu, ca, cb)]
+    gs = torch.tensor([gscale], device=d)
+    pp = lambda v: C.c_void_p(v.data_ptr())
+    flag = int(relu) | (_lib.BN_BWD_INJ_RAW if inject == "raw" else 0)
+    _lib.check(_lib.lib().vitta_bn_bwd_cm_f32(pp(keep[0]), pp(keep[1]), pp(keep[2]), pp(keep[3]) if mask else None, pp(keep[4]) if rowadd else None,
+                                              1.0 / hw, _ptr4(*keep[5:9]), 1e-5, *( (pp(keep[9]), pp(keep[10]), pp(keep[11]), pp(gs)) if inject else (None,) * 4),
+                                              flag, pp(dx), pp(gm), pp(dgam), pp(dbet), c, nb, t, hw, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "vitta_bn_bwd_cm_f32")
+    assert (dx.cpu().double() - xd.grad).abs().max().item() <= 1e-5 * xd.grad.abs().max().item()
+    assert ((dgam - 0.5).cpu().double() - gd.grad).abs().max().item() <= 1e-4 * gd.grad.abs().max().item() + 1e-5
+    assert ((dbet + 1.0).cpu().double() - bd.grad).abs().max().item() <= 1e-4 * bd.grad.abs().max().item() + 1e-5
+    mref = gtot * (((other.double() > 0) if mask else (z.detach() > 0)) if relu else 1.0)
+    assert (gm.cpu().double() - mref).abs().max().item() <= 1e-6 * mref.abs().max().item()
+
+
 @pytest.mark.parametrize("c", [128, 512, 1024])
 def test_fused_layernorm_passthrough_joins_the_two_gradients_of_its_input(c):
     """FusedLayerNorm(..., passthrough=True) -> (x, y): the returned x stands for the block input's second reader (the residual

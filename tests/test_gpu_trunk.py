@@ -55,8 +55,9 @@ def test_eval_forward_equals_module_path(tmp_path, size):
 
 
 @pytest.mark.parametrize("size,over", [(64, {}), (112, {}), (64, dict(if_pred_consistency=False)), (64, dict(reg_type="mse_loss")),
-                                       (112, dict(reg_type="mse_loss"))])
-def test_adapt_step_equals_module_path(tmp_path, size, over):
+                                       (112, dict(reg_type="mse_loss")), (112, dict(reg_type="mse_loss", before_norm=True)),
+                                       (64, dict(before_norm=True))])
+def test_adapt_step_equals_module_path(tmp_path, size, over, abi_calls):
     """One adaptation step (statistics alignment on the hooked layers + consistency, Adam on the BN affine parameters):
     losses, every affine gradient and the evaluation logits after the update, hand-written trunk vs module path."""
     from vitta_amd import trunk
@@ -72,7 +73,11 @@ def test_adapt_step_equals_module_path(tmp_path, size, over):
                 x = x * (1.0 + 1e-6 * torch.sign(H.seeded_randn(tuple(x.shape), 70 + int(fast[1]))))
             x = x.to(_dev())
             adapter.set_adapt_mode()
+            calls0 = dict(abi_calls.abi)
             _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+            if fast is True:  # the node ran (before_norm hooks included: raw-output statistics, raw injection)
+                assert abi_calls.abi.get("vitta_conv_f32", 0) > calls0.get("vitta_conv_f32", 0)
+                assert abi_calls.abi.get("vitta_bn_bwd_cm_ld_f32", 0) > calls0.get("vitta_bn_bwd_cm_ld_f32", 0)
             grads = {k: v.grad.detach().clone() for k, v in adapter.model.named_parameters() if v.requires_grad}
             adapter.close_hooks()
             ev = adapter.evaluate(adapter.shape_eval_input(H.seeded_randn((1, T * 3, size, size), 8).to(_dev()))).clone()

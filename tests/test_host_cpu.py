@@ -293,6 +293,26 @@ def test_statistics_loss_alone_still_adapts(tmp_path, over):
     assert sum(float(v.abs().sum()) for v in d_e.values()) > 0
 
 
+@pytest.mark.parametrize("reg_type", ["l1_loss", "mse_loss"])
+def test_before_norm_hooks_on_the_batched_engine_equal_the_stand_alone_hooks(tmp_path, reg_type):
+    """--before_norm (utils/norm_stats_utils.py:185: the hooked feature is the norm layer's INPUT): the batched engine takes such
+    hooks since round 4 (it only ever sees a feature tensor) -- same statistics loss and the same gradients as the per-layer
+    hooks that follow the reference's formulation; and the gradients differ from the after-norm configuration's (the option is
+    honoured, not ignored)."""
+    for d in "abc":
+        (tmp_path / d).mkdir()
+    over = dict(before_norm=True, reg_type=reg_type)
+    lr_e, _, g_e, d_e = _one_step_grads(tmp_path / "a", True, torch.device("cpu"), OracleBackend, **over)
+    lr_h, _, g_h, _ = _one_step_grads(tmp_path / "b", False, torch.device("cpu"), OracleBackend, **over)
+    lr_a, _, g_a, _ = _one_step_grads(tmp_path / "c", True, torch.device("cpu"), OracleBackend, reg_type=reg_type)
+    assert abs(lr_e - lr_h) <= 1e-5 * abs(lr_h), (lr_e, lr_h)
+    for k in g_h:
+        bound = 5e-3 * float(g_h[k].abs().max()) + 1e-9
+        assert float((g_e[k] - g_h[k]).abs().max()) <= bound, k
+    assert abs(lr_e - lr_a) > 1e-3 * abs(lr_a)
+    assert sum(float(v.abs().sum()) for v in d_e.values()) > 0
+
+
 def test_reference_import_paths_resolve():
     """Every module path DESIGN.md section 1 lists as the Python boundary imports and exposes the reference's names."""
     import importlib

@@ -32,7 +32,8 @@ class WgradDesc(C.Structure):
                 ("dh", C.c_int8 * 9), ("dw", C.c_int8 * 9), ("wt", C.c_int8 * 9), ("flags", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("x_ld", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
-CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW = 16, 32, 64, 128, 256, 512
+CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW, CONV_INJ_RAW = 16, 32, 64, 128, 256, 512, 1024
+BN_BWD_INJ_RAW = 2
 WGRAD_DEFER_REDUCE = 1024
 LN_BRANCH_BF16, LN_Y_BF16, LN_GY_BF16, LN_GBRANCH_BF16 = 1, 2, 4, 8
 CONV_KERNEL_TILE, CONV_KERNEL_SK, CONV_KERNEL_PW, CONV_KERNEL_B3 = 0, 1, 2, 3

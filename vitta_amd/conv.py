@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_BWD_BN, CONV_BWD_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_PRO_BN_RELU, CONV_RES, CONV_RES_HALF,
-                   CONV_STATS, CONV_STATS_RAW, ConvDesc, check, lib)
+                   CONV_INJ_RAW, CONV_STATS, CONV_STATS_RAW, ConvDesc, check, lib)
 
 
 def to_cm(x):
@@ -382,4 +382,4 @@ def stem_conv(x, wp):
 
 
 __all__ = ["Geometry", "launch", "Pack", "pack_b3", "make_pack", "b3_eligible", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
-           "CONV_EPI_RELU", "CONV_STATS", "CONV_STATS_RAW", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]
+           "CONV_EPI_RELU", "CONV_INJ_RAW", "CONV_STATS", "CONV_STATS_RAW", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

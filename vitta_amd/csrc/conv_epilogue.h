@@ -120,6 +120,7 @@ struct TileEpilogue {
     const bool RES = (flags & VITTA_CONV_RES) && d.res;
     const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
     const bool BRELU = flags & VITTA_CONV_BWD_RELU;
+    const bool IRAW = (flags & VITTA_CONV_INJ_RAW) && d.inj_mu;
     const int HWy = d.Hy * d.Wy;
     const int k = k0 + wn * 32 + li;
     float es = 1.f, et = 0.f, sh = c_sh, bsc = 0.f, bt = 0.f, brm = 0.f, brs = 0.f, ia = 0.f, ib = 0.f;
@@ -173,10 +174,11 @@ struct TileEpilogue {
             const float z = fmaf(xv[e], bsc, bt);
             const float mm = (BRELU && !d.bwd_mask) ? (z > 0.f ? 1.f : 0.f) : mk[e];
             gm[e] = v[e] * mm;
-            const float dz = gm[e] + fmaf(ib, z - sh, ia);
+            // (VITTA_CONV_INJ_RAW: the hooked feature is the raw input of the BatchNorm -- its statistics-loss gradient joins dx)
+            const float dz = IRAW ? gm[e] : gm[e] + fmaf(ib, z - sh, ia);
             r1 += dz * (xv[e] - brm) * brs;
             r2 += dz;
-            o[e] = dz * bsc;
+            o[e] = IRAW ? fmaf(dz, bsc, fmaf(ib, xv[e] - sh, ia)) : dz * bsc;
           }
           *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
           if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(gm[0], gm[1], gm[2], gm[3]);

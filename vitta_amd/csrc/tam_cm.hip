@@ -278,6 +278,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
     ib = gsc * a.cb[c];
     mu = a.mu[c];
   }
+  const bool relu = a.relu & 1, raw = (a.relu & 2) && a.mu;
   float sg = 0.f, sb = 0.f;
   const int64_t p0 = ((int64_t)blockIdx.x * VITTA_BLOCK * BB_UNROLL + threadIdx.x) * 4;
 #pragma unroll
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
       }
     }
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
-    if (a.relu && a.mask) {
+    if (relu && a.mask) {
       const float4 mv = *reinterpret_cast<const float4*>(a.mask + xbase + p);
       mk[0] = mv.x > 0.f; mk[1] = mv.y > 0.f; mk[2] = mv.z > 0.f; mk[3] = mv.w > 0.f;
     }
@@ -308,12 +309,14 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float z = fmaf(xr[e], s, t);
-      const float m = (a.relu && !a.mask) ? (z > 0.f ? 1.f : 0.f) : mk[e];
+      const float m = (relu && !a.mask) ? (z > 0.f ? 1.f : 0.f) : mk[e];
       gmv[e] = g[e] * m;
-      const float dz = gmv[e] + fmaf(ib, z - mu, ia);
+      // statistics-loss gradient of the hooked feature: of z (added before the affine map is differentiated) or -- before_norm
+      // hooks, utils/norm_stats_utils.py:185 -- of the RAW input x (added to dx as it is; d gamma / d beta do not see it)
+      const float dz = raw ? gmv[e] : gmv[e] + fmaf(ib, z - mu, ia);
       sg += dz * (xr[e] - rm) * rstd;
       sb += dz;
-      o[e] = dz * s;
+      o[e] = raw ? fmaf(dz, s, fmaf(ib, xr[e] - mu, ia)) : dz * s;
     }
     *reinterpret_cast<float4*>(a.dx + base + p) = make_float4(o[0], o[1], o[2], o[3]);
     if (a.gm) *reinterpret_cast<float4*>(a.gm + base + p) = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]);

@@ -438,8 +438,10 @@ class CombineNormStatsRegHook_onereg:
             self.source_mean_spatiotemp = torch.as_tensor(self.source_mean_spatiotemp, dtype=torch.float32)
             self.source_var_spatiotemp = torch.as_tensor(self.source_var_spatiotemp, dtype=torch.float32)
             if engine is not None:
-                if before_norm or not moving_avg:
-                    raise NotImplementedError("the batched engine covers before_norm=False, moving_avg=True")
+                if not moving_avg:
+                    raise NotImplementedError("the batched engine covers moving_avg=True")
+                # before_norm (utils/norm_stats_utils.py:185: feature = input[0]): the engine only sees a feature tensor; the
+                # fused module passes decline such a hook (it fires as a callback), the trunk reads the raw convolution output
                 self.engine = engine
                 self.index = engine.register(self, self.source_mean_spatiotemp, self.source_var_spatiotemp)
         if self.moving_avg:
@@ -447,9 +449,22 @@ class CombineNormStatsRegHook_onereg:
             self.var_avgmeter_spatiotemp = MovingAverageTensor(momentum=momentum)
         else:
             self.mean_avgmeter_spatiotemp, self.var_avgmeter_spatiotemp = AverageMeterTensor(), AverageMeterTensor()
-        self.hook = module.register_forward_hook(self.hook_fn)
+        self.pre_hook = None
+        self.add_hook_back(module)
+
+    def pre_hook_fn(self, module, input):
+        """before_norm on the batched engine: the engine's injection node (identity forward, statistics-loss gradient added in the
+        backward) must sit on the layer's INPUT -- a forward hook can only replace the output -- so the feature is collected by
+        a forward PRE-hook that hands the module the wrapped input."""
+        feature = input[0]
+        _check_feature(feature, self.kind)
+        if self.kind == "bn2d" and feature.shape[0] % self.clip_len != 0:
+            raise ValueError(f"{feature.shape[0]} frames are not a multiple of clip_len {self.clip_len}")
+        return (self.engine.collect(self.index, feature, self.kind),) + tuple(input[1:])
 
     def hook_fn(self, module, input, output):
+        if self.pre_hook is not None:  # collected on the way in
+            return None
         feature = input[0] if self.before_norm else output
         if self.kind == "bn1d":
             # BatchNorm1d carries temporal statistics only ('temp' not in ['spatiotemp']): contributes 0
@@ -487,6 +502,11 @@ class CombineNormStatsRegHook_onereg:
 
     def add_hook_back(self, module):
         self.hook = module.register_forward_hook(self.hook_fn)
+        if self.engine is not None and self.before_norm and self.kind != "bn1d":
+            self.pre_hook = module.register_forward_pre_hook(self.pre_hook_fn)
 
     def close(self):
         self.hook.remove()
+        if self.pre_hook is not None:
+            self.pre_hook.remove()
+            self.pre_hook = None

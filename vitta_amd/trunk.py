@@ -142,11 +142,13 @@ def _engine_hook(bn):
         if owner is not None and any(owner is p for p in producers):
             continue
         if (owner is not None and getattr(owner, "engine", None) is not None and hasattr(owner, "index")
-                and getattr(owner, "kind", None) == "bn2d" and not owner.before_norm and hook is None):
+                and getattr(owner, "kind", None) == "bn2d" and hook is None):
             hook = owner
         else:
             return False, None
-    return not bn._forward_pre_hooks, hook
+    # (a before_norm hook of the batched engine collects through its own forward PRE-hook: the node reads the raw output instead)
+    pre_ok = all(hook is not None and getattr(fn, "__self__", None) is hook for fn in bn._forward_pre_hooks.values())
+    return pre_ok, hook
 
 
 def _noop_hooks_only(module):
@@ -166,10 +168,12 @@ def _sflags(site):
 
 class Site:
     """A hooked BatchNorm2d of this step: where the convolution epilogue deposits the additive statistics and which
-    coefficient slices its backward injects."""
-    raw = False
+    coefficient slices its backward injects.  raw (before_norm hooks, utils/norm_stats_utils.py:185: the hooked feature is the
+    BatchNorm's INPUT): the statistics are those of the raw convolution output (VITTA_CONV_STATS_RAW) and the statistics-loss
+    gradient joins the gradient w.r.t. that output (VITTA_CONV_INJ_RAW / VITTA_BN_BWD_INJ_RAW)."""
 
-    def __init__(self, engine, plan, index):
+    def __init__(self, engine, plan, index, raw=False):
+        self.raw = bool(raw)
         sl = plan.channel_slice(index)
         self.stats = (engine.src_mean[sl], plan.s1[sl], plan.s2[sl])
         self.inj = (plan.mu[sl], plan.coef_a[sl], plan.coef_b[sl], engine.gscale)
@@ -435,7 +439,7 @@ class TrunkRunner:
         shapes = self.feature_shapes(x)
         by_index = sorted(hooked, key=lambda p: p[1].index)
         plan = engine.begin_direct([shapes[id(bn)] for bn, _ in by_index], x.device)
-        return {id(bn): Site(engine, plan, hook.index) for bn, hook in hooked}
+        return {id(bn): Site(engine, plan, hook.index, hook.before_norm) for bn, hook in hooked}
 
     def feature_shapes(self, x):
         """{id(bn): (frames, C, HW, NCHW)} of every BatchNorm2d output for input x (what a hook would see)."""
@@ -677,7 +681,8 @@ class TrunkRunner:
             dg, db = sink(bn.weight), sink(bn.bias)
             inj = site.inj if site else (None, None, None, None)
             check(L.vitta_bn_bwd_cm_ld_f32(_p(g), None, _p(x), _p(mask), ld, _p(rowadd), (1.0 / hw) if rowadd is not None else 0.0,
-                                           _bn_ptrs(bn), float(bn.eps), _p(inj[0]), _p(inj[1]), _p(inj[2]), _p(inj[3]), int(relu),
+                                           _bn_ptrs(bn), float(bn.eps), _p(inj[0]), _p(inj[1]), _p(inj[2]), _p(inj[3]),
+                                           int(relu) | (_lib.BN_BWD_INJ_RAW if (site and site.raw) else 0),
                                            _p(dx), _p(gm), _p(dg), _p(db), c, nb, t, hw, st), "vitta_bn_bwd_cm_ld_f32")
             return dx
 
@@ -709,7 +714,8 @@ class TrunkRunner:
         dx2 = torch.empty(p, Po, **f)
         i2 = s2.inj if s2 else None
         CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b", True), dx2, 4 * p, p,
-                  flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=_bn_t(net.bn2), eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
+                  flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU | (CV.CONV_INJ_RAW if (s2 and s2.raw) else 0), bwd_bn=_bn_t(net.bn2),
+                  eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
                   dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias), bwd_ld=ldPo)
         if net.conv3.weight.requires_grad:
             wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p, x_ld=ldPo)

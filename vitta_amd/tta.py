@@ -8,8 +8,8 @@ Same call signatures, same per-video protocol (adapt on video i -> evaluate vide
 without resetting the model), same log-line formats.  MI355X-first differences:
 
 * statistics hooks run in the batched engine (one moments launch + one align launch per step, gradient
-  injected during backward) whenever the configuration allows it (stat_reg 'mean_var', moving_avg,
-  before_norm False); otherwise each hook falls back to the stand-alone HIP op;
+  injected during backward) whenever the configuration allows it (stat_reg 'mean_var', moving_avg; before_norm hooks
+  collect through a forward pre-hook); otherwise each hook falls back to the stand-alone HIP op;
 * device-agnostic (no hard-coded .cuda()); one process per GPU.  Under torch.distributed (RCCL) the
   test videos are sharded round-robin over ranks, the packed moments [cnt|s1|s2] are all-reduced once
   per step before the EMA update and the gradients once before the optimizer step -- R ranks x 1
@@ -379,7 +379,7 @@ class ViTTAAdapter:
             raise NotImplementedError("args.stat_type of str is deprecated, use list instead.")
         means, vars_ = load_source_statistics(args, self.chosen_layers)
         if use_engine is None:
-            use_engine = bool(args.moving_avg) and not args.before_norm
+            use_engine = bool(args.moving_avg)
         if engine_backend is None and BACKEND_FACTORY is not None:
             engine_backend = BACKEND_FACTORY()
         self.backend = engine_backend
