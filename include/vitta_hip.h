@@ -753,15 +753,6 @@ int vitta_gemm_nt_bf16x_f32(const void* d_a, const void* d_b, const float* d_bia
 int vitta_gemm_nt_bf16x(const void* d_a, const void* d_b, const float* d_bias, const void* d_aux, void* d_y, void* d_pre, int64_t M,
                         int64_t N, int64_t K, int32_t mode, int32_t out_bf16, void* stream);
 
-/* The same products at fp32 accuracy on the bf16 matrix pipe (gemm_b3.hip): every fp32 operand split into three bf16
- * terms, six products per multiply-add, fp32 accumulation -- the arithmetic of conv_b3.hip.  d_b_b3 = the split image
- * of b [N][K] made by vitta_gemm_pack_b3 (vitta_gemm_pack_b3_bytes(N, K) bytes, 16-byte aligned source); N % 128 == 0,
- * K % 32 == 0 (vitta_gemm_b3_supported).  Modes and the other arguments as vitta_gemm_nt_f32. */
-int vitta_gemm_b3_supported(int64_t M, int32_t N, int32_t K);
-size_t vitta_gemm_pack_b3_bytes(int32_t N, int32_t K);
-int vitta_gemm_pack_b3(const float* d_b, void* d_dst, int32_t N, int32_t K, void* stream);
-int vitta_gemm_nt_b3_f32(const float* d_a, const void* d_b_b3, const float* d_bias, const float* d_aux, float* d_y, float* d_pre,
-                         int64_t M, int32_t N, int32_t K, int32_t mode, void* stream);
 
 /* --------------------------------------------------------------------------
  * N1 -- decoded RGB frames -> network input, bit-identical to the reference's PIL pipeline

@@ -181,72 +181,6 @@ def test_patch_embedding_as_dense_product_matches_conv3d(train):
         assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item() + 1e-6
 
 
-B3_SHAPES = [(3136, 1536, 512), (784, 1024, 4096), (392, 3072, 1024), (12544, 256, 256), (12544, 384, 128), (200, 128, 32),
-             (1, 256, 64), (3136, 512, 2048), (25088, 128, 96)]
-
-
-@pytest.mark.parametrize("m,n,k", B3_SHAPES)
-def test_gemm_b3_modes_vs_fp64(m, n, k):
-    """gemm_b3.hip (fp32 operands split into three bf16 terms, six bf16-MFMA products per multiply-add, fp32 accumulation;
-    the weight as the pre-split image of vitta_gemm_pack_b3): the three epilogue modes against fp64 at the bound of the
-    exact-fp32 kernel."""
-    from vitta_amd import ops
-    g = torch.Generator().manual_seed(m + n + k)
-    a = torch.randn(m, k, generator=g)
-    w = torch.randn(n, k, generator=g) * k ** -0.5
-    b = torch.randn(n, generator=g)
-    aux = torch.randn(m, n, generator=g) * 1.5
-    ad, wd, bd, auxd = (t.to(_dev()) for t in (a, w, b, aux))
-    assert ops.lib().vitta_gemm_b3_supported(m, n, k)
-    op = ops.B3Operand(wd)
-    y0 = ops.gemm_nt(ad, op, bd)
-    y0n = ops.gemm_nt(ad, op)
-    pre = torch.empty(m, n, device=_dev())
-    y1 = ops.gemm_nt(ad, op, bd, mode=1, pre=pre)
-    y2 = ops.gemm_nt(ad, op, mode=2, aux=auxd)
-    a64, w64, b64, x64 = a.double(), w.double(), b.double(), aux.double()
-    lin = a64 @ w64.t()
-    _close(y0, lin + b64)
-    _close(y0n, lin)
-    _close(pre, lin + b64)
-    _close(y1, F.gelu(lin + b64))
-    x = x64.clone().requires_grad_(True)
-    (dg,) = torch.autograd.grad(F.gelu(x).sum(), x)
-    _close(y2, lin * dg, rel=4e-5)
-
-
-def test_frozen_dense_layers_take_the_split_bf16_kernel_and_trainable_ones_the_fp32_kernel(abi_calls, monkeypatch):
-    """ops.DenseLinear / FusedMlp with VITTA_DENSE_ARITH=b3 (opt-in): a frozen weight (LN-affine adaptation) is split once and
-    runs on gemm_b3.hip, forward and data gradient; a trainable weight (SGD over all parameters) stays on the exact-fp32
-    kernel (its image would have to be re-made every step).  Same outputs and input gradients either way."""
-    from vitta_amd import ops
-    monkeypatch.setattr(ops, "DENSE_B3", True)
-    dev = _dev()
-    g = torch.Generator().manual_seed(7)
-    x = torch.randn(2, 3136, 512, generator=g).to(dev)  # 6272 tokens x 1024 outputs: 392 tiles of 128 x 128, K = 512
-    res = {}
-    for train in (False, True):
-        lin = torch.nn.Linear(512, 1024).to(dev)
-        with torch.no_grad():
-            lin.weight.copy_(torch.randn(1024, 512, generator=g) * 0.04)
-            lin.bias.copy_(torch.randn(1024, generator=g))
-        lin.weight.requires_grad_(train)
-        xi = x.clone().requires_grad_(True)
-        before = dict(abi_calls.abi)
-        y = ops.DenseLinear.apply(xi, lin.weight, lin.bias)
-        y.square().sum().backward()
-        n_b3 = abi_calls.abi.get("vitta_gemm_nt_b3_f32", 0) - before.get("vitta_gemm_nt_b3_f32", 0)
-        assert n_b3 == (0 if train else 2), (train, abi_calls.abi)  # (the data gradient: 6272 x 512 outputs, K = 1024: 196 tiles)
-        # the trainable weight's gradient g^T x: one pointwise vitta_conv_f32 launch (tokens as channel axis), no library product
-        n_dw = abi_calls.abi.get("vitta_conv_f32", 0) - before.get("vitta_conv_f32", 0)
-        assert n_dw == (1 if train else 0), (train, abi_calls.abi)
-        if train:
-            _close(lin.weight.grad, (2 * y.detach().double().cpu().reshape(-1, 1024)).t() @ x.double().cpu().reshape(-1, 512), rel=4e-5)
-        res[train] = (y.detach().cpu().double(), xi.grad.cpu().double())
-        g = torch.Generator().manual_seed(7)  # same weights for the second pass
-        torch.randn(2, 3136, 512, generator=g)
-    _close(res[False][0].float(), res[True][0], rel=2e-5)
-    _close(res[False][1].float(), res[True][1], rel=4e-5)
 
 
 @pytest.mark.parametrize("m,n,k,acc", [(6272, 384, 128, True), (784, 1024, 4096, True), (3136, 512, 2048, False), (50176, 128, 96, True),

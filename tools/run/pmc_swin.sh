@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out
 T=$1
 shift
-export PMC_MATCH='(gemm_nt\w*_kernel<[^>]*>|gemm_b3_kernel|wmsa\w*_kernel<[^>]*>|wmsa\w*_kernel|ln_\w+_kernel<[^>]*>)'
+export PMC_MATCH='(gemm_nt\w*_kernel<[^>]*>|wmsa\w*_kernel<[^>]*>|wmsa\w*_kernel|ln_\w+_kernel<[^>]*>)'
 run() {  # name, counters...
   N=$1; shift
   rm -rf $O/pmc_$N

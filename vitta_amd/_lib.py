@@ -157,10 +157,6 @@ SIGNATURES = {
     "vitta_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "vitta_gemm_nt_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "vitta_gemm_nt_bf16w_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
-    "vitta_gemm_b3_supported": (C.c_int, [_i64, _i32, _i32]),
-    "vitta_gemm_pack_b3_bytes": (_sz, [_i32, _i32]),
-    "vitta_gemm_pack_b3": (C.c_int, [_p, _p, _i32, _i32, _p]),
-    "vitta_gemm_nt_b3_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "vitta_tam_pool_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_bwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),

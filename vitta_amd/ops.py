@@ -880,30 +880,6 @@ def head_linear_supported(x, linear):
 KTIMING = None
 GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128) / 3 (64 x 64)
 DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
-# fp32-accuracy dense layers on the bf16 matrix pipe (gemm_b3.hip: operands split into three bf16 terms, six products per
-# multiply-add -- the arithmetic of conv_b3.hip) wherever the weight is frozen (its split image is made once) and the shape
-# qualifies.  Opt-in (VITTA_DENSE_ARITH=b3): on large products the kernel's main loop runs at 210 TF-equivalent against 136 TF for
-# the fp32 kernel, but at Video Swin-B's token counts (3136 .. 196 x 16 rows per product) it reaches the same ~80 TF as the
-# fp32 kernel and the step measures slower with it (C3 shape, same box, round 3: 22.9 ms against 20.9)
-DENSE_B3 = __import__("os").environ.get("VITTA_DENSE_ARITH", "f32") == "b3"
-
-
-class B3Operand:
-    """Split-bf16 image of a dense layer's B operand [N][K] (vitta_gemm_pack_b3)."""
-    __slots__ = ("img", "n", "k")
-
-    def __init__(self, b):
-        n, k = b.shape
-        self.n, self.k = int(n), int(k)
-        self.img = torch.empty(int(lib().vitta_gemm_pack_b3_bytes(self.n, self.k)), dtype=torch.uint8, device=b.device)
-        check(lib().vitta_gemm_pack_b3(_p(b), _p(self.img), self.n, self.k, _stream()), "vitta_gemm_pack_b3")
-
-    @property
-    def shape(self):
-        return (self.n, self.k)
-
-_W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, operand copy): frozen weights are prepared once
-
 
 def gemm_nt_supported(m, n, k):
     return bool(lib().vitta_gemm_nt_supported(m, n, k))
@@ -947,16 +923,6 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     gelu'(aux)).  b float32: vitta_gemm_nt_f32 (exact fp32 MFMA); b bfloat16: vitta_gemm_nt_bf16w_f32 (a is rounded to
     bf16 while staged)."""
     _require_cuda_f32(a, "a")
-    if isinstance(b, B3Operand):
-        m, k = a.shape
-        assert a.is_contiguous() and k == b.k
-        y = out if out is not None else torch.empty(m, b.n, dtype=torch.float32, device=a.device)
-        tm = KTIMING("gemm_b3", 2.0 * m * b.n * k) if KTIMING is not None else None
-        check(lib().vitta_gemm_nt_b3_f32(_p(a), _p(b.img), _p(bias), _p(aux), _p(y), _p(pre), m, b.n, k, mode, _stream()),
-              "vitta_gemm_nt_b3_f32")
-        if tm is not None:
-            tm.stop()
-        return y
     if not b.is_cuda or b.dtype not in (torch.float32, torch.bfloat16):
         raise _lib.VittaHipError(f"b must be a float32 or bfloat16 device tensor (got {b.dtype} on {b.device})")
     m, k = a.shape
@@ -981,27 +947,19 @@ def _operand(weight, transposed, m_rows=None):
     kred = w2d.shape[0] if transposed else w2d.shape[1]
     nout = w2d.shape[1] if transposed else w2d.shape[0]
     bf16 = bool(DENSE_BF16 and kred % 64 == 0)
-    # gemm_b3.hip's 128 x 128 tiles pay off where the launch has enough of them and a long enough K walk (measured on the
-    # Swin-B shapes, tools/debug/gemm_b3_probe.py: +10-15 % at >= 192 tiles and K >= 256, behind the 64 x 64 fp32 tiles
-    # below that; 210 vs 136 TF on 100+ GFLOP products)
-    b3 = bool(DENSE_B3 and not bf16 and not weight.requires_grad and m_rows is not None and kred >= 256
-              and ((int(m_rows) + 127) // 128) * (int(nout) // 128) >= 192
-              and lib().vitta_gemm_b3_supported(int(m_rows), int(nout), int(kred)))
-    if not transposed and not bf16 and not b3:
+    if not transposed and not bf16:
         return w2d
 
     def make():
         w = w2d.t() if transposed else w2d
-        if b3:
-            return B3Operand(w.contiguous())
         return w.to(torch.bfloat16).contiguous() if bf16 else w.contiguous()
 
     if weight.requires_grad:
         return make()
     import weakref
-    key = (id(weight), transposed, bf16, b3)
+    key = (id(weight), transposed, bf16)
     ent = _W_CACHE.get(key)
-    if ent is not None and ent[0]() is weight and ent[1] == weight._version and (b3 or ent[2].device == weight.device):
+    if ent is not None and ent[0]() is weight and ent[1] == weight._version and ent[2].device == weight.device:
         return ent[2]
     op = make()
     _W_CACHE[key] = (weakref.ref(weight), weight._version, op)

@@ -47,10 +47,8 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-# measured (round 3, same box, hipGraph replay): 5.88 ms per step without, 6.00 ms with either fork -- the event edges
-# cost more than the overlap returns; opt-in ("f" forward, "b" backward, "1" both)
-_SIDE = os.environ.get("VITTA_TRUNK_SIDE_STREAM", "0")
-SIDE_FWD, SIDE_BWD = _SIDE in ("1", "f"), _SIDE in ("1", "b")
+# (Round 3 measured the identity / downsample path of a stage's first bottleneck on a helper stream beside the main chain: 6.00 ms
+# per step against 5.88 -- with launches that fill the chip the event edges cost more than the overlap returns; removed in round 4.)
 # weight gradients (SGD over all parameters) on a helper stream beside the data-gradient chain: nothing in the backward waits
 # for them, so a block's three or four wgrad + reduce launches run while the main stream is already in the next block
 WGRAD_SIDE = os.environ.get("VITTA_TRUNK_WGRAD_STREAM", "1") != "0"
@@ -59,10 +57,8 @@ _side_pool = {}
 
 
 class _Fork:
-    """The downsample path of a block's first bottleneck beside its conv1 -> TAM -> conv2 chain: a helper stream that waits
-    for the work queued so far on the current stream, and that the current stream waits for at `join()`.  Every launch at
-    these sizes is latency-bound, so two independent chains side by side should cost little more than the longer one (they
-    do not: see VITTA_TRUNK_SIDE_STREAM).  Works the
+    """A helper stream that waits for the work queued so far on the current stream, and that the current stream waits for at
+    `join()` (the weight-gradient launches of SGD over all parameters beside the data-gradient chain, WGRAD_SIDE).  Works the
     same eagerly and under hipGraph capture (the helper stream is pulled into the capture by the first wait and leaves it
     at the join).  Tensors the helper's kernels touch are allocated by the caller on the main stream and outlive the join."""
 
@@ -527,7 +523,7 @@ class TrunkRunner:
         ng = n if ng is None else ng  # frames of the adaptation batch (a prefix); the rest ride along (evaluation clip)
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
         # identity path (first bottleneck of a stage: 1x1 convolution + BN, beside the main chain)
-        xd, fork = None, None
+        xd = None
         if net.downsample is not None:
             dconv, dbn = net.downsample[0], net.downsample[1]
             sd = sites.get(id(dbn))
@@ -540,13 +536,7 @@ class TrunkRunner:
             def identity_path():
                 CV.launch(gdn, xin, wd, ident, cin, 4 * p, flags=CV.CONV_EPI_APPLY | _sflags(sd), y_raw=xd,
                           epi_bn=_bn_t(dbn), eps=dbn.eps, stats=sd.stats if sd else None, stat_m=ng * gdn.hy * gdn.wy if ng != n else 0)
-            if SIDE_FWD and keep:  # the evaluation pass already runs beside the adaptation pass (a fork nested in that fork
-                # crashes hipStreamEndCapture on ROCm 7.2)
-                fork = _Fork(dev)
-                with fork:
-                    identity_path()
-            else:
-                identity_path()
+            identity_path()
         else:
             ident = xin
         # conv1 -> x1 raw
@@ -588,8 +578,6 @@ class TrunkRunner:
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | _sflags(s2), y_raw=x2,
                   epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None, stat_m=ng * ho * wo if ng != n else 0)
         # conv3 -> x3 raw, out
-        if fork is not None:
-            fork.join()
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
         CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f", keep), out, p, 4 * p,
@@ -690,7 +678,6 @@ class TrunkRunner:
         g_id = torch.empty_like(G)
         dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo, ld=ldPo)
         # identity / downsample path of a stage's first bottleneck, beside the main chain: bn_d backward, its data gradient
-        fork = None
         if net.downsample is not None:
             dconv, dbn = net.downsample[0], net.downsample[1]
             sd = sites.get(id(dbn))
@@ -704,12 +691,7 @@ class TrunkRunner:
                 if dconv.weight.requires_grad:
                     wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p, x_ld=ldP)
                 CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, wdb, gd, 4 * p, cin)
-            if SIDE_BWD:
-                fork = _Fork(dev)
-                with fork:
-                    identity_path()
-            else:
-                identity_path()
+            identity_path()
         # conv3 data gradient, epilogue = bn2 (+ReLU) backward
         dx2 = torch.empty(p, Po, **f)
         i2 = s2.inj if s2 else None
@@ -767,8 +749,6 @@ class TrunkRunner:
         # join the identity / downsample path
         gin = torch.empty(cin, P, **f)
         if net.downsample is not None:
-            if fork is not None:
-                fork.join()
             res, rflag = gd, (CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES)
         else:
             res, rflag = g_id, CV.CONV_RES
