@@ -127,7 +127,9 @@ __device__ __forceinline__ float add_term(const AddTerms& a, int q, int key, int
 }
 
 // S^T tile t for the wave's 16 queries: acc[r] = S[query q][key = 16t + 4*(lane>>4) + r] (scaled, + bias + mask)
-template <bool REL>
+// REG: the window carries region ids (a shifted block; else every packed entry is a bare code and the mask arithmetic -- three
+// vector instructions per score -- is compiled out).  FULL: all sixteen keys of the tile exist (every tile but a ragged last one).
+template <bool REL, bool REG = true, bool FULL = false>
 __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, const float (&qf)[8], int t, int lane,
                                             const AddTerms& a, int q, int N) {
   const int j = lane & 15, kk = lane >> 4;
@@ -149,15 +151,15 @@ __device__ __forceinline__ f32x4 score_tile(const float* __restrict__ k_lds, con
     // serialised LDS latencies each: 36 k cycles per row tile against 12.8 k cycles of MFMA)
     const int4 ck = *reinterpret_cast<const int4*>(a.cr + key0);
     const int pq = a.cr[q];
-    const int cq = pk_code(pq) + a.off, rq = pk_region(pq);
+    const int cq = (REG ? pk_code(pq) : pq) + a.off, rq = pk_region(pq);
     const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
     float tv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tv[r] = a.tab[cq - pk_code(kc[r])];
+    for (int r = 0; r < 4; ++r) tv[r] = a.tab[cq - (REG ? pk_code(kc[r]) : kc[r])];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = pk_region(kc[r]) != rq ? tv[r] - 100.f : tv[r];
-      acc[r] = key0 + r < N ? acc[r] + v : -INFINITY;
+      const float v = (REG && pk_region(kc[r]) != rq) ? tv[r] - 100.f : tv[r];
+      acc[r] = (FULL || key0 + r < N) ? acc[r] + v : -INFINITY;
     }
   } else {
     if (key0 + 3 < N && (N & 3) == 0) {  // 4 consecutive keys of one row: one 16-byte load each
@@ -232,7 +234,7 @@ __device__ __forceinline__ AddTerms setup_terms(const Carve& c, const float* bia
 // NTC: compile-time number of 16-token tiles (25 for the (8,7,7) window of every Swin-B stage) -- the unrolled tile loops
 // then carry no per-tile guard and the scheduler can overlap the LDS reads of one tile with the MFMAs of another;
 // 0 = run-time count.
-template <bool REL, int NTC>
+template <bool REL, int NTC, bool REG>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __restrict__ qkv,
                                                                 const float* __restrict__ bias,
                                                                 const float* __restrict__ mask,
@@ -276,7 +278,9 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
 #pragma unroll
     for (int t = 0; t < (NTC ? NTC : NT_MAX); ++t) {
       if (NTC || t < nt) {
-        acc[t] = score_tile<REL>(k_lds, qf, t, lane, terms, q, N);
+        // (t is a compile-time constant of the unrolled loop when NTC is: every tile but the last takes the unguarded form)
+        acc[t] = (NTC ? t + 1 < NTC : t + 1 < nt) ? score_tile<REL, REG, true>(k_lds, qf, t, lane, terms, q, N)
+                                                  : score_tile<REL, REG, false>(k_lds, qf, t, lane, terms, q, N);
         m = fmaxf(m, fmaxf(fmaxf(acc[t][0], acc[t][1]), fmaxf(acc[t][2], acc[t][3])));
         if (NTC) __builtin_amdgcn_sched_barrier(0);  // keep one tile's loads from being hoisted over the previous tiles
       }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_fwd_kernel(const float* __r
 // backward 1: dQ (query-tile major, K and V staged) + optional dbias via atomics
 //   P = exp(S - lse); dP = dO V^T; dS = P o (dP - delta); dQ = scale * dS K
 // ------------------------------------------------------------------------------------------------
-template <bool REL>
+template <bool REL, bool REG>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
     const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
     const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
@@ -385,7 +389,8 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
 
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < nt; ++t) {
-      f32x4 s = score_tile<REL>(k_lds, qf, t, lane, terms, q, N);
+      f32x4 s = t + 1 < nt ? score_tile<REL, REG, true>(k_lds, qf, t, lane, terms, q, N)
+                           : score_tile<REL, REG, false>(k_lds, qf, t, lane, terms, q, N);
       // dP^T tile = V dO^T (same C layout as S^T)
       float vf[8];
       load8(vf, v_lds + (16 * t + i) * KPAD + 8 * kk);
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
 // backward 2: dK, dV (key-tile major, Q and dO staged)
 //   dV = P^T dO ; dK = scale * dS^T Q
 // ------------------------------------------------------------------------------------------------
-template <bool REL>
+template <bool REL, bool REG>
 __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
     const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
@@ -492,18 +497,34 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
         dp = mfma(gf[u], vf[u], dp);
       }
       f32x4 p, ds;
+      if constexpr (REL) {
+        // No validity test per score: a padded QUERY row has lse = +inf in LDS (p = exp(finite - inf) = 0), its packed code and its
+        // zero-filled q row exist; a padded KEY lane (clamped to the last key) produces values nobody stores.  The four queries of
+        // this lane are consecutive: one 16-byte read each for their packed codes, lse and delta.
+        const int q0 = 16 * qt + 4 * kk;
+        const int4 cq4 = *reinterpret_cast<const int4*>(terms.cr + q0);
+        const float4 l4 = *reinterpret_cast<const float4*>(l_lds + q0), d4 = *reinterpret_cast<const float4*>(d_lds + q0);
+        const int cq[4] = {cq4.x, cq4.y, cq4.z, cq4.w};
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+        const int ck = (REG ? pk_code(pkey) : pkey) - terms.off, rk = pk_region(pkey);
+        float tv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = 16 * qt + 4 * kk + r;
-        float sv = -INFINITY;
-        if constexpr (REL) {
-          const float term = rel_term(terms, terms.cr[q], pkey);
-          sv = (q < N && kvalid) ? fmaf(s[r], scale, term) : -INFINITY;
-        } else {
-          if (q < N && kvalid) sv = s[r] * scale + add_term<false>(terms, q, key, N);
+        for (int r = 0; r < 4; ++r) tv[r] = terms.tab[(REG ? pk_code(cq[r]) : cq[r]) - ck];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float term = (REG && pk_region(cq[r]) != rk) ? tv[r] - 100.f : tv[r];
+          p[r] = __expf(fmaf(s[r], scale, term) - lq[r]);
+          ds[r] = p[r] * (dp[r] - dq_[r]);
         }
-        p[r] = __expf(sv - l_lds[q]);
-        ds[r] = p[r] * (dp[r] - d_lds[q]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * qt + 4 * kk + r;
+          float sv = -INFINITY;
+          if (q < N && kvalid) sv = s[r] * scale + add_term<false>(terms, q, key, N);
+          p[r] = __expf(sv - l_lds[q]);
+          ds[r] = p[r] * (dp[r] - d_lds[q]);
+        }
       }
       // dV[key][d] += P^T dO ; dK[key][d] += dS^T Q   (A = C-layout values, B rows = queries 16qt + 4kk + r)
 #pragma unroll
@@ -966,18 +987,24 @@ int launch_fwd(const WmsaArgs& a, float* out, float* lse, hipStream_t st) {
   const int nt = (a.N + 15) / 16;
   const int qs = pick_qsplit(a.B_ * a.nH, nt);
   const size_t lds = lds_bytes(a.N, 0, REL ? a.T : 0);
-#define WMSA_FWD(NTC)                                                                                                    \
+#define WMSA_FWD(NTC, REG)                                                                                               \
   do {                                                                                                                 \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_fwd_kernel<REL, NTC>),                                  \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_fwd_kernel<REL, NTC, REG>),                             \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                       \
       return VITTA_ERR_LAUNCH;                                                                                         \
-    VITTA_LAUNCH((wmsa_fwd_kernel<REL, NTC>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds, st, a.qkv, a.bias,  \
-                 a.mask, a.code, a.region, REL ? a.T : 0, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, lse);        \
+    VITTA_LAUNCH((wmsa_fwd_kernel<REL, NTC, REG>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds, st, a.qkv,   \
+                 a.bias, a.mask, a.code, a.region, REL ? a.T : 0, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, lse); \
   } while (0)
   // the compile-time variant (NTC = 25) lets the scheduler hoist every tile's loads: 256 VGPRs + 1.4 KB of scratch per
   // lane and 15 % slower end to end (measured); the per-tile guard of the run-time variant keeps live ranges short
-  if (nt == NT_MAX) WMSA_FWD(NT_MAX);
-  else WMSA_FWD(0);
+  const bool reg = REL && a.region;  // region ids present (a shifted block): the kernels without them carry no mask arithmetic
+  if (nt == NT_MAX) {
+    if (reg) WMSA_FWD(NT_MAX, true);
+    else WMSA_FWD(NT_MAX, false);
+  } else {
+    if (reg) WMSA_FWD(0, true);
+    else WMSA_FWD(0, false);
+  }
 #undef WMSA_FWD
   return VITTA_OK;
 }
@@ -989,15 +1016,21 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
   const int qs = pick_qsplit(a.B_ * a.nH, nt);
   const int T = REL ? a.T : 0;
   const size_t lds1 = lds_bytes(a.N, (REL && dbias) ? ((T + 3) & ~3) : 0, T), lds2 = lds_bytes(a.N, 2 * 16 * nt, T);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel<REL>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dkv_kernel<REL>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
-    return VITTA_ERR_LAUNCH;
-  VITTA_LAUNCH(wmsa_bwd_dq_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, a.mask,
-               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dbias);
-  VITTA_LAUNCH(wmsa_bwd_dkv_kernel<REL>, dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, a.mask,
-               a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, dout, lse, delta, dqkv);
+#define WMSA_BWD(REG)                                                                                                   \
+  do {                                                                                                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel<REL, REG>),                               \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess ||                    \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dkv_kernel<REL, REG>),                              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)                      \
+      return VITTA_ERR_LAUNCH;                                                                                         \
+    VITTA_LAUNCH((wmsa_bwd_dq_kernel<REL, REG>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, \
+                 a.mask, a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dbias); \
+    VITTA_LAUNCH((wmsa_bwd_dkv_kernel<REL, REG>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, \
+                 a.mask, a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, dout, lse, delta, dqkv);       \
+  } while (0)
+  if (REL && a.region) WMSA_BWD(true);
+  else WMSA_BWD(false);
+#undef WMSA_BWD
   return VITTA_OK;
 }
 

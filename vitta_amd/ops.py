@@ -881,6 +881,9 @@ KTIMING = None
 GEMM_TILE = 0       # 0: the library's choice; tools force 1 (128 x 128) / 2 (64 x 128) / 3 (64 x 64)
 DENSE_BF16 = False  # opt-in (--dense_bf16): bf16 MFMA operands for the dense layers, fp32 accumulation / epilogues
 
+_W_CACHE = {}       # (id(weight), transposed, bf16) -> (weakref, version, operand copy): frozen weights are prepared once
+
+
 def gemm_nt_supported(m, n, k):
     return bool(lib().vitta_gemm_nt_supported(m, n, k))
 
