@@ -251,17 +251,19 @@ int vitta_wmsa_bwd_f32(const float* d_qkv, const float* d_bias, const float* d_m
  *   d_gpooled: N*C*T floats of result followed by N*(C/4)*T floats of scratch;
  *   backward: h_dbn = {dG.weight, dG.bias, dL.weight, dL.bias} and h_dw = {dG.0.w, dG.3.w, dL.0.w, dL.3.w}
  *   (entries or the whole array may be NULL when the weights are frozen) are ACCUMULATED: zero them first.
+ *   pooled_tc: 0 = d_pooled is float [N, C, T]; 1 = int64 fixed point (32 fractional bits) [N, T, C] -- frame-major, what a
+ *   convolution's VITTA_CONV_POOL epilogue accumulates.
  * Supported: T <= 16, C % 4 == 0 (vitta_tam_branch_supported). */
 int vitta_tam_branch_supported(int32_t C, int32_t T);
 int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                              const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                             float* d_hpre, void* stream);
+                             float* d_hpre, int32_t pooled_tc, void* stream);
 int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                              const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
-                             float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* stream);
+                             float* d_gpooled, float* const* h_dbn, float* const* h_dw, int32_t pooled_tc, void* stream);
 /* N_saved >= N: clips of the forward launch that wrote d_hpre (its second plane starts N_saved * (C/4) * T floats in); the
  * backward covers the first N of them (d_pooled / d_kern / d_gate are clip-major, so their first N clips are a prefix). */
 /* The same two passes with their two launches each fused into ONE (F1 -> F2, B1 -> B2): the workgroups of a clip meet on a
@@ -277,12 +279,12 @@ int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T);
 int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                                   float* d_hpre, void* d_sync, void* stream);
+                                   float* d_hpre, void* d_sync, int32_t pooled_tc, void* stream);
 int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
-                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, void* stream);
+                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc, void* stream);
 
 
 /* --------------------------------------------------------------------------
@@ -441,6 +443,13 @@ int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_
 /* With VITTA_CONV_BWD_BN and inj_*: the hooked feature is the RAW input of the BatchNorm (before_norm hooks,
  * utils/norm_stats_utils.py:185): gscale (a_k + b_k (x - mu_k)) is added to the output gradient itself, d gamma / d beta do not see it. */
 #define VITTA_CONV_INJ_RAW 1024
+/* Forward launches with a contiguous output and epi_bn: the per-(frame, channel) means of relu(z), z = the eval-mode BatchNorm of
+ * the raw output -- TAM's adaptive average pooling of relu(bn1(conv1(x))) (temporal_module.py:53: F.adaptive_avg_pool2d) taken from
+ * the accumulators instead of a pass over x1 -- ADDED (atomics) to pool[N frames][K] of int64 FIXED-POINT numbers with 32
+ * fractional bits (order-independent sums: the means are forward activations), frame-major (the 32 channels a half-wave adds are
+ * contiguous; channel-major costs 10-18x, tools/ubench/atomic_line_probe.hip), which the caller zeroes; pool_scale = 1 / (Hy * Wy).
+ * Hy * Wy >= 32.  The TAM branch entry points read this tensor with pooled_tc = 1. */
+#define VITTA_CONV_POOL 2048
 #define VITTA_CONV_MAX_TAPS 9
 
 typedef struct vitta_conv_desc {
@@ -493,6 +502,8 @@ typedef struct vitta_conv_desc {
    *   stat_m  VITTA_CONV_STATS counts, and y_raw is written for, output pixels m < stat_m only (0 = all; a multiple of 4;
    *           contiguous forward outputs). */
   int64_t bwd_ld, stat_m;
+  void* pool;        /* VITTA_CONV_POOL: int64 [N][K], 32 fractional bits, accumulated */
+  float pool_scale;  /* 1 / (Hy * Wy) */
 } vitta_conv_desc;
 
 /* 1 if the shape is covered: C % 16 == 0 (or C < 16 handled by the stem entry), K % 32 == 0, pixel counts % 4 == 0. */

@@ -67,6 +67,48 @@ def test_forward_matches_fp64_conv(n, c, k, h, ksz, stride, tile):
     _close(CV.from_cm(y, n, geom.hy, geom.wy), ref)
 
 
+@pytest.mark.parametrize("n,t,c,k,h,hooked,tile,ksplit", [
+    (16, 8, 64, 64, 56, False, 0, 0), (16, 8, 256, 64, 28, True, 0, 0), (16, 8, 512, 128, 28, False, 0, 0), (16, 8, 1024, 256, 14, True, 0, 0),
+    (16, 8, 2048, 512, 7, False, 0, 0), (24, 8, 2048, 512, 7, True, 0, 0), (8, 8, 1024, 256, 14, False, 0, 4), (32, 16, 256, 64, 8, False, 0, 0),
+    (8, 4, 128, 128, 28, False, (64 << 16) | 64, 1), (8, 4, 64, 64, 13, False, 0, 0)])
+def test_frame_pooled_means_from_the_epilogue(n, t, c, k, h, hooked, tile, ksplit):
+    """VITTA_CONV_POOL: TAM's adaptive average pooling of relu(bn1(conv1(x))) (temporal_module.py:53) taken from conv1's
+    accumulators -- per (frame, channel) means added as 64-bit fixed-point numbers into a zeroed frame-major [N, K] tensor -- against fp64; planes of 49 and 64
+    pixels put two frames into one 32-pixel block, 13 x 13 planes leave ragged blocks, split K runs the epilogue once per tile;
+    together with the hooked layer's moments and the raw output the launch also writes."""
+    from vitta_amd import conv as CV
+    g = torch.Generator().manual_seed(n + c + k + h)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, 1, 1, generator=g) * c ** -0.5
+    bn = _bn(k, g)
+    raw = F.conv2d(x.double(), w.double())
+    z = _bn_apply(raw, bn)
+    ref = z.clamp_min(0).mean((2, 3))  # [frames, K]
+    d = _dev()
+    geom = CV.Geometry.forward(n, h, h, 1, 1, 0)
+    y = torch.full((k, n * h * h), float("nan"), device=d)
+    pooled = torch.zeros(n, k, dtype=torch.int64, device=d)  # fixed point, 32 fractional bits
+    dec = lambda q: q.cpu().double() * 2.0 ** -32
+    shift = z.mean((0, 2, 3)).float()
+    stats = (shift.to(d), torch.zeros(k, device=d), torch.zeros(k, device=d)) if hooked else None
+    CV.launch(geom, CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k, flags=CV.CONV_STATS if hooked else 0, epi_bn=[b.to(d) for b in bn],
+              stats=stats, pool=pooled, tile=tile, ksplit=ksplit)
+    _close(CV.from_cm(y, n, h, h), raw, what="raw output")
+    _close(dec(pooled), ref, what="pooled means")
+    if hooked:
+        dd = z - shift.double().view(1, -1, 1, 1)
+        # (the shift is the mean: s1 is a cancelling sum, bounded against the sum of magnitudes)
+        assert (stats[1].cpu().double() - dd.sum((0, 2, 3))).abs().max().item() <= 1e-5 * dd.abs().sum((0, 2, 3)).max().item()
+        _close(stats[2], (dd * dd).sum((0, 2, 3)), tol=1e-4, what="s2")
+    # added, not stored: a second launch doubles the sums
+    CV.launch(geom, CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k, epi_bn=[b.to(d) for b in bn], pool=pooled, tile=tile, ksplit=ksplit)
+    _close(dec(pooled), 2 * ref, what="accumulation")
+    # integer sums do not depend on the arrival order of the workgroups: a third launch into a fresh buffer repeats the first bit for bit
+    again = torch.zeros_like(pooled)
+    CV.launch(geom, CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k, epi_bn=[b.to(d) for b in bn], pool=again, tile=tile, ksplit=ksplit)
+    assert torch.equal(again * 2, pooled)
+
+
 @pytest.mark.parametrize("n,c,k,h,ksz,ksplit", [(16, 2048, 512, 7, 1, 0), (16, 512, 512, 7, 3, 0), (8, 1024, 256, 14, 1, 4),
                                                 (8, 256, 256, 14, 3, 7), (4, 512, 128, 14, 1, 16), (16, 256, 256, 14, 3, 2)])
 def test_split_k_matches_fp64_conv_and_leaves_the_workspace_clean(n, c, k, h, ksz, ksplit):

@@ -879,7 +879,8 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
     """vitta_tam_branch_{fwd,bwd}_fused_f32 (F1 -> F2 / B1 -> B2 inside one launch, the clip's workgroups meeting on a
     device-scope counter) against the two-launch entry points: identical outputs (the arithmetic is the same code; only
     the atomically accumulated parameter gradients may differ in summation order), the counters back at zero, and the
-    same again on a second and third launch."""
+    same again on a second and third launch.  Both also read a FRAME-major int64 fixed-point pooled tensor [N, T, C] (pooled_tc = 1:
+    what a convolution's VITTA_CONV_POOL epilogue accumulates): same outputs as from the [N, C, T] form, bit for bit."""
     import ctypes as C
     from vitta_amd import _lib
     from vitta_amd.ops import _p, _ptr4, _stream
@@ -888,28 +889,30 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
     g = torch.Generator().manual_seed(c + t + n)
     o = c // 4
     r = lambda *s: torch.randn(*s, generator=g).to(d)
-    pooled = r(n, c, t)
+    pooled = torch.round(r(n, c, t) * 4096) / 4096  # (exactly representable with 32 fractional bits: the fixed-point form below is lossless)
     wg1, wg3, w0, w3 = r(2 * t, t) * 0.3, r(3, 2 * t) * 0.3, r(o, c, 3) * (3 * c) ** -0.5, r(c, o) * o ** -0.5
     bng = [torch.rand(2 * t, generator=g).to(d) + 0.5, r(2 * t) * 0.1, r(2 * t) * 0.1, torch.rand(2 * t, generator=g).to(d) + 0.5]
     bnl = [torch.rand(o, generator=g).to(d) + 0.5, r(o) * 0.1, r(o) * 0.1, torch.rand(o, generator=g).to(d) + 0.5]
     gkern, ggate = r(n * c, 3), r(n, c, t)
     sync = torch.zeros(256, dtype=torch.int32, device=d)
 
-    def run(fused):
+    pooled_tc = torch.round(pooled.permute(0, 2, 1).double() * 2.0 ** 32).to(torch.int64).contiguous()  # [N, T, C] fixed point
+
+    def run(fused, tc=0):
         kern, gate, hpre = torch.empty(n * c, 3, device=d), torch.empty(n, c, t, device=d), torch.empty(2, n, o, t, device=d)
-        args = (_p(pooled), _p(wg1), _ptr4(*bng), 1e-5, _p(wg3), _p(w0), _ptr4(*bnl), 1e-5, _p(w3), n, c, t)
+        args = (_p(pooled_tc if tc else pooled), _p(wg1), _ptr4(*bng), 1e-5, _p(wg3), _p(w0), _ptr4(*bnl), 1e-5, _p(w3), n, c, t)
         if fused:
-            _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), _stream()), "fwd fused")
+            _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), tc, _stream()), "fwd fused")
         else:
-            _lib.check(L.vitta_tam_branch_fwd_f32(*args, _p(kern), _p(gate), _p(hpre), _stream()), "fwd")
+            _lib.check(L.vitta_tam_branch_fwd_f32(*args, _p(kern), _p(gate), _p(hpre), tc, _stream()), "fwd")
         gbuf = torch.empty(n * c * t + n * o * t, device=d)
         dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
         dw = [torch.zeros_like(wg1), torch.zeros_like(wg3), torch.zeros_like(w0), torch.zeros_like(w3)]
         bargs = args + (n, _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
         if fused:
-            _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), _stream()), "bwd fused")
+            _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), tc, _stream()), "bwd fused")
         else:
-            _lib.check(L.vitta_tam_branch_bwd_f32(*bargs, _stream()), "bwd")
+            _lib.check(L.vitta_tam_branch_bwd_f32(*bargs, tc, _stream()), "bwd")
         torch.cuda.synchronize()
         return kern, gate, hpre, gbuf[:n * c * t].clone(), dbn, dw
 
@@ -919,5 +922,11 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
         assert int(sync.abs().sum()) == 0, "meeting counters must be zero at rest"
         for a, b in zip(got[:4], ref[:4]):
             assert torch.equal(a, b), rep
+        for a, b in zip(got[4] + got[5], ref[4] + ref[5]):
+            assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7
+    for fused in (False, True):
+        got = run(fused, tc=1)
+        for a, b in zip(got[:4], ref[:4]):
+            assert torch.equal(a, b), ("frame-major pooled", fused)
         for a, b in zip(got[4] + got[5], ref[4] + ref[5]):
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7

@@ -106,6 +106,42 @@ def test_adapt_step_equals_module_path(tmp_path, size, over, abi_calls):
     assert (a[3] - b[3]).abs().max().item() <= max(2e-3 * b[3].abs().max().item(), 4.0 * floor), (floor, b[3].abs().max().item())
 
 
+@pytest.mark.parametrize("size", [112, 224])
+def test_pooling_from_the_convolution_epilogue_equals_the_pooling_launch(tmp_path, size, abi_calls):
+    """trunk.POOL_FOLD: TAM's pooled means come out of conv1's accumulators (VITTA_CONV_POOL, atomics-ordered sums, frame-major)
+    instead of a vitta_tam_pool_cm_f32 launch per block: same evaluation logits and the same adaptation step to summation-order
+    accuracy (mse alignment: no sign() discontinuity), and the stand-alone launch is gone wherever a plane has >= 32 pixels."""
+    from vitta_amd import trunk
+    res = {}
+    old = trunk.POOL_FOLD
+    try:
+        for fold in (True, False):
+            (tmp_path / str(fold)).mkdir()
+            trunk.POOL_FOLD = fold
+            adapter, T = _adapter(tmp_path / str(fold), size, True, reg_type="mse_loss")
+            x = H.seeded_randn((1, 2 * T * 3, size, size), 7).to(_dev())
+            adapter.set_adapt_mode()
+            n0 = abi_calls.abi.get("vitta_tam_pool_cm_f32", 0)
+            _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+            pools = abi_calls.abi.get("vitta_tam_pool_cm_f32", 0) - n0
+            grads = {k: v.grad.detach().clone() for k, v in adapter.model.named_parameters() if v.requires_grad}
+            adapter.close_hooks()
+            ev = adapter.evaluate(adapter.shape_eval_input(H.seeded_randn((1, T * 3, size, size), 8).to(_dev()))).clone()
+            res[fold] = (float(loss_reg), float(loss_consis), grads, ev, pools)
+    finally:
+        trunk.POOL_FOLD = old
+    a, b = res[True], res[False]
+    small = {112: 2, 224: 0}[size]  # blocks whose input planes have fewer than 32 pixels keep the launch (112^2 input: layer4.1 / 4.2 see 4 x 4)
+    assert b[4] == 16 and a[4] == small, (a[4], b[4])
+    assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-4 * abs(b[1]) + 1e-7
+    for k, gb in b[2].items():
+        # (summation-order noise of the pooled means, amplified through up to sixteen blocks of ReLU masks on the way back to the stem:
+        # 2e-3 of the norm there, 1e-5 at the last stage; test_adapt_step_equals_module_path uses 2e-2 for the same reason)
+        assert (a[2][k] - gb).norm().item() <= 1e-2 * gb.norm().item() + 1e-9, (k, (a[2][k] - gb).norm().item(), gb.norm().item())
+    # (logits AFTER the update: Adam's first step is lr * sign(g), a gradient within round-off of zero moves its parameter by 2 lr)
+    assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
+
+
 def test_sgd_all_step_equals_module_path(tmp_path):
     """The reference's default optimizer (SGD over ALL parameters, corpus/basics.py:547-560) on the hand-written trunk:
     convolution weight gradients from vitta_conv_wgrad_f32, TAM / head weights from their own kernels, the stem as torch

@@ -32,7 +32,7 @@ class WgradDesc(C.Structure):
                 ("dh", C.c_int8 * 9), ("dw", C.c_int8 * 9), ("wt", C.c_int8 * 9), ("flags", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("x_ld", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
-CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW, CONV_INJ_RAW = 16, 32, 64, 128, 256, 512, 1024
+CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW, CONV_INJ_RAW, CONV_POOL = 16, 32, 64, 128, 256, 512, 1024, 2048
 BN_BWD_INJ_RAW = 2
 WGRAD_DEFER_REDUCE = 1024
 LN_BRANCH_BF16, LN_Y_BF16, LN_GY_BF16, LN_GBRANCH_BF16 = 1, 2, 4, 8
@@ -55,7 +55,8 @@ class ConvDesc(C.Structure):
                 ("dh", C.c_int8 * CONV_MAX_TAPS), ("dw", C.c_int8 * CONV_MAX_TAPS), ("wt", C.c_int8 * CONV_MAX_TAPS),
                 ("flags", C.c_int32), ("tile", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("w_b3", C.c_void_p),
-                ("cls_ntaps", C.c_int8 * 4), ("bwd_ld", C.c_int64), ("stat_m", C.c_int64)]
+                ("cls_ntaps", C.c_int8 * 4), ("bwd_ld", C.c_int64), ("stat_m", C.c_int64),
+                ("pool", C.c_void_p), ("pool_scale", C.c_float)]
 
 
 _p = C.c_void_p
@@ -100,13 +101,13 @@ SIGNATURES = {
     "vitta_tam_branch_supported": (C.c_int, [_i32, _i32]),
     "vitta_tam_branch_fused_supported": (C.c_int, [_i32, _i32, _i32]),
     "vitta_tam_branch_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
-                                           _p, _p, _p, _p]),
+                                           _p, _p, _p, _i32, _p]),
     "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
-                                           _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p]),
+                                           _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "vitta_tam_branch_fwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
-                                                 _p, _p, _p, _p, _p]),
+                                                 _p, _p, _p, _p, _i32, _p]),
     "vitta_tam_branch_bwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
-                                                 _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p]),
+                                                 _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _i32, _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_bn_act_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i64, _i32, _i32, _p, _p]),
     "vitta_bn_act_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _i64, _i32, _i64, _i32,

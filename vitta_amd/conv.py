@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from ._lib import (CONV_BWD_BN, CONV_BWD_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_PRO_BN_RELU, CONV_RES, CONV_RES_HALF,
-                   CONV_INJ_RAW, CONV_STATS, CONV_STATS_RAW, ConvDesc, check, lib)
+                   CONV_INJ_RAW, CONV_POOL, CONV_STATS, CONV_STATS_RAW, ConvDesc, check, lib)
 
 
 def to_cm(x):
@@ -214,10 +214,12 @@ def workspace(device):
 
 
 def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,
-           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0, bwd_ld=0, stat_m=0):
+           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0, bwd_ld=0, stat_m=0, pool=None):
     """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K] (fp32 tensor or Pack), y [K, *].
     stats = (shift, s1, s2); inj = (mu, a, b, gscale).  bwd_ld: pixels per channel row of bwd_x / bwd_mask when they hold
-    more frames than this pass covers; stat_m: the statistics count output pixels below it only (0: all)."""
+    more frames than this pass covers; stat_m: the statistics count output pixels below it only (0: all).
+    pool: a zeroed int64 [frames, K] tensor the per-(frame, channel) means of relu(epi_bn(raw output)) are ADDED to as
+    fixed-point numbers with 32 fractional bits (CONV_POOL)."""
     if isinstance(wp, Pack):
         wp, b3 = wp.f32, wp.b3
     else:
@@ -239,6 +241,11 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if inj is not None:
         d.inj_mu, d.inj_a, d.inj_b, d.inj_gscale = (_ptr(t) for t in inj)
     d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
+    if pool is not None:
+        flags = int(flags) | CONV_POOL
+        if pool.dtype != torch.int64 or not pool.is_contiguous():
+            raise _lib.VittaHipError("pool must be a contiguous int64 tensor (fixed-point sums)")
+        d.pool, d.pool_scale = pool.data_ptr(), 1.0 / (geom.hy * geom.wy)
     d.C, d.K, d.flags, d.tile, d.ksplit = int(c), int(k), int(flags) | (_lib.CONV_PARITY4 if geom.cls_ntaps is not None else 0), int(tile), int(ksplit)
     geom.fill(d)
     if ksplit not in (1, -1):
@@ -382,4 +389,4 @@ def stem_conv(x, wp):
 
 
 __all__ = ["Geometry", "launch", "Pack", "pack_b3", "make_pack", "b3_eligible", "wgrad", "stem_wgrad", "pack_stem", "stem_conv", "to_cm", "from_cm", "pack_fwd", "pack_bwd", "out_size", "CONV_PRO_BN_RELU", "CONV_EPI_APPLY",
-           "CONV_EPI_RELU", "CONV_INJ_RAW", "CONV_STATS", "CONV_STATS_RAW", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]
+           "CONV_EPI_RELU", "CONV_INJ_RAW", "CONV_POOL", "CONV_STATS", "CONV_STATS_RAW", "CONV_RES", "CONV_RES_HALF", "CONV_BWD_BN", "CONV_BWD_RELU"]

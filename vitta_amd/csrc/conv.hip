@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "conv_common.h"
+#include "conv_epilogue.h"
 
 using namespace vitta;
 using namespace vitta_conv;
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
   const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
   const bool BRELU = flags & VITTA_CONV_BWD_RELU;
   const bool IRAW = (flags & VITTA_CONV_INJ_RAW) && d.inj_mu;
+  const bool POOL = (flags & VITTA_CONV_POOL) && d.pool;
   const int HWy = d.Hy * d.Wy;
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
     const int64_t yrow = (int64_t)k * a.yP;
 #pragma unroll
     for (int x = 0; x < MT; ++x) {
+      PoolSums pool(a, m0 + wm * TM + 32 * x);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int m = m0 + wm * TM + 32 * x + 8 * qd + 4 * lk;
@@ -481,6 +484,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
                 r1 += dd;
                 r2 = fmaf(dd, dd, r2);
               }
+              if (POOL) pool.add(m + e, z);
               o[e] = APPLY ? z : v[e];
             }
             if (RES) {
@@ -505,6 +509,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
           }
         }
       }
+      if (POOL) pool.flush(a, k, lk);
     }
     if (STATS || BWD) {
       r1 += __shfl_xor(r1, 32, 64);
@@ -686,6 +691,10 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   if ((d.flags & (VITTA_CONV_EPI_APPLY | VITTA_CONV_STATS)) && (!d.epi_bn[0] || !d.epi_bn[1] || !d.epi_bn[2] || !d.epi_bn[3]))
     return VITTA_ERR_INVALID_ARG;
   if ((d.flags & VITTA_CONV_STATS) && (!d.st_shift || !d.st_s1 || !d.st_s2)) return VITTA_ERR_INVALID_ARG;
+  if (d.flags & VITTA_CONV_POOL) {
+    if (!d.pool || !d.epi_bn[0] || !d.epi_bn[1] || !d.epi_bn[2] || !d.epi_bn[3]) return VITTA_ERR_INVALID_ARG;
+    if (!a.contig || (d.flags & VITTA_CONV_BWD_BN) || d.Hy * d.Wy < 32) return VITTA_ERR_UNSUPPORTED;
+  }
   if ((d.flags & VITTA_CONV_BWD_BN) && (!d.bwd_x || !d.bwd_bn[0] || !d.bwd_bn[1] || !d.bwd_bn[2] || !d.bwd_bn[3]))
     return VITTA_ERR_INVALID_ARG;
   if ((d.flags & VITTA_CONV_BWD_BN) && (d.flags & (VITTA_CONV_STATS | VITTA_CONV_EPI_APPLY | VITTA_CONV_EPI_RELU)))

@@ -8,6 +8,38 @@
 
 namespace vitta_conv {
 
+// VITTA_CONV_POOL: relu(z) of ONE 32-pixel block of one channel summed per frame.  A block of 32 consecutive pixels touches at most
+// two frames (Hy * Wy >= 32); the two lane halves (lk = 0 / 1: the same channel, interleaved pixel quads) meet by one shuffle, then
+// one atomic per (block, channel, frame) into pool[frame][channel] -- the 32 lanes of a half-wave add into contiguous bytes.  The sums
+// are 64-bit FIXED-POINT (32 fractional bits of the mean): integer addition is associative, so the pooled means -- forward
+// activations of the TAM -- do not depend on the order in which the workgroups arrive (float atomics made two runs of the same step
+// differ by sign flips of the L1 alignment; same cost: tools/ubench/atomic_line_probe.hip).
+struct PoolSums {
+  int mblk, mB, fA;
+  float s0 = 0.f, s1 = 0.f;
+  __device__ __forceinline__ PoolSums(const ConvK& a, int mblk_) : mblk(mblk_) {
+    const int hw = a.d.Hy * a.d.Wy;
+    fA = mblk / hw;
+    mB = (fA + 1) * hw;
+  }
+  __device__ __forceinline__ void add(int m, float z) {
+    const float r = fmaxf(z, 0.f);
+    if (m < mB) s0 += r;
+    else s1 += r;
+  }
+  __device__ __forceinline__ void flush(const ConvK& a, int k, int lk) {
+    const vitta_conv_desc& d = a.d;
+    s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    if (lk == 0 && mblk < a.Mtot) {
+      unsigned long long* pool = reinterpret_cast<unsigned long long*>(d.pool);
+      const float sc = d.pool_scale * 4294967296.f;
+      atomicAdd(pool + (int64_t)fA * d.K + k, (unsigned long long)__float2ll_rn(s0 * sc));
+      if (mB < mblk + 32 && mB < a.Mtot) atomicAdd(pool + (int64_t)(fA + 1) * d.K + k, (unsigned long long)__float2ll_rn(s1 * sc));
+    }
+  }
+};
+
 struct TileEpilogue {
   const ConvK& a;
   const vitta_conv_desc& d;
@@ -121,8 +153,10 @@ struct TileEpilogue {
     const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
     const bool BRELU = flags & VITTA_CONV_BWD_RELU;
     const bool IRAW = (flags & VITTA_CONV_INJ_RAW) && d.inj_mu;
+    const bool POOL = (flags & VITTA_CONV_POOL) && d.pool;
     const int HWy = d.Hy * d.Wy;
     const int k = k0 + wn * 32 + li;
+    PoolSums pool(a, m0 + wm * (BM >> 1) + 32 * xb);
     float es = 1.f, et = 0.f, sh = c_sh, bsc = 0.f, bt = 0.f, brm = 0.f, brs = 0.f, ia = 0.f, ib = 0.f;
     if (BWD) {
       brs = rsqrtf(c_var + d.bwd_eps);
@@ -193,6 +227,7 @@ struct TileEpilogue {
               r1 += dd;
               r2 = fmaf(dd, dd, r2);
             }
+            if (POOL) pool.add(m + e, z);
             o[e] = APPLY ? z : v[e];
           }
           if (RES) {
@@ -220,6 +255,7 @@ struct TileEpilogue {
         }
       }
     }
+    if (POOL) pool.flush(a, k, lk);
   }
 
   // per-channel sums of the tile -> statistics / d gamma, d beta

@@ -30,6 +30,7 @@ struct TamBranchArgs {
   BnEval bnl;            // L.1
   const float* w3;       // L.3.weight [C, C/4]  (k = 1)
   int N, C, T;
+  int pooled_tc;         // 1: pooled is int64 fixed point [N][T][C] (frame-major, what a convolution's VITTA_CONV_POOL epilogue accumulates)
 };
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
@@ -117,8 +118,41 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ dst, const float*
 // most of F1's 9-11 us)
 __device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, int c0, int nc, float* pl) {
   const int C = a.C, T = a.T, TP = T + 2;
-  const float* src = a.pooled + ((int64_t)n * C + c0) * T;
   const int ncv = min(nc, C - c0);  // valid channels of the tile
+  if (a.pooled_tc) {
+    // frame-major int64 fixed-point source [N][T][C] (32 fractional bits): 16-byte vectors = two channels, converted exactly
+    // (integer part + fraction) and transposed into the [c][T + 2] rows.  C % 4 == 0, c0 % 2 == 0.
+    const long long* srct = reinterpret_cast<const long long*>(a.pooled) + (int64_t)n * T * C + c0;
+    const int c2n = (ncv + 1) >> 1, n2 = c2n * T;
+    for (int i0 = threadIdx.x; i0 < n2; i0 += SU * TBW) {
+      longlong2 v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = min(i0 + u * TBW, n2 - 1);
+        v[u] = *reinterpret_cast<const longlong2*>(srct + (int64_t)(i / c2n) * C + 2 * (i % c2n));
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * TBW;
+        if (i < n2) {
+          const int t = i / c2n, c = 2 * (i % c2n);
+          const long long e[2] = {v[u].x, v[u].y};
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (c + j < ncv)
+              pl[(c + j) * TP + 1 + t] = (float)(int)(e[j] >> 32) + (float)(unsigned)(e[j] & 0xffffffffll) * 2.3283064365386963e-10f;
+        }
+      }
+    }
+    for (int c = threadIdx.x; c < nc; c += TBW) {  // the two pad columns; whole rows of channels past C
+      pl[c * TP] = 0.f;
+      pl[c * TP + T + 1] = 0.f;
+      if (c >= ncv)
+        for (int t = 0; t < T; ++t) pl[c * TP + 1 + t] = 0.f;
+    }
+    return;
+  }
+  const float* src = a.pooled + ((int64_t)n * C + c0) * T;
   if ((T & 3) == 0 && aligned16(src)) {
     const int t4 = T >> 2, n4 = ncv * t4;
     const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -455,6 +489,7 @@ __device__ __forceinline__ void b2_body(const TamBranchArgs& a, const float* __r
   if (PHASE == 0) {  // d(conv1 output) [O][T] of the clip -> [O][T+2]: the same padded staging as the pooled rows
     TamBranchArgs tmp = a;
     tmp.pooled = dpre_g;
+    tmp.pooled_tc = 0;
     tmp.C = O;
     load_pooled_t(tmp, n, 0, O, dpre);
   }
@@ -673,12 +708,12 @@ int vitta_tam_branch_supported(int32_t C, int32_t T) {
 int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                              const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                             float* d_hpre, void* stream) {
+                             float* d_hpre, int32_t pooled_tc, void* stream) {
   // d_hpre: 2 * N * (C/4) * T floats: conv1 output before BN, then after BN + ReLU
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre) return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T)) return VITTA_ERR_UNSUPPORTED;
   TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
   if (tb_bad(a)) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int O = C / 4;
@@ -705,11 +740,11 @@ int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T) {
 int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                                   float* d_hpre, void* d_sync, void* stream) {
+                                   float* d_hpre, void* d_sync, int32_t pooled_tc, void* stream) {
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_sync) return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T) || N > 32) return VITTA_ERR_UNSUPPORTED;
   TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
   if (tb_bad(a)) return VITTA_ERR_INVALID_ARG;
   const int O = C / 4;
   int nt1, nt2;
@@ -727,13 +762,13 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
-                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, void* stream) {
+                                   float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc, void* stream) {
   if (N_saved < N) return VITTA_ERR_INVALID_ARG;
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn || !d_sync)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T) || N > 32) return VITTA_ERR_UNSUPPORTED;
   TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
   if (tb_bad(a) || !h_dbn[0] || !h_dbn[1] || !h_dbn[2] || !h_dbn[3]) return VITTA_ERR_INVALID_ARG;
   TamBranchGrads g{d_gpooled, h_dbn[0], h_dbn[1], h_dbn[2], h_dbn[3], h_dw ? h_dw[0] : nullptr, h_dw ? h_dw[1] : nullptr,
                    h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};
@@ -755,14 +790,14 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
                              const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                              float* d_gpooled, float* const* h_dbn /* {dG.w, dG.b, dL.w, dL.b} accumulated into */,
-                             float* const* h_dw /* {dwg1, dwg3, dw0, dw3} accumulated into, or NULL entries */, void* stream) {
+                             float* const* h_dw /* {dwg1, dwg3, dw0, dw3} accumulated into, or NULL entries */, int32_t pooled_tc, void* stream) {
   // d_gpooled doubles as scratch: it must have room for N*C*T + N*(C/4)*T floats (result, then d conv1-output)
   if (N_saved < N) return VITTA_ERR_INVALID_ARG;
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T)) return VITTA_ERR_UNSUPPORTED;
   TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T};
+                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
   if (tb_bad(a) || !h_dbn[0] || !h_dbn[1] || !h_dbn[2] || !h_dbn[3]) return VITTA_ERR_INVALID_ARG;
   TamBranchGrads g{d_gpooled, h_dbn[0], h_dbn[1], h_dbn[2], h_dbn[3], h_dw ? h_dw[0] : nullptr, h_dw ? h_dw[1] : nullptr,
                    h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};

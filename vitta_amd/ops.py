@@ -647,7 +647,7 @@ class TamFused(torch.autograd.Function):
         check(lib().vitta_tam_pool_f32(_p(x), n, t, c, hw, _p(pooled), st), "vitta_tam_pool_f32")
         check(lib().vitta_tam_branch_fwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), float(eps_g),
                                              _p(wg3), _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), float(eps_l), _p(w3),
-                                             n, c, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
+                                             n, c, t, _p(kern), _p(gate), _p(hpre), 0, st), "vitta_tam_branch_fwd_f32")
         check(lib().vitta_tam_agg_fwd_f32(_p(x), _p(gate), _p(kern), n, t, c, hw, _p(out), st), "vitta_tam_agg_fwd_f32")
         ctx.save_for_backward(x, pooled, wg1, bng_w, bng_b, wg3, w0, bnl_w, bnl_b, w3, bng_rm, bng_rv, bnl_rm, bnl_rv,
                               kern, gate, hpre)
@@ -677,7 +677,7 @@ class TamFused(torch.autograd.Function):
         check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), eps_g, _p(wg3),
                                              _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), eps_l, _p(w3), n, c, t, n,
                                              _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf),
-                                             _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), st),
+                                             _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), 0, st),
               "vitta_tam_branch_bwd_f32")
         check(lib().vitta_tam_pool_bwd_f32(_p(gbuf), n, t, c, hw, _p(gx), st), "vitta_tam_pool_bwd_f32")
         return (gx, None, r_wg1, r_gw, r_gb, r_wg3, r_w0, r_lw, r_lb, r_w3, None, None, None, None, None, None)

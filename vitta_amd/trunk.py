@@ -52,6 +52,10 @@ def _p(t):
 # weight gradients (SGD over all parameters) on a helper stream beside the data-gradient chain: nothing in the backward waits
 # for them, so a block's three or four wgrad + reduce launches run while the main stream is already in the next block
 WGRAD_SIDE = os.environ.get("VITTA_TRUNK_WGRAD_STREAM", "1") != "0"
+# TAM's adaptive average pooling of relu(bn1(conv1(x))) taken from conv1's accumulators (VITTA_CONV_POOL: frame-major [N][T][C]
+# fixed-point sums -- order-independent --, which the branch kernels read with pooled_tc = 1) instead of a pass over x1: 16 launches fewer per pass; "0": the
+# stand-alone pooling launch (tests hold the two forms together)
+POOL_FOLD = os.environ.get("VITTA_TRUNK_POOL_FOLD", "1") != "0"
 _side_streams = {}
 _side_pool = {}
 
@@ -209,6 +213,7 @@ class TrunkRunner:
         self._repack = {}
         self._geo = {}
         self._wgrad_pending = []
+        self._pool = None  # [zeroed buffer, next offset] of the pass in progress (POOL_FOLD)
         # tta.py, for the span of one overlapped step: the adaptation set of packs was rebuilt on the main stream BEFORE the
         # evaluation stream forked and the weights do not change until both passes are done -- neither pass re-packs, the
         # evaluation reads the adaptation set's forward packs
@@ -541,13 +546,19 @@ class TrunkRunner:
             ident = xin
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
+        pooled, ptc = None, 0
+        if self._pool is not None and h * w >= 32:  # this block's [frames, p] piece of the pass's zeroed pooling buffer
+            buf, off = self._pool
+            pooled, ptc = buf[off:off + n * p].view(nb, t, p), 1
+            self._pool[1] = off + n * p
         CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=_sflags(s1),
-                  epi_bn=_bn_t(net.bn1) if s1 else None, eps=net.bn1.eps, stats=s1.stats if s1 else None,
-                  stat_m=ng * h * w if ng != n else 0)
+                  epi_bn=_bn_t(net.bn1) if (s1 or pooled is not None) else None, eps=net.bn1.eps, stats=s1.stats if s1 else None,
+                  stat_m=ng * h * w if ng != n else 0, pool=pooled)
         # TAM on relu(bn1(x1))
         bn1p = _bn_ptrs(net.bn1)
-        pooled = torch.empty(nb, p, t, **f)
-        check(L.vitta_tam_pool_cm_f32(_p(x1), bn1p, float(net.bn1.eps), p, nb, t, h * w, _p(pooled), st), "vitta_tam_pool_cm_f32")
+        if pooled is None:
+            pooled = torch.empty(nb, p, t, **f)
+            check(L.vitta_tam_pool_cm_f32(_p(x1), bn1p, float(net.bn1.eps), p, nb, t, h * w, _p(pooled), st), "vitta_tam_pool_cm_f32")
         bg, bl = tam.G[1], tam.L[1]
         kern, gate, hpre = torch.empty(nb * p, 3, **f), torch.empty(nb, p, t, **f), torch.empty(2, nb, p // 4, t, **f)
         from .ops import _ptr4
@@ -556,13 +567,13 @@ class TrunkRunner:
             check(L.vitta_tam_branch_fwd_fused_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                                    _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                                   _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), st),
+                                                   _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), ptc, st),
                   "vitta_tam_branch_fwd_fused_f32")
         else:  # two launches, no device-side meeting point
             check(L.vitta_tam_branch_fwd_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                              float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                              _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                             _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), st), "vitta_tam_branch_fwd_f32")
+                                             _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), ptc, st), "vitta_tam_branch_fwd_f32")
         a1 = torch.empty(p, P, **f)
         check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
               "vitta_tam_agg_fwd_cm_f32")
@@ -586,7 +597,7 @@ class TrunkRunner:
                   stat_m=ng * ho * wo if ng != n else 0)
         saved = None
         if keep:
-            saved = dict(xin=xin, x1=x1, pooled=pooled, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
+            saved = dict(xin=xin, x1=x1, pooled=pooled, ptc=ptc, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
                          a1=a1 if net.conv2.weight.requires_grad else None,
                          a2=a2 if net.conv3.weight.requires_grad else None, dims=(ng, h, w, ho, wo), frames=n)
         return out, ho, wo, saved
@@ -617,9 +628,15 @@ class TrunkRunner:
         n, _, h, w = pooled.shape
         cur = CV.to_cm(pooled)
         tape = []
-        for b in self.blocks():
-            cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng)
-            tape.append(saved)
+        blocks = self.blocks()
+        # one zeroed buffer for the pooled means of every block of this pass (conv1's epilogue ADDS into it)
+        self._pool = [torch.zeros(n * sum(b.net.conv1.out_channels for b in blocks), dtype=torch.int64, device=x.device), 0] if POOL_FOLD else None
+        try:
+            for b in blocks:
+                cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng)
+                tape.append(saved)
+        finally:
+            self._pool = None
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
@@ -733,14 +750,14 @@ class TrunkRunner:
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                                    _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
                                                    _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
-                                                   _p(ggate), _p(gbuf), bn_sinks, w_sinks, _p(_sync(dev)), st),
+                                                   _p(ggate), _p(gbuf), bn_sinks, w_sinks, _p(_sync(dev)), sv["ptc"], st),
                   "vitta_tam_branch_bwd_fused_f32")
         else:
             check(L.vitta_tam_branch_bwd_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                              float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                              _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
                                              _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
-                                             _p(ggate), _p(gbuf), bn_sinks, w_sinks, st), "vitta_tam_branch_bwd_f32")
+                                             _p(ggate), _p(gbuf), bn_sinks, w_sinks, sv["ptc"], st), "vitta_tam_branch_bwd_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
         dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w, ld=ldP)
         del ga
