@@ -574,6 +574,11 @@ def run_cpu_baseline(opt):
                        f"{cores} threads")
 
 
+def _trunk_pool_fold():
+    from vitta_amd import conv as _cv, trunk as _tr
+    return _tr.POOL_FOLD and _cv.ARITH == "b3"
+
+
 def launch_ranks(opt):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) under torch.distributed.run on
     this node and hand rank 0's line through.  Returns the launcher's exit code."""
@@ -731,7 +736,11 @@ def main():
                         "algorithmic_flops_per_step": conv["flops"] / conv["steps"],
                         "kernel_ms_per_step": conv["ms"] / conv["steps"],
                         "share_of_step": conv["ms"] / conv["steps"] / (1e3 * elapsed / opt.steps),
-                        "note": "per-launch durations from hipEvent pairs attached to each dispatch in an eager repeat of "
+                        "pooled_means_in_epilogue": bool(_trunk_pool_fold()),
+                        "note": ("the conv1 launches of the bottlenecks (32 per step) also carry TAM's spatial average pooling "
+                                 "(VITTA_CONV_POOL, +1.5-3 us each in place of 32 pooling launches: the family's time, hence frac, "
+                                 "includes it; VITTA_TRUNK_POOL_FOLD=0 measures 0.015 higher on the same box).  "
+                                 if _trunk_pool_fold() else "") + "per-launch durations from hipEvent pairs attached to each dispatch in an eager repeat of "
                                 "the timed steps (a replayed hipGraph cannot carry events); flops = 2 x output positions "
                                 "x C x K x taps per launch (vitta_conv_flops), whatever the instruction; peak = flops / "
                                 "(sum over launches of flops / the peak of the instruction that launch issues); "

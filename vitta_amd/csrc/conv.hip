@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
     const int64_t yrow = (int64_t)k * a.yP;
 #pragma unroll
     for (int x = 0; x < MT; ++x) {
-      PoolSums pool(a, m0 + wm * TM + 32 * x);
+      PoolSums pool(a, m0 + wm * TM + 32 * x, POOL);
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const int m = m0 + wm * TM + 32 * x + 8 * qd + 4 * lk;
@@ -709,6 +709,8 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
     const int form = is_vector_geometry(d) ? 1 : b3_patch_geometry(d, 63) ? 2 : 3;
     static const int gather_on = env_int("VITTA_CONV_B3_GATHER", 1);  // 0: gathered geometries stay on the exact-fp32 kernels (A/B)
     if (form == 3 && !gather_on) goto exact_fp32;
+    // the pooled-means epilogue exists in the plain pointwise instantiation (and in the tile kernel below)
+    if ((d.flags & VITTA_CONV_POOL) && (form != 1 || (d.flags & (VITTA_CONV_RES | VITTA_CONV_RES_HALF)))) goto exact_fp32;
     const bool parity4 = d.flags & VITTA_CONV_PARITY4;
     if (parity4) {
       int sum = 0;
@@ -810,6 +812,9 @@ exact_fp32:
   // keep their ranges on tile boundaries (no partial tiles).
   // Pointwise launches whose tiles fit the chip in one round of four workgroups per CU, with K short enough that a tile
   // is not the whole launch's critical path: conv_pw.hip (VITTA_CONV_PW=0 keeps them on the stream-K kernel)
+  // (VITTA_CONV_POOL outside conv_b3.hip: the tile kernel, whose epilogue has it)
+  if (d.flags & VITTA_CONV_POOL) {
+  } else
   if (bm == 64 && bn == 64 && bk_ == 32 && h->tile == 0 && h->ksplit == 0 && pw_enabled() && is_vector_geometry(d) && a.contig &&
       !(d.flags & VITTA_CONV_PRO_BN_RELU) && tiles >= pw_min_tiles() && tiles <= MAX_SPLIT_TILES && nslab <= pw_max_slabs() &&
       (int64_t)d.C * a.xP * 4 < (1ll << 31)) {

@@ -76,7 +76,7 @@ __device__ unsigned long long b3_trace_buf[16 * 8192];
   } while (0)
 #endif
 
-template <int MODE, bool PRE>
+template <int MODE, bool PRE, bool POOLT>
 __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
   constexpr int NB = PATCH ? 3 : 2;       // B stages (A: NA)
@@ -494,8 +494,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   // ---- epilogue: the wave's two column blocks; per-channel sums of the four waves meet in LDS ----------------------------
   B3_STAMP(7);
   float r1[2] = {0.f, 0.f}, r2[2] = {0.f, 0.f};
-  epi0.template body<PRE>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
-  epi1.template body<PRE>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
+  epi0.template body<PRE, POOLT>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
+  epi1.template body<PRE, POOLT>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
 #ifdef B3_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   B3_STAMP(8);
@@ -538,21 +538,21 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
 }
 #undef SGB
 
-template <int MODE, bool PRE>
+template <int MODE, bool PRE, bool POOLT = false>
 int launch_one(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   constexpr int NB = MODE == 1 ? 3 : 2;
   constexpr size_t lds = (size_t)(MODE == 1 ? 1 : NB) * 32 * (MODE == 1 ? 256 : 128) * 4 + NB * 12 * 64 * 16 + 384 * 4 + 16;
   static bool raised = false;
   if (!raised) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_b3_kernel<MODE, PRE, POOLT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return VITTA_ERR_LAUNCH;
     raised = true;
   }
   const dim3 grid((unsigned)a.hot.nwg), block(256);
   (void)hipGetLastError();
-  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE>), grid, block, lds, st, e0, e1, 0, a);
-  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE>), grid, block, lds, st, a);
+  if (e0) hipExtLaunchKernelGGL((conv_b3_kernel<MODE, PRE, POOLT>), grid, block, lds, st, e0, e1, 0, a);
+  else hipLaunchKernelGGL((conv_b3_kernel<MODE, PRE, POOLT>), grid, block, lds, st, a);
   return hipGetLastError() == hipSuccess ? VITTA_OK : VITTA_ERR_LAUNCH;
 }
 
@@ -613,6 +613,8 @@ namespace vitta_conv {
 int launch_b3(const ConvK& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   if (a.b3 == 2) return a.pw_prefetch ? launch_one<1, true>(a, st, e0, e1) : launch_one<1, false>(a, st, e0, e1);
   if (a.b3 == 3) return a.pw_prefetch ? launch_one<2, true>(a, st, e0, e1) : launch_one<2, false>(a, st, e0, e1);
+  // (the pooled-means epilogue is its own instantiation of the pointwise form without an epilogue input stream: conv1 of a bottleneck)
+  if ((a.d.flags & VITTA_CONV_POOL) && a.d.pool) return launch_one<0, false, true>(a, st, e0, e1);
   return a.pw_prefetch ? launch_one<0, true>(a, st, e0, e1) : launch_one<0, false>(a, st, e0, e1);
 }
 

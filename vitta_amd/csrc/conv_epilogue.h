@@ -17,10 +17,12 @@ namespace vitta_conv {
 struct PoolSums {
   int mblk, mB, fA;
   float s0 = 0.f, s1 = 0.f;
-  __device__ __forceinline__ PoolSums(const ConvK& a, int mblk_) : mblk(mblk_) {
-    const int hw = a.d.Hy * a.d.Wy;
-    fA = mblk / hw;
-    mB = (fA + 1) * hw;
+  __device__ __forceinline__ PoolSums(const ConvK& a, int mblk_, bool on) : mblk(mblk_), mB(0), fA(0) {
+    if (on) {  // (one integer division per block: only where the launch pools)
+      const int hw = a.d.Hy * a.d.Wy;
+      fA = mblk / hw;
+      mB = (fA + 1) * hw;
+    }
   }
   __device__ __forceinline__ void add(int m, float z) {
     const float r = fmaxf(z, 0.f);
@@ -140,7 +142,9 @@ struct TileEpilogue {
   }
 
   // one 32 x 32 accumulator block (block xb of this wave's rows); r1 / r2 collect the lane's per-channel sums
-  template <bool PRE = false>
+  // POOLT: the kernel instantiation that carries the VITTA_CONV_POOL sums (conv_b3.hip compiles one for the launches that pool:
+  // with the code behind a run-time flag in every instantiation all 156 launches of a step ran 2 % slower, measured)
+  template <bool PRE = false, bool POOLT = false>
   __device__ __forceinline__ void body(int L, int xb, const f32x16& acc, float& r1, float& r2, float4 p0 = float4{}, float4 p1 = float4{},
                                        float4 p2 = float4{}, float4 p3 = float4{}) {
     const int flags = d.flags;
@@ -153,10 +157,10 @@ struct TileEpilogue {
     const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
     const bool BRELU = flags & VITTA_CONV_BWD_RELU;
     const bool IRAW = (flags & VITTA_CONV_INJ_RAW) && d.inj_mu;
-    const bool POOL = (flags & VITTA_CONV_POOL) && d.pool;
+    const bool POOL = POOLT && (flags & VITTA_CONV_POOL) && d.pool;
     const int HWy = d.Hy * d.Wy;
     const int k = k0 + wn * 32 + li;
-    PoolSums pool(a, m0 + wm * (BM >> 1) + 32 * xb);
+    PoolSums pool(a, m0 + wm * (BM >> 1) + 32 * xb, POOL);
     float es = 1.f, et = 0.f, sh = c_sh, bsc = 0.f, bt = 0.f, brm = 0.f, brs = 0.f, ia = 0.f, ib = 0.f;
     if (BWD) {
       brs = rsqrtf(c_var + d.bwd_eps);

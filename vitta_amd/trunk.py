@@ -547,7 +547,8 @@ class TrunkRunner:
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
         pooled, ptc = None, 0
-        if self._pool is not None and h * w >= 32:  # this block's [frames, p] piece of the pass's zeroed pooling buffer
+        if self._pool is not None and h * w >= 32 and CV.ARITH == "b3":  # this block's [frames, p] piece of the pass's zeroed pooling
+            # buffer (the exact-fp32 kernels keep the pooling launch: only their tile kernel carries the epilogue)
             buf, off = self._pool
             pooled, ptc = buf[off:off + n * p].view(nb, t, p), 1
             self._pool[1] = off + n * p
