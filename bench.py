@@ -351,7 +351,10 @@ def run_gpu(opt, rank, world, device):
                 r[3] += key[4]
                 r[4] += tr
             names = {0: "conv_igemm (fp32)", 1: "conv_sk (fp32)", 2: "conv_pw (fp32)", 3: "conv_b3 (split bf16)", None: "?"}
+            pooled = np.array([bool(key[5]) if len(key) > 5 else False for _, key, _ in conv_events])  # launches that also pool (VITTA_CONV_POOL)
             run_gpu.conv = dict(launches=len(fl), steps=n_rep, flops=float(fl.sum()), ms=float(ms.sum()),
+                                pooled_launches=int(pooled.sum()), plain_flops=float(fl[~pooled].sum()), plain_ms=float(ms[~pooled].sum()),
+                                plain_ms_at_peak=float((fl / (peak * 1e9))[~pooled].sum()),
                                 ms_at_peak=float((fl / (peak * 1e9)).sum()), b3_launches=int(b3.sum()), b3_flops=float(fl[b3].sum()),
                                 bytes=float(by.sum()), ms_at_roof=float(t_roof.sum()),
                                 hbm_bound_launches=int((by / (HBM_PEAK_GBS * 1e6) > fl / (peak * 1e9)).sum()),
@@ -737,6 +740,11 @@ def main():
                         "kernel_ms_per_step": conv["ms"] / conv["steps"],
                         "share_of_step": conv["ms"] / conv["steps"] / (1e3 * elapsed / opt.steps),
                         "pooled_means_in_epilogue": bool(_trunk_pool_fold()),
+                        # the same two fractions over the launches that are convolutions only (the conv1 launches that also pool left out)
+                        "pooling_launches_per_step": conv["pooled_launches"] / conv["steps"],
+                        "frac_plain_launches": (conv["plain_ms_at_peak"] / conv["plain_ms"]) if conv["plain_ms"] > 0 else None,
+                        "frac_of_fp32_matrix_peak_plain_launches": (conv["plain_flops"] / conv["plain_ms"] / 1e9 / MFMA_F32_PEAK_TF)
+                        if conv["plain_ms"] > 0 else None,
                         "note": ("the conv1 launches of the bottlenecks (32 per step) also carry TAM's spatial average pooling "
                                  "(VITTA_CONV_POOL, +1.5-3 us each in place of 32 pooling launches: the family's time, hence frac, "
                                  "includes it; VITTA_TRUNK_POOL_FOLD=0 measures 0.015 higher on the same box).  "
