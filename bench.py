@@ -263,12 +263,23 @@ def run_gpu(opt, rank, world, device):
     if use_graph:
         x, _ = tta_set[0]
         ev, _ = eval_set[0]
-        adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
-                               segmented=opt.segmented_graph and not opt.graph_collectives, overlap_eval=not opt.sequential,
-                               collectives_in_graph=True if opt.graph_collectives else (False if opt.segmented_graph else None))
-        one_step(opt.warmup)  # first replay outside the timed region
-        torch.cuda.synchronize()
-        log("hipGraphs captured")
+        try:
+            adapter.capture_graphs(adapter.shape_tta_input(x.unsqueeze(0)), adapter.shape_eval_input(ev.unsqueeze(0)),
+                                   segmented=opt.segmented_graph and not opt.graph_collectives, overlap_eval=not opt.sequential,
+                                   collectives_in_graph=True if opt.graph_collectives else (False if opt.segmented_graph else None))
+            one_step(opt.warmup)  # first replay outside the timed region
+            torch.cuda.synchronize()
+            log("hipGraphs captured")
+        except Exception as e:  # noqa: BLE001
+            if world == 1 and not opt.force_exchanges:
+                raise
+            # data-parallel: a rank whose capture failed goes on eagerly -- the exchanges of the segmented form are eager launches in
+            # the same order either way, so the ranks' collective sequences still match; the line says what ran
+            log(f"graph capture failed on rank {rank} ({e!r}): this rank runs the timed steps eagerly")
+            adapter._abandon_step()
+            torch.cuda.synchronize()
+            use_graph = False
+            run_gpu.capture_error = repr(e)[:200]
     log("warm-up done")
     if not use_graph:
         adapter.engine.timing_events = new_events
@@ -595,7 +606,39 @@ def launch_ranks(opt):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log(f"--gpus {opt.gpus} without a launcher: starting {opt.gpus} ranks: {' '.join(cmd[1:9])} ...")
-    return subprocess.call(cmd, env=env)
+
+    def attempt(extra_env, extra_args):
+        """One launch of the N ranks; returns (exit code, rank 0's JSON line or None).  stderr passes through."""
+        p = subprocess.run(cmd + extra_args, env=dict(env, **extra_env), stdout=subprocess.PIPE)
+        line = None
+        for ln in p.stdout.decode(errors="replace").splitlines():
+            ln = ln.strip()
+            if ln.startswith("{") and ln.endswith("}"):
+                try:
+                    json.loads(ln)
+                    line = ln
+                except ValueError:
+                    pass
+        return p.returncode, line
+
+    # The first multi-GPU contact must not come back empty: a rank that dies (e.g. the process-group watchdog aborting the
+    # process, which no `except` in the rank can catch) costs this attempt only.  Fallbacks, each said in the line's `dp_graph`:
+    # (1) as asked; (2) collectives outside every capture (three graph segments); (3) eager launches.
+    ladder = [({}, []),
+              ({"VITTA_GRAPH_COLLECTIVES": "0", "VITTA_BENCH_NOTE": "segments forced after a failed attempt (rc={rc})"}, ["--segmented-graph"]),
+              ({"VITTA_GRAPH_COLLECTIVES": "0", "VITTA_BENCH_NOTE": "eager launches after two failed attempts (rc={rc})"}, ["--no-graph"])]
+    rc = 0
+    for k, (e, extra) in enumerate(ladder):
+        if opt.graph_collectives and "--segmented-graph" in extra:
+            extra = [x for x in extra if x != "--segmented-graph"]
+        e = {kk: vv.format(rc=rc) for kk, vv in e.items()}
+        rc, line = attempt(e, extra)
+        if rc == 0 and line is not None:
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+            return 0
+        log(f"attempt {k + 1} of {len(ladder)} gave rc={rc}, line={'yes' if line else 'none'}" + ("; retrying" if k + 1 < len(ladder) else ""))
+    return rc or 1
 
 
 def rank_report(rank, local, device):
@@ -686,6 +729,10 @@ def main():
     # what every rank saw (the driver can verify N ranks on N devices)
     ranks = rank_report(rank, local, device)
     dp_graph = getattr(adapter, "dp_graph", "eager") if "hipGraph" in mode else "eager"
+    if getattr(run_gpu, "capture_error", None):
+        dp_graph += f" (capture failed on this rank: {run_gpu.capture_error})"
+    if os.environ.get("VITTA_BENCH_NOTE"):
+        dp_graph += f" ({os.environ['VITTA_BENCH_NOTE']})"
 
     if opt.arch == "swin":
         algo_bytes = 4.0 * sum(o * c * i for o, c, i, _ in adapter.engine.plan.shapes)  # 253.7 MB at 2x16x224^2

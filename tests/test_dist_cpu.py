@@ -266,16 +266,21 @@ def test_swin_bucket_plan_partitions_the_arena_at_block_boundaries():
     first_of_stage = {0, 3, 6, 25}  # blocks 2, 2, 18, 2 with a PatchMerging after each of the first three stages
     for i, (m, rel) in enumerate(units):
         assert rel == (i if (i in first_of_stage or isinstance(m, PatchMerging)) else i - 1), (i, rel)
-    plan = ad.bucket_plan()
     n = ad.arena.grad.numel()
-    pieces = sorted([(lo, hi) for _, lo, hi in plan["buckets"]] + [r for r in plan["rest"] if r[1] > r[0]])
-    assert pieces[0][0] == 0 and pieces[-1][1] == n and all(pieces[i][1] == pieces[i + 1][0] for i in range(len(pieces) - 1))
+    plan = None
+    for nb in (8, 12, 16, 4):  # (8, 12 and 16 cuts used to give two buckets one signal: the armed table dropped one of them)
+        ad.grad_buckets, ad._bucket_plan = nb, None
+        plan = ad.bucket_plan()
+        pieces = sorted([(lo, hi) for _, lo, hi in plan["buckets"]] + [r for r in plan["rest"] if r[1] > r[0]])
+        assert pieces[0][0] == 0 and pieces[-1][1] == n and all(pieces[i][1] == pieces[i + 1][0] for i in range(len(pieces) - 1))
+        assert 2 <= len(plan["buckets"]) <= nb + 1
+        los = [lo for _, lo, _ in plan["buckets"]]
+        sigs = [sig for sig, _, _ in plan["buckets"]]
+        # launch order = backward order, and NO two buckets share a release signal (the armed table is keyed by it)
+        assert los == sorted(los, reverse=True) and all(sigs[i] > sigs[i + 1] for i in range(len(sigs) - 1)), (nb, sigs)
+        for sig, lo, hi in plan["buckets"]:  # the signal's unit starts at or before the bucket's first parameter
+            assert ad.arena.span(list(units[sig][0].parameters()))[0] <= lo
     assert 2 <= len(plan["buckets"]) <= 5
-    los = [lo for _, lo, _ in plan["buckets"]]
-    sigs = [sig for sig, _, _ in plan["buckets"]]
-    assert los == sorted(los, reverse=True) and sigs == sorted(sigs, reverse=True)  # launch order = backward order
-    for sig, lo, hi in plan["buckets"]:  # the signal's unit starts at or before the bucket's first parameter
-        assert ad.arena.span(list(units[sig][0].parameters()))[0] <= lo
     assert ad.bucket_plan() is plan
     # the TANet plan comes from structure too: a rank that never ran the trunk holds it
     t = A(tta.SingleDeviceParallel(H.build_tanet(11, 8, 0)), H.tanet_args("/tmp", update_only_bn_affine=False))

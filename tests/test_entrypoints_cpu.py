@@ -276,3 +276,34 @@ def test_bench_gpus_n_starts_n_ranks_that_rendezvous():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_retries_a_failed_attempt_and_says_so(monkeypatch, capsys):
+    """launch_ranks: when the ranks die (exit code != 0) or print no line, the launch is repeated -- first with the collectives
+    outside every capture, then with eager launches -- and the line of the attempt that worked is handed through; the fallback is
+    named in the environment the ranks report from (`dp_graph`)."""
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    calls = []
+
+    def fake_run(cmd, env=None, stdout=None, **kw):
+        calls.append((cmd, env))
+        if len(calls) == 1:
+            return types.SimpleNamespace(returncode=134, stdout=b"")  # the watchdog's abort: no line
+        if len(calls) == 2:
+            return types.SimpleNamespace(returncode=0, stdout=b"NCCL version banner\n")  # rc 0 but no line
+        return types.SimpleNamespace(returncode=0, stdout=b'banner\n{"metric": "m", "n_gpus": 2}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    opt = types.SimpleNamespace(gpus=2, graph_collectives=False)
+    assert bench.launch_ranks(opt) == 0
+    assert len(calls) == 3
+    assert "VITTA_BENCH_NOTE" not in calls[0][1] and "--segmented-graph" in calls[1][0] and "--no-graph" in calls[2][0]
+    assert calls[1][1]["VITTA_GRAPH_COLLECTIVES"] == "0" and "rc=134" in calls[1][1]["VITTA_BENCH_NOTE"]
+    assert "eager" in calls[2][1]["VITTA_BENCH_NOTE"]
+    assert capsys.readouterr().out.strip() == '{"metric": "m", "n_gpus": 2}'

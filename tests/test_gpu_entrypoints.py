@@ -247,16 +247,17 @@ def test_rccl_exchanges_between_graph_segments_with_a_one_rank_group():
 
 
 def test_rccl_exchanges_captured_inside_one_graph_with_a_one_rank_group():
-    """bench.py --force-exchanges (the data-parallel DEFAULT over RCCL since round 3): the same step with both all-reduces
-    CAPTURED in the step's single hipGraph (no host round trip between segments); and under SGD over all parameters, with
-    the gradient arena's buckets reduced from inside the captured backward."""
+    """bench.py --force-exchanges --graph-collectives (opt-in since round 5: the default keeps collectives outside captures until
+    an N > 1 RCCL run has passed with them inside): the same step with both all-reduces CAPTURED in the step's single hipGraph
+    (no host round trip between segments); and under SGD over all parameters, with the gradient arena's buckets reduced from
+    inside the captured backward.  Without the flag the same command runs the three-segment form."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
     for extra in ([], ["--optimizer", "sgd_all"]):
-        cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "8", "--warmup", "4",
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--graph-collectives", "--steps", "8", "--warmup", "4",
                "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--no-swin", "--size", "112"] + extra
         out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
@@ -264,6 +265,34 @@ def test_rccl_exchanges_captured_inside_one_graph_with_a_one_rank_group():
         assert len(lines) == 1, lines
         rec = json.loads(lines[0])
         assert "one graph" in rec["launch_mode"] and "all-reduce" in rec["config"]["exchanges"] and rec["value"] > 0, rec["launch_mode"]
+        assert rec["dp_graph"] == "one"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-exchanges", "--steps", "6", "--warmup", "4",
+           "--no-cpu-baseline", "--no-streaming", "--no-sgd-all", "--no-swin", "--size", "112"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["dp_graph"] == "segments" and "3 segments" in rec["launch_mode"]
+
+
+def test_bench_gpus_2_end_to_end_without_a_launcher_on_one_gpu():
+    """`python bench.py --gpus 2 --steps 3` exactly as typed on a node (no launcher around it): bench.py starts its two ranks
+    itself, they run the data-parallel step (gloo here: both ranks share the one GPU of the test box, RCCL refuses duplicate
+    devices) and rank 0's single line reports the gathered world."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "3", "--warmup", "4",
+           "--no-cpu-baseline", "--no-streaming", "--size", "112"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and len(rec["ranks"]) == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["dp_graph"] == "segments" and rec["config"]["parallelism"] == "dp2"
 
 
 def test_bucketed_exchange_from_inside_the_backward_equals_the_monolithic_one_on_gpu(tmp_path, monkeypatch):

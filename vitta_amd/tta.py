@@ -623,7 +623,13 @@ class ViTTAAdapter:
         for i in range(len(units) - 1, -1, -1):  # walk the units the way the backward does
             acc += spans[i][1] - spans[i][0]
             if acc >= total / self.grad_buckets or i == 0:
-                plan.append((units[i][1], spans[i][0], hi))
+                if plan and plan[-1][0] == units[i][1]:
+                    # two cuts released by the SAME signal (a stage's second block leaves with its first block's signal) are
+                    # one bucket: the armed table is keyed by signal, a second entry would overwrite the first and that range
+                    # would never be reduced on an armed step -- while an un-armed rank still reduced it
+                    plan[-1] = (plan[-1][0], spans[i][0], plan[-1][2])
+                else:
+                    plan.append((units[i][1], spans[i][0], hi))
                 hi, acc = spans[i][0], 0
         n = self.arena.grad.numel()
         self._bucket_plan = dict(buckets=plan, rest=[(0, spans[0][0]), (spans[-1][1], n)], blocks=[m for m, _ in units])
@@ -793,18 +799,17 @@ class ViTTAAdapter:
         if self.engine.plan is None:
             raise RuntimeError("run at least one eager step before capturing")
         if collectives_in_graph is None:
-            # data-parallel over RCCL: ONE graph with both all-reduces (and the bucketed gradient exchange inside the
-            # backward) captured -- no host round trip between segments; gloo (host collectives) and
-            # VITTA_GRAPH_COLLECTIVES=0 keep three segments with the exchanges launched eagerly between them
+            # Default: three segments with the two exchanges launched eagerly between them -- no collective inside a capture.
+            # ONE graph with both all-reduces (and the bucketed gradient exchange inside the backward) captured measured the
+            # same on a one-rank RCCL group (173.2 vs 174.1 videos/s) and has a failure mode no `except` can catch: torch's
+            # process-group watchdog polls the end events of the eager collectives it still lists, and an event query on a
+            # stream that is capturing is hipErrorCapturedEvent, which takes the PROCESS down (seen in about one run of four
+            # before the quiesce below).  Until an N > 1 RCCL run has passed with it, the one-graph form is opt-in:
+            # VITTA_GRAPH_COLLECTIVES=1 / bench.py --graph-collectives.
             collectives_in_graph = (self.bucket is not None and not segmented and torch.distributed.is_initialized()
-                                    and torch.distributed.get_backend() == "nccl" and os.environ.get("VITTA_GRAPH_COLLECTIVES", "1") != "0")
+                                    and torch.distributed.get_backend() == "nccl" and os.environ.get("VITTA_GRAPH_COLLECTIVES", "0") == "1")
         if collectives_in_graph:
-            # The collectives' own stream joins the capture.  torch's process-group watchdog polls the end events of the EAGER
-            # collectives it still lists (every 100 ms); an event query on a stream that is capturing at that moment is
-            # hipErrorCapturedEvent and the watchdog thread takes the process down (seen in about one run of four).  Let it
-            # retire what the eager steps left before the capture starts.
-            torch.cuda.synchronize()
-            time.sleep(0.35)
+            self._quiesce_collectives()
             try:
                 self._capture(tta_input, eval_input, segmented, overlap_eval, True)
                 self.dp_graph = "one"
@@ -815,6 +820,18 @@ class ViTTAAdapter:
                 torch.cuda.synchronize()
         self._capture(tta_input, eval_input, segmented, overlap_eval, False)
         self.dp_graph = "segments" if "seg_fwd" in self._graph else "one"
+
+    def _quiesce_collectives(self):
+        """Before a capture that the collectives' own stream joins: nothing of the eager steps may still be listed by the
+        process group's watchdog.  Every pending Work of the arena is waited for, the device drained, the ranks meet (so no
+        peer is still issuing eager collectives into a communicator whose stream is about to capture), and the watchdog is
+        given three of its 100 ms polling periods to retire the completed entries (it exposes no "list empty" query)."""
+        self.arena.wait_pending()
+        torch.cuda.synchronize()
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+        time.sleep(0.35)
 
     def _abandon_step(self):
         """Forget everything a step that did not finish (a capture that raised inside the backward) left armed or pending:
