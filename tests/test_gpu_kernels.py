@@ -874,7 +874,8 @@ def test_fused_stem_pool_matches_torch(shape):
     assert (bg.grad.cpu().double() + 0.25 - bd.grad).abs().max().item() <= 1e-4 * bd.grad.abs().max().item() + 1e-5
 
 
-@pytest.mark.parametrize("c,t,n", [(64, 8, 2), (128, 8, 1), (256, 8, 2), (512, 8, 2), (512, 8, 3), (256, 16, 1)])
+@pytest.mark.parametrize("c,t,n", [(64, 8, 2), (128, 8, 1), (256, 8, 2), (512, 8, 2), (512, 8, 3), (256, 16, 1), (96, 8, 2), (512, 16, 1),
+                                   (320, 4, 2)])
 def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
     """vitta_tam_branch_{fwd,bwd}_fused_f32 (F1 -> F2 / B1 -> B2 inside one launch, the clip's workgroups meeting on a
     device-scope counter) against the two-launch entry points: identical outputs (the arithmetic is the same code; only
@@ -916,10 +917,19 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
         torch.cuda.synchronize()
         return kern, gate, hpre, gbuf[:n * c * t].clone(), dbn, dw
 
+    # round 5: shapes with C % 64 == 0, C <= 512, T % 4 == 0, C * T <= 4096 take the one-batch kernels (every operand of a workgroup
+    # requested at once; a growing arrival counter + a generation word in the SECOND half of the meeting buffer instead of the
+    # zero-at-rest pair); (96, 8), (512, 16) stay on the first fused kernels
+    fast = c % 64 == 0 and c <= 512 and t % 4 == 0 and c * t <= 4096
     ref = run(False)
     for rep in range(3):
         got = run(True)
-        assert int(sync.abs().sum()) == 0, "meeting counters must be zero at rest"
+        assert int(sync[:128].abs().sum()) == 0, "meeting counters must be zero at rest"
+        words = sync[128:128 + 2 * n].view(n, 2).cpu()
+        if fast:  # arrivals == base at rest == the workgroups of a clip over all launches so far (forward C / 8, backward C / 16)
+            assert (words[:, 1] == words[:, 0]).all() and (words[:, 0] == (rep + 1) * (c // 8 + c // 16)).all(), words
+        else:
+            assert int(words.abs().sum()) == 0
         for a, b in zip(got[:4], ref[:4]):
             assert torch.equal(a, b), rep
         for a, b in zip(got[4] + got[5], ref[4] + ref[5]):
@@ -930,3 +940,61 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
             assert torch.equal(a, b), ("frame-major pooled", fused)
         for a, b in zip(got[4] + got[5], ref[4] + ref[5]):
             assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-7
+
+
+def test_tam_branch_launches_of_different_grids_share_one_meeting_buffer():
+    """The trunk issues the fused branch launches of its sixteen blocks back to back on one stream: 64 -> 128 -> 256 -> 512 channels
+    forward, the reverse order backward, all with the SAME per-stream meeting buffer.  The one-batch kernels wait for
+    `arrivals so far + workgroups of THIS launch` (a growing counter, never reset): launches with different grids must not read each
+    other's arrival counts (round 5's first form counted generations x workgroups and dead-locked at the first change of grid).
+    Outputs equal the two-launch entry points bit for bit at every stage."""
+    from vitta_amd import _lib
+    from vitta_amd.ops import _p, _ptr4, _stream
+    L = _lib.lib()
+    d = _dev()
+    g = torch.Generator().manual_seed(11)
+    n, t = 2, 8
+    r = lambda *s: torch.randn(*s, generator=g).to(d)
+    sync = torch.zeros(256, dtype=torch.int32, device=d)
+    stages = []
+    for c in (64, 128, 256, 512, 256, 64):
+        o = c // 4
+        pooled = torch.round(r(n, c, t) * 4096) / 4096
+        st = dict(c=c, o=o, pooled=pooled, wg1=r(2 * t, t) * 0.3, wg3=r(3, 2 * t) * 0.3, w0=r(o, c, 3) * (3 * c) ** -0.5, w3=r(c, o) * o ** -0.5,
+                  bng=[torch.rand(2 * t, generator=g).to(d) + 0.5, r(2 * t) * 0.1, r(2 * t) * 0.1, torch.rand(2 * t, generator=g).to(d) + 0.5],
+                  bnl=[torch.rand(o, generator=g).to(d) + 0.5, r(o) * 0.1, r(o) * 0.1, torch.rand(o, generator=g).to(d) + 0.5],
+                  gkern=r(n * c, 3), ggate=r(n, c, t))
+        stages.append(st)
+
+    def run(fused):
+        outs = []
+        for st in stages:  # forward chain
+            c, o = st["c"], st["o"]
+            st["kern"], st["gate"], st["hpre"] = torch.empty(n * c, 3, device=d), torch.empty(n, c, t, device=d), torch.empty(2, n, o, t, device=d)
+            args = (_p(st["pooled"]), _p(st["wg1"]), _ptr4(*st["bng"]), 1e-5, _p(st["wg3"]), _p(st["w0"]), _ptr4(*st["bnl"]), 1e-5, _p(st["w3"]), n, c, t)
+            if fused:
+                _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(st["kern"]), _p(st["gate"]), _p(st["hpre"]), _p(sync), 0, _stream()), "fwd fused")
+            else:
+                _lib.check(L.vitta_tam_branch_fwd_f32(*args, _p(st["kern"]), _p(st["gate"]), _p(st["hpre"]), 0, _stream()), "fwd")
+        for st in reversed(stages):  # backward chain
+            c, o = st["c"], st["o"]
+            gbuf = torch.empty(n * c * t + n * o * t, device=d)
+            dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
+            args = (_p(st["pooled"]), _p(st["wg1"]), _ptr4(*st["bng"]), 1e-5, _p(st["wg3"]), _p(st["w0"]), _ptr4(*st["bnl"]), 1e-5, _p(st["w3"]), n, c, t)
+            bargs = args + (n, _p(st["kern"]), _p(st["gate"]), _p(st["hpre"]), _p(st["gkern"]), _p(st["ggate"]), _p(gbuf), _ptr4(*dbn), None)
+            if fused:
+                _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), 0, _stream()), "bwd fused")
+            else:
+                _lib.check(L.vitta_tam_branch_bwd_f32(*bargs, 0, _stream()), "bwd")
+            outs.append((st["kern"].clone(), st["gate"].clone(), gbuf[:n * c * t].clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    ref = run(False)
+    for rep in range(2):
+        got = run(True)
+        for a, b in zip(got, ref):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y), rep
+    words = sync[128:128 + 2 * n].view(n, 2).cpu()
+    assert (words[:, 0] == words[:, 1]).all() and int(words[0, 0]) == 2 * sum(st["c"] // 8 + st["c"] // 16 for st in stages)

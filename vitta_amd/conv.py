@@ -201,16 +201,38 @@ class Geometry:
 
 WORKSPACE_BYTES = 48 << 20
 _workspaces = {}
+_spares = {}
+
+
+def zeroed_per_stream(table, device, nbytes, spares=2):
+    """A zero-filled uint8 buffer that belongs to the CURRENT stream (`table`: {(device index, stream): buffer}); its users
+    leave it zero at rest, so it is filled exactly once -- and never inside a hipGraph capture: torch.cuda.graph captures on a
+    stream of its own, and a buffer first touched there would have its zero fill RECORDED and replayed with every step (round 5
+    found the 48 MB fill of the split-K workspace, 9.4 us, and the fill of the TAM meeting counters, 5.9 us, in the replayed
+    adaptation chain).  A few zeroed spares are therefore made eagerly with the first buffer and handed to streams that show up
+    while capturing."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = table.get(key)
+    if buf is not None:
+        return buf
+    pool = _spares.setdefault((id(table), device.index, nbytes), [])
+    if torch.cuda.is_current_stream_capturing():
+        if not pool:
+            raise RuntimeError("vitta_amd: a per-stream zeroed buffer was first requested inside a graph capture with no spare left; "
+                               "run one eager step before capturing")
+        buf = pool.pop()
+    else:
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        while len(pool) < spares:
+            pool.append(torch.zeros(nbytes, dtype=torch.uint8, device=device))
+    table[key] = buf
+    return buf
 
 
 def workspace(device):
     """The split-K workspace of the CURRENT stream (zero-filled once; the kernels leave their counters at zero).  One
     per stream: launches on different streams may overlap and must not share slabs."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
-    if ws is None:
-        ws = _workspaces[key] = torch.zeros(WORKSPACE_BYTES, dtype=torch.uint8, device=device)
-    return ws
+    return zeroed_per_stream(_workspaces, device, WORKSPACE_BYTES)
 
 
 def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,

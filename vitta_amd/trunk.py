@@ -102,11 +102,7 @@ _sync_bufs = {}
 def _sync(device):
     """Meeting counters of the fused TAM branch launches on the CURRENT stream (zero at rest; one buffer per stream: launches
     on different streams may overlap)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _sync_bufs.get(key)
-    if buf is None:
-        buf = _sync_bufs[key] = torch.zeros(256, dtype=torch.int32, device=device)
-    return buf
+    return CV.zeroed_per_stream(_sync_bufs, device, 1024, spares=4)  # (never zero-filled inside a graph capture)
 
 
 def _bn_ptrs(bn):
