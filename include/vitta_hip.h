@@ -729,6 +729,31 @@ int vitta_linear_fwd_f32(const float* d_x, const float* d_w, const float* d_b, i
 int vitta_linear_bwd_f32(const float* d_dy, const float* d_x, const float* d_w, int64_t M, int32_t N, int32_t K, float* d_dx,
                          float* d_dw, float* d_db, void* stream);
 
+/* The head of the ADAPTATION pass as two launches (round 5): segment consensus, view logits, prediction consistency and the
+ * video logits in one forward launch; their whole backward down to the gradient of the pooled features in one more.
+ * Replaces, at the reference's call sites, dropout's consumer chain `new_fc -> consensus -> compute_pred_consis -> mean(1)`
+ * (models/tanet_models/tanet.py:243-251, corpus/basics.py:640-668, utils/pred_consistency_utils.py:15-31).
+ *   d_y [B V T][D]: per-frame features AFTER dropout, row (b V + v) T + t; d_w [K][D], d_b [K] (or NULL): new_fc.
+ *   forward : d_ybar [B V][D] (or NULL) = mean over the T segments; d_view_logits [B V][K] = ybar w^T + b (scratch the last
+ *             workgroup re-reads: written through); d_out [B][K] = mean over the views; d_loss [1] = compute_pred_consis summed
+ *             over the videos; d_gradc [B V][K] = d loss / d view logits.  d_ticket: 4 bytes, zero at rest (left zero).
+ *   backward: dl = g_loss[0] * gradc + g_out[b] / V (d_g_loss, d_g_out device pointers or NULL = 0);
+ *             d_dfeat [B V T][D] = (dl w)[b v] * scale, zeroed where d_mask (dropout's keep mask, one byte per element, or NULL)
+ *             is 0 -- scale = 1 / (T (1 - p)); trainable head: d_dw [K][D] / d_db [K] ACCUMULATED (needs d_ybar and the
+ *             scratch d_dl [B V][K]); NULL: skipped.
+ * Supported: D % 4 == 0, B V <= 8, vitta_tanet_head_lds_bytes(...) <= 128 KB. */
+size_t vitta_tanet_head_lds_bytes(int32_t B, int32_t V, int32_t K, int32_t D);
+int vitta_tanet_head_fwd_f32(const float* d_y, const float* d_w, const float* d_b, int32_t B, int32_t V, int32_t T, int32_t K, int32_t D,
+                             float* d_ybar, float* d_view_logits, void* d_ticket, float* d_out, float* d_loss, float* d_gradc,
+                             void* stream);
+int vitta_tanet_head_bwd_f32(const float* d_gradc, const float* d_g_loss, const float* d_g_out, const float* d_w, const void* d_mask,
+                             float scale, int32_t B, int32_t V, int32_t T, int32_t K, int32_t D, float* d_dfeat, const float* d_ybar,
+                             float* d_dl, float* d_dw, float* d_db, void* stream);
+/* total loss of a step, corpus/basics.py:668: d_out[0] = la * d_a[0] + lb * d_b[0] (d_b NULL: 0); its backward in one launch:
+ * d_ga[0] = la * g, d_gb[0] = lb * g (d_g NULL: g = 1; d_gb NULL: skipped). */
+int vitta_loss_axpby_f32(const float* d_a, const float* d_b, float la, float lb, float* d_out, void* stream);
+int vitta_loss_axpby_bwd_f32(const float* d_g, float la, float lb, float* d_ga, float* d_gb, void* stream);
+
 /* --------------------------------------------------------------------------
  * A10 -- dense layers of Video Swin-B: d_y[m][n] = epi(sum_k d_a[m][k] d_b[n][k]), all row-major fp32, K % 32 == 0
  * (the qkv / proj Linear of WindowAttention3D, models/videoswintransformer_models/swin_transformer.py:144, 165;

@@ -219,3 +219,83 @@ def test_source_statistics_producer_runs_on_the_trunk_node(before_norm, dead_gam
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item() + 1e-6
     for a, b in zip(res[True][1], res[False][1]):
         assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("b,v,t,k,d,p", [(1, 2, 8, 101, 2048, 0.8), (2, 2, 8, 400, 2048, 0.5), (1, 2, 16, 174, 2048, 0.0), (3, 1, 4, 11, 512, 0.3),
+                                         (2, 4, 8, 101, 2048, 0.8)])
+def test_fused_head_equals_the_module_chain_in_fp64(b, v, t, k, d, p):
+    """ops.TanetHead (dropout -> new_fc -> segment consensus -> compute_pred_consis -> mean over the views: ONE launch behind ATen's
+    dropout forward, ONE backward) against the reference's chain in fp64 on the same dropout mask (same seed, same draw):
+    video logits, consistency loss, and the gradients w.r.t. the pooled features, the head's weight and bias -- with upstream
+    gradients on BOTH outputs.  models/tanet_models/tanet.py:243-251, utils/pred_consistency_utils.py:15-31."""
+    from oracle import vitta_oracle as O
+    from vitta_amd import ops
+    dev = _dev()
+    feat = (H.seeded_randn((b * v * t, d), 3) * 0.5 + 0.2).to(dev).requires_grad_(True)
+    w = (H.seeded_randn((k, d), 4) * 0.05).to(dev).requires_grad_(True)
+    bias = (H.seeded_randn((k,), 5) * 0.1).to(dev).requires_grad_(True)
+    gout = H.seeded_randn((b, k), 6).to(dev)
+    gl = 0.7
+    torch.manual_seed(1234)
+    out, loss = ops.TanetHead.apply(feat, w, bias, p, True, t, v)
+    (gl * loss + (out * gout).sum()).backward()
+    got = [out.detach().cpu().double(), float(loss.detach()), feat.grad.cpu().double(), w.grad.cpu().double(), bias.grad.cpu().double()]
+    torch.manual_seed(1234)
+    if p > 0:
+        _, mask = torch.native_dropout(feat.detach(), p, True)
+    else:
+        mask = torch.ones_like(feat, dtype=torch.bool)
+    f64 = feat.detach().cpu().double().requires_grad_(True)
+    w64, b64 = w.detach().cpu().double().requires_grad_(True), bias.detach().cpu().double().requires_grad_(True)
+    y = f64 * mask.cpu().double() / (1.0 - p)
+    lv = (y @ w64.t() + b64).view(b * v, t, k).mean(1).view(b, v, k)
+    loss_ref = O.compute_pred_consis(lv)
+    out_ref = lv.mean(1)
+    (gl * loss_ref + (out_ref * gout.cpu().double()).sum()).backward()
+    ref = [out_ref.detach(), float(loss_ref), f64.grad, w64.grad, b64.grad]
+    assert (got[0] - ref[0]).abs().max().item() <= 1e-5 * ref[0].abs().max().item() + 1e-6
+    assert abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-7
+    for a, r, name in zip(got[2:], ref[2:], ("d feat", "d weight", "d bias")):
+        assert (a - r).abs().max().item() <= 2e-5 * r.abs().max().item() + 1e-8, (name, (a - r).abs().max().item(), r.abs().max().item())
+    # a loss-only backward (what the adaptation step does: the video logits are only logged) and the frozen head of affine mode
+    feat2 = feat.detach().clone().requires_grad_(True)
+    torch.manual_seed(1234)
+    out2, loss2 = ops.TanetHead.apply(feat2, w.detach(), bias.detach(), p, True, t, v)
+    loss2.backward()
+    f3 = feat.detach().cpu().double().requires_grad_(True)
+    y3 = f3 * mask.cpu().double() / (1.0 - p)
+    O.compute_pred_consis((y3 @ w64.detach().t() + b64.detach()).view(b * v, t, k).mean(1).view(b, v, k)).backward()
+    assert (feat2.grad.cpu().double() - f3.grad).abs().max().item() <= 2e-5 * f3.grad.abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("mode,over", [("adam", {}), ("sgd", {}), ("adam", dict(if_pred_consistency=False))])
+def test_adapt_step_with_the_fused_head_equals_the_module_chain(tmp_path, mode, over, abi_calls, monkeypatch):
+    """One adaptation step with the stock head (nn.Dropout, p = 0 so both arms see the same forward) through ops.TanetHead /
+    ops.WeightedLoss against the module chain (VITTA_FUSED_HEAD=0: Linear over the frames, consensus, PredConsis, ATen's loss
+    arithmetic): losses and every gradient."""
+    from vitta_amd import tta
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(tta, "FUSED_HEAD", fused)
+        (tmp_path / str(fused)).mkdir()
+        adapter, T = _adapter(tmp_path / str(fused), 64, True, mode=mode, **over)
+        adapter.model.module.base_model.fc = nn.Dropout(p=0.0)
+        x = H.seeded_randn((1, 2 * T * 3, 64, 64), 7).to(_dev())
+        adapter.set_adapt_mode()
+        calls0 = dict(abi_calls.abi)
+        out, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+        ran = abi_calls.abi.get("vitta_tanet_head_fwd_f32", 0) > calls0.get("vitta_tanet_head_fwd_f32", 0)
+        assert ran == fused
+        grads = {k: v.grad.detach().clone() for k, v in adapter.model.named_parameters() if v.requires_grad and v.grad is not None}
+        res[fused] = (out.clone(), float(loss_reg), None if loss_consis is None else float(loss_consis), grads)
+    a, b = res[True], res[False]
+    assert (a[0] - b[0]).abs().max().item() <= 1e-5 * b[0].abs().max().item() + 1e-6
+    assert abs(a[1] - b[1]) <= 1e-6 * abs(b[1]) + 1e-8
+    if b[2] is not None:
+        assert abs(a[2] - b[2]) <= 1e-5 * abs(b[2]) + 1e-8
+    assert set(a[3]) == set(b[3])
+    va = torch.cat([a[3][k].flatten() for k in b[3]])
+    vb = torch.cat([b[3][k].flatten() for k in b[3]])
+    assert float(torch.dot(va, vb) / (va.norm() * vb.norm())) >= 0.99999
+    for k, gb in b[3].items():
+        assert (a[3][k] - gb).norm().item() <= 1e-3 * gb.norm().item() + 1e-7 * max(1.0, float(gb.numel()) ** 0.5), k

@@ -155,6 +155,11 @@ SIGNATURES = {
     "vitta_stem_bn_relu_pool_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p, _p]),
     "vitta_linear_fwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "vitta_linear_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
+    "vitta_tanet_head_lds_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "vitta_tanet_head_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "vitta_tanet_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "vitta_loss_axpby_f32": (C.c_int, [_p, _p, C.c_float, C.c_float, _p, _p]),
+    "vitta_loss_axpby_bwd_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p, _p]),
     "vitta_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "vitta_gemm_nt_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "vitta_gemm_nt_bf16w_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),

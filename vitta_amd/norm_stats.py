@@ -198,7 +198,8 @@ class _LossReg(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ctx.engine.gscale.copy_(g.reshape(1))
+        if g.data_ptr() != ctx.engine.gscale.data_ptr():  # (ops.WeightedLoss writes the upstream gradient into gscale itself)
+            ctx.engine.gscale.copy_(g.reshape(1))
         ctx.engine._gscale_set = True
         # `tie` (the model output) receives a zero gradient: its only purpose is to make this backward walk the model's
         # graph -- the injection nodes hang off it -- when loss_reg is the WHOLE loss (no consistency term)

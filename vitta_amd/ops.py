@@ -867,6 +867,93 @@ class HeadLinear(torch.autograd.Function):
         return dx, r_w, r_b
 
 
+_tickets = {}
+
+
+class TanetHead(torch.autograd.Function):
+    """(video logits [B, K], loss_consis) = the TANet head of the adaptation pass from the pooled frame features [B V T, D]:
+    dropout -> new_fc -> segment consensus -> compute_pred_consis over the views -> mean over the views
+    (models/tanet_models/tanet.py:243-251, corpus/basics.py:640-668, utils/pred_consistency_utils.py:15-31) as ONE launch behind
+    ATen's dropout forward and ONE launch backward (vitta_tanet_head_{fwd,bwd}_f32).  The segment consensus is linear, so it is
+    taken before the product.  Parameter gradients go straight into their `.grad` storage (_grad_sink)."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias, p, train, T, V):
+        _require_cuda_f32(feat, "feat")
+        _require_cuda_f32(weight, "weight")
+        ctx.set_materialize_grads(False)
+        feat = feat.contiguous()
+        f, d = feat.shape
+        k = weight.shape[0]
+        b = f // (V * T)
+        if b * V * T != f:
+            raise VittaHipError(f"TanetHead: {f} frame rows are not B x {V} views x {T} segments")
+        mask = None
+        y = feat
+        if train and p > 0.0:
+            y, mask = torch.native_dropout(feat, float(p), True)
+        dev = feat.device
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        ybar, lv, out, loss, gradc = e(b * V, d), e(b * V, k), e(b, k), e(1), e(b * V, k)
+        from . import conv as CV
+        ticket = CV.zeroed_per_stream(_tickets, dev, 64, spares=4)
+        check(lib().vitta_tanet_head_fwd_f32(_p(y), _p(weight), _p(bias), b, V, T, k, d, _p(ybar), _p(lv), _p(ticket), _p(out), _p(loss),
+                                             _p(gradc), _stream()), "vitta_tanet_head_fwd_f32")
+        ctx.save_for_backward(weight, bias, mask, gradc, ybar)
+        ctx.dims = (b, V, T, k, d, (1.0 / (T * (1.0 - float(p)))) if mask is not None else 1.0 / T)
+        return out, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_out, g_loss):
+        weight, bias, mask, gradc, ybar = ctx.saved_tensors
+        b, V, T, k, d, scale = ctx.dims
+        dev = gradc.device
+        dfeat = torch.empty(b * V * T, d, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        if g_out is not None:
+            g_out = g_out.contiguous()
+        if g_loss is not None:
+            g_loss = g_loss.reshape(1)
+        dw, r_w = _grad_sink(weight, ctx.needs_input_grad[1])
+        db, r_b = _grad_sink(bias, bias is not None and ctx.needs_input_grad[2])
+        dl = torch.empty(b * V, k, dtype=torch.float32, device=dev) if (dw is not None or db is not None) else None
+        if dfeat is None:  # (the kernel always writes the feature gradient)
+            dfeat = torch.empty(b * V * T, d, dtype=torch.float32, device=dev)
+        check(lib().vitta_tanet_head_bwd_f32(_p(gradc), _p(g_loss), _p(g_out), _p(weight), _p(mask), float(scale), b, V, T, k, d, _p(dfeat),
+                                             _p(ybar), _p(dl), _p(dw), _p(db), _stream()), "vitta_tanet_head_bwd_f32")
+        return (dfeat if ctx.needs_input_grad[0] else None), r_w, r_b, None, None, None, None
+
+
+def tanet_head_supported(feat, linear, b, v):
+    return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2 and feat.shape[1] % 4 == 0 and b * v <= 8
+            and linear.weight.dtype == torch.float32 and not linear._forward_hooks and not linear._forward_pre_hooks
+            and int(lib().vitta_tanet_head_lds_bytes(b, v, linear.weight.shape[0], feat.shape[1])) <= 128 * 1024)
+
+
+class WeightedLoss(torch.autograd.Function):
+    """total = la * loss_a + lb * loss_b (corpus/basics.py:668) as one launch, its backward as one launch that writes BOTH upstream
+    gradients -- the first one into `slot` (the statistics engine's device scalar `gscale`, which the injection kernels read:
+    norm_stats._LossReg then finds its gradient already in place)."""
+
+    @staticmethod
+    def forward(ctx, loss_a, loss_b, la, lb, slot):
+        _require_cuda_f32(loss_a, "loss_a")
+        ctx.set_materialize_grads(False)
+        out = torch.empty(1, dtype=torch.float32, device=loss_a.device)
+        check(lib().vitta_loss_axpby_f32(_p(loss_a.reshape(1)), _p(None if loss_b is None else loss_b.reshape(1)), float(la), float(lb), _p(out),
+                                         _stream()), "vitta_loss_axpby_f32")
+        ctx.la, ctx.lb, ctx.slot, ctx.has_b = float(la), float(lb), slot, loss_b is not None
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        dev = ctx.slot.device if ctx.slot is not None else g.device
+        ga = ctx.slot if ctx.slot is not None else torch.empty(1, dtype=torch.float32, device=dev)
+        gb = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_b else None
+        check(lib().vitta_loss_axpby_bwd_f32(_p(None if g is None else g.reshape(1)), ctx.la, ctx.lb, _p(ga), _p(gb), _stream()),
+              "vitta_loss_axpby_bwd_f32")
+        return ga.reshape(()), (gb.reshape(()) if gb is not None else None), None, None, None
+
+
 def head_linear_supported(x, linear):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 4 == 0 and x.shape[0] <= 4096
             and linear.weight.dtype == torch.float32 and not linear._forward_hooks and not linear._forward_pre_hooks)

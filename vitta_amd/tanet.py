@@ -209,6 +209,23 @@ class TSN(nn.Module):
         base_out = base_out.view((-1, self.num_segments) + base_out.size()[1:])
         return self.consensus(base_out).squeeze(1)
 
+    def fused_head_ok(self):
+        """The adaptation head can run as ops.TanetHead (dropout -> new_fc -> consensus -> view consistency -> view mean in two
+        launches): the stock modules, no hooks on them."""
+        fc, lin = self.base_model.fc, self.new_fc
+        return (self.tam and self.dropout > 0 and type(fc) is nn.Dropout and type(lin) is nn.Linear and self.consensus_type == "avg"
+                and self.before_softmax and not fc._forward_hooks and not fc._forward_pre_hooks and not lin._forward_hooks
+                and not lin._forward_pre_hooks and not self.consensus._forward_hooks and not self._forward_hooks
+                and not self._forward_pre_hooks and not self.base_model._forward_hooks)
+
+    def trunk_features(self, input, no_reshape=False):
+        """Pooled per-frame features [frames, 2048] of the hand-written trunk BEFORE the dropout (`base_model.fc`), or None when the
+        configuration needs the module path (vitta_amd.trunk.run)."""
+        from . import trunk
+        if not no_reshape:
+            input = input.view((-1, 3 * self.new_length) + input.size()[-2:])
+        return trunk.run(self.base_model, input)
+
     def ride_along_ok(self, input, rider):
         """True when `forward(input, rider=rider)` can take the evaluation clips `rider` through the trunk inside the
         adaptation forward of `input` (same weights, every BatchNorm in eval(): the per-frame arithmetic is the same)."""

@@ -40,6 +40,8 @@ GRAPH_AFTER_STEPS = 3
 # hipStreamCaptureModeThreadLocal: other threads of the process (the RCCL watchdog of a data-parallel run, data-loader
 # pin-memory threads) may keep calling into the runtime while this thread captures
 CAPTURE_MODE = "thread_local"
+# the TANet head of the adaptation pass + the loss combination as our own launches (ops.TanetHead, ops.WeightedLoss); "0": module chain
+FUSED_HEAD = os.environ.get("VITTA_FUSED_HEAD", "1") != "0"
 # the evaluation clip of the previous video inside the adaptation forward of the next (ViTTAAdapter.ride_along_ok): one launch
 # sequence over 24 frames instead of 16 + 8 on two streams.  Measured on MI355X (round 3, same box, hipGraph replay): 104
 # instead of 156 convolution launches per video and 4.38 instead of 4.57 ms of convolution kernel time, but 6.20 ms per video
@@ -472,10 +474,16 @@ class ViTTAAdapter:
                 loss_consis = compute_pred_consis(output)
             output = output.mean(1)
         elif a.arch == "tanet":
-            output = self.model(input).reshape(actual_bz, self.n_views, -1)
-            if self.if_pred_consistency:
-                loss_consis = compute_pred_consis(output)
-            output = output.mean(1)
+            fused = self._fused_head(input, actual_bz)
+            if fused is not None:
+                output, loss_consis = fused
+                if not self.if_pred_consistency:
+                    loss_consis = None
+            else:
+                output = self.model(input).reshape(actual_bz, self.n_views, -1)
+                if self.if_pred_consistency:
+                    loss_consis = compute_pred_consis(output)
+                output = output.mean(1)
         else:
             output, view_cls_score = self.model(input)
             if self.if_pred_consistency:
@@ -484,9 +492,37 @@ class ViTTAAdapter:
             self.engine.reduce_local()
         return output, loss_consis
 
+    def _fused_head(self, input, actual_bz):
+        """(video logits, loss_consis) through ops.TanetHead when the model is our TSN on the hand-written trunk with its stock head
+        (tanet.TSN.fused_head_ok): the head of the adaptation pass as dropout + ONE launch forward and ONE backward instead of
+        fourteen (VITTA_FUSED_HEAD=0: the module chain).  None: not applicable, the caller takes the module chain."""
+        if not FUSED_HEAD or self.device.type != "cuda" or not torch.is_grad_enabled():
+            return None
+        net = self._net()
+        if not (hasattr(net, "fused_head_ok") and net.fused_head_ok()) or self.model is not net and (
+                self.model._forward_hooks or self.model._forward_pre_hooks):
+            return None
+        from . import fused_bn, ops
+        if not fused_bn.ENABLED:
+            return None
+        T = net.num_segments
+        frames = input.view((-1, 3 * net.new_length) + input.size()[-2:]).shape[0]
+        if frames != actual_bz * self.n_views * T or not ops.tanet_head_supported(
+                torch.empty(0, net.new_fc.in_features, dtype=torch.float32, device=self.device), net.new_fc, actual_bz, self.n_views):
+            return None
+        feat = net.trunk_features(input)
+        if feat is None:
+            return None
+        fc = net.base_model.fc
+        return ops.TanetHead.apply(feat, net.new_fc.weight, net.new_fc.bias, float(fc.p), bool(fc.training), T, self.n_views)
+
     def total_loss(self, loss_reg, loss_consis):
         a = self.args
         if self.if_pred_consistency:
+            if (FUSED_HEAD and self.engine is not None and loss_reg.is_cuda and loss_reg.requires_grad and loss_consis.requires_grad
+                    and loss_reg.dtype == torch.float32):
+                from . import ops  # one launch forward, one backward (which leaves lambda_feature_reg * g in the engine's gscale)
+                return ops.WeightedLoss.apply(loss_reg, loss_consis, a.lambda_feature_reg, a.lambda_pred_consis, self.engine.gscale)
             return a.lambda_feature_reg * loss_reg + a.lambda_pred_consis * loss_consis
         return loss_reg
 
