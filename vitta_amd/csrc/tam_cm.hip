@@ -12,7 +12,7 @@
 //   D[t', j] = <gout[t'-j+1], a[t']>  -> d gate, d K (tam_finish)                  vitta_bn_bwd_cm_f32's row_add)
 // and vitta_bn_bwd_cm_f32 is the BatchNorm(+ReLU) backward of any layer of the block in this layout:
 //   dz = g * mask + gscale (a_c + b_c (z - mu_c)),  d gamma += sum dz x_hat, d beta += sum dz,  dx = dz * s_c.
-#include "common.h"
+#include "conv_common.h"
 
 using namespace vitta;
 
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(VITTA_BLOCK) void pool_kernel(const float* __restri
   if (r.ok && sub == 0) pool[((int64_t)r.n * C + r.c) * T + r.t] = acc / (float)HW;
 }
 
+constexpr int EWU = 4;  // 16-byte pieces per lane and stream that the element-wise row kernels keep in flight
+
 template <int LPR>
 __global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
                                                               const float* __restrict__ kern, int C, int N, int T, int HW,
@@ -108,14 +110,25 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __res
     const float4 *p4 = reinterpret_cast<const float4*>(xp), *c4 = reinterpret_cast<const float4*>(xc),
                  *n4 = reinterpret_cast<const float4*>(xn);
     float4* o4 = reinterpret_cast<float4*>(o);
-    for (int i = sub; i < (HW >> 2); i += LPR) {
-      const float4 a = p4[i], b = c4[i], c = n4[i];
-      float4 q;
-      q.x = fmaf(w2, act(c.x, s, sh), fmaf(w1, act(b.x, s, sh), w0 * act(a.x, s, sh)));
-      q.y = fmaf(w2, act(c.y, s, sh), fmaf(w1, act(b.y, s, sh), w0 * act(a.y, s, sh)));
-      q.z = fmaf(w2, act(c.z, s, sh), fmaf(w1, act(b.z, s, sh), w0 * act(a.z, s, sh)));
-      q.w = fmaf(w2, act(c.w, s, sh), fmaf(w1, act(b.w, s, sh), w0 * act(a.w, s, sh)));
-      o4[i] = q;
+    // (round 5: EWU pieces per lane and stream in flight together -- the one-piece loop was a chain of HW / (4 LPR) dependent round
+    // trips per lane, 12 at 56 x 56, which is what these launches cost: 2 TB/s at layer 1)
+    const int q4 = HW >> 2;
+    for (int i0 = sub; i0 < q4; i0 += LPR * EWU) {
+      float4 a[EWU], b[EWU], c[EWU];
+#pragma unroll
+      for (int u = 0; u < EWU; ++u) {
+        const int i = min(i0 + u * LPR, q4 - 1);
+        a[u] = p4[i]; b[u] = c4[i]; c[u] = n4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < EWU; ++u) {
+        float4 q;
+        q.x = fmaf(w2, act(c[u].x, s, sh), fmaf(w1, act(b[u].x, s, sh), w0 * act(a[u].x, s, sh)));
+        q.y = fmaf(w2, act(c[u].y, s, sh), fmaf(w1, act(b[u].y, s, sh), w0 * act(a[u].y, s, sh)));
+        q.z = fmaf(w2, act(c[u].z, s, sh), fmaf(w1, act(b[u].z, s, sh), w0 * act(a[u].z, s, sh)));
+        q.w = fmaf(w2, act(c[u].w, s, sh), fmaf(w1, act(b[u].w, s, sh), w0 * act(a[u].w, s, sh)));
+        if (i0 + u * LPR < q4) o4[i0 + u * LPR] = q;
+      }
     }
   } else {
     for (int i = sub; i < HW; i += LPR)
@@ -157,18 +170,31 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __res
       const float4 *x4 = reinterpret_cast<const float4*>(xc), *c4 = reinterpret_cast<const float4*>(gc),
                    *n4 = reinterpret_cast<const float4*>(gn), *p4 = reinterpret_cast<const float4*>(gp);
       float4* o4 = reinterpret_cast<float4*>(o);
-      for (int i = sub; i < (HW >> 2); i += LPR) {
-        const float4 xr = x4[i], a = n4[i], b = c4[i], c = p4[i];
-        const float4 xv = make_float4(act(xr.x, s, sh), act(xr.y, s, sh), act(xr.z, s, sh), act(xr.w, s, sh));
-        float4 q;
-        q.x = fmaf(v2, c.x, fmaf(v1, b.x, v0 * a.x));
-        q.y = fmaf(v2, c.y, fmaf(v1, b.y, v0 * a.y));
-        q.z = fmaf(v2, c.z, fmaf(v1, b.z, v0 * a.z));
-        q.w = fmaf(v2, c.w, fmaf(v1, b.w, v0 * a.w));
-        o4[i] = q;
-        d0 += a.x * xv.x + a.y * xv.y + a.z * xv.z + a.w * xv.w;
-        d1 += b.x * xv.x + b.y * xv.y + b.z * xv.z + b.w * xv.w;
-        d2 += c.x * xv.x + c.y * xv.y + c.z * xv.z + c.w * xv.w;
+      const int q4 = HW >> 2;
+      for (int i0 = sub; i0 < q4; i0 += LPR * EWU) {  // (batches of EWU pieces per stream in flight, as agg_fwd_kernel; same order of sums)
+        float4 xr_[EWU], a_[EWU], b_[EWU], c_[EWU];
+#pragma unroll
+        for (int u = 0; u < EWU; ++u) {
+          const int i = min(i0 + u * LPR, q4 - 1);
+          xr_[u] = x4[i]; a_[u] = n4[i]; b_[u] = c4[i]; c_[u] = p4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < EWU; ++u) {
+          const bool on = i0 + u * LPR < q4;
+          const float4 xr = xr_[u], a = a_[u], b = b_[u], c = c_[u];
+          const float4 xv = make_float4(act(xr.x, s, sh), act(xr.y, s, sh), act(xr.z, s, sh), act(xr.w, s, sh));
+          float4 q;
+          q.x = fmaf(v2, c.x, fmaf(v1, b.x, v0 * a.x));
+          q.y = fmaf(v2, c.y, fmaf(v1, b.y, v0 * a.y));
+          q.z = fmaf(v2, c.z, fmaf(v1, b.z, v0 * a.z));
+          q.w = fmaf(v2, c.w, fmaf(v1, b.w, v0 * a.w));
+          if (on) {
+            o4[i0 + u * LPR] = q;
+            d0 += a.x * xv.x + a.y * xv.y + a.z * xv.z + a.w * xv.w;
+            d1 += b.x * xv.x + b.y * xv.y + b.z * xv.z + b.w * xv.w;
+            d2 += c.x * xv.x + c.y * xv.y + c.z * xv.z + c.w * xv.w;
+          }
+        }
       }
     } else {
       for (int i = sub; i < HW; i += LPR) {
@@ -262,8 +288,14 @@ struct BnBwd {
   float *dgamma, *dbeta;
   int C, N, T, HW, relu;
   int64_t xld;         // pixels between channel rows of x / mask (P unless they hold more frames)
+  vitta_conv::FastDiv d_hw, d_t;  // host-made reciprocals of HW and T (the frame of a pixel, the clip of a frame)
 };
 
+// G2 / MASK: the optional streams exist; ROWADD 0: none, 1: HW % 4 == 0 (a 16-byte piece lies in one frame: one row value per piece),
+// 2: any HW.  Compile-time, and every load of the lane's BB_UNROLL pieces is issued before the first use: with run-time flags and a
+// `break` in the piece loop the loads of a piece waited for the previous piece's stores -- four dependent round trips per lane, and with
+// the pooling gradient eight integer divisions per piece in front of a dependent gather: 2 TB/s on the 56 x 56 layers (round 5).
+template <bool G2, bool MASK, int ROWADD>
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
   __shared__ float red[2][VITTA_BLOCK / VITTA_WAVE];
   const int c = blockIdx.y;
@@ -281,45 +313,65 @@ __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
   const bool relu = a.relu & 1, raw = (a.relu & 2) && a.mu;
   float sg = 0.f, sb = 0.f;
   const int64_t p0 = ((int64_t)blockIdx.x * VITTA_BLOCK * BB_UNROLL + threadIdx.x) * 4;
+  const int64_t plast = P - 4;
+  float4 gv[BB_UNROLL], xv[BB_UNROLL], hv[BB_UNROLL], mv[BB_UNROLL];
+  float ra[BB_UNROLL][4];
+#pragma unroll
+  for (int u = 0; u < BB_UNROLL; ++u) {
+    const int64_t p = min(p0 + (int64_t)u * VITTA_BLOCK * 4, plast);
+    gv[u] = *reinterpret_cast<const float4*>(a.g + base + p);
+    xv[u] = *reinterpret_cast<const float4*>(a.x + xbase + p);
+    if (G2) hv[u] = *reinterpret_cast<const float4*>(a.g2 + base + p);
+    if (MASK) mv[u] = *reinterpret_cast<const float4*>(a.mask + xbase + p);
+    if (ROWADD == 1) {
+      const int f = vitta_conv::fdiv((int)p, a.d_hw), n = vitta_conv::fdiv(f, a.d_t), tt = f - n * a.T;
+      ra[u][0] = a.rowadd[((int64_t)n * a.C + c) * a.T + tt];
+    } else if (ROWADD == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = vitta_conv::fdiv((int)p + e, a.d_hw), n = vitta_conv::fdiv(f, a.d_t), tt = f - n * a.T;
+        ra[u][e] = a.rowadd[((int64_t)n * a.C + c) * a.T + tt];
+      }
+    }
+  }
 #pragma unroll
   for (int u = 0; u < BB_UNROLL; ++u) {
     const int64_t p = p0 + (int64_t)u * VITTA_BLOCK * 4;
-    if (p >= P) break;
-    const float4 gv = *reinterpret_cast<const float4*>(a.g + base + p);
-    const float4 xv = *reinterpret_cast<const float4*>(a.x + xbase + p);
-    float g[4] = {gv.x, gv.y, gv.z, gv.w};
-    const float xr[4] = {xv.x, xv.y, xv.z, xv.w};
-    if (a.g2) {
-      const float4 hv = *reinterpret_cast<const float4*>(a.g2 + base + p);
-      g[0] += hv.x; g[1] += hv.y; g[2] += hv.z; g[3] += hv.w;
-    }
-    if (a.rowadd) {
+    const bool on = p < P;
+    float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+    const float xr[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+    if (G2) { g[0] += hv[u].x; g[1] += hv[u].y; g[2] += hv[u].z; g[3] += hv[u].w; }
+    if (ROWADD == 1) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int f = (int)((p + e) / a.HW), n = f / a.T, tt = f - n * a.T;
-        g[e] += a.rowadd_scale * a.rowadd[((int64_t)n * a.C + c) * a.T + tt];
-      }
+      for (int e = 0; e < 4; ++e) g[e] += a.rowadd_scale * ra[u][0];
+    } else if (ROWADD == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] += a.rowadd_scale * ra[u][e];
     }
     float mk[4] = {1.f, 1.f, 1.f, 1.f};
-    if (relu && a.mask) {
-      const float4 mv = *reinterpret_cast<const float4*>(a.mask + xbase + p);
-      mk[0] = mv.x > 0.f; mk[1] = mv.y > 0.f; mk[2] = mv.z > 0.f; mk[3] = mv.w > 0.f;
+    if (MASK) {
+      if (relu) { mk[0] = mv[u].x > 0.f; mk[1] = mv[u].y > 0.f; mk[2] = mv[u].z > 0.f; mk[3] = mv[u].w > 0.f; }
     }
     float o[4], gmv[4];
+    float sgu = 0.f, sbu = 0.f;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float z = fmaf(xr[e], s, t);
-      const float m = (relu && !a.mask) ? (z > 0.f ? 1.f : 0.f) : mk[e];
+      const float m = (relu && !MASK) ? (z > 0.f ? 1.f : 0.f) : mk[e];
       gmv[e] = g[e] * m;
       // statistics-loss gradient of the hooked feature: of z (added before the affine map is differentiated) or -- before_norm
       // hooks, utils/norm_stats_utils.py:185 -- of the RAW input x (added to dx as it is; d gamma / d beta do not see it)
       const float dz = raw ? gmv[e] : gmv[e] + fmaf(ib, z - mu, ia);
-      sg += dz * (xr[e] - rm) * rstd;
-      sb += dz;
+      sgu += dz * (xr[e] - rm) * rstd;
+      sbu += dz;
       o[e] = raw ? fmaf(dz, s, fmaf(ib, xr[e] - mu, ia)) : dz * s;
     }
-    *reinterpret_cast<float4*>(a.dx + base + p) = make_float4(o[0], o[1], o[2], o[3]);
-    if (a.gm) *reinterpret_cast<float4*>(a.gm + base + p) = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]);
+    if (on) {
+      sg += sgu;
+      sb += sbu;
+      *reinterpret_cast<float4*>(a.dx + base + p) = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.gm) *reinterpret_cast<float4*>(a.gm + base + p) = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]);
+    }
   }
   sg = wave_sum(sg);
   sb = wave_sum(sb);
@@ -459,9 +511,24 @@ int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x
   a.dx = d_dx; a.gm = d_gm; a.dgamma = d_dgamma; a.dbeta = d_dbeta;
   a.C = C; a.N = N; a.T = T; a.HW = HW; a.relu = relu;
   a.xld = x_ld ? x_ld : P;
+  if (P >= (1ll << 31) - 4) return VITTA_ERR_UNSUPPORTED;
+  a.d_hw = vitta_conv::make_fastdiv(HW);
+  a.d_t = vitta_conv::make_fastdiv(T);
   const int64_t per = (int64_t)VITTA_BLOCK * BB_UNROLL * 4;
-  VITTA_LAUNCH(bn_bwd_kernel, dim3((unsigned)((P + per - 1) / per), (unsigned)C), dim3(VITTA_BLOCK), 0,
-               static_cast<hipStream_t>(stream), a);
+  const dim3 grid((unsigned)((P + per - 1) / per), (unsigned)C), block(VITTA_BLOCK);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ra = !d_rowadd ? 0 : (HW % 4 == 0 ? 1 : 2);
+#define BN_BWD_GO(G2, MK)                                                             \
+  do {                                                                                \
+    if (ra == 0) VITTA_LAUNCH((bn_bwd_kernel<G2, MK, 0>), grid, block, 0, st, a);      \
+    else if (ra == 1) VITTA_LAUNCH((bn_bwd_kernel<G2, MK, 1>), grid, block, 0, st, a); \
+    else VITTA_LAUNCH((bn_bwd_kernel<G2, MK, 2>), grid, block, 0, st, a);              \
+  } while (0)
+  if (d_g2 && d_mask) BN_BWD_GO(true, true);
+  else if (d_g2) BN_BWD_GO(true, false);
+  else if (d_mask) BN_BWD_GO(false, true);
+  else BN_BWD_GO(false, false);
+#undef BN_BWD_GO
   return VITTA_OK;
 }
 
