@@ -252,7 +252,7 @@ def test_fused_head_equals_the_module_chain_in_fp64(b, v, t, k, d, p):
     loss_ref = O.compute_pred_consis(lv)
     out_ref = lv.mean(1)
     (gl * loss_ref + (out_ref * gout.cpu().double()).sum()).backward()
-    ref = [out_ref.detach(), float(loss_ref), f64.grad, w64.grad, b64.grad]
+    ref = [out_ref.detach(), float(loss_ref.detach()), f64.grad, w64.grad, b64.grad]
     assert (got[0] - ref[0]).abs().max().item() <= 1e-5 * ref[0].abs().max().item() + 1e-6
     assert abs(got[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-7
     for a, r, name in zip(got[2:], ref[2:], ("d feat", "d weight", "d bias")):

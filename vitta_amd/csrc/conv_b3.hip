@@ -76,6 +76,227 @@ __device__ unsigned long long b3_trace_buf[16 * 8192];
   } while (0)
 #endif
 
+// ---- round 5: the epilogue of a CONTIGUOUS output through an LDS turn-around -------------------------------------------------------
+// In the accumulator layout a lane owns ONE output channel and four consecutive pixels per register quad, so every epilogue access of a
+// wave -- output stores, residual / BatchNorm-backward input / mask loads -- is 64 pieces of 16 bytes in 64 different channel rows:
+// 64 cache lines per instruction for 1 KB of data.  A 128 x 64 tile with one input stream and one or two outputs is ~6 000 such line
+// accesses per workgroup through the CU's one L1 port (~2.7 us: "epilogue until its stores have landed", profiles/r4_conv_b3_phase_timeline.txt),
+// and the launches whose workgroups are short -- 64 -> 256 at 56 x 56: 6 workgroups per CU of 1.8 us of K walk each -- are bound by it.
+// Here every wave writes its two 32 x 32 accumulator blocks to a private 8 KB LDS area as [channel][32 pixels] (16-byte pieces XOR-
+// swizzled by channel pair: writes and reads are both bank-conflict free) and reads them back with lane = (channel row lane / 8,
+// piece lane % 8): an access instruction then covers 8 channel rows x 128 contiguous bytes = 8 lines, the same arithmetic as
+// TileEpilogue::body runs on (channel, four pixels) items, the per-channel sums meet over the 8 lanes of a row by shuffles.
+struct EpiConst {  // per-channel constants of the tile, derived once: forward es, et, shift; backward s, t, mean, rstd, ia, ib, mu
+  float c0, c1, c2, c3, c4, c5, c6;
+};
+
+template <bool PRE, bool POOLT>
+__device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int wave, int lane, const f32x16 (&acc)[2], const TileEpilogue& e0,
+                                           const TileEpilogue& e1, const float4 (&pre)[8], unsigned char* lds, float* red) {
+  const vitta_conv_desc& d = a.d;
+  const int li = lane & 31, lk = lane >> 5;
+  const int flags = d.flags;
+  const bool BWD = flags & VITTA_CONV_BWD_BN;
+  const bool STATS = (flags & VITTA_CONV_STATS) && d.st_s1;
+  const bool RAWST = flags & VITTA_CONV_STATS_RAW;
+  const bool APPLY = flags & VITTA_CONV_EPI_APPLY;
+  const bool RELU = flags & VITTA_CONV_EPI_RELU;
+  const bool RES = (flags & VITTA_CONV_RES) && d.res;
+  const bool RESH = (flags & VITTA_CONV_RES_HALF) && d.res;
+  const bool BRELU = flags & VITTA_CONV_BWD_RELU;
+  const bool IRAW = (flags & VITTA_CONV_INJ_RAW) && d.inj_mu;
+  const bool POOL = POOLT && (flags & VITTA_CONV_POOL) && d.pool;
+  float* const W = reinterpret_cast<float*>(lds + wave * 8192);             // [64 channels][32 pixels], pieces swizzled
+  float* const cst = reinterpret_cast<float*>(lds + 32768 + wave * 2048);   // [7][64]
+  // ---- accumulators -> LDS (lane = channel li of block y, pixel quad 8 qd + 4 lk) ----
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int ch = 32 * y + li, f = (ch >> 1) & 3;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int q = 2 * qd + lk;
+      const f32x4 v = {acc[y][4 * qd], acc[y][4 * qd + 1], acc[y][4 * qd + 2], acc[y][4 * qd + 3]};
+      *reinterpret_cast<f32x4*>(W + ch * 32 + ((q ^ f) << 2)) = v;
+    }
+  }
+  // ---- derived per-channel constants (the lanes of the lower half hold channel li of either block) ----
+  if (lk == 0) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const TileEpilogue& e = y ? e1 : e0;
+      const int ch = 32 * y + li;
+      float c0 = 1.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f, c5 = 0.f, c6 = e.c_sh;
+      if (BWD) {
+        c3 = rsqrtf(e.c_var + d.bwd_eps);   // rstd
+        c0 = e.c_gam * c3;                  // s
+        c1 = e.c_bet - e.c_mean * c0;       // t
+        c2 = e.c_mean;
+        c4 = e.c_gs * e.c_a;
+        c5 = e.c_gs * e.c_b;
+        c6 = e.c_mu;
+      } else if (d.epi_bn[0]) {
+        c0 = e.c_gam * rsqrtf(e.c_var + d.epi_eps);
+        c1 = e.c_bet - e.c_mean * c0;
+      }
+      cst[ch] = c0; cst[64 + ch] = c1; cst[128 + ch] = c2; cst[192 + ch] = c3; cst[256 + ch] = c4; cst[320 + ch] = c5; cst[384 + ch] = c6;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private areas: no barrier)
+  // ---- items: (channel row 8 i + lane / 8, 16-byte piece lane % 8) ----
+  const int r = lane >> 3, q = lane & 7;
+  const int m = m0 + 32 * wave + 4 * q;
+  const bool live = m < a.Mtot;
+  const bool head = m < a.statM, counted = STATS && head;
+  const int HWy = d.Hy * d.Wy;
+  PoolSums pool(a, m0 + 32 * wave, POOL);
+  float s1v[8], s2v[8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 v[4], x2[4], x3[4];
+    // the tile values and every remaining input piece of these four items first ...
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch = 8 * (4 * half + j) + r;
+      v[j] = *reinterpret_cast<const f32x4*>(W + ch * 32 + ((q ^ ((ch >> 1) & 3)) << 2));
+      const int64_t k = k0 + ch;
+      const int mm = live ? m : a.Mtot - 4;
+      x2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      x3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (BWD) {
+        if (!PRE) x2[j] = *reinterpret_cast<const f32x4*>(d.bwd_x + k * a.bP + mm);
+        if (RES) x3[j] = *reinterpret_cast<const f32x4*>(d.res + k * a.rP + mm);
+      } else if (RES && !PRE) {
+        x2[j] = *reinterpret_cast<const f32x4*>(d.res + k * a.rP + mm);
+      }
+    }
+    f32x4 mk[4];
+    if (BWD && BRELU && d.bwd_mask) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[j] = *reinterpret_cast<const f32x4*>(d.bwd_mask + (int64_t)(k0 + 8 * (4 * half + j) + r) * a.bP + (live ? m : a.Mtot - 4));
+    }
+    // ... then the arithmetic of TileEpilogue::body per item
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 4 * half + j, ch = 8 * i + r;
+      const int64_t k = k0 + ch;
+      const float c0 = cst[ch], c1 = cst[64 + ch], c6 = cst[384 + ch];
+      float vv[4] = {v[j][0], v[j][1], v[j][2], v[j][3]};
+      float r1 = 0.f, r2 = 0.f;
+      float* yp = d.y + k * a.yP + m;
+      if (RESH) {
+        const int Hh = (d.Hy + 1) >> 1, Wh = (d.Wy + 1) >> 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int p = (live ? m : 0) + e;
+          const int n = p / HWy, rr = p - n * HWy, h = rr / d.Wy, w = rr - h * d.Wy;
+          if (!((h | w) & 1)) vv[e] += d.res[k * a.rP + (int64_t)n * Hh * Wh + (h >> 1) * Wh + (w >> 1)];
+        }
+      }
+      if (BWD) {
+        const float c2 = cst[128 + ch], c3 = cst[192 + ch], c4 = cst[256 + ch], c5 = cst[320 + ch];
+        f32x4 xr = x2[j];
+        if constexpr (PRE) xr = f32x4{pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+        if (RES) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] += x3[j][e];
+        }
+        float o[4], gm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(xr[e], c0, c1);
+          const float mmk = BRELU ? (d.bwd_mask ? (mk[j][e] > 0.f ? 1.f : 0.f) : (z > 0.f ? 1.f : 0.f)) : 1.f;
+          gm[e] = vv[e] * mmk;
+          const float dz = IRAW ? gm[e] : gm[e] + fmaf(c5, z - c6, c4);
+          r1 += dz * (xr[e] - c2) * c3;
+          r2 += dz;
+          o[e] = IRAW ? fmaf(dz, c0, fmaf(c5, xr[e] - c6, c4)) : dz * c0;
+        }
+        if (live) {
+          *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+          if (d.y_raw) *reinterpret_cast<f32x4*>(d.y_raw + k * a.yP + m) = f32x4{gm[0], gm[1], gm[2], gm[3]};
+        }
+      } else {
+        if (live && d.y_raw && head) *reinterpret_cast<f32x4*>(d.y_raw + k * a.yP + m) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(vv[e], c0, c1);
+          if (counted) {
+            const float dd = (RAWST ? vv[e] : z) - c6;
+            r1 += dd;
+            r2 = fmaf(dd, dd, r2);
+          }
+          if (POOL && live) pool.add(m + e, z);
+          o[e] = APPLY ? z : vv[e];
+        }
+        if (RES) {
+          f32x4 rr = x2[j];
+          if constexpr (PRE) rr = f32x4{pre[i].x, pre[i].y, pre[i].z, pre[i].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rr[e];
+        }
+        if (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (live) *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
+      }
+      if (!live) r1 = r2 = 0.f;
+      if (POOL) {  // the item's two frame sums over the row's eight lanes -> one atomic per (block, channel, frame)
+        pool.s0 += __shfl_xor(pool.s0, 1, 64); pool.s1 += __shfl_xor(pool.s1, 1, 64);
+        pool.s0 += __shfl_xor(pool.s0, 2, 64); pool.s1 += __shfl_xor(pool.s1, 2, 64);
+        pool.s0 += __shfl_xor(pool.s0, 4, 64); pool.s1 += __shfl_xor(pool.s1, 4, 64);
+        if (q == 0 && pool.mblk < a.Mtot) {
+          unsigned long long* pl = reinterpret_cast<unsigned long long*>(d.pool);
+          const float sc = d.pool_scale * 4294967296.f;
+          atomicAdd(pl + (int64_t)pool.fA * d.K + k, (unsigned long long)__float2ll_rn(pool.s0 * sc));
+          if (pool.mB < pool.mblk + 32 && pool.mB < a.Mtot)
+            atomicAdd(pl + (int64_t)(pool.fA + 1) * d.K + k, (unsigned long long)__float2ll_rn(pool.s1 * sc));
+        }
+        pool.s0 = pool.s1 = 0.f;
+      }
+      s1v[i] = r1;
+      s2v[i] = r2;
+    }
+  }
+  // ---- per-channel sums: the eight lanes of a row, then the four waves (pixel quarters of the tile), one atomic per (tile, channel) ----
+  if (STATS || BWD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s1v[i] += __shfl_xor(s1v[i], 1, 64); s2v[i] += __shfl_xor(s2v[i], 1, 64);
+      s1v[i] += __shfl_xor(s1v[i], 2, 64); s2v[i] += __shfl_xor(s2v[i], 2, 64);
+      s1v[i] += __shfl_xor(s1v[i], 4, 64); s2v[i] += __shfl_xor(s2v[i], 4, 64);
+    }
+    if (wave > 0 && q == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red[((wave - 1) * 64 + 8 * i + r) * 2] = s1v[i];
+        red[((wave - 1) * 64 + 8 * i + r) * 2 + 1] = s2v[i];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && q == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ch = 8 * i + r;
+        float t1 = s1v[i], t2 = s2v[i];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          t1 += red[(w * 64 + ch) * 2];
+          t2 += red[(w * 64 + ch) * 2 + 1];
+        }
+        if (BWD) {
+          if (d.dgamma) atomicAdd(d.dgamma + k0 + ch, t1);
+          if (d.dbeta) atomicAdd(d.dbeta + k0 + ch, t2);
+        } else {
+          atomicAdd(d.st_s1 + k0 + ch, t1);
+          atomicAdd(d.st_s2 + k0 + ch, t2);
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, bool PRE, bool POOLT>
 __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   constexpr bool PATCH = MODE == 1, GATHER = MODE == 2;
@@ -317,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  float4 pre[2][4] = {};
+  float4 pre[8] = {};  // the epilogue's first input stream in the mapping of epilogue_t: item i = channel row 8 i + lane / 8, piece lane % 8
   // requests run NB steps ahead: (cs_q, t_q) = the step to request next, clamped to the slice's last step (the tail
   // re-requests it into a stage nobody reads again: the instruction count per step stays fixed for the counted waits).
   // tq_w = the table word of that step's tap, fetched when the step BEFORE it was requested (pointwise: one tap, a constant):
@@ -345,9 +566,12 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   B3_STAMP(13);
   epi0.load_consts(L);
   epi1.load_consts(L);
-  if constexpr (PRE) {
+  if constexpr (PRE) {  // (the host sets pw_prefetch for contiguous outputs only: BWD_BN -> its input, else the residual)
+    const bool bwd = d.flags & VITTA_CONV_BWD_BN;
+    const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + (lane >> 3)) * (bwd ? a.bP : a.rP) + min(m0 + 32 * wave + 4 * (lane & 7), Mtot - 4);
+    const int64_t step = 8 * (bwd ? a.bP : a.rP);
 #pragma unroll
-    for (int y = 0; y < 2; ++y) tile_prefetch_at(a, m0, k0, wave >> 1, y, li, lk, pre[y][0], pre[y][1], pre[y][2], pre[y][3], BM, xb);
+    for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const float4*>(row + i * step);
   }
   // step 0 (requested first) has landed; loads the compiler placed behind the requests only make this wait longer
   B3_STAMP(1);
@@ -493,9 +717,17 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
 
   // ---- epilogue: the wave's two column blocks; per-channel sums of the four waves meet in LDS ----------------------------
   B3_STAMP(7);
+  if (a.contig) {  // through the LDS turn-around (every access a whole 128-byte line per channel row)
+    epilogue_t<PRE, POOLT>(a, m0, k0, wave, lane, acc, epi0, epi1, pre, lds, red);
+#ifdef B3_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    B3_STAMP(8);
+#endif
+    return;
+  }
   float r1[2] = {0.f, 0.f}, r2[2] = {0.f, 0.f};
-  epi0.template body<PRE, POOLT>(L, xb, acc[0], r1[0], r2[0], pre[0][0], pre[0][1], pre[0][2], pre[0][3]);
-  epi1.template body<PRE, POOLT>(L, xb, acc[1], r1[1], r2[1], pre[1][0], pre[1][1], pre[1][2], pre[1][3]);
+  epi0.template body<false, false>(L, xb, acc[0], r1[0], r2[0]);
+  epi1.template body<false, false>(L, xb, acc[1], r1[1], r2[1]);
 #ifdef B3_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   B3_STAMP(8);

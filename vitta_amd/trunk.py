@@ -56,6 +56,12 @@ WGRAD_SIDE = os.environ.get("VITTA_TRUNK_WGRAD_STREAM", "1") != "0"
 # fixed-point sums -- order-independent --, which the branch kernels read with pooled_tc = 1) instead of a pass over x1: 16 launches fewer per pass; "0": the
 # stand-alone pooling launch (tests hold the two forms together)
 POOL_FOLD = os.environ.get("VITTA_TRUNK_POOL_FOLD", "1") != "0"
+# bn3 (+ identity add + ReLU) backward of block i inside the epilogue of block i+1's conv1 data gradient -- the launch that produces
+# the gradient w.r.t. block i's output -- instead of its own pass (VITTA_CONV_BWD_BN | VITTA_CONV_BWD_RELU | VITTA_CONV_RES with
+# bwd_x = x3, bwd_mask = out, y_raw = the masked gradient that feeds the identity path): 15 launches and two streams of a
+# 4p-channel tensor fewer per backward.  (Measured slower on the round-2 fp32 kernels, 79.8 vs 57.7 us + the pass; re-measured on
+# conv_b3.hip in round 5.)  "0": the stand-alone pass.
+BN3_FOLD = os.environ.get("VITTA_TRUNK_BN3_FOLD", "1") != "0"
 _side_streams = {}
 _side_pool = {}
 
@@ -651,11 +657,11 @@ class TrunkRunner:
                           last=(c, ng, h, w))
 
     # -- backward ----------------------------------------------------------------------------------------------
-    def block_backward(self, b, sv, G, sites, sink):
-        """G [4p, Po] = gradient w.r.t. the block output (all consumers) -> gradient w.r.t. the block input.
-        (Differentiating the previous block's bn3 + add + ReLU in the epilogue of this block's last launch was measured:
-        the three extra streams of a 4p-channel tensor cost the convolution epilogue more than the stand-alone pass they
-        replace, 79.8 vs 57.7 us on the layer1 launches -- kept as its own kernel.)"""
+    def block_backward(self, b, sv, G, sites, sink, prev=None):
+        """G [4p, Po] = gradient w.r.t. the block output (all consumers) -> gradient w.r.t. the block input; or G = (dx3, g_id):
+        the block's bn3 + add + ReLU backward already applied by the launch that produced the gradient (BN3_FOLD).
+        prev = (block, tape entry) of the block in FRONT of this one: its bn3 backward rides in the epilogue of this block's last
+        launch, and the pair (dx3, g_id) of THAT block is returned instead of the plain gradient."""
         net, tam = b.net, b.tam
         t = b.n_segment
         n, h, w, ho, wo = sv["dims"]
@@ -670,7 +676,7 @@ class TrunkRunner:
         fr = sv["frames"]  # frames per channel row of the saved tensors (> n when an evaluation clip rode along)
         ldP, ldPo = (fr * h * w, fr * ho * wo) if fr != n else (0, 0)
         cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
-        dev = G.device
+        dev = (G[0] if isinstance(G, tuple) else G).device
         f = dict(dtype=torch.float32, device=dev)
         L = lib()
         st = _stream()
@@ -688,9 +694,13 @@ class TrunkRunner:
                                            _p(dx), _p(gm), _p(dg), _p(db), c, nb, t, hw, st), "vitta_bn_bwd_cm_ld_f32")
             return dx
 
-        # bn3 (+ identity add + ReLU) backward
-        g_id = torch.empty_like(G)
-        dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo, ld=ldPo)
+        # bn3 (+ identity add + ReLU) backward -- unless the launch that produced G did it (BN3_FOLD)
+        if isinstance(G, tuple):
+            dx3, g_id = G
+            G = g_id  # (device, shape)
+        else:
+            g_id = torch.empty_like(G)
+            dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo, ld=ldPo)
         # identity / downsample path of a stage's first bottleneck, beside the main chain: bn_d backward, its data gradient
         if net.downsample is not None:
             dconv, dbn = net.downsample[0], net.downsample[1]
@@ -766,7 +776,18 @@ class TrunkRunner:
             res, rflag = gd, (CV.CONV_RES_HALF if ds == 2 else CV.CONV_RES)
         else:
             res, rflag = g_id, CV.CONV_RES
-        CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
+        fold = None
+        if BN3_FOLD and prev is not None and fr == n and prev[1]["frames"] == prev[1]["dims"][0]:
+            pnet, psv = prev[0].net, prev[1]
+            ps3 = sites.get(id(pnet.bn3))
+            g_idp = torch.empty(cin, P, **f)  # the masked gradient: the previous block's identity path reads it
+            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin,
+                      flags=rflag | CV.CONV_BWD_BN | CV.CONV_BWD_RELU | (CV.CONV_INJ_RAW if (ps3 and ps3.raw) else 0), res=res,
+                      bwd_bn=_bn_t(pnet.bn3), eps=pnet.bn3.eps, bwd_x=psv["x3"], bwd_mask=psv["out"], inj=ps3.inj if ps3 else None,
+                      dgamma=sink(pnet.bn3.weight), dbeta=sink(pnet.bn3.bias), y_raw=g_idp)
+            fold = (gin, g_idp)  # gin now holds dx3 of the previous block
+        else:
+            CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
         if wq:
             helper = _Fork(dev, role=1)  # waits for everything this block has queued
             with helper:  # four launches + ONE reduction of their partial tiles
@@ -780,7 +801,7 @@ class TrunkRunner:
             while len(self._wgrad_pending) > 2:
                 h0, _, ev0 = self._wgrad_pending.pop(0)
                 h0.main.wait_event(ev0)
-        return gin
+        return fold if fold is not None else gin
 
     def join_wgrads(self):
         """The current stream waits for the weight gradients issued on the helper stream; their operands may be freed."""
@@ -796,7 +817,7 @@ class TrunkRunner:
         try:
             for i in range(len(blocks) - 1, -1, -1):
                 sv = ctxd["tape"][i]
-                G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink)
+                G = self.block_backward(blocks[i], sv, G, ctxd["sites"], sink, prev=(blocks[i - 1], ctxd["tape"][i - 1]) if i > 0 else None)
                 sv.clear()
                 if self.after_block is not None:
                     self.join_wgrads()  # a gradient bucket may leave now
