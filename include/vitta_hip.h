@@ -702,6 +702,13 @@ int vitta_stem_bn_relu_pool_bwd_affine_f32(const float* d_x, const float* d_gpoo
  * W % 4 == 0, W <= 256. */
 int vitta_stem_bn_relu_pool_bwd_f32(const float* d_x, const float* d_gpool, const float* const* h_bn, float eps, int64_t N,
                                     int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta, float* d_dy, void* stream);
+/* The two passes with the POOLED tensor (forward output, backward upstream gradient) in channel-major planes
+ * [C][N * PH * PW], the layout of the trunk's convolutions: no transposing copy between the stem and layer1.  Tiled path only
+ * (W % 4 == 0, W <= 256, d_x 16-byte aligned: VITTA_ERR_UNSUPPORTED otherwise); d_dy as above (NULL: affine-only). */
+int vitta_stem_bn_relu_pool_fwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, int64_t N, int32_t C, int32_t H,
+                                       int32_t W, float* d_out_cm, void* stream);
+int vitta_stem_bn_relu_pool_bwd_cm_f32(const float* d_x, const float* d_gpool_cm, const float* const* h_bn, float eps, int64_t N,
+                                       int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta, float* d_dy, void* stream);
 /* Weight gradient of the stem convolution: d_dw [64, 3, 7, 7] += sum over frames and output pixels of d_dy [N, 64, OH, OW]
  * times the 7x7 / stride 2 / pad 3 patches of d_x [N, 3, H, W] (v_mfma_f32_32x32x2_f32; per-workgroup partial sums meet in
  * d_ws, >= vitta_stem_conv7_wgrad_workspace_bytes() bytes, no initial content required).  W % 4 == 0. */

@@ -182,6 +182,8 @@ SIGNATURES = {
     "vitta_colsum2_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p]),
     "vitta_stem_bn_relu_pool_fwd_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p]),
     "vitta_stem_bn_relu_pool_bwd_affine_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    "vitta_stem_bn_relu_pool_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p]),
+    "vitta_stem_bn_relu_pool_bwd_cm_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p, _p]),
     "vitta_frames_resample_norm_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _p, _i32, _p, _p, _i32,
                                                  _i32, _i32, _i32, _p]),
     "vitta_frames_cv2_resize": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p]),

@@ -17,6 +17,7 @@ namespace {
 
 struct StemGeom {
   int64_t N; int C, H, W, PH, PW;
+  int cm;  // 1: the pooled tensor (forward output / backward upstream gradient) is CHANNEL-MAJOR [C][N * PH * PW] (tiled kernels)
 };
 
 // y values of the window of pooled pixel (ph, pw); returns the maximum, *arg = its x value (pre-BN) for the backward
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void stem_tiled_kernel(const float* __
         if (!found || y > best) { best = y; bx = xv; bpos = h * g.W + w; found = true; }
       }
     }
-    const int64_t o = nc * (int64_t)g.PH * g.PW + (int64_t)(ph0 + pr) * g.PW + pw;
+    const int64_t o = (g.cm ? ((int64_t)c * g.N + nc / g.C) : nc) * (int64_t)g.PH * g.PW + (int64_t)(ph0 + pr) * g.PW + pw;
     if (!BWD) {
       out[o] = best;
     } else {
@@ -195,7 +196,7 @@ inline bool tiled_ok(const StemGeom& g, const void* x) {
 
 inline int geom(int64_t N, int C, int H, int W, StemGeom* g) {
   if (N <= 0 || C <= 0 || H < 2 || W < 2) return VITTA_ERR_INVALID_ARG;
-  g->N = N; g->C = C; g->H = H; g->W = W;
+  g->N = N; g->C = C; g->H = H; g->W = W; g->cm = 0;
   g->PH = (H + 2 - 3) / 2 + 1;
   g->PW = (W + 2 - 3) / 2 + 1;
   return VITTA_OK;
@@ -252,6 +253,36 @@ int vitta_stem_bn_relu_pool_bwd_f32(const float* d_x, const float* d_gpool, cons
   const dim3 grid(po > 8192 ? 2u : 1u, (unsigned)(N * C));
   VITTA_LAUNCH(stem_bwd_affine_kernel, grid, dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream), d_x, d_gpool, h_bn[0],
                h_bn[1], h_bn[2], h_bn[3], eps, g, d_dgamma, d_dbeta);
+  return VITTA_OK;
+}
+
+// The same two passes with the POOLED tensor in channel-major planes [C][N * PH * PW] -- the layout of the trunk's convolutions
+// (conv.hip) -- so that no transposing copy sits between the stem and layer1 (forward) / in front of the stem's backward.
+int vitta_stem_bn_relu_pool_fwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, int64_t N, int32_t C, int32_t H,
+                                       int32_t W, float* d_out_cm, void* stream) {
+  StemGeom g;
+  if (!d_x || !h_bn || !h_bn[0] || !h_bn[1] || !h_bn[2] || !h_bn[3] || !d_out_cm) return VITTA_ERR_INVALID_ARG;
+  const int rc = geom(N, C, H, W, &g);
+  if (rc != VITTA_OK) return rc;
+  if (N * C > 65535 || !tiled_ok(g, d_x)) return VITTA_ERR_UNSUPPORTED;
+  g.cm = 1;
+  VITTA_LAUNCH(stem_tiled_kernel<false>, dim3((g.PH + SR - 1) / SR, (unsigned)(N * C)), dim3(VITTA_BLOCK), 0,
+               static_cast<hipStream_t>(stream), d_x, nullptr, h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps, g, d_out_cm, nullptr, nullptr,
+               nullptr);
+  return VITTA_OK;
+}
+
+int vitta_stem_bn_relu_pool_bwd_cm_f32(const float* d_x, const float* d_gpool_cm, const float* const* h_bn, float eps, int64_t N,
+                                       int32_t C, int32_t H, int32_t W, float* d_dgamma, float* d_dbeta, float* d_dy, void* stream) {
+  StemGeom g;
+  if (!d_x || !d_gpool_cm || !h_bn || !h_bn[0] || !h_bn[1] || !h_bn[2] || !h_bn[3] || !d_dgamma || !d_dbeta)
+    return VITTA_ERR_INVALID_ARG;
+  const int rc = geom(N, C, H, W, &g);
+  if (rc != VITTA_OK) return rc;
+  if (N * C > 65535 || !tiled_ok(g, d_x)) return VITTA_ERR_UNSUPPORTED;
+  g.cm = 1;
+  VITTA_LAUNCH(stem_tiled_kernel<true>, dim3(1, (unsigned)(N * C)), dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream), d_x,
+               d_gpool_cm, h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps, g, nullptr, d_dgamma, d_dbeta, d_dy);
   return VITTA_OK;
 }
 

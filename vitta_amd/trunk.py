@@ -470,10 +470,16 @@ class TrunkRunner:
         net, bn = self.net, self.net.bn1
         y = CV.stem_conv(x.contiguous(), self.packed(net.conv1, "s"))
         n, c, h, w = y.shape
-        pooled = torch.empty(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, dtype=torch.float32, device=y.device)
+        ph, pw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        if w % 4 == 0 and w <= 256:  # the tiled pass writes the trunk's channel-major planes directly (no transposing copy)
+            cm = torch.empty(c, n * ph * pw, dtype=torch.float32, device=y.device)
+            check(lib().vitta_stem_bn_relu_pool_fwd_cm_f32(_p(y), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
+                                                           n, c, h, w, _p(cm), _stream()), "vitta_stem_bn_relu_pool_fwd_cm_f32")
+            return y, cm, (n, ph, pw)
+        pooled = torch.empty(n, c, ph, pw, dtype=torch.float32, device=y.device)
         check(lib().vitta_stem_bn_relu_pool_fwd_f32(_p(y), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var), float(bn.eps),
                                                     n, c, h, w, _p(pooled), _stream()), "vitta_stem_bn_relu_pool_fwd_f32")
-        return y, pooled
+        return y, CV.to_cm(pooled), (n, ph, pw)
 
     def stem_producer(self, y, hooks):
         from . import ops
@@ -489,11 +495,25 @@ class TrunkRunner:
                 h.batch_mean = (bn.bias.detach().double() + (mean_x.double() - bn.running_mean.double()) * scale).float()
                 h.batch_var = (var_x.double() * scale * scale).float()
 
-    def stem_backward(self, y, gpool, sink, x=None):
+    def stem_backward(self, y, gcm, dims, sink, x=None):
+        """gcm: the gradient w.r.t. the pooled stem output as channel-major planes [64, n * ph * pw] (dims = (n, ph, pw))."""
         from .ops import _ptr4
         bn = self.net.bn1
         dw, db = sink(bn.weight), sink(bn.bias)
         conv_w = self.net.conv1.weight
+        trainable = conv_w.requires_grad and x is not None
+        if y.shape[3] % 4 == 0 and y.shape[3] <= 256 and (trainable or dw is not None or db is not None):
+            dw = dw if dw is not None else torch.zeros_like(bn.weight)
+            db = db if db is not None else torch.zeros_like(bn.bias)
+            n, c, h, w = y.shape
+            dy = torch.zeros_like(y) if trainable else None
+            check(lib().vitta_stem_bn_relu_pool_bwd_cm_f32(_p(y), _p(gcm), _ptr4(bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                                                           float(bn.eps), n, c, h, w, _p(dw), _p(db), _p(dy), _stream()),
+                  "vitta_stem_bn_relu_pool_bwd_cm_f32")
+            if trainable:
+                CV.stem_wgrad(x, dy, sink(conv_w))
+            return
+        gpool = CV.from_cm(gcm, *dims)
         if conv_w.requires_grad and x is not None:
             # trainable stem convolution: the same pass also scatters the gradient w.r.t. the convolution output, then
             # vitta_stem_conv7_wgrad_f32 turns it into the weight gradient (the clip itself needs no gradient)
@@ -625,11 +645,12 @@ class TrunkRunner:
                 raise RuntimeError("a BatchNorm2d carries both an engine hook and a statistics-producer hook: use the module path")
             sites = {**sites, **producers}
         if pooled_in is None:
-            y, pooled = self.stem(x)  # raw 7x7 output, [N, 64, h, w] after the max-pool
+            y, cur, (n, h, w) = self.stem(x)  # raw 7x7 output; the max-pooled planes, channel-major
         else:
-            y, pooled = None, pooled_in.contiguous()
-        n, _, h, w = pooled.shape
-        cur = CV.to_cm(pooled)
+            y = None
+            n, _, h, w = pooled_in.shape
+            cur = CV.to_cm(pooled_in.contiguous())
+        h0w0 = (h, w)
         tape = []
         blocks = self.blocks()
         # one zeroed buffer for the pooled means of every block of this pass (conv1's epilogue ADDS into it)
@@ -653,7 +674,7 @@ class TrunkRunner:
                 self.stem_producer(y, stem_hooks)
             sites = {k: v for k, v in sites.items() if k not in producers}
         return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None,
-                          x=x if (keep and pooled_in is None and self.net.conv1.weight.requires_grad) else None, pooled_hw=(pooled.shape[2], pooled.shape[3]),
+                          x=x if (keep and pooled_in is None and self.net.conv1.weight.requires_grad) else None, pooled_hw=h0w0,
                           last=(c, ng, h, w))
 
     # -- backward ----------------------------------------------------------------------------------------------
@@ -830,7 +851,7 @@ class TrunkRunner:
             return CV.from_cm(G, n, h0, w0)
         # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
         x0 = ctxd.get("x")
-        self.stem_backward(ctxd["stem"][:n], CV.from_cm(G, n, h0, w0), sink, x=None if x0 is None else x0[:n])
+        self.stem_backward(ctxd["stem"][:n], G, (n, h0, w0), sink, x=None if x0 is None else x0[:n])
         return None
 
 
