@@ -661,3 +661,65 @@ def test_parity_merged_stride2_data_gradient_is_one_launch(n, c, k, h, arith):
         CV.KERNEL_COUNTS = None
     assert sum(counts.values()) == 1
     _close(CV.from_cm(gx, n, h, h), x.grad)
+
+
+@pytest.mark.parametrize("bad", ["nan", "inf", "1e12"])
+def test_pooled_means_are_poisoned_by_non_finite_or_out_of_range_activations(bad, arith):
+    """VITTA_CONV_POOL sums are 64-bit fixed point: a NaN / Inf activation has no integer image and |mean| >= 2^31 would wrap.  The
+    reference's adaptive_avg_pool2d (temporal_module.py:53) hands NaN / Inf to the TAM; here such a contribution -- non-finite, or a
+    32-pixel block's share of a frame mean reaching 2^22 -- exchanges the word for INT64_MIN (poisoned band |v| >= 2^61, which no
+    later addition leaves), and the TAM branch kernels decode the band as NaN.  Stated deviation: Inf and finite means beyond ~5e8
+    arrive as NaN.  Frames without such an activation keep their exact sums; the convolution output itself is untouched."""
+    from vitta_amd import _lib, conv as CV
+    from vitta_amd.ops import _p, _ptr4, _stream
+    n, t, c, k, h = 16, 8, 64, 64, 28
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(k, c, 1, 1, generator=g) * c ** -0.5
+    bn = _bn(k, g)
+    f_bad, ch_bad = 3, 7
+    x[f_bad, ch_bad, 5, 9] = {"nan": float("nan"), "inf": float("inf"), "1e12": 1e12}[bad]
+    clean = x.clone()
+    clean[f_bad, ch_bad, 5, 9] = 0.0
+    ref = _bn_apply(F.conv2d(clean.double(), w.double()), bn).clamp_min(0).mean((2, 3))
+    d = _dev()
+    geom = CV.Geometry.forward(n, h, h, 1, 1, 0)
+    y = torch.empty(k, n * h * h, device=d)
+    pooled = torch.zeros(n, k, dtype=torch.int64, device=d)
+    CV.launch(geom, CV.to_cm(x.to(d)), CV.pack_fwd(w.to(d)), y, c, k, epi_bn=[b.to(d) for b in bn], pool=pooled)
+    q = pooled.cpu()
+    poisoned = (q >= 2 ** 61) | (q < -2 ** 61)
+    # which channels of the bad frame see a non-finite / huge activation: every one for NaN / Inf (the pixel feeds all of them through
+    # relu(bn(.)) -- a negative infinity is rectified to 0 and stays exact), the positively weighted ones for 1e10
+    z_full = _bn_apply(F.conv2d(x.double(), w.double()), bn)
+    z_bad = z_full[f_bad, :, 5, 9]
+    thr = 2.0 ** 22 * h * h  # the pixel's value at which its 32-pixel block's share of the frame mean reaches 2^22
+    must = torch.isnan(z_bad) | (z_bad > 4 * thr)
+    may = torch.isnan(z_bad) | (z_bad > 0.25 * thr)
+    if bad == "inf" and arith == "b3":  # the split arithmetic turns an infinite operand into NaN (x - bf16(x) is NaN for x = Inf:
+        must = may = torch.ones_like(must)  # conv_b3.hip's header, test_non_finite_inputs_...): every channel of the pixel is poisoned
+    assert (poisoned[f_bad] | ~must).all() and (~poisoned[f_bad] | may).all(), (poisoned[f_bad].sum(), must.sum(), may.sum())
+    assert int(poisoned.sum()) == int(poisoned[f_bad].sum()) and int(must.sum()) > 0  # no other frame
+    ok = ~poisoned
+    got = q.double() * 2.0 ** -32
+    want = torch.where(torch.isfinite(z_full), z_full, torch.zeros_like(z_full)).clamp_min(0).mean((2, 3))  # (-inf is rectified to 0)
+    assert ((got[ok] - want[ok]).abs() <= 1e-5 * want[ok].abs() + 1e-5 * ref.abs().max()).all()
+    # the TAM branch kernels decode the band as NaN for the clip that holds the frame, and only for it
+    L = _lib.lib()
+    nb, o = n // t, k // 4
+    r = lambda *s: torch.randn(*s, generator=g).to(d)
+    wg1, wg3, w0, w3 = r(2 * t, t) * 0.3, r(3, 2 * t) * 0.3, r(o, k, 3) * (3 * k) ** -0.5, r(k, o) * o ** -0.5
+    bng = [torch.rand(2 * t, generator=g).to(d) + 0.5, r(2 * t) * 0.1, r(2 * t) * 0.1, torch.rand(2 * t, generator=g).to(d) + 0.5]
+    bnl = [torch.rand(o, generator=g).to(d) + 0.5, r(o) * 0.1, r(o) * 0.1, torch.rand(o, generator=g).to(d) + 0.5]
+    sync = torch.zeros(256, dtype=torch.int32, device=d)
+    for fused in (False, True):
+        kern, gate, hpre = torch.empty(nb * k, 3, device=d), torch.empty(nb, k, t, device=d), torch.empty(2, nb, o, t, device=d)
+        args = (_p(pooled.view(nb, t, k)), _p(wg1), _ptr4(*bng), 1e-5, _p(wg3), _p(w0), _ptr4(*bnl), 1e-5, _p(w3), nb, k, t)
+        if fused:
+            _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), 1, _stream()), "fwd fused")
+        else:
+            _lib.check(L.vitta_tam_branch_fwd_f32(*args, _p(kern), _p(gate), _p(hpre), 1, _stream()), "fwd")
+        torch.cuda.synchronize()
+        clip = f_bad // t
+        assert torch.isnan(gate[clip]).any() and torch.isnan(kern.view(nb, k, 3)[clip]).any()
+        assert torch.isfinite(gate[1 - clip]).all() and torch.isfinite(kern.view(nb, k, 3)[1 - clip]).all()

@@ -104,7 +104,31 @@ def test_config2_tanet_full_size_step_matches_cpu_oracle(tmp_path, classes, abi_
     # measured (r3, K = 101 / 400): 48 / 2 of 55 520 elements over 5e-3 of their tensor's max|g| (worst 1.2e-2 / 5.4e-3; with
     # the exact-fp32 kernels, VITTA_CONV_ARITH=f32: 31 / 3, worst 9.1e-3 / 6.2e-3 -- a property of the L1 sign flips in the
     # early layers, whose gradients cross the whole trunk, not of the arithmetic form), cosine 0.99999
-    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], grad_frac=5e-3, max_outliers=128)
+    _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], grad_frac=5e-3, max_outliers=64)
+
+
+@pytest.mark.parametrize("mode", ["adam", "sgd"])
+@pytest.mark.parametrize("arith", ["b3", "f32"])
+def test_config2_full_size_step_matches_the_reference_itself(tmp_path, mode, arith, abi_calls):
+    """BASELINE config 2 at the BENCHMARKED size against the REFERENCE, not against the product's own host logic: the fixture
+    tests/golden/tta1_224.npz holds one online step of the reference's own `tta_standard` (corpus/basics.py:516-738) on
+    TANet-R50, 2 views x 8 frames x 224^2 -- Adam on the BN affine parameters and SGD over everything --, with its dropout
+    mask, losses, sampled gradients, updated parameters, the evaluation logits after the update and the noise floors of eight
+    perturbed reference re-runs (tools/refgen/gen_golden.py tta224).  The HIP path replays it (same weights, clip, mask) under
+    the first-step bounds of the small-size golden tests, floors weighted 2x (round 4: 4x)."""
+    from test_host_cpu import check_tta_records, run_product_tta
+    from vitta_amd import conv as CV
+    old = CV.ARITH
+    CV.ARITH = arith
+    try:
+        g = H.golden("tta1_224.npz")
+        recs = run_product_tta(g, mode, tmp_path, _dev(), None)
+        base = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.1)
+        for row in check_tta_records(g, mode, recs, base, floor_mult=2.0):
+            print("step %d %-60s err %.3e bound %.3e" % row)
+        abi_calls.assert_tanet_trunk(arith)
+    finally:
+        CV.ARITH = old
 
 
 def test_config3_swin_full_size_step_matches_cpu_oracle(tmp_path, abi_calls):

@@ -124,7 +124,8 @@ def run_product_tta(g, mode, tmp_path, device, backend_factory, batch_size=1, us
     args = H.tanet_args(tmp_path, clip_length=T, input_size=size, batch_size=batch_size,
                         spatiotemp_mean_clean_file=mp, spatiotemp_var_clean_file=vp,
                         update_only_bn_affine=(mode == "adam"), lr=cfg["lr_sgd"] if mode == "sgd" else cfg["lr_adam"])
-    masks = [H.unpack_mask(g[f"{mode}_step{i}_dropmask"], g[f"{mode}_step{i}_dropmask_shape"]) for i in range(3)]
+    n_steps = int(cfg.get("n_steps", 3))
+    masks = [H.unpack_mask(g[f"{mode}_step{i}_dropmask"], g[f"{mode}_step{i}_dropmask_shape"]) for i in range(n_steps)]
     wrapped = tta.SingleDeviceParallel(model).to(device)
     tta.BACKEND_FACTORY = backend_factory
     try:
@@ -135,7 +136,7 @@ def run_product_tta(g, mode, tmp_path, device, backend_factory, batch_size=1, us
     tta_set = data.SyntheticVideoDataset(cfg["n_videos"], 2, T, size, 101, "tanet", seed0=cfg["seed0"])
     eval_set = data.SyntheticVideoDataset(cfg["n_videos"], 1, T, size, 101, "tanet", seed0=cfg["seed0"])
     records = []
-    for step in range(3):
+    for step in range(n_steps):
         idx = range(step * batch_size, (step + 1) * batch_size)
         x = torch.stack([tta_set[i][0] for i in idx]).to(device)
         adapter.set_adapt_mode()

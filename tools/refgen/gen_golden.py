@@ -339,10 +339,12 @@ def source_stats_for(ref, T, size):
 NOISE_TRIALS = int(os.environ.get("VITTA_REFGEN_NOISE_TRIALS", "8"))
 
 
-def gen_tta(batch_size=1, tag="tta3"):
-    """A11/A7: three online steps through the reference's own tta_standard, SGD-all and Adam-affine."""
+def gen_tta(batch_size=1, tag="tta3", size=64, n_steps=3):
+    """A11/A7: n_steps online steps through the reference's own tta_standard, SGD-all and Adam-affine (tta3: three steps at 64^2;
+    tta1_224: ONE step at the benchmarked size 2 x 8 x 224^2 -- BASELINE configs 2 / 4 -- so that the full-size GPU test compares
+    with the reference itself, not with the product's host logic on the CPU)."""
     from utils.opts import get_opts
-    K_dataset, T, size, n_videos = "ucf101", 8, 64, 3 * batch_size
+    K_dataset, T, n_videos = "ucf101", 8, n_steps * batch_size
     out = {}
     for mode in ("sgd", "adam"):
         ref, _ = ref_tanet(101, T, 0)
@@ -372,8 +374,8 @@ def gen_tta(batch_size=1, tag="tta3"):
                 torch.manual_seed(1234)
                 run_reference_tta(args, ref, n_videos, batch_size, c2, perturb=1e-7, perturb_seed=90000 + 1000 * trial)
                 caps.append(c2)
-        assert len(cap.steps) == 3, len(cap.steps)
-        for i in range(3):
+        assert len(cap.steps) == n_steps, len(cap.steps)
+        for i in range(n_steps):
             a = cap.steps[i]
             noise = {}
 
@@ -410,8 +412,12 @@ def gen_tta(batch_size=1, tag="tta3"):
     out["sampled_params"] = np.array(SAMPLED_PARAMS)
     out["sample_rows"] = np.array(SAMPLE_ROWS)
     out["config"] = np.array(json.dumps(dict(T=T, size=size, n_videos=n_videos, batch_size=batch_size, seed0=500,
-                                             lr_sgd=5e-5, lr_adam=1e-3)))
+                                             lr_sgd=5e-5, lr_adam=1e-3, n_steps=n_steps)))
     save(f"{tag}.npz", **out)
+
+
+def gen_tta224():
+    gen_tta(batch_size=1, tag="tta1_224", size=224, n_steps=1)
 
 
 def gen_episodic():
@@ -803,7 +809,7 @@ def gen_bns():
     save("bns.npz", **out)
 
 
-SECTIONS = dict(l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
+SECTIONS = dict(tta224=gen_tta224, l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
                 opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic, data=gen_data, epoch=gen_epoch)
 
 if __name__ == "__main__":

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
             }
             if (RELU) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+              for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? 0.f : o[e];  // (keeps NaN, as torch's relu)
             }
             *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
           }

@@ -237,7 +237,7 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
         }
         if (RELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+          for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? 0.f : o[e];  // (keeps NaN, as torch's relu)
         }
         if (live) *reinterpret_cast<f32x4*>(yp) = f32x4{o[0], o[1], o[2], o[3]};
       }
@@ -248,10 +248,8 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
         pool.s0 += __shfl_xor(pool.s0, 4, 64); pool.s1 += __shfl_xor(pool.s1, 4, 64);
         if (q == 0 && pool.mblk < a.Mtot) {
           unsigned long long* pl = reinterpret_cast<unsigned long long*>(d.pool);
-          const float sc = d.pool_scale * 4294967296.f;
-          atomicAdd(pl + (int64_t)pool.fA * d.K + k, (unsigned long long)__float2ll_rn(pool.s0 * sc));
-          if (pool.mB < pool.mblk + 32 && pool.mB < a.Mtot)
-            atomicAdd(pl + (int64_t)(pool.fA + 1) * d.K + k, (unsigned long long)__float2ll_rn(pool.s1 * sc));
+          pool_add(pl + (int64_t)pool.fA * d.K + k, pool.s0 * d.pool_scale);
+          if (pool.mB < pool.mblk + 32 && pool.mB < a.Mtot) pool_add(pl + (int64_t)(pool.fA + 1) * d.K + k, pool.s1 * d.pool_scale);
         }
         pool.s0 = pool.s1 = 0.f;
       }

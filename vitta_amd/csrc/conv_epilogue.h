@@ -14,6 +14,17 @@ namespace vitta_conv {
 // are 64-bit FIXED-POINT (32 fractional bits of the mean): integer addition is associative, so the pooled means -- forward
 // activations of the TAM -- do not depend on the order in which the workgroups arrive (float atomics made two runs of the same step
 // differ by sign flips of the L1 alignment; same cost: tools/ubench/atomic_line_probe.hip).
+// One contribution to a fixed-point pooled mean.  Range / non-finite semantics (round 5): the reference's adaptive_avg_pool2d
+// (temporal_module.py:53) hands NaN / Inf on to the TAM; an integer sum cannot, and |mean| >= 2^31 would wrap silently.  A
+// contribution that is not finite, or whose magnitude reaches 2^22 (a 32-pixel block's share of a frame mean: activations of ~1e8),
+// POISONS the sum instead: the word is exchanged for INT64_MIN, which later additions (each < 2^54) cannot move out of the poisoned
+// band |v| >= 2^61; the readers (tam_branch.hip: pooled_tc) decode that band as NaN.  Legitimate sums stay below 2^29 in magnitude
+// (at most 128 blocks per frame).  Deviation, stated: Inf arrives as NaN, and finite means beyond ~5e8 do too.
+__device__ __forceinline__ void pool_add(unsigned long long* word, float contribution) {
+  if (fabsf(contribution) < 4194304.f) atomicAdd(word, (unsigned long long)__float2ll_rn(contribution * 4294967296.f));
+  else atomicExch(word, 0x8000000000000000ull);
+}
+
 struct PoolSums {
   int mblk, mB, fA;
   float s0 = 0.f, s1 = 0.f;
@@ -25,7 +36,7 @@ struct PoolSums {
     }
   }
   __device__ __forceinline__ void add(int m, float z) {
-    const float r = fmaxf(z, 0.f);
+    const float r = z < 0.f ? 0.f : z;  // relu that keeps NaN (fmaxf would return 0 for it: the reference's relu hands NaN on)
     if (m < mB) s0 += r;
     else s1 += r;
   }
@@ -35,9 +46,8 @@ struct PoolSums {
     s1 += __shfl_xor(s1, 32, 64);
     if (lk == 0 && mblk < a.Mtot) {
       unsigned long long* pool = reinterpret_cast<unsigned long long*>(d.pool);
-      const float sc = d.pool_scale * 4294967296.f;
-      atomicAdd(pool + (int64_t)fA * d.K + k, (unsigned long long)__float2ll_rn(s0 * sc));
-      if (mB < mblk + 32 && mB < a.Mtot) atomicAdd(pool + (int64_t)(fA + 1) * d.K + k, (unsigned long long)__float2ll_rn(s1 * sc));
+      pool_add(pool + (int64_t)fA * d.K + k, s0 * d.pool_scale);
+      if (mB < mblk + 32 && mB < a.Mtot) pool_add(pool + (int64_t)(fA + 1) * d.K + k, s1 * d.pool_scale);
     }
   }
 };
@@ -242,7 +252,7 @@ struct TileEpilogue {
           }
           if (RELU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            for (int e = 0; e < 4; ++e) o[e] = o[e] < 0.f ? 0.f : o[e];  // (keeps NaN, as torch's relu)
           }
           *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
         }

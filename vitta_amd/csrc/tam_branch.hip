@@ -39,6 +39,16 @@ struct TamBranchArgs {
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v; }  // (fmaxf(NaN, 0) is 0; torch's relu hands NaN on)
+
+// 64-bit fixed point (32 fractional bits: integer word, fraction word) -> float, exactly (integer part + fraction); a word in the
+// poisoned band |v| >= 2^61 -- a non-finite or out-of-range activation met the sum (conv_epilogue.h: pool_add) -- is NaN, which the
+// branches hand on as the reference's pooling would
+__device__ __forceinline__ float fixed_to_float(int hi, unsigned lo) {
+  const float v = (float)hi + (float)lo * 2.3283064365386963e-10f;
+  return ((unsigned)(hi + 0x20000000) >= 0x40000000u) ? __uint_as_float(0x7fc00000u) : v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The work of one clip is spread over several workgroups (a clip is only N = B*V = 2 workgroups otherwise):
 //   forward  F1 grid (N, O/OBF): h_pre / h for OBF conv1 output channels + the G branch of a slice of channels
@@ -144,7 +154,7 @@ __device__ __forceinline__ void load_pooled_t(const TamBranchArgs& a, int n, int
 #pragma unroll
           for (int j = 0; j < 2; ++j)
             if (c + j < ncv)
-              pl[(c + j) * TP + 1 + t] = (float)(int)(e[j] >> 32) + (float)(unsigned)(e[j] & 0xffffffffll) * 2.3283064365386963e-10f;
+              pl[(c + j) * TP + 1 + t] = fixed_to_float((int)(e[j] >> 32), (unsigned)(e[j] & 0xffffffffll));
         }
       }
     }
@@ -228,7 +238,7 @@ __device__ __forceinline__ void g_forward(const GLds& p, int T, int sub, bool ac
     float acc = 0.f, y = 0.f;
     if (active && m < M) {
       for (int t = 0; t < T; ++t) acc = fmaf(p.wg1[m * T + t], prow[t], acc);
-      y = fmaxf(fmaf(acc - p.rm[m], p.s[m], p.b[m]), 0.f);
+      y = relu_keep_nan(fmaf(acc - p.rm[m], p.s[m], p.b[m]));
       v0 = fmaf(p.wg3[m], y, v0);
       v1 = fmaf(p.wg3[M + m], y, v1);
       v2 = fmaf(p.wg3[2 * M + m], y, v2);
@@ -321,7 +331,7 @@ __device__ __forceinline__ void f1_compute(const TamBranchArgs& a, float* __rest
     const float sc = bw * rsqrtf(brv + a.bnl.eps);
     const int64_t idx = ((int64_t)n * O + o) * T + t;
     h_pre[idx] = pre_;
-    const float hv = fmaxf(fmaf(pre_ - brm, sc, bb), 0.f);
+    const float hv = relu_keep_nan(fmaf(pre_ - brm, sc, bb));
     if (WT) store_wt(h_act, idx, hv);
     else h_act[idx] = hv;
   }
@@ -764,7 +774,7 @@ struct StagePool {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {  // (integer part + fraction: the exact conversion of load_pooled_t)
         float* d = i < n2 ? pl + (c + j) * TP + 1 + t : trash + j;
-        *d = (float)(int)w[2 * j + 1] + (float)w[2 * j] * 2.3283064365386963e-10f;
+        *d = fixed_to_float((int)w[2 * j + 1], w[2 * j]);
       }
     } else {
       const int t4 = T >> 2, n4 = nc * t4;

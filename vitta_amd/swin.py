@@ -513,6 +513,9 @@ class I3DHead(nn.Module):
             x = x.reshape(x.shape[0], -1)
         if self.dropout is not None:
             x = self.dropout(x)
+        from . import fused_ln, ops
+        if fused_ln.ENABLED and ops.head_linear_supported(x, self.fc_cls):  # head.hip: no library GEMM for [views, 1024] x [1024, K]
+            return ops.HeadLinear.apply(x, self.fc_cls.weight, self.fc_cls.bias)
         return self.fc_cls(x)
 
 
