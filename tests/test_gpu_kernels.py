@@ -353,7 +353,8 @@ def test_wmsa_relative_table_variant(ws, clamp, B, nh, shift):
                                                         ((16, 7, 7), (16, 7, 7), 1, 4, True, False), ((16, 7, 7), (16, 7, 7), 1, 8, True, True),
                                                         ((16, 7, 7), (9, 7, 7), 1, 4, True, False), ((8, 7, 7), (4, 7, 7), 1, 8, False, True)])
 @pytest.mark.parametrize("io16", [False, True])
-def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap, io16):
+@pytest.mark.parametrize("bwd_form", ["one", "two"])
+def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap, io16, bwd_form, monkeypatch):
     """vitta_wmsa_rel_{fwd,bwd}_bf16_io (BASELINE config 5: bf16 MFMA W-MSA, window (16,7,7) = 784 tokens in ONE pass) against the
     fp64 composed reference evaluated on bf16-ROUNDED q (x scale), k, v.  Tolerances (bf16 operands, fp32 accumulation: the
     probabilities and dS are rounded to 8 bits of mantissa before their GEMMs): output 1e-2, gradients 3e-2 of the tensor's
@@ -361,6 +362,9 @@ def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap, io16):
     gradient ARE bfloat16 tensors, the context and the qkv gradient come back as bfloat16 (one more rounding each, inside the
     same bounds)."""
     from vitta_amd import ops, swin
+    # bwd_form: the one-pass backward kernel of round 5 (dQ, dK, dV from ONE evaluation of every score tile; the default wherever a
+    # workgroup per (window, head) fills the chip) / the two-kernel form (dQ query-major, dK / dV key-major); same bounds
+    monkeypatch.setenv("VITTA_WMSA_BF16_BWD", bwd_form)
     g = torch.Generator().manual_seed(29)
     N = clamp[0] * clamp[1] * clamp[2]
     C = nh * 32

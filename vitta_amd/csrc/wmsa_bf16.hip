@@ -14,6 +14,8 @@
 //     the forward stages V TRANSPOSED ([d][token], one 8-byte read), the backward kernels gather the four 2-byte values
 //     from the row-major copy they hold anyway (a transposed second copy would not fit LDS at 784 tokens).
 // Relative-position form only; the bias table is an input (its gradient -- SGD over all parameters -- stays on the fp32 kernels).
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace vitta;
@@ -473,6 +475,229 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward, ONE pass (round 5): dQ, dK, dV of a (window, head) from a single evaluation of every score tile.
+// The two kernels above evaluate S = K Q^T, dP = dO V^T and -- the expensive part: the tiles are vector-ALU bound (bias / mask terms,
+// exp, dS: ~8 vector instructions per element against 128 matrix flops) -- P and dS TWICE, once query-major for dQ and once key-major
+// for dK / dV (config 5: 111-150 us each per stage-0 launch against 80 us forward).  Here a wave owns key tiles (dK / dV accumulate in
+// its registers, as in the key-major kernel) and the queries are walked in CHUNKS of <= QC tiles whose scaled Q and dO rows sit in LDS
+// beside the whole K tile.  dQ: in step s of a chunk wave w works on query tile (s + w) mod chunk -- eight waves, eight DIFFERENT query
+// tiles --, sums the shares of all its key tiles in registers and adds them to the chunk's fp32 dQ tile in LDS with plain
+// read-modify-writes; one barrier per step keeps the waves on distinct tiles.  (LDS float atomics instead -- every wave adding every
+// pair's share -- measured 6.7 ms per launch against 0.75 ms without the accumulation: tools/bench_wmsa.py.)  The one operand the
+// key-major tile layout does not give -- dS with the QUERY on the operand's row, for dQ = dS K -- comes from a 640-byte per-wave LDS
+// turn-around: the packed tile is written key-major and read back with the transpose read (ds_read_b64_tr_b16).
+// Per tile: 10 MFMAs, ONE pass of the vector arithmetic.  Eight waves (a wave owns up to 7 key tiles: 112 accumulator registers);
+// workgroup = one (window, head) pair (launches with fewer pairs than CUs keep the two kernels above, which split a pair over several
+// workgroups).  Chunks are balanced and must hold >= 8 tiles each (bwd1_chunks; otherwise the two kernels above).
+// ------------------------------------------------------------------------------------------------
+constexpr int TH_BWD1 = 512;
+constexpr int KT_MAX = 7;      // key tiles a wave can own: 8 waves x 7 >= 50
+constexpr int DQP = 36;        // pitch of the fp32 dQ tile in floats: the four row groups of a tile land 16 banks apart
+constexpr int TSP = 20;        // pitch of the per-wave turn-around tile in bf16 elements
+
+struct Carve1 {
+  unsigned short *kb, *qb, *gb, *tscr;
+  float *dq, *l, *dl, *tab;
+  int *cr, *rows;
+};
+__host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T) {
+  const size_t qrows = 16 * (size_t)qc;
+  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + 8 * 16 * TSP) + 4 * (qrows * DQP + 2 * qrows + ((T + 3) & ~3) + 2 * 16 * (size_t)nt) + 64;
+}
+// query tiles per chunk: the largest of 13 / 10 that fits LDS, balanced over the chunks; 0: no admissible chunking (< 8 tiles somewhere)
+inline int bwd1_chunks(int nt, int T, int* nchunks) {
+  for (int cap = 13; cap >= 8; --cap) {
+    const int nc = (nt + cap - 1) / cap, qc = (nt + nc - 1) / nc;
+    if (bwd1_lds_bytes(nt, qc, T) > 160 * 1024) continue;
+    if (nt - (nc - 1) * qc < 8) continue;  // the last chunk
+    *nchunks = nc;
+    return qc;
+  }
+  return 0;
+}
+__device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, int T) {
+  Carve1 c;
+  const int qrows = 16 * qc;
+  c.kb = reinterpret_cast<unsigned short*>(smem);
+  c.qb = c.kb + 16 * nt * RP;
+  c.gb = c.qb + qrows * RP;
+  c.tscr = c.gb + qrows * RP;
+  c.dq = reinterpret_cast<float*>(c.tscr + 8 * 16 * TSP);
+  c.l = c.dq + qrows * DQP;
+  c.dl = c.l + qrows;
+  c.tab = c.dl + qrows;
+  c.cr = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
+  c.rows = c.cr + 16 * nt;
+  return c;
+}
+
+template <bool REG, bool TAIL>
+__global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args a, const float* __restrict__ out,
+                                                                      const float* __restrict__ dout, const float* __restrict__ lse,
+                                                                      float* __restrict__ delta, float* __restrict__ dqkv, int qc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
+  const Carve1 cv = carve1(smem, nt, qc, a.T);
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  fill_rows(cv.rows, a.rm, b, N, nt);
+  stage_rows(cv.kb, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);  // K, row-major, the whole window
+  {  // table column of the head + packed code | region of the window's tokens (setup_terms on this carve)
+    Carve tmp;
+    tmp.tab = cv.tab; tmp.cr = cv.cr;
+    setup_terms(tmp, a, h, b, nt);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  unsigned short* const tscr = cv.tscr + wave * 16 * TSP;
+  // key tiles of this wave: wave, wave + 8, ...: V fragments, code / region of the lane's key, dK / dV accumulators -- in registers
+  bf16x4 va[KT_MAX], vb[KT_MAX];
+  f32x4 dk0[KT_MAX], dk1[KT_MAX], dv0[KT_MAX], dv1[KT_MAX];
+  __syncthreads();  // rows / code table in place
+#pragma unroll
+  for (int j = 0; j < KT_MAX; ++j) {
+    dk0[j] = dk1[j] = dv0[j] = dv1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt = min(wave + 8 * j, nt - 1), key = min(16 * kt + i, N - 1);
+    float vf_[8];
+    load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va[j], vb[j], vf_);
+  }
+  const bool kvalid_all = !TAIL;
+  const int nchunks = (nt + qc - 1) / qc;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int qt0 = ch * qc, qtn = min(qc, nt - qt0), qrows = 16 * qtn;
+    __syncthreads();  // (the previous chunk's readers are done)
+    // ---- stage the chunk: scaled Q rows, dO rows (bf16), lse, delta = sum_d dO O (also stored for the record), zero the dQ tile ----
+    for (int it = threadIdx.x; it < qrows * 8; it += TH_BWD1) {
+      const int row = it >> 3, c4 = it & 7, q = 16 * qt0 + row;
+      const bool in = q < N;
+      const int tok = cv.rows[in ? q : N - 1];
+      float qv[4], gv[4], ov[4];
+      if (a.io16) {
+        const ushort4 q4 = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.qkv) + (int64_t)tok * rs + h * HD + 4 * c4);
+        const ushort4 g4 = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(dout) + (int64_t)tok * C + h * HD + 4 * c4);
+        const ushort4 o4 = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(out) + (int64_t)tok * C + h * HD + 4 * c4);
+        qv[0] = bf2f(q4.x); qv[1] = bf2f(q4.y); qv[2] = bf2f(q4.z); qv[3] = bf2f(q4.w);
+        gv[0] = bf2f(g4.x); gv[1] = bf2f(g4.y); gv[2] = bf2f(g4.z); gv[3] = bf2f(g4.w);
+        ov[0] = bf2f(o4.x); ov[1] = bf2f(o4.y); ov[2] = bf2f(o4.z); ov[3] = bf2f(o4.w);
+      } else {
+        const float4 q4 = *reinterpret_cast<const float4*>(a.qkv + (int64_t)tok * rs + h * HD + 4 * c4);
+        const float4 g4 = *reinterpret_cast<const float4*>(dout + (int64_t)tok * C + h * HD + 4 * c4);
+        const float4 o4 = *reinterpret_cast<const float4*>(out + (int64_t)tok * C + h * HD + 4 * c4);
+        qv[0] = q4.x; qv[1] = q4.y; qv[2] = q4.z; qv[3] = q4.w;
+        gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+        ov[0] = o4.x; ov[1] = o4.y; ov[2] = o4.z; ov[3] = o4.w;
+      }
+      if (!in) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qv[e] = gv[e] = ov[e] = 0.f;
+      }
+      *reinterpret_cast<bf16x4*>(cv.qb + row * RP + 4 * c4) = pack4(qv[0] * a.scale, qv[1] * a.scale, qv[2] * a.scale, qv[3] * a.scale);
+      *reinterpret_cast<bf16x4*>(cv.gb + row * RP + 4 * c4) = pack4(gv[0], gv[1], gv[2], gv[3]);
+      float dsum = gv[0] * ov[0] + gv[1] * ov[1] + gv[2] * ov[2] + gv[3] * ov[3];
+      dsum += __shfl_xor(dsum, 1, 64);
+      dsum += __shfl_xor(dsum, 2, 64);
+      dsum += __shfl_xor(dsum, 4, 64);
+      if (c4 == 0) {
+        cv.dl[row] = in ? dsum : 0.f;
+        cv.l[row] = in ? lse[(b * nH + h) * N + q] : INFINITY;  // exp(s - inf) = 0 for padded queries
+        if (in && delta) delta[(b * nH + h) * N + q] = dsum;
+      }
+    }
+    for (int it = threadIdx.x; it < qrows * DQP; it += TH_BWD1) cv.dq[it] = 0.f;
+    __syncthreads();
+    // ---- step s: wave w on query tile (s + w) mod qtn (qtn >= 8: eight distinct tiles), against all of its key tiles ----
+    for (int st = 0; st < qtn; ++st) {
+      int qt = st + wave;
+      qt = qt >= qtn ? qt - qtn : qt;
+      const bf16x8 qf = *reinterpret_cast<const bf16x8*>(cv.qb + (16 * qt + i) * RP + 8 * g);
+      const bf16x8 gf = *reinterpret_cast<const bf16x8*>(cv.gb + (16 * qt + i) * RP + 8 * g);
+      const bf16x4 gq0 = gather4(cv.gb, qt, g, i, 0), gq1 = gather4(cv.gb, qt, g, i, 1);
+      const bf16x4 qq0 = gather4(cv.qb, qt, g, i, 0), qq1 = gather4(cv.qb, qt, g, i, 1);
+      const int ql = 16 * qt + 4 * g, q0 = 16 * qt0 + ql;
+      const int4 cq = *reinterpret_cast<const int4*>(cv.cr + q0);
+      const float4 lq = *reinterpret_cast<const float4*>(cv.l + ql);
+      const float4 dq4 = *reinterpret_cast<const float4*>(cv.dl + ql);
+      const int qcd[4] = {REG ? pk_code(cq.x) : cq.x, REG ? pk_code(cq.y) : cq.y, REG ? pk_code(cq.z) : cq.z, REG ? pk_code(cq.w) : cq.w};
+      const int qrg[4] = {pk_region(cq.x), pk_region(cq.y), pk_region(cq.z), pk_region(cq.w)};
+      const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+      f32x4 dqa = {0.f, 0.f, 0.f, 0.f}, dqb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KT_MAX; ++j) {
+        const int kt = wave + 8 * j;
+        if (kt < nt) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cv.kb + (16 * kt + i) * RP + 8 * g);
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sacc = mfma(__builtin_shufflevector(qf, qf, 0, 1, 2, 3), __builtin_shufflevector(kf, kf, 0, 1, 2, 3), sacc);
+          sacc = mfma(__builtin_shufflevector(qf, qf, 4, 5, 6, 7), __builtin_shufflevector(kf, kf, 4, 5, 6, 7), sacc);
+          dp = mfma(__builtin_shufflevector(gf, gf, 0, 1, 2, 3), va[j], dp);
+          dp = mfma(__builtin_shufflevector(gf, gf, 4, 5, 6, 7), vb[j], dp);
+          const bool kvalid = kvalid_all || 16 * kt + i < N;
+          const int pkey = cv.cr[min(16 * kt + i, N - 1)];
+          const int ckey_j = REG ? pk_code(pkey) : pkey, rkey_j = pk_region(pkey);
+          float p[4], ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float term = cv.tab[qcd[r] - ckey_j + a.off];
+            if (REG && qrg[r] != rkey_j) term -= 100.f;
+            const float sv = (!TAIL || (q0 + r < N && kvalid)) ? sacc[r] + term : -INFINITY;
+            p[r] = __expf(sv - lv[r]);
+            ds[r] = p[r] * (dp[r] - dv[r]);
+          }
+          const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
+          dv0[j] = mfma(pa, gq0, dv0[j]);
+          dv1[j] = mfma(pa, gq1, dv1[j]);
+          dk0[j] = mfma(da, qq0, dk0[j]);
+          dk1[j] = mfma(da, qq1, dk1[j]);
+          // dQ share of this key tile: dS with the query on the operand's row = the tile written key-major and read transposed
+          *reinterpret_cast<bf16x4*>(tscr + i * TSP + 4 * g) = da;  // M[key i][queries 4 g ..]
+          const bf16x4 dst = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) bf16x4*)(tscr + (4 * g + (i >> 2)) * TSP + 4 * (i & 3)));  // M[keys 4 g ..][query i]
+          dqa = mfma(dst, gather4(cv.kb, kt, g, i, 0), dqa);
+          dqb = mfma(dst, gather4(cv.kb, kt, g, i, 1), dqb);
+        }
+      }
+      // this wave is the only one on query tile qt in this step: plain read-modify-write of its rows of the dQ tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cv.dq[(ql + r) * DQP + i] += dqa[r];
+        cv.dq[(ql + r) * DQP + 16 + i] += dqb[r];
+      }
+      __syncthreads();
+    }
+    // ---- the chunk's dQ ----
+    for (int it = threadIdx.x; it < qrows * 8; it += TH_BWD1) {
+      const int row = it >> 3, c4 = it & 7, q = 16 * qt0 + row;
+      if (q >= N) continue;
+      const float4 v = *reinterpret_cast<const float4*>(cv.dq + row * DQP + 4 * c4);
+      const int64_t o = (int64_t)cv.rows[q] * rs + (int64_t)h * HD + 4 * c4;
+      if (a.io16) {
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(dqkv) + o) = pack4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+      } else {
+        *reinterpret_cast<float4*>(dqkv + o) = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+      }
+    }
+  }
+  // ---- dK, dV of the wave's key tiles ----
+#pragma unroll
+  for (int j = 0; j < KT_MAX; ++j) {
+    const int kt = wave + 8 * j;
+    if (kt >= nt) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = 16 * kt + 4 * g + r;
+      if (krow < N) {
+        const int64_t ok = (int64_t)cv.rows[krow] * rs + (int64_t)(nH + h) * HD, ov = (int64_t)cv.rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
+        store_el(dqkv, ok + i, a.io16, dk0[j][r]);
+        store_el(dqkv, ok + 16 + i, a.io16, dk1[j][r]);
+        store_el(dqkv, ov + i, a.io16, dv0[j][r]);
+        store_el(dqkv, ov + 16 + i, a.io16, dv1[j][r]);
+      }
+    }
+  }
+}
+
 inline int pick_split(int64_t pairs, int nt, int waves) {
   int qs = 1;  // one workgroup per CU (LDS): split the tiles of a (window, head) pair only while CUs would sit idle
   while (pairs * qs < 256 && (nt + qs * waves - 1) / (qs * waves) >= 2 && qs < 8) qs *= 2;
@@ -577,6 +802,24 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const size_t l1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, T), l2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, T);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool reg = a.region != nullptr, tail = (N % 16) != 0;
+  // VITTA_WMSA_BF16_BWD: "one" / "two" force a form (tests, A/B); default: one pass wherever a workgroup per pair fills the chip
+  const char* form = std::getenv("VITTA_WMSA_BF16_BWD");
+  const bool force_one = form && form[0] == 'o', force_two = form && form[0] == 't';
+  int nchunks1 = 0;
+  const int qc1 = bwd1_chunks(nt, T, &nchunks1);
+  const size_t lf = qc1 ? bwd1_lds_bytes(nt, qc1, T) : 0;
+  if (!force_two && (qs == 1 || force_one) && qc1 > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
+#define WMSA_BWD1(R, TL)                                                                                                              \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL>, lf)) return VITTA_ERR_LAUNCH;                                                       \
+    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf, st, a, d_out, d_dout, d_lse, d_delta, \
+                 d_dqkv, qc1);                                                                                                        \
+  } while (0)
+    if (reg) { if (tail) WMSA_BWD1(true, true); else WMSA_BWD1(true, false); }
+    else { if (tail) WMSA_BWD1(false, true); else WMSA_BWD1(false, false); }
+#undef WMSA_BWD1
+    return VITTA_OK;
+  }
 #define WMSA_BWD(R, TL)                                                                                                               \
   do {                                                                                                                                \
     if (!set_lds(wmsa_bf16_bwd_dq_kernel<R, TL>, l1) || !set_lds(wmsa_bf16_bwd_dkv_kernel<R, TL>, l2)) return VITTA_ERR_LAUNCH;         \
