@@ -276,6 +276,13 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
  * another stream.  0: use the two-launch forms (vitta_tam_branch_fwd_f32 / _bwd_f32); the fused entry points return
  * VITTA_ERR_UNSUPPORTED themselves when asked anyway. */
 int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T);
+/* The L branch's weight gradients as their own launch (the backward entry points called with NULL dw0 / dw3 leave them out):
+ * d_dw0 [C/4, C, 3] += sum over clips and t of dpre[n, o, t] pooled[n, c, t + j - 1];  d_dw3 [C, C/4] += sum of
+ * (d gate * gate * (1 - gate))[n, c, t] h[n, o, t].  d_hact = the SECOND half of the forward's d_hpre (after N_saved * C/4 * T floats),
+ * d_dpre = the scratch behind d_gpooled's first N * C * T floats that the backward left.  Single writer per element (plain
+ * read-modify-write): may run on another stream than the backward, after it. */
+int vitta_tam_branch_wgrad_f32(const float* d_pooled, int32_t pooled_tc, const float* d_gate, const float* d_ggate, const float* d_hact,
+                               const float* d_dpre, int32_t N, int32_t C, int32_t T, float* d_dw0, float* d_dw3, void* stream);
 int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "vitta_tam_pool_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_branch_supported": (C.c_int, [_i32, _i32]),
     "vitta_tam_branch_fused_supported": (C.c_int, [_i32, _i32, _i32]),
+    "vitta_tam_branch_wgrad_f32": (C.c_int, [_p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "vitta_tam_branch_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                            _p, _p, _p, _i32, _p]),
     "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,

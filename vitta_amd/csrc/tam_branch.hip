@@ -1014,6 +1014,54 @@ __global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   b2_finish(a, g, n, c0, gpo, gacc);
 }
 
+// The L branch's two weight gradients as their own launch (round 5: SGD over all parameters -- inside the fused backward they are
+// C x C/4 x 4 global atomics per clip on the MAIN chain of the step, 37 us per block instead of 17-21; nothing in the backward waits for
+// them, so the trunk issues this launch on its weight-gradient helper stream):
+//   dW3[c, o]    += sum_n sum_t dz[n, c, t] h[n, o, t],                dz = d gate * gate * (1 - gate)
+//   dW0[o, c, j] += sum_n sum_t dpre[n, o, t] pooled[n, c, t + j - 1]  (zero padding in t)
+// one thread per output element, both clips summed in registers: single writer, plain read-modify-write, deterministic.
+__global__ __launch_bounds__(TBW) void tam_branch_wgrad_kernel(TamBranchArgs a, const float* __restrict__ gate, const float* __restrict__ ggate,
+                                                               const float* __restrict__ h_act, const float* __restrict__ dpre,
+                                                               float* __restrict__ dw0, float* __restrict__ dw3) {
+  const int C = a.C, T = a.T, O = C / 4;
+  const int64_t n3 = (int64_t)C * O, n0 = (int64_t)O * C * 3;
+  const int64_t idx = (int64_t)blockIdx.x * TBW + threadIdx.x;
+  if (idx < n3 && dw3) {
+    const int c = (int)(idx / O), o = (int)(idx - (int64_t)c * O);
+    float s = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+      const float* gt = gate + ((int64_t)n * C + c) * T;
+      const float* gg = ggate + ((int64_t)n * C + c) * T;
+      const float* hh = h_act + ((int64_t)n * O + o) * T;
+      for (int t = 0; t < T; ++t) {
+        const float g1 = gt[t];
+        s = fmaf(gg[t] * g1 * (1.f - g1), hh[t], s);
+      }
+    }
+    dw3[idx] += s;
+  } else if (idx >= n3 && idx < n3 + n0 && dw0) {
+    const int64_t e = idx - n3;
+    const int j = (int)(e % 3), c = (int)((e / 3) % C), o = (int)(e / (3 * (int64_t)C));
+    float s = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+      const float* dp = dpre + ((int64_t)n * O + o) * T;
+      for (int t = 0; t < T; ++t) {
+        const int tp = t + j - 1;
+        if (tp < 0 || tp >= T) continue;
+        float pv;
+        if (a.pooled_tc) {
+          const long long q = reinterpret_cast<const long long*>(a.pooled)[((int64_t)n * T + tp) * C + c];
+          pv = fixed_to_float((int)(q >> 32), (unsigned)(q & 0xffffffffll));
+        } else {
+          pv = a.pooled[((int64_t)n * C + c) * T + tp];
+        }
+        s = fmaf(dp[t], pv, s);
+      }
+    }
+    dw0[e] += s;
+  }
+}
+
 inline bool fast_ok(int C, int T) { return C % 64 == 0 && C <= 512 && T % 4 == 0 && T <= T_MAX && C * T <= 4096; }
 
 inline size_t g_floats(int T) { return (size_t)2 * T * T + 3 * 2 * T + 5 * 2 * T; }
@@ -1232,6 +1280,18 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
   VITTA_LAUNCH(tam_branch_b1_kernel, dim3(N, (O + OBB - 1) / OBB), dim3(TBW), b1_lds(C, T), st, a, d_gate, d_hpre, d_hact,
                d_ggate, d_dpre, g);
   VITTA_LAUNCH(tam_branch_b2_kernel, dim3(N, (C + CBB - 1) / CBB), dim3(TBW), b2_lds(C, T), st, a, d_kern, d_gkern, d_dpre, g);
+  return VITTA_OK;
+}
+
+int vitta_tam_branch_wgrad_f32(const float* d_pooled, int32_t pooled_tc, const float* d_gate, const float* d_ggate, const float* d_hact,
+                               const float* d_dpre, int32_t N, int32_t C, int32_t T, float* d_dw0, float* d_dw3, void* stream) {
+  if (!d_pooled || !d_gate || !d_ggate || !d_hact || !d_dpre || N <= 0 || C <= 0 || T <= 0 || C % 4) return VITTA_ERR_INVALID_ARG;
+  if (!d_dw0 && !d_dw3) return VITTA_OK;
+  TamBranchArgs a{};
+  a.pooled = d_pooled; a.N = N; a.C = C; a.T = T; a.pooled_tc = pooled_tc ? 1 : 0;
+  const int64_t total = (int64_t)C * (C / 4) * 4;
+  VITTA_LAUNCH(tam_branch_wgrad_kernel, dim3((unsigned)((total + TBW - 1) / TBW)), dim3(TBW), 0, static_cast<hipStream_t>(stream), a, d_gate,
+               d_ggate, d_hact, d_dpre, d_dw0, d_dw3);
   return VITTA_OK;
 }
 

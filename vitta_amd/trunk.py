@@ -772,7 +772,18 @@ class TrunkRunner:
         gbuf = torch.empty(nb * p * t + nb * (p // 4) * t, **f)  # d pooled | scratch
         from .ops import tam_branch_fused_supported
         bn_sinks = _ptr4(sink(bg.weight), sink(bg.bias), sink(bl.weight), sink(bl.bias))
-        w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), sink(tam.L[0].weight), sink(tam.L[3].weight))
+        dw0, dw3 = sink(tam.L[0].weight), sink(tam.L[3].weight)
+        tq = []  # launches for the helper stream besides the convolutions' weight gradients
+        if WGRAD_SIDE and (dw0 is not None or dw3 is not None):
+            # the L branch's weight gradients (C x C/4 x 4 accumulations per clip) leave the main chain: the fused backward runs
+            # without them (17-21 us instead of 37) and vitta_tam_branch_wgrad_f32 follows on the weight-gradient helper stream
+            w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), None, None)
+            pooled_sv, gate_sv, hpre_sv, ptc_sv = sv["pooled"], sv["gate"], sv["hpre"], sv["ptc"]
+            tq.append(lambda: check(L.vitta_tam_branch_wgrad_f32(
+                _p(pooled_sv), ptc_sv, _p(gate_sv), _p(ggate), C.c_void_p(hpre_sv.data_ptr() + 4 * (fr // t) * (p // 4) * t),
+                C.c_void_p(gbuf.data_ptr() + 4 * nb * p * t), nb, p, t, _p(dw0), _p(dw3), _stream()), "vitta_tam_branch_wgrad_f32"))
+        else:
+            w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), dw0, dw3)
         if tam_branch_fused_supported(nb, p, t):
             check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
@@ -809,13 +820,15 @@ class TrunkRunner:
             fold = (gin, g_idp)  # gin now holds dx3 of the previous block
         else:
             CV.launch(self.geo("b", n, h, w)[0], dx1, self.packed(net.conv1, "b", True), gin, p, cin, flags=rflag, res=res)
-        if wq:
+        if wq or tq:
             helper = _Fork(dev, role=1)  # waits for everything this block has queued
             with helper:  # four launches + ONE reduction of their partial tiles
+                for fn in tq:
+                    fn()
                 CV.wgrad_reduce([CV.wgrad(*wa, defer=i, **wkw) for i, (wa, wkw) in enumerate(wq)])
             done = torch.cuda.Event()
             done.record(helper.side)
-            self._wgrad_pending.append((helper, wq, done))
+            self._wgrad_pending.append((helper, (wq, tq, ggate, gbuf), done))
             # the operands of a block's weight gradients (its saved activations and gradient tensors) stay alive until the
             # main stream has waited for THAT block's helper work; two blocks back it has long finished, so the wait is free
             # and the tensors of at most three blocks are held instead of all sixteen
