@@ -65,6 +65,7 @@ if ROOT not in sys.path:
 
 HOOKED_ELEMENTS_PER_VIDEO = 44556288  # 29 BN2d outputs of layer3/4 at 2x8x224^2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+VALU_LANE_OPS_PER_S = 78.6e12  # 256 CUs x 4 SIMD-32 x 2.4 GHz (one lane-operation per lane and cycle = the 157.3 TFLOP/s fp32 FMA rate / 2)
 MFMA_F32_PEAK_TF = 157.3  # same guide: fp32 matrix peak (v_mfma_f32_32x32x2_f32 / 16x16x4), 155 TF measured
 MFMA_BF16_PEAK_TF = 2500.0  # same guide: bf16 dense matrix peak (v_mfma_f32_32x32x16_bf16), 2495 TF measured
 B3_PRODUCTS = 6             # conv_b3.hip: bf16 MFMA products per fp32-grade multiply-add
@@ -353,6 +354,7 @@ def run_gpu(opt, rank, world, device):
             # per launch: the composite bound t_roof = max(flops / the instruction's matrix peak, algorithmic bytes / 8 TB/s) --
             # the 64 -> 256 layer at 56 x 56 is bandwidth-bound, layer 4 matrix-bound; frac_roof = t_roof / duration
             by = np.array([key[4] for _, key, _ in conv_events], dtype=np.float64)
+            by_min = np.array([key[7] if len(key) > 7 else key[4] for _, key, _ in conv_events], dtype=np.float64)  # x + weights + y only
             t_roof = np.maximum(fl / (peak * 1e9), by / (HBM_PEAK_GBS * 1e6))  # ms
             for (f, key, _), t, kid, tr in zip(conv_events, ms, fam, t_roof):
                 r = by_shape.setdefault(key[:4] + (kid,), [0, 0.0, 0.0, 0.0, 0.0])
@@ -363,11 +365,14 @@ def run_gpu(opt, rank, world, device):
                 r[4] += tr
             names = {0: "conv_igemm (fp32)", 1: "conv_sk (fp32)", 2: "conv_pw (fp32)", 3: "conv_b3 (split bf16)", None: "?"}
             pooled = np.array([bool(key[5]) if len(key) > 5 else False for _, key, _ in conv_events])  # launches that also pool (VITTA_CONV_POOL)
+            folded = np.array([bool(key[6]) if len(key) > 6 else False for _, key, _ in conv_events])  # ... that carry a bn3 + add + ReLU backward
+            n_folded = int(folded.sum())
+            pooled = pooled | folded  # "plain" below = convolution + its own BatchNorm epilogue only
             run_gpu.conv = dict(launches=len(fl), steps=n_rep, flops=float(fl.sum()), ms=float(ms.sum()),
-                                pooled_launches=int(pooled.sum()), plain_flops=float(fl[~pooled].sum()), plain_ms=float(ms[~pooled].sum()),
+                                pooled_launches=int(pooled.sum()) - n_folded, folded_launches=n_folded, plain_flops=float(fl[~pooled].sum()), plain_ms=float(ms[~pooled].sum()),
                                 plain_ms_at_peak=float((fl / (peak * 1e9))[~pooled].sum()),
                                 ms_at_peak=float((fl / (peak * 1e9)).sum()), b3_launches=int(b3.sum()), b3_flops=float(fl[b3].sum()),
-                                bytes=float(by.sum()), ms_at_roof=float(t_roof.sum()),
+                                bytes=float(by.sum()), bytes_min=float(by_min.sum()), ms_at_roof=float(t_roof.sum()),
                                 hbm_bound_launches=int((by / (HBM_PEAK_GBS * 1e6) > fl / (peak * 1e9)).sum()),
                                 by_shape=[dict(C=k[0], K=k[1], taps=k[2], positions=k[3], kernel=names.get(k[4], str(k[4])),
                                                launches_per_step=v[0] / n_rep, avg_us=1e3 * v[2] / v[0], tflops=v[1] / v[2] / 1e9,
@@ -457,8 +462,8 @@ class _StreamTimer:
     microseconds of the event records -- small against the 50-500 us dense and attention launches of Video Swin-B."""
     records = None
 
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, valu_ops=0.0):
+        self.kind, self.flops, self.valu_ops = kind, flops, valu_ops
         self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.a.record()
 
@@ -529,17 +534,25 @@ def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3
         adapter._graph = graph
         kinds = {}
         for r in _StreamTimer.records:
-            k = kinds.setdefault(r.kind, [0, 0.0, 0.0])
+            k = kinds.setdefault(r.kind, [0, 0.0, 0.0, 0.0])
             k[0] += 1
             k[1] += r.flops
             k[2] += r.a.elapsed_time(r.b)
+            k[3] += getattr(r, "valu_ops", 0.0)
         _StreamTimer.records = None
         roof = {}
-        for kind, (n, fl, ms) in sorted(kinds.items()):
+        for kind, (n, fl, ms, vops) in sorted(kinds.items()):
             peak = MFMA_BF16_PEAK_TF if kind.endswith("bf16") else MFMA_F32_PEAK_TF
             tf = fl / ms / 1e9
             roof[kind] = {"launches_per_step": n / 2, "gflop_per_step": fl / 2e9, "ms_per_step": ms / 2, "achieved": tf, "peak": peak,
                           "unit": "TFLOP/s", "frac": tf / peak}
+            if vops > 0:
+                # composite bound of the attention family: with head dim 32 a score is 128 (forward) / 320 (backward) matrix flops but ~8 /
+                # ~10 vector lane-operations (bias + mask terms, exp, dS, packing), and the vector pipe does 78.6e12 lane-operations a
+                # second (157.3 TFLOP/s of fp32 FMA / 2): t_roof = max(matrix time, vector time)
+                t_m, t_v = fl / (peak * 1e9), vops / (VALU_LANE_OPS_PER_S * 1e-3)
+                roof[kind].update({"valu_lane_ops_per_step": vops / 2, "t_roof_ms_per_step": max(t_m, t_v) / 2,
+                                   "bound": "valu" if t_v > t_m else "mfma", "frac_composite": max(t_m, t_v) / ms})
         out = {"value": 1.0 / dt, "unit": "videos/s", "ms_per_step": 1e3 * dt, "steps": steps, "blocks_ms": [round(1e3 * b, 3) for b in blocks],
                "launch_mode": "hipGraph replay",
                "dtype": "f32 residual stream / statistics / softmax / accumulation; bf16 MFMA operands AND bf16 activations between the "
@@ -552,8 +565,10 @@ def swin_leg(device, views, frames, window_depth, classes, bf16, steps, warmup=3
                           "schedule": "overlapped"},
                "roofline": roof,
                "roofline_note": "dense (gemm.hip) and window attention launches of two eager steps bracketed by stream events; flops = "
-                                "2 M N K per product, 4 / 14 x tokens^2 x head_dim per (window, head) forward / backward; peak = the "
-                                "matrix rate of the instruction the kernel issues (157.3 fp32, 2500 bf16 dense)",
+                                "2 M N K per product, 4 / 10 x tokens^2 x head_dim per (window, head) forward / backward (ALGORITHMIC: "
+                                "S, dP, dV, dK, dQ once each; rounds 1-4 counted the 14 x the two-kernel backward executes); peak = the "
+                                "matrix rate of the instruction the kernel issues (157.3 fp32, 2500 bf16 dense); attention also carries "
+                                "the composite bound max(matrix time, vector-ALU time at ~8 / ~10 lane-operations per score)",
                "max_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
         del adapter, model
         torch.cuda.empty_cache()
@@ -762,7 +777,9 @@ def main():
         if conv:
             tf = conv["flops"] / conv["ms"] / 1e9
             conv_pmc = None
-            cpf = os.path.join(ROOT, "profiles", "r4_conv_traffic_pmc.json")
+            cpf = os.path.join(ROOT, "profiles", "r5_conv_traffic_pmc.json")
+            if not os.path.exists(cpf):
+                cpf = os.path.join(ROOT, "profiles", "r4_conv_traffic_pmc.json")
             if os.path.exists(cpf) and opt.size == 224 and opt.clip_length == 8:
                 conv_pmc = json.load(open(cpf)).get("hbm_bytes_per_launch")
             frac = conv["ms_at_peak"] / conv["ms"]
@@ -773,13 +790,15 @@ def main():
                         # composite: every launch against max(flops / its matrix peak, algorithmic bytes / 8 TB/s); time-weighted
                         "frac_composite": conv["ms_at_roof"] / conv["ms"],
                         "algorithmic_bytes_per_step": conv["bytes"] / conv["steps"],
+                        # the round-3 definition (x + fp32 weights + y, no epilogue input streams), kept so that rounds stay comparable
+                        "algorithmic_bytes_per_step_x_w_y_only": conv["bytes_min"] / conv["steps"],
                         "hbm_bound_launches_per_step": conv["hbm_bound_launches"] / conv["steps"],
                         "peaks": {"conv_b3 (v_mfma_f32_32x32x16_bf16, 6 split products per multiply-add)": MFMA_BF16_PEAK_TF / B3_PRODUCTS,
                                   "fp32 kernels (v_mfma_f32_32x32x2_f32)": MFMA_F32_PEAK_TF},
                         "split_bf16_share_of_flops": conv["b3_flops"] / conv["flops"],
                         "traffic": conv_pmc,
-                        "traffic_source": "profiles/r4_conv_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                          "passes, FETCH x2 per the gfx950 note; per launch)" if conv_pmc else None,
+                        "traffic_source": (os.path.relpath(cpf, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                           "passes, FETCH x2 per the gfx950 note; per launch)") if conv_pmc else None,
                         "launches_per_step": conv["launches"] / conv["steps"],
                         "algorithmic_flops_per_launch": conv["flops"] / conv["launches"],
                         "avg_launch_us": 1e3 * conv["ms"] / conv["launches"],
@@ -789,10 +808,15 @@ def main():
                         "pooled_means_in_epilogue": bool(_trunk_pool_fold()),
                         # the same two fractions over the launches that are convolutions only (the conv1 launches that also pool left out)
                         "pooling_launches_per_step": conv["pooled_launches"] / conv["steps"],
+                        "bn3_fold_launches_per_step": conv["folded_launches"] / conv["steps"],
                         "frac_plain_launches": (conv["plain_ms_at_peak"] / conv["plain_ms"]) if conv["plain_ms"] > 0 else None,
                         "frac_of_fp32_matrix_peak_plain_launches": (conv["plain_flops"] / conv["plain_ms"] / 1e9 / MFMA_F32_PEAK_TF)
                         if conv["plain_ms"] > 0 else None,
-                        "note": ("the conv1 launches of the bottlenecks (32 per step) also carry TAM's spatial average pooling "
+                        "note": ("round 5: the conv1 data-gradient launches (15 per step) also carry the previous block's bn3 + add + ReLU "
+                                 "backward in their epilogue (three more input streams, a second output, d gamma / d beta: 15 stand-alone "
+                                 "passes of 4p-channel tensors less per step; VITTA_TRUNK_BN3_FOLD=0 measures frac_of_fp32_matrix_peak 0.02 "
+                                 "higher and the step 0.13 ms slower); frac_plain_launches leaves those and the pooling launches out.  "
+                                 "the conv1 launches of the bottlenecks (32 per step) also carry TAM's spatial average pooling "
                                  "(VITTA_CONV_POOL, +1.5-3 us each in place of 32 pooling launches: the family's time, hence frac, "
                                  "includes it; VITTA_TRUNK_POOL_FOLD=0 measures 0.015 higher on the same box).  "
                                  if _trunk_pool_fold() else "") + "per-launch durations from hipEvent pairs attached to each dispatch in an eager repeat of "

@@ -1,8 +1,13 @@
-"""vitta_conv_f32 (hand-written fp32-MFMA implicit GEMM, vitta_amd/csrc/conv.hip) against fp64 torch CPU convolutions:
-every geometry the TANet trunk uses (pointwise, 3x3, stride 2, their data gradients) and every epilogue.
+"""vitta_conv_f32 against fp64 torch CPU convolutions, in BOTH arithmetic forms (the autouse `arith` fixture): the shipped
+split-bf16 kernel (vitta_amd/csrc/conv_b3.hip: every fp32 operand as three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per
+multiply-add, fp32 accumulation; round 5: the epilogue of contiguous outputs through an LDS turn-around) and the exact-fp32 MFMA
+kernels (conv_sk.hip / conv_pw.hip / conv.hip) -- every geometry the TANet trunk uses (pointwise, 3x3, stride 2, their data
+gradients, the parity-merged stride-2 data gradient) and every epilogue (eval BN / residual / ReLU / hooked moments / raw copy /
+pooled means; BatchNorm backward with mask, residual, injection, d gamma / d beta).
 
-Tolerance: fp32 accumulation in k order (v_mfma_f32_32x32x2_f32 is an fmaf chain) against an fp64 reference:
-|err| <= 2e-5 * max|ref| for K up to 4608 terms per output."""
+Tolerance, the same for both forms: |err| <= 2e-5 * max|ref| against the fp64 reference for K up to 4608 terms per output (measured
+~3e-7 for either form); element-wise bounds under 16 decades of dynamic range, large-mean inputs and non-finite inputs have their own
+tests below."""
 import pytest
 import torch
 import torch.nn.functional as F

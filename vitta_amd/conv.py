@@ -287,7 +287,9 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
         abytes = 4 * (int(c) * xp + int(c) * int(k) * len(geom.taps) + int(k) * yp + (int(k) * rp if res is not None else 0)
                       + (int(k) * yp if bwd_x is not None else 0) + (int(k) * yp if bwd_mask is not None else 0))
         ev = TIMING(int(lib().vitta_conv_flops(C.byref(d))), (int(c), int(k), len(geom.taps), geom.n * geom.hg * geom.wg, abytes,
-                                                             pool is not None))
+                                                             pool is not None,
+                                                             bool(bwd_mask is not None and res is not None and (int(flags) & CONV_BWD_BN)),
+                                                             4 * (int(c) * xp + int(c) * int(k) * len(geom.taps) + int(k) * yp)))
         check(lib().vitta_conv_timed_f32(C.byref(d), st, ev.start, ev.stop), "vitta_conv_timed_f32")
         return y
     check(lib().vitta_conv_f32(C.byref(d), st), "vitta_conv_f32")

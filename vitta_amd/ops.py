@@ -471,7 +471,7 @@ class WindowAttentionRel(torch.autograd.Function):
         bf16 = bool(WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0]))
         if io16 and not bf16:
             raise _lib.VittaHipError("a bfloat16 qkv needs the bf16-operand attention kernels (ops.wmsa_io16_ok)")
-        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 4.0 * n * n * hd * b_ * num_heads) if KTIMING is not None else None
+        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 4.0 * n * n * hd * b_ * num_heads, 8.0 * n * n * b_ * num_heads) if KTIMING is not None else None
         if bf16:
             check(lib().vitta_wmsa_rel_fwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), int(code_off), _p(region), nw,
                                                    b_, n, num_heads, hd, float(scale), _p(rowmap), nwm, tokens, _p(out), _p(lse),
@@ -495,7 +495,9 @@ class WindowAttentionRel(torch.autograd.Function):
             dout = dout.to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         delta = torch.empty_like(lse)
-        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 14.0 * n * n * hd * b_ * nh) if KTIMING is not None else None
+        # algorithmic flops of the backward: S, dP, dV, dK, dQ once each = 10 N^2 d (until round 4 the line counted the 14 N^2 d the two-kernel
+        # form executes: S and dP twice); vector lane-operations per score: ~8 forward, ~10 backward (bias / mask terms, exp, dS, packing)
+        tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 10.0 * n * n * hd * b_ * nh, 10.0 * n * n * b_ * nh) if KTIMING is not None else None
         if bf16:
             check(lib().vitta_wmsa_rel_bwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                                    hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
@@ -1028,7 +1030,7 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     return y
 
 
-def _operand(weight, transposed, m_rows=None):
+def _operand(weight, transposed, m_rows=None, force_bf16=False):
     """The B operand of a dense product: the nn.Linear weight itself ([out][in], forward) or its [in][out] transpose (data
     gradient), as bfloat16 when DENSE_BF16 is on and the reduction length allows.  A frozen weight (LN-affine adaptation)
     is prepared once per version; a trainable one on every call (the flat-arena optimizer updates storage without touching
@@ -1036,7 +1038,9 @@ def _operand(weight, transposed, m_rows=None):
     w2d = weight.detach().reshape(weight.shape[0], -1)  # a Conv3d patch-embedding kernel counts as [out][in * kd * kh * kw]
     kred = w2d.shape[0] if transposed else w2d.shape[1]
     nout = w2d.shape[1] if transposed else w2d.shape[0]
-    bf16 = bool(DENSE_BF16 and kred % 64 == 0)
+    # force_bf16 (gemm_bf16x's weight copies): an explicit argument, not a flip of the module global -- backward passes run on
+    # autograd's worker threads; the reduction-length condition is gemm_bf16x_supported's (K % 32), the fp32-activation bf16 kernel's K % 64
+    bf16 = bool((force_bf16 and kred % 32 == 0) or (DENSE_BF16 and kred % 64 == 0))
     if not transposed and not bf16:
         return w2d
 
@@ -1116,12 +1120,7 @@ def _bias_grad(bias, needed, g2):
 
 def _bf16_weight(weight, transposed):
     """bfloat16 [out][in] (or [in][out]) copy of a dense weight for gemm_bf16x (cached per version while frozen)."""
-    global DENSE_BF16
-    keep, DENSE_BF16 = DENSE_BF16, True
-    try:
-        return _operand(weight, transposed)
-    finally:
-        DENSE_BF16 = keep
+    return _operand(weight, transposed, force_bf16=True)
 
 
 def _x_dtype_grad(dx, like_bf16):

@@ -122,6 +122,8 @@ class Mlp(nn.Module):
             if ops.dense_supported(x, self.fc1, self.fc2):
                 # bias + GELU in fc1's epilogue, gelu' in the epilogue of fc2's data gradient
                 return ops.FusedMlp.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, out_f32)
+        if x.dtype != self.fc1.weight.dtype:  # a bfloat16 x of the bf16 data flow reaching the module chain (dropout > 0, another activation)
+            x = x.to(self.fc1.weight.dtype)
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 

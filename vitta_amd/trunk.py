@@ -215,7 +215,6 @@ class TrunkRunner:
         self._repack = {}
         self._geo = {}
         self._wgrad_pending = []
-        self._pool = None  # [zeroed buffer, next offset] of the pass in progress (POOL_FOLD)
         # tta.py, for the span of one overlapped step: the adaptation set of packs was rebuilt on the main stream BEFORE the
         # evaluation stream forked and the weights do not change until both passes are done -- neither pass re-packs, the
         # evaluation reads the adaptation set's forward packs
@@ -537,7 +536,8 @@ class TrunkRunner:
                                                            n, c, h, w, _p(dw), _p(db), _stream()),
               "vitta_stem_bn_relu_pool_bwd_affine_f32")
 
-    def block_forward(self, b, xin, n, h, w, keep, sites, ng=None):
+    def block_forward(self, b, xin, n, h, w, keep, sites, ng=None, pool=None):
+        """pool: [zeroed int64 buffer, next offset] of the pass in progress (POOL_FOLD) -- a local of forward(), not runner state."""
         net, tam = b.net, b.tam
         t = b.n_segment
         nb = n // t
@@ -569,11 +569,13 @@ class TrunkRunner:
         # conv1 -> x1 raw
         x1 = torch.empty(p, P, **f)
         pooled, ptc = None, 0
-        if self._pool is not None and h * w >= 32 and CV.ARITH == "b3":  # this block's [frames, p] piece of the pass's zeroed pooling
+        if pool is not None and h * w >= 32 and CV.ARITH == "b3":  # this block's [frames, p] piece of the pass's zeroed pooling
             # buffer (the exact-fp32 kernels keep the pooling launch: only their tile kernel carries the epilogue)
-            buf, off = self._pool
+            buf, off = pool
+            if off + n * p > buf.numel():
+                raise RuntimeError("vitta_amd.trunk: the pass's pooling buffer is smaller than its blocks need")
             pooled, ptc = buf[off:off + n * p].view(nb, t, p), 1
-            self._pool[1] = off + n * p
+            pool[1] = off + n * p
         CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=_sflags(s1),
                   epi_bn=_bn_t(net.bn1) if (s1 or pooled is not None) else None, eps=net.bn1.eps, stats=s1.stats if s1 else None,
                   stat_m=ng * h * w if ng != n else 0, pool=pooled)
@@ -654,13 +656,10 @@ class TrunkRunner:
         tape = []
         blocks = self.blocks()
         # one zeroed buffer for the pooled means of every block of this pass (conv1's epilogue ADDS into it)
-        self._pool = [torch.zeros(n * sum(b.net.conv1.out_channels for b in blocks), dtype=torch.int64, device=x.device), 0] if POOL_FOLD else None
-        try:
-            for b in blocks:
-                cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng)
-                tape.append(saved)
-        finally:
-            self._pool = None
+        pool = [torch.zeros(n * sum(b.net.conv1.out_channels for b in blocks), dtype=torch.int64, device=x.device), 0] if POOL_FOLD else None
+        for b in blocks:
+            cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng, pool)
+            tape.append(saved)
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
