@@ -292,33 +292,6 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                                    float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc, void* stream);
-/* TAM's backward of a block as ONE launch = vitta_tam_agg_bwd_cm_ld_f32, vitta_tam_branch_bwd_fused_f32 and bn1's
- * vitta_bn_bwd_cm_ld_f32 (g = d_ga, no second gradient / mask tensor, rowadd = d_gpooled with scale 1 / HW) in that order: the
- * aggregation workgroups first, the branch workgroups behind them, the BatchNorm-backward workgroups last; each kind waits on the
- * arrival word of the kind in front of it (d_sync as vitta_tam_fwd_agg_f32) and reads what it produced coherently.  d_ggate: room for
- * N * C * T floats (the finishing launch of the unmerged path is not needed here).  Same results as the three entry points (d gamma /
- * d beta: atomics, summation order).  VITTA_ERR_UNSUPPORTED (nothing launched): shapes outside the one-batch branch kernels,
- * (256 / lanes per row) % T != 0, N * T * HW % 4 != 0, or VITTA_TAM_MERGE_OFF set. */
-int vitta_tam_bwd_all_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
-                          const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                          const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
-                          const float* d_gate, const float* d_hpre, float* d_gkern, float* d_ggate,
-                          float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc,
-                          const float* d_x, int64_t x_ld, const float* const* h_bn1, float eps1, const float* d_gout, int32_t HW, float* d_ga,
-                          const float* d_mu, const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu,
-                          float* d_dx, float* d_dgamma1, float* d_dbeta1, void* stream);
-/* TAM.forward of a block (temporal_module.py:43-65) as ONE launch: the branches (arguments of vitta_tam_branch_fwd_fused_f32) and the
- * aggregation pass (arguments of vitta_tam_agg_fwd_cm_f32: d_x = the raw conv1 output, h_bn1 / eps1 = bn1, d_out) -- the branch
- * workgroups come first in the grid, the row workgroups of the pass request their first activations, wait for the branches' arrival
- * flags in d_sync and read gate / kern coherently.  d_sync: 32 KiB per stream (8192 uint32: counters, then three areas of 64 flag
- * words in 128-byte lines of their own), ZERO when first used, left zero.  Results
- * are bit-identical to the two entry points called one after the other.  VITTA_ERR_UNSUPPORTED (nothing launched) for shapes outside
- * the one-batch branch kernels (C % 64, C <= 512, T % 4, C * T <= 4096, 16-byte aligned operands) or with VITTA_TAM_MERGE_OFF set. */
-int vitta_tam_fwd_agg_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
-                          const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                          const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                          float* d_hpre, void* d_sync, int32_t pooled_tc, const float* d_x, const float* const* h_bn1, float eps1,
-                          int32_t HW, float* d_out, void* stream);
 
 
 /* --------------------------------------------------------------------------

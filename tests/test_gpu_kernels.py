@@ -1002,95 +1002,3 @@ def test_tam_branch_launches_of_different_grids_share_one_meeting_buffer():
                 assert torch.equal(x, y), rep
     words = sync[128:128 + 2 * n].view(n, 2).cpu()
     assert (words[:, 0] == words[:, 1]).all() and int(words[0, 0]) == 2 * sum(st["c"] // 8 + st["c"] // 16 for st in stages)
-
-
-@pytest.mark.parametrize("c,hw,n,t,tc,inj", [(64, 3136, 2, 8, 1, True), (128, 784, 2, 8, 1, False), (256, 196, 2, 8, 0, True), (512, 49, 2, 8, 1, True),
-                                             (64, 784, 1, 8, 0, False), (256, 196, 3, 4, 1, False)])
-def test_tam_merged_launches_equal_the_separate_entry_points(c, hw, n, t, tc, inj):
-    """vitta_tam_fwd_agg_f32 (branches + aggregation pass in one launch) and vitta_tam_bwd_all_f32 (aggregation backward + branches +
-    bn1's backward with the pooling gradient in one launch: the producers first in the grid, the consumers waiting on arrival words
-    inside the launch) against the separate entry points the trunk issued before: every tensor bit for bit (same arithmetic, same
-    order), the atomically accumulated parameter gradients within summation order; the words at rest (zero) after every launch; three
-    repetitions on one meeting buffer, the forward and backward launches of different grids alternating."""
-    from vitta_amd import _lib
-    from vitta_amd.ops import _p, _ptr4, _stream
-    L = _lib.lib()
-    d = _dev()
-    g = torch.Generator().manual_seed(c + hw + n)
-    o, P = c // 4, n * t * hw
-    r = lambda *s: torch.randn(*s, generator=g).to(d)
-    x1 = r(c, P)
-    bn1 = [torch.rand(c, generator=g).to(d) + 0.5, r(c) * 0.2, r(c) * 0.2, torch.rand(c, generator=g).to(d) + 0.5]
-    a_ref = torch.relu((x1 - bn1[2][:, None]) * (bn1[0] / torch.sqrt(bn1[3] + 1e-5))[:, None] + bn1[1][:, None])
-    pooled = a_ref.view(c, n, t, hw).mean(-1).permute(1, 0, 2).contiguous()  # [N, C, T]
-    pooled = torch.round(pooled * 4096) / 4096
-    pooled_in = torch.round(pooled.permute(0, 2, 1).double() * 2.0 ** 32).to(torch.int64).contiguous() if tc else pooled
-    wg1, wg3, w0, w3 = r(2 * t, t) * 0.3, r(3, 2 * t) * 0.3, r(o, c, 3) * (3 * c) ** -0.5, r(c, o) * o ** -0.5
-    bng = [torch.rand(2 * t, generator=g).to(d) + 0.5, r(2 * t) * 0.1, r(2 * t) * 0.1, torch.rand(2 * t, generator=g).to(d) + 0.5]
-    bnl = [torch.rand(o, generator=g).to(d) + 0.5, r(o) * 0.1, r(o) * 0.1, torch.rand(o, generator=g).to(d) + 0.5]
-    gout = r(c, P)
-    mu, ca, cb, gs = (r(c) * 0.1, r(c) * 1e-3, r(c) * 1e-3, torch.full((1,), 0.7, device=d)) if inj else (None, None, None, None)
-    sync = torch.zeros(8192, dtype=torch.int32, device=d)
-    args = (_p(pooled_in), _p(wg1), _ptr4(*bng), 1e-5, _p(wg3), _p(w0), _ptr4(*bnl), 1e-5, _p(w3), n, c, t)
-
-    def run(merged):
-        kern, gate, hpre = torch.empty(n * c, 3, device=d), torch.empty(n, c, t, device=d), torch.empty(2, n, o, t, device=d)
-        a1 = torch.empty(c, P, device=d)
-        if merged:
-            _lib.check(L.vitta_tam_fwd_agg_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), tc, _p(x1), _ptr4(*bn1), 1e-5, hw, _p(a1), _stream()),
-                       "fwd merged")
-        else:
-            _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), tc, _stream()), "fwd")
-            _lib.check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), _ptr4(*bn1), 1e-5, _p(gate), _p(kern), c, n, t, hw, _p(a1), _stream()), "agg")
-        ga, ggate, gkern = torch.empty(c, P, device=d), torch.empty(n * c * t * 4, device=d), torch.empty(n * c, 3, device=d)
-        gbuf = torch.empty(n * c * t + n * o * t, device=d)
-        dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
-        dw = [torch.zeros_like(wg1), torch.zeros_like(wg3), torch.zeros_like(w0), torch.zeros_like(w3)]
-        dx, dg1, db1 = torch.empty(c, P, device=d), torch.zeros(c, device=d), torch.zeros(c, device=d)
-        bargs = args + (n, _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
-        if merged:
-            _lib.check(L.vitta_tam_bwd_all_f32(*bargs, _p(sync), tc, _p(x1), 0, _ptr4(*bn1), 1e-5, _p(gout), hw, _p(ga), _p(mu), _p(ca), _p(cb),
-                                               _p(gs), 1, _p(dx), _p(dg1), _p(db1), _stream()), "bwd merged")
-        else:
-            _lib.check(L.vitta_tam_agg_bwd_cm_ld_f32(_p(x1), 0, _ptr4(*bn1), 1e-5, _p(gate), _p(kern), _p(gout), c, n, t, hw, _p(ga), _p(ggate),
-                                                     _p(gkern), _stream()), "agg bwd")
-            _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), tc, _stream()), "bwd")
-            _lib.check(L.vitta_bn_bwd_cm_ld_f32(_p(ga), None, _p(x1), None, 0, _p(gbuf), 1.0 / hw, _ptr4(*bn1), 1e-5, _p(mu), _p(ca), _p(cb),
-                                                _p(gs), 1, _p(dx), None, _p(dg1), _p(db1), c, n, t, hw, _stream()), "bn bwd")
-        torch.cuda.synchronize()
-        return [kern, gate, hpre, a1, ga, ggate[:n * c * t].clone(), gkern, gbuf[:n * c * t].clone(), dx], [dg1, db1] + dbn + dw
-
-    ref_t, ref_s = run(False)
-    for rep in range(3):
-        got_t, got_s = run(True)
-        assert int(sync[:128].abs().sum()) == 0 and int(sync[192:].abs().sum()) == 0, "arrival counters and flag lines must be zero at rest"
-        for i, (a, b) in enumerate(zip(got_t, ref_t)):
-            assert torch.equal(a, b), (rep, i, (a - b).abs().max().item())
-        for a, b in zip(got_s, ref_s):
-            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6
-    # the aggregation against its definition (the two paths above share their arithmetic)
-    kern, gate, a1 = ref_t[0].view(n, c, 3), ref_t[1], ref_t[3]
-    av = a_ref.view(c, n, t, hw).double()
-    w = (kern.permute(1, 0, 2)[:, :, None, :].double() * 1.0)  # [c, n, 1, 3]
-    gt = gate.permute(1, 0, 2).double()  # [c, n, t]
-    ga_ = av * gt[..., None]
-    pad = torch.zeros(c, n, 1, hw, dtype=torch.float64, device=d)
-    want = w[..., 0, None] * torch.cat([pad, ga_[:, :, :-1]], 2) + w[..., 1, None] * ga_ + w[..., 2, None] * torch.cat([ga_[:, :, 1:], pad], 2)
-    assert (a1.view(c, n, t, hw).double() - want).abs().max().item() <= 1e-5 * want.abs().max().item()
-
-
-def test_tam_merged_launches_say_unsupported_outside_the_one_batch_shapes():
-    """C = 96 (not a multiple of 64) is outside the one-batch branch kernels: the merged entry points launch nothing and return
-    VITTA_ERR_UNSUPPORTED (-4); the trunk then issues the separate launches."""
-    from vitta_amd import _lib
-    from vitta_amd.ops import _p, _ptr4, _stream
-    L = _lib.lib()
-    d = _dev()
-    c, n, t, hw = 96, 2, 8, 196
-    o = c // 4
-    z = lambda *s: torch.zeros(*s, device=d)
-    bn = lambda k: [torch.ones(k, device=d), z(k), z(k), torch.ones(k, device=d)]
-    rc = L.vitta_tam_fwd_agg_f32(_p(z(n, c, t)), _p(z(2 * t, t)), _ptr4(*bn(2 * t)), 1e-5, _p(z(3, 2 * t)), _p(z(o, c, 3)), _ptr4(*bn(o)), 1e-5,
-                                 _p(z(c, o)), n, c, t, _p(z(n * c, 3)), _p(z(n, c, t)), _p(z(2, n, o, t)), _p(torch.zeros(8192, dtype=torch.int32, device=d)),
-                                 0, _p(z(c, n * t * hw)), _ptr4(*bn(c)), 1e-5, hw, _p(z(c, n * t * hw)), _stream())
-    assert rc == _lib.VITTA_ERR_UNSUPPORTED

@@ -107,11 +107,6 @@ SIGNATURES = {
                                            _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "vitta_tam_branch_fwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                                  _p, _p, _p, _p, _i32, _p]),
-    "vitta_tam_bwd_all_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
-                                        _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _i32,
-                                        _p, _i64, C.POINTER(_p), _f32, _p, _i32, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
-    "vitta_tam_fwd_agg_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
-                                        _p, _p, _p, _p, _i32, _p, C.POINTER(_p), _f32, _i32, _p, _p]),
     "vitta_tam_branch_bwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
                                                  _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _i32, _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
@@ -234,9 +229,6 @@ def lib():
 
 # {ABI entry point name: calls} while it is a dict (tests assert which path ran; the product leaves it None)
 CALL_COUNTS = None
-
-
-VITTA_ERR_UNSUPPORTED = -4  # include/vitta_hip.h
 
 
 def check(status, what=""):

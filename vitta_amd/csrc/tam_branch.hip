@@ -13,7 +13,6 @@
 #include <mutex>
 #include <utility>
 #include "conv_common.h"
-#include "tam_rows.h"
 
 using namespace vitta;
 
@@ -290,7 +289,7 @@ struct BnItem {  // eval-BatchNorm parameters of one conv1 output channel (+ its
 
 // conv1 of the L branch for OBF output channels + the G branch of a slice of channels, operands in LDS.  PRE: the item's
 // BatchNorm parameters were requested by the caller together with everything else the workgroup stages
-template <bool WT, bool PRE, bool WTK = false>  // WTK: the adaptive kernel too leaves with write-through stores (merged launches below)
+template <bool WT, bool PRE>
 __device__ __forceinline__ void f1_compute(const TamBranchArgs& a, float* __restrict__ kern, float* __restrict__ h_pre,
                                            float* __restrict__ h_act, int n, int tile, int ntiles, const float* wl, const float* pl,
                                            float* red, const GLds& gp, BnItem pre) {
@@ -303,11 +302,7 @@ __device__ __forceinline__ void f1_compute(const TamBranchArgs& a, float* __rest
     const bool active = c < cend;
     float u_pre[GM], u[GM], k3[3];
     g_forward(gp, T, sub, active, pl + (active ? c : 0) * TP + 1, u_pre, u, k3);
-    if (active && sub < 3) {
-      const float kv = sub == 0 ? k3[0] : (sub == 1 ? k3[1] : k3[2]);
-      if (WTK) store_wt(kern, ((int64_t)n * C + c) * 3 + sub, kv);
-      else kern[((int64_t)n * C + c) * 3 + sub] = kv;
-    }
+    if (active && sub < 3) kern[((int64_t)n * C + c) * 3 + sub] = sub == 0 ? k3[0] : (sub == 1 ? k3[1] : k3[2]);
   }
   // conv1 for OBF output channels: item (o_local, t), CS lanes split the C reduction
   const int items = OBF * T;
@@ -367,7 +362,6 @@ __global__ __launch_bounds__(TBW) void tam_branch_f1_kernel(TamBranchArgs a, flo
 }
 
 // gate for CB channels of clip n: operands in LDS (wl [CB][O] conv2 weights of the tile, hl [O][T])
-template <bool WT = false>
 __device__ __forceinline__ void f2_compute(const TamBranchArgs& a, float* __restrict__ gate, int n, int c0, const float* wl, const float* hl) {
   const int C = a.C, T = a.T, O = C / 4;
   for (int i = threadIdx.x; i < CB * T; i += TBW) {
@@ -376,8 +370,7 @@ __device__ __forceinline__ void f2_compute(const TamBranchArgs& a, float* __rest
     const float* w = wl + (i / T) * O;
     float acc = 0.f;
     for (int o = 0; o < O; ++o) acc = fmaf(w[o], hl[o * T + t], acc);
-    if (WT) store_wt(gate, ((int64_t)n * C + c) * T + t, sigmoidf(acc));
-    else gate[((int64_t)n * C + c) * T + t] = sigmoidf(acc);
+    gate[((int64_t)n * C + c) * T + t] = sigmoidf(acc);
   }
 }
 
@@ -608,15 +601,11 @@ __device__ __forceinline__ void b2_g_compute(const TamBranchArgs& a, const TamBr
   }
 }
 
-template <bool WT = false>  // WT: d pooled leaves with write-through stores (merged launches: the BatchNorm-backward workgroups read it)
 __device__ __forceinline__ void b2_finish(const TamBranchArgs& a, const TamBranchGrads& g, int n, int c0, const float* gp, const float* gacc) {
   const int C = a.C, T = a.T, M = 2 * T;
   for (int i = threadIdx.x; i < CBB * T; i += TBW) {
     const int c = c0 + i / T;
-    if (c < C) {
-      if (WT) store_wt(g.gpooled, ((int64_t)n * C + c) * T + i % T, gp[i]);
-      else g.gpooled[((int64_t)n * C + c) * T + i % T] = gp[i];
-    }
+    if (c < C) g.gpooled[((int64_t)n * C + c) * T + i % T] = gp[i];
   }
   for (int i = threadIdx.x; i < M; i += TBW) {
     atomicAdd(g.dbng_w + i, gacc[i]);
@@ -753,12 +742,6 @@ struct Stage16 {
   __device__ __forceinline__ void issue(const float* __restrict__ src, int units, int64_t sstride) {
     issue_(src, units, sstride, std::make_integer_sequence<int, K>{});
   }
-  // the same batch with sc1 loads (a tensor written by other workgroups of this launch); UPR == 0 only
-  template <int... I>
-  __device__ __forceinline__ void issue_coh_(const float* src, int units, std::integer_sequence<int, I...>) {
-    ((v[I] = tamrows::coh_load4(src, 4 * (int64_t)min((int)threadIdx.x + I * TBW, units - 1))), ...);
-  }
-  __device__ __forceinline__ void issue_coh(const float* src, int units) { issue_coh_(src, units, std::make_integer_sequence<int, K>{}); }
   __device__ __forceinline__ void commit(float* __restrict__ dst, int units, int dstride, float* trash) const {
     commit_(dst, units, dstride, trash, std::make_integer_sequence<int, K>{});
   }
@@ -894,11 +877,12 @@ struct StageCoherent2 {
 
 // (every workgroup of these launches has an F1 / B1 tile -- fast_ok's shapes give nt1 >= nt2 --, so the loads are issued
 // unconditionally, straight-line: a conditional issue makes the compiler copy the loaded registers at the join, i.e. wait for them)
-// WTO: kern / gate leave with write-through stores (consumer workgroups of the same launch read them)
-template <bool TC, bool WTO>
-__device__ __forceinline__ void fwd_fast_body(const TamBranchArgs& a, float* __restrict__ kern, float* __restrict__ h_pre,
-                                              float* __restrict__ h_act, float* __restrict__ gate, unsigned* sync,
-                                              int nt1, int nt2, int lds1_floats, int n, int tile, int ny, float* smem) {
+template <bool TC>
+__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_branch_fwd_fast_kernel(TamBranchArgs a, float* __restrict__ kern, float* __restrict__ h_pre,
+                                                                  float* __restrict__ h_act, float* __restrict__ gate, unsigned* sync,
+                                                                  int nt1, int nt2, int lds1_floats) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tile = blockIdx.y;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2;
   const bool do2 = tile < nt2;
   float* wl1 = smem;                 // F1 (f1_body's layout): [OBF][C*3] | pl [C][T+2] | red | G parameters
@@ -930,8 +914,8 @@ __device__ __forceinline__ void fwd_fast_body(const TamBranchArgs& a, float* __r
   s_w3.commit(wl2, do2 ? u_w3 : 0, 0, trash);
   red[threadIdx.x] = bn.w + bn.rv + bn.rm + bn.b;  // (an unconditional use: the four loads stay up here, see Stage16::commit)
   __syncthreads();
-  f1_compute<true, true, WTO>(a, kern, h_pre, h_act, n, tile, nt1, wl1, pl, red, gp, bn);
-  meet(fast, ny, gen, tile == 0);
+  f1_compute<true, true>(a, kern, h_pre, h_act, n, tile, nt1, wl1, pl, red, gp, bn);
+  meet(fast, gridDim.y, gen, tile == 0);
   {
     StageCoherent2 s_h;
     const int u_h = O * T / 4, u0 = threadIdx.x, u1 = threadIdx.x + TBW;
@@ -940,51 +924,18 @@ __device__ __forceinline__ void fwd_fast_body(const TamBranchArgs& a, float* __r
     *reinterpret_cast<float4*>((do2 && u1 < u_h) ? hl + 4 * u1 : trash) = s_h.v1;
   }
   lds_barrier();
-  if (do2) f2_compute<WTO>(a, gate, n, c0, wl2, hl);
+  if (do2) f2_compute(a, gate, n, c0, wl2, hl);
 }
 
 template <bool TC>
-__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_branch_fwd_fast_kernel(TamBranchArgs a, float* __restrict__ kern, float* __restrict__ h_pre,
-                                                                  float* __restrict__ h_act, float* __restrict__ gate, unsigned* sync,
-                                                                  int nt1, int nt2, int lds1_floats) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  fwd_fast_body<TC, false>(a, kern, h_pre, h_act, gate, sync, nt1, nt2, lds1_floats, blockIdx.x, blockIdx.y, gridDim.y, smem);
-}
-
-// ---- merged launches (round 5) -------------------------------------------------------------------------------------------------
-// The TAM of a block was three dependent launches forward (pooling epilogue of conv1 -> branches -> aggregation pass) and three
-// backward; every boundary between dependent launches costs ~4.5 us on the chain plus the cold start of the consumer.  One launch
-// now holds the branch workgroups FIRST and the row workgroups of the element pass behind them (tam_rows.h: dispatch order makes the
-// wait deadlock-free): the row workgroups request their first batch of activations, wait for the branches' arrival word, read gate /
-// kern coherently and stream.  Hand-over point 0 of the stream's meeting buffer (tam_rows.h), leave word FUSE_CNT_OFF + 3.
-
-template <bool TC, int LPR>
-__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_fwd_agg_kernel(TamBranchArgs a, float* __restrict__ kern, float* __restrict__ h_pre,
-                                                                  float* __restrict__ h_act, float* __restrict__ gate, unsigned* sync,
-                                                                  int nt1, int nt2, int lds1_floats, int ny, tamrows::AggFwd g, int ncons) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int nprod = a.N * ny;
-  const tamrows::Handover hd = tamrows::handover(sync, 0);
-  if ((int)blockIdx.x < nprod) {
-    const int n = blockIdx.x / ny, tile = blockIdx.x - n * ny;
-    fwd_fast_body<TC, true>(a, kern, h_pre, h_act, gate, sync, nt1, nt2, lds1_floats, n, tile, ny, smem);
-    tamrows::signal_done(hd, (unsigned)nprod);
-    return;
-  }
-  tamrows::agg_fwd_rows<LPR, true>(g, blockIdx.x - nprod, hd);
-  tamrows::leave(&hd, 1, sync + tamrows::FUSE_CNT_OFF + 3, ncons);
-}
-
-// FUSED (merged launch): ggate / gkern are written by the aggregation workgroups in front of this one in the grid (hand-over point
-// ha): everything else is requested first, then the wait, then those two with sc1 loads; d pooled leaves with write-through stores
-template <bool TC, bool FUSED>
-__device__ __forceinline__ void bwd_fast_body(const TamBranchArgs& a, const float* __restrict__ kern,
-                                              const float* __restrict__ gate, const float* __restrict__ h_pre,
-                                              const float* __restrict__ h_act, const float* gkern,
-                                              const float* ggate, float* __restrict__ dpre_g,
-                                              const TamBranchGrads& g, unsigned* sync, int nt1, int nt2, int lds1_floats, int n, int tile, int ny,
-                                              float* smem, const tamrows::Handover ha = tamrows::Handover{nullptr, nullptr}) {
+__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_branch_bwd_fast_kernel(TamBranchArgs a, const float* __restrict__ kern,
+                                                                  const float* __restrict__ gate, const float* __restrict__ h_pre,
+                                                                  const float* __restrict__ h_act, const float* __restrict__ gkern,
+                                                                  const float* __restrict__ ggate, float* __restrict__ dpre_g,
+                                                                  TamBranchGrads g, unsigned* sync, int nt1, int nt2, int lds1_floats) {
   // (fast_ok's shapes: nt1 == nt2 == C / 16, every workgroup has a B1 and a B2 tile)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.x, tile = blockIdx.y;
   const int C = a.C, T = a.T, O = C / 4, TP = T + 2, M = 2 * T;
   float* dz = smem;                  // B1 (b1_body's layout): dz [C][T] | gg [C][T] | wl [C][OBB] | red
   float* gg = dz + C * T;
@@ -1007,7 +958,7 @@ __device__ __forceinline__ void bwd_fast_body(const TamBranchArgs& a, const floa
   const int u_ct = C * T / 4;
   // ---- every global operand of this workgroup, in flight together ----
   s_gate.issue(gate + (int64_t)n * C * T, u_ct, 0);
-  if constexpr (!FUSED) s_gg.issue(ggate + (int64_t)n * C * T, u_ct, 0);
+  s_gg.issue(ggate + (int64_t)n * C * T, u_ct, 0);
   s_w3.issue(a.w3 + tile * OBB, C, O);
   {
     const int64_t idx0 = ((int64_t)n * O + ob) * T + t;
@@ -1017,20 +968,10 @@ __device__ __forceinline__ void bwd_fast_body(const TamBranchArgs& a, const floa
   s_w0.issue(a.w0 + (int64_t)c0 * 3, O * (CBB * 3 / 4), (int64_t)C * 3);
   s_pool.issue(a, n, c0, CBB, a.d_c2b);
   s_g.issue(a);
+  const float* gk = gkern + ((int64_t)n * C + c0 + threadIdx.x / GL) * 3;
+  const float gk0 = gk[0], gk1 = gk[1], gk2 = gk[2];
   unsigned* const fast = sync + FAST_SYNC_OFF + 2 * n;
   const unsigned gen = __hip_atomic_load(fast + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  float gk0, gk1, gk2;
-  {
-    const int64_t gi = ((int64_t)n * C + c0 + threadIdx.x / GL) * 3;
-    if constexpr (FUSED) {
-      asm volatile("" ::: "memory");
-      tamrows::wait_done(ha, n * ny + tile);
-      s_gg.issue_coh(ggate + (int64_t)n * C * T, u_ct);
-      gk0 = tamrows::coh_load1(gkern, gi); gk1 = tamrows::coh_load1(gkern, gi + 1); gk2 = tamrows::coh_load1(gkern, gi + 2);
-    } else {
-      gk0 = gkern[gi]; gk1 = gkern[gi + 1]; gk2 = gkern[gi + 2];
-    }
-  }
   asm volatile("" ::: "memory");  // (every load above is issued before the first LDS store below)
   float* const trash = gl + 2 * T * T + 16 * T;  // the 64 spare bytes behind the G parameters (b2_lds, g_floats)
   s_gate.commit(dz, u_ct, 0, trash);
@@ -1045,7 +986,7 @@ __device__ __forceinline__ void bwd_fast_body(const TamBranchArgs& a, const floa
   __syncthreads();
   b1_compute<true, true>(a, h_pre, h_act, dpre_g, g, n, tile, dz, gg, wl1, red, bn);
   b2_g_compute<true>(a, g, gp, gkern, n, c0, pl, gpo, gacc, gk0, gk1, gk2);
-  meet(fast, ny, gen, tile == 0);
+  meet(fast, gridDim.y, gen, tile == 0);
   {
     StageCoherent2 s_d;
     const int u_d = O * T / 4, t4 = T >> 2;
@@ -1070,50 +1011,7 @@ __device__ __forceinline__ void bwd_fast_body(const TamBranchArgs& a, const floa
   lds_barrier();
   b2_l_compute(a, g, c0, wl2, dpre, pl, gpo);
   lds_barrier();
-  b2_finish<FUSED>(a, g, n, c0, gpo, gacc);
-}
-
-template <bool TC>
-__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_branch_bwd_fast_kernel(TamBranchArgs a, const float* __restrict__ kern,
-                                                                  const float* __restrict__ gate, const float* __restrict__ h_pre,
-                                                                  const float* __restrict__ h_act, const float* __restrict__ gkern,
-                                                                  const float* __restrict__ ggate, float* __restrict__ dpre_g,
-                                                                  TamBranchGrads g, unsigned* sync, int nt1, int nt2, int lds1_floats) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  bwd_fast_body<TC, false>(a, kern, gate, h_pre, h_act, gkern, ggate, dpre_g, g, sync, nt1, nt2, lds1_floats, blockIdx.x, blockIdx.y, gridDim.y, smem);
-}
-
-// The TAM backward of a block in one launch: [aggregation backward: na row workgroups][branches: N x ny][bn1 (+ReLU) backward with
-// the pooling gradient: nbn workgroups].  Hand-over points 1 (aggregation done) and 2 (branches done), leave word FUSE_CNT_OFF + 4.
-
-template <bool TC, int LPR, int ROWADD>
-__global__ __launch_bounds__(TBW) __attribute__((amdgpu_waves_per_eu(1, 2))) void tam_bwd_all_kernel(TamBranchArgs a, const float* __restrict__ kern,
-                                                                  const float* __restrict__ gate, const float* __restrict__ h_pre,
-                                                                  const float* __restrict__ h_act, const float* gkern,
-                                                                  const float* ggate, float* __restrict__ dpre_g,
-                                                                  TamBranchGrads g, unsigned* sync, int nt1, int nt2, int lds1_floats, int ny,
-                                                                  tamrows::AggBwd ab, int na, tamrows::BnBwd bb, int bgx, int nbn) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float red[2][TBW / VITTA_WAVE];
-  const tamrows::Handover hs[2] = {tamrows::handover(sync, 1), tamrows::handover(sync, 2)};
-  const int nprod = a.N * ny;
-  int id = blockIdx.x;
-  if (id < na) {
-    tamrows::agg_bwd_rows_fin<LPR, true>(ab, id, smem);
-    tamrows::signal_done(hs[0], (unsigned)na);
-    return;
-  }
-  id -= na;
-  if (id < nprod) {
-    const int n = id / ny, tile = id - n * ny;
-    bwd_fast_body<TC, true>(a, kern, gate, h_pre, h_act, gkern, ggate, dpre_g, g, sync, nt1, nt2, lds1_floats, n, tile, ny, smem, hs[0]);
-    tamrows::signal_done(hs[1], (unsigned)nprod);
-    return;
-  }
-  id -= nprod;
-  const int c = id / bgx, bx = id - c * bgx;
-  tamrows::bn_bwd_body<false, false, ROWADD, true>(bb, bx, c, red, hs[0], hs[1], id);
-  tamrows::leave(hs, 2, sync + tamrows::FUSE_CNT_OFF + 4, (unsigned)nbn);
+  b2_finish(a, g, n, c0, gpo, gacc);
 }
 
 // The L branch's two weight gradients as their own launch (round 5: SGD over all parameters -- inside the fused backward they are
@@ -1323,52 +1221,6 @@ int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, co
   return VITTA_OK;
 }
 
-// The TAM forward of a block as ONE launch: branches (the fast one-batch form) + aggregation pass (tam_cm.hip's, on the raw conv1
-// output d_x with relu(bn1(.)) applied while loading).  VITTA_ERR_UNSUPPORTED where the fast form does not apply: the caller then
-// issues vitta_tam_branch_fwd_fused_f32 / vitta_tam_branch_fwd_f32 and vitta_tam_agg_fwd_cm_f32.
-int vitta_tam_fwd_agg_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
-                          const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                          const float* d_w3, int32_t N, int32_t C, int32_t T, float* d_kern, float* d_gate,
-                          float* d_hpre, void* d_sync, int32_t pooled_tc, const float* d_x, const float* const* h_bn1, float eps1,
-                          int32_t HW, float* d_out, void* stream) {
-  if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_sync || !d_x || !d_out || !h_bn1 || !h_bn1[0] || !h_bn1[1] || !h_bn1[2] ||
-      !h_bn1[3] || HW <= 0)
-    return VITTA_ERR_INVALID_ARG;
-  if (!vitta_tam_branch_supported(C, T) || N > 32 || std::getenv("VITTA_TAM_MERGE_OFF")) return VITTA_ERR_UNSUPPORTED;
-  TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
-  if (tb_bad(a)) return VITTA_ERR_INVALID_ARG;
-  const int O = C / 4;
-  int nt1, nt2;
-  size_t l1, lds;
-  if (!fused_geometry(N, C, T, false, nt1, nt2, l1, lds)) return VITTA_ERR_UNSUPPORTED;
-  float* d_hact = d_hpre + (int64_t)N * O * T;
-  if (!use_fast(a, {d_pooled, d_w0, d_w3, d_hact}) || ((HW & 3) == 0 && (!al16(d_x) || !al16(d_out)))) return VITTA_ERR_UNSUPPORTED;
-  if ((int64_t)C * N * T * HW >= (1ll << 29)) return VITTA_ERR_UNSUPPORTED;
-  const int ny = nt1 > nt2 ? nt1 : nt2;
-  const int lpr = HW > 256 ? 64 : 16;
-  const int64_t rows = (int64_t)C * N * T;
-  const int ncons = (int)((rows + TBW / lpr - 1) / (TBW / lpr));
-  const tamrows::AggFwd g{d_x, tamrows::BN{h_bn1[0], h_bn1[1], h_bn1[2], h_bn1[3], eps1}, d_gate, d_kern, (int)C, (int)N, (int)T, (int)HW, d_out};
-#define TAM_FWD_AGG_GO(TCV, LPRV)                                                                                                  \
-  do {                                                                                                                             \
-    auto kfn = tam_fwd_agg_kernel<TCV, LPRV>;                                                                                       \
-    if (!set_lds(kfn, lds)) return VITTA_ERR_LAUNCH;                                                                               \
-    if ((int64_t)N * ny > fused_capacity(kfn, lds)) return VITTA_ERR_UNSUPPORTED; /* the branch workgroups meet: all resident */    \
-    VITTA_LAUNCH(kfn, dim3((unsigned)(N * ny + ncons)), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern, d_hpre, d_hact, \
-                 d_gate, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4), ny, g, ncons);                                   \
-  } while (0)
-  if (a.pooled_tc) {
-    if (lpr == 64) TAM_FWD_AGG_GO(true, 64);
-    else TAM_FWD_AGG_GO(true, 16);
-  } else {
-    if (lpr == 64) TAM_FWD_AGG_GO(false, 64);
-    else TAM_FWD_AGG_GO(false, 16);
-  }
-#undef TAM_FWD_AGG_GO
-  return VITTA_OK;
-}
-
 int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
                                    const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
@@ -1401,80 +1253,6 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
   if ((int64_t)N * (nt1 > nt2 ? nt1 : nt2) > fused_capacity(tam_branch_bwd_fused_kernel, lds)) return VITTA_ERR_UNSUPPORTED;
   VITTA_LAUNCH(tam_branch_bwd_fused_kernel, dim3(N, nt1 > nt2 ? nt1 : nt2), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern,
                d_gate, d_hpre, d_hact, d_gkern, d_ggate, d_dpre, g, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4));
-  return VITTA_OK;
-}
-
-// The TAM backward of a block as ONE launch: vitta_tam_agg_bwd_cm_ld_f32 (d_x / x_ld / h_bn1 / d_gout -> d_ga, d_ggate, d_gkern), the
-// branches (arguments of vitta_tam_branch_bwd_fused_f32) and bn1's (+ReLU) backward with the pooling gradient added per (n, c, t) row
-// (vitta_bn_bwd_cm_ld_f32 with g = d_ga, rowadd = d_gpooled / HW: -> d_dx, d gamma / d beta of bn1, the hooked site's injection).
-// VITTA_ERR_UNSUPPORTED (nothing launched) outside the one-batch branch kernels' shapes: the caller issues the three entry points.
-int vitta_tam_bwd_all_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
-                          const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                          const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
-                          const float* d_gate, const float* d_hpre, float* d_gkern, float* d_ggate,
-                          float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc,
-                          const float* d_x, int64_t x_ld, const float* const* h_bn1, float eps1, const float* d_gout, int32_t HW, float* d_ga,
-                          const float* d_mu, const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu,
-                          float* d_dx, float* d_dgamma1, float* d_dbeta1, void* stream) {
-  if (N_saved < N) return VITTA_ERR_INVALID_ARG;
-  if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn || !d_sync || !d_x || !h_bn1 ||
-      !h_bn1[0] || !h_bn1[1] || !h_bn1[2] || !h_bn1[3] || !d_gout || !d_ga || !d_dx || HW <= 0)
-    return VITTA_ERR_INVALID_ARG;
-  if (d_mu && (!d_coef_a || !d_coef_b)) return VITTA_ERR_INVALID_ARG;
-  if (!vitta_tam_branch_supported(C, T) || N > 32 || std::getenv("VITTA_TAM_MERGE_OFF")) return VITTA_ERR_UNSUPPORTED;
-  TamBranchArgs a{d_pooled, d_wg1, BnEval{h_bn_g[0], h_bn_g[1], h_bn_g[2], h_bn_g[3], eps_g}, d_wg3, d_w0,
-                  BnEval{h_bn_l[0], h_bn_l[1], h_bn_l[2], h_bn_l[3], eps_l}, d_w3, N, C, T, pooled_tc ? 1 : 0};
-  if (tb_bad(a) || !h_dbn[0] || !h_dbn[1] || !h_dbn[2] || !h_dbn[3]) return VITTA_ERR_INVALID_ARG;
-  TamBranchGrads g{d_gpooled, h_dbn[0], h_dbn[1], h_dbn[2], h_dbn[3], h_dw ? h_dw[0] : nullptr, h_dw ? h_dw[1] : nullptr,
-                   h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};
-  const int O = C / 4;
-  int nt1, nt2;
-  size_t l1, lds;
-  if (!fused_geometry(N, C, T, true, nt1, nt2, l1, lds)) return VITTA_ERR_UNSUPPORTED;
-  const float* d_hact = d_hpre + (int64_t)N_saved * O * T;
-  float* d_dpre = d_gpooled + (int64_t)N * C * T;
-  const int64_t P = (int64_t)N * T * HW;
-  const int64_t xld = x_ld ? x_ld : P;
-  if (xld < P || ((HW & 3) == 0 && (xld & 3))) return VITTA_ERR_INVALID_ARG;
-  if (!use_fast(a, {d_pooled, d_w0, d_w3, d_gate, d_ggate, d_dpre, d_x, d_gout, d_ga, d_dx})) return VITTA_ERR_UNSUPPORTED;
-  const int lpr = HW > 256 ? 32 : 16;
-  if ((TBW / lpr) % T != 0 || (P & 3) || (xld & 3) || (HW > 256 && (HW & 3)) || C > 65535 || (int64_t)C * xld >= (1ll << 29)) return VITTA_ERR_UNSUPPORTED;
-  const int ny = nt1 > nt2 ? nt1 : nt2;
-  const int64_t rows = (int64_t)C * N * T;
-  const int na = (int)((rows + TBW / lpr - 1) / (TBW / lpr));
-  const tamrows::BN bn1{h_bn1[0], h_bn1[1], h_bn1[2], h_bn1[3], eps1};
-  const tamrows::AggBwd ab{d_x, bn1, d_gate, d_kern, d_gout, (int)C, (int)N, (int)T, (int)HW, xld, d_ga, d_ggate, d_gkern};
-  tamrows::BnBwd bb;
-  bb.g = d_ga; bb.g2 = nullptr; bb.x = d_x; bb.mask = nullptr; bb.rowadd = d_gpooled; bb.rowadd_scale = 1.f / (float)HW;
-  bb.bn = bn1;
-  bb.mu = d_mu; bb.ca = d_coef_a; bb.cb = d_coef_b; bb.gs = d_gscale;
-  bb.dx = d_dx; bb.gm = nullptr; bb.dgamma = d_dgamma1; bb.dbeta = d_dbeta1;
-  bb.C = C; bb.N = N; bb.T = T; bb.HW = HW; bb.relu = relu;
-  bb.xld = xld;
-  bb.d_hw = vitta_conv::make_fastdiv(HW);
-  bb.d_t = vitta_conv::make_fastdiv(T);
-  const int64_t per = (int64_t)TBW * tamrows::BB_UNROLL * 4;
-  const int bgx = (int)((P + per - 1) / per), nbn = bgx * C;
-  const int ra = (HW & 3) == 0 ? 1 : 2;
-#define TAM_BWD_ALL_GO(TCV, LPRV, RAV)                                                                                            \
-  do {                                                                                                                            \
-    auto kfn = tam_bwd_all_kernel<TCV, LPRV, RAV>;                                                                                 \
-    if (!set_lds(kfn, lds)) return VITTA_ERR_LAUNCH;                                                                              \
-    if ((int64_t)N * ny > fused_capacity(kfn, lds)) return VITTA_ERR_UNSUPPORTED; /* the branch workgroups meet: all resident */   \
-    VITTA_LAUNCH(kfn, dim3((unsigned)(na + N * ny + nbn)), dim3(TBW), lds, static_cast<hipStream_t>(stream), a, d_kern, d_gate,     \
-                 d_hpre, d_hact, d_gkern, d_ggate, d_dpre, g, static_cast<unsigned*>(d_sync), nt1, nt2, (int)(l1 / 4), ny, ab, na, \
-                 bb, bgx, nbn);                                                                                                   \
-  } while (0)
-  if (a.pooled_tc) {
-    if (lpr == 32) TAM_BWD_ALL_GO(true, 32, 1);
-    else if (ra == 1) TAM_BWD_ALL_GO(true, 16, 1);
-    else TAM_BWD_ALL_GO(true, 16, 2);
-  } else {
-    if (lpr == 32) TAM_BWD_ALL_GO(false, 32, 1);
-    else if (ra == 1) TAM_BWD_ALL_GO(false, 16, 1);
-    else TAM_BWD_ALL_GO(false, 16, 2);
-  }
-#undef TAM_BWD_ALL_GO
   return VITTA_OK;
 }
 

@@ -12,18 +12,58 @@
 //   D[t', j] = <gout[t'-j+1], a[t']>  -> d gate, d K (tam_finish)                  vitta_bn_bwd_cm_f32's row_add)
 // and vitta_bn_bwd_cm_f32 is the BatchNorm(+ReLU) backward of any layer of the block in this layout:
 //   dz = g * mask + gscale (a_c + b_c (z - mu_c)),  d gamma += sum dz x_hat, d beta += sum dz,  dx = dz * s_c.
-#include "tam_rows.h"
+#include "conv_common.h"
 
 using namespace vitta;
-using namespace tamrows;
 
 namespace {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int m = LPR / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, VITTA_WAVE);
+  return v;
+}
+
+struct Row {
+  int c, f, n, t;
+  bool ok;
+};
+
+// rows are enumerated (c, n, t) with t fastest == memory order
+template <int LPR>
+__device__ __forceinline__ Row row_of(int C, int N, int T, int* sub) {
+  constexpr int RPB = VITTA_BLOCK / LPR;
+  const int F = N * T;
+  *sub = threadIdx.x % LPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  Row r;
+  r.ok = row < (int64_t)C * F;
+  const int64_t rr = r.ok ? row : 0;
+  r.c = (int)(rr / F);
+  r.f = (int)(rr - (int64_t)r.c * F);
+  r.n = r.f / T;
+  r.t = r.f - r.n * T;
+  return r;
+}
+
+struct BN {
+  const float *g, *b, *m, *v;
+  float eps;
+};
+
+__device__ __forceinline__ void bn_coef(const BN& bn, int c, float& s, float& t) {
+  s = bn.g[c] * rsqrtf(bn.v[c] + bn.eps);
+  t = bn.b[c] - bn.m[c] * s;
+}
+
+__device__ __forceinline__ float act(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.f); }
 
 template <int LPR>
 __global__ __launch_bounds__(VITTA_BLOCK) void pool_kernel(const float* __restrict__ x, BN bn, int C, int N, int T, int HW,
                                                            float* __restrict__ pool) {
   int sub;
-  const Row r = row_of<LPR>(blockIdx.x, C, N, T, &sub);
+  const Row r = row_of<LPR>(C, N, T, &sub);
   float acc = 0.f;
   if (r.ok) {
     float s, t;
@@ -43,8 +83,58 @@ __global__ __launch_bounds__(VITTA_BLOCK) void pool_kernel(const float* __restri
   if (r.ok && sub == 0) pool[((int64_t)r.n * C + r.c) * T + r.t] = acc / (float)HW;
 }
 
+constexpr int EWU = 4;  // 16-byte pieces per lane and stream that the element-wise row kernels keep in flight
+
 template <int LPR>
-__global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const AggFwd g) { agg_fwd_rows<LPR, false>(g, blockIdx.x); }
+__global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
+                                                              const float* __restrict__ kern, int C, int N, int T, int HW,
+                                                              float* __restrict__ out) {
+  int sub;
+  const Row r = row_of<LPR>(C, N, T, &sub);
+  if (!r.ok) return;
+  float s, sh;
+  bn_coef(bn, r.c, s, sh);
+  const int64_t nc = (int64_t)r.n * C + r.c;
+  const float* g = gate + nc * T;
+  const float* k = kern + nc * 3;
+  const int t = r.t;
+  const float w0 = t > 0 ? k[0] * g[t - 1] : 0.f;
+  const float w1 = k[1] * g[t];
+  const float w2 = t + 1 < T ? k[2] * g[t + 1] : 0.f;
+  const int64_t off = ((int64_t)r.c * N * T + r.f) * HW;
+  const float* xc = x + off;
+  const float* xp = t > 0 ? xc - HW : xc;
+  const float* xn = t + 1 < T ? xc + HW : xc;
+  float* o = out + off;
+  if ((HW & 3) == 0) {
+    const float4 *p4 = reinterpret_cast<const float4*>(xp), *c4 = reinterpret_cast<const float4*>(xc),
+                 *n4 = reinterpret_cast<const float4*>(xn);
+    float4* o4 = reinterpret_cast<float4*>(o);
+    // (round 5: EWU pieces per lane and stream in flight together -- the one-piece loop was a chain of HW / (4 LPR) dependent round
+    // trips per lane, 12 at 56 x 56, which is what these launches cost: 2 TB/s at layer 1)
+    const int q4 = HW >> 2;
+    for (int i0 = sub; i0 < q4; i0 += LPR * EWU) {
+      float4 a[EWU], b[EWU], c[EWU];
+#pragma unroll
+      for (int u = 0; u < EWU; ++u) {
+        const int i = min(i0 + u * LPR, q4 - 1);
+        a[u] = p4[i]; b[u] = c4[i]; c[u] = n4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < EWU; ++u) {
+        float4 q;
+        q.x = fmaf(w2, act(c[u].x, s, sh), fmaf(w1, act(b[u].x, s, sh), w0 * act(a[u].x, s, sh)));
+        q.y = fmaf(w2, act(c[u].y, s, sh), fmaf(w1, act(b[u].y, s, sh), w0 * act(a[u].y, s, sh)));
+        q.z = fmaf(w2, act(c[u].z, s, sh), fmaf(w1, act(b[u].z, s, sh), w0 * act(a[u].z, s, sh)));
+        q.w = fmaf(w2, act(c[u].w, s, sh), fmaf(w1, act(b[u].w, s, sh), w0 * act(a[u].w, s, sh)));
+        if (i0 + u * LPR < q4) o4[i0 + u * LPR] = q;
+      }
+    }
+  } else {
+    for (int i = sub; i < HW; i += LPR)
+      o[i] = fmaf(w2, act(xn[i], s, sh), fmaf(w1, act(xc[i], s, sh), w0 * act(xp[i], s, sh)));
+  }
+}
 
 // FIN: the block holds whole (c, n) groups of T rows (rows per block % T == 0): d gate / d K of its groups are finished here
 // from LDS (the arithmetic of finish_kernel, same order) instead of by a second launch
@@ -57,7 +147,7 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __res
   constexpr int RPB = VITTA_BLOCK / LPR;
   __shared__ float sd[FIN ? RPB * 3 : 1];
   int sub;
-  const Row r = row_of<LPR>(blockIdx.x, C, N, T, &sub);
+  const Row r = row_of<LPR>(C, N, T, &sub);
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;
   if (r.ok) {
     float s, sh;
@@ -180,17 +270,127 @@ __global__ __launch_bounds__(VITTA_BLOCK) void finish_kernel(const float* __rest
   gkern[i * 3 + 2] = g2;
 }
 
-// ---- BatchNorm (+ReLU) backward, channel-major planes: tam_rows.h ---------------------------------------------------------------
+// ---- BatchNorm (+ReLU) backward, channel-major planes ----------------------------------------------------------------
+// workgroup = (pixel chunk, channel): per-channel constants are workgroup-uniform, d gamma / d beta leave with one atomic
+// pair per workgroup.
+constexpr int BB_UNROLL = 4;  // float4 per lane
+struct BnBwd {
+  const float* g;      // gradient arriving at the (activated) BN output [C][P]
+  const float* g2;     // optional second gradient, added
+  const float* x;      // raw convolution output [C][P]
+  const float* mask;   // optional: tensor whose sign is the ReLU mask (else z > 0)
+  const float* rowadd; // optional [N][C][T]: added to g per (n, c, t) row, scaled by rowadd_scale (TAM pooling gradient)
+  float rowadd_scale;
+  BN bn;
+  const float *mu, *ca, *cb, *gs;
+  float* dx;           // [C][P]  dz * s
+  float* gm;           // optional [C][P]  (g + g2 + rowadd) * mask
+  float *dgamma, *dbeta;
+  int C, N, T, HW, relu;
+  int64_t xld;         // pixels between channel rows of x / mask (P unless they hold more frames)
+  vitta_conv::FastDiv d_hw, d_t;  // host-made reciprocals of HW and T (the frame of a pixel, the clip of a frame)
+};
+
+// G2 / MASK: the optional streams exist; ROWADD 0: none, 1: HW % 4 == 0 (a 16-byte piece lies in one frame: one row value per piece),
+// 2: any HW.  Compile-time, and every load of the lane's BB_UNROLL pieces is issued before the first use: with run-time flags and a
+// `break` in the piece loop the loads of a piece waited for the previous piece's stores -- four dependent round trips per lane, and with
+// the pooling gradient eight integer divisions per piece in front of a dependent gather: 2 TB/s on the 56 x 56 layers (round 5).
 template <bool G2, bool MASK, int ROWADD>
 __global__ __launch_bounds__(VITTA_BLOCK) void bn_bwd_kernel(const BnBwd a) {
   __shared__ float red[2][VITTA_BLOCK / VITTA_WAVE];
-  bn_bwd_body<G2, MASK, ROWADD, false>(a, blockIdx.x, blockIdx.y, red);
-}
-
-template <int LPR>
-__global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_fin_kernel(const AggBwd g) {
-  __shared__ float sd[VITTA_BLOCK / LPR * 3];
-  agg_bwd_rows_fin<LPR, false>(g, blockIdx.x, sd);
+  const int c = blockIdx.y;
+  const int64_t P = (int64_t)a.N * a.T * a.HW;
+  const int64_t base = (int64_t)c * P, xbase = (int64_t)c * a.xld;
+  const float rstd = rsqrtf(a.bn.v[c] + a.bn.eps);
+  const float s = a.bn.g[c] * rstd, t = a.bn.b[c] - a.bn.m[c] * s, rm = a.bn.m[c];
+  float ia = 0.f, ib = 0.f, mu = 0.f;
+  if (a.mu) {
+    const float gsc = a.gs ? a.gs[0] : 1.f;
+    ia = gsc * a.ca[c];
+    ib = gsc * a.cb[c];
+    mu = a.mu[c];
+  }
+  const bool relu = a.relu & 1, raw = (a.relu & 2) && a.mu;
+  float sg = 0.f, sb = 0.f;
+  const int64_t p0 = ((int64_t)blockIdx.x * VITTA_BLOCK * BB_UNROLL + threadIdx.x) * 4;
+  const int64_t plast = P - 4;
+  float4 gv[BB_UNROLL], xv[BB_UNROLL], hv[BB_UNROLL], mv[BB_UNROLL];
+  float ra[BB_UNROLL][4];
+#pragma unroll
+  for (int u = 0; u < BB_UNROLL; ++u) {
+    const int64_t p = min(p0 + (int64_t)u * VITTA_BLOCK * 4, plast);
+    gv[u] = *reinterpret_cast<const float4*>(a.g + base + p);
+    xv[u] = *reinterpret_cast<const float4*>(a.x + xbase + p);
+    if (G2) hv[u] = *reinterpret_cast<const float4*>(a.g2 + base + p);
+    if (MASK) mv[u] = *reinterpret_cast<const float4*>(a.mask + xbase + p);
+    if (ROWADD == 1) {
+      const int f = vitta_conv::fdiv((int)p, a.d_hw), n = vitta_conv::fdiv(f, a.d_t), tt = f - n * a.T;
+      ra[u][0] = a.rowadd[((int64_t)n * a.C + c) * a.T + tt];
+    } else if (ROWADD == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int f = vitta_conv::fdiv((int)p + e, a.d_hw), n = vitta_conv::fdiv(f, a.d_t), tt = f - n * a.T;
+        ra[u][e] = a.rowadd[((int64_t)n * a.C + c) * a.T + tt];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < BB_UNROLL; ++u) {
+    const int64_t p = p0 + (int64_t)u * VITTA_BLOCK * 4;
+    const bool on = p < P;
+    float g[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+    const float xr[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+    if (G2) { g[0] += hv[u].x; g[1] += hv[u].y; g[2] += hv[u].z; g[3] += hv[u].w; }
+    if (ROWADD == 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] += a.rowadd_scale * ra[u][0];
+    } else if (ROWADD == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] += a.rowadd_scale * ra[u][e];
+    }
+    float mk[4] = {1.f, 1.f, 1.f, 1.f};
+    if (MASK) {
+      if (relu) { mk[0] = mv[u].x > 0.f; mk[1] = mv[u].y > 0.f; mk[2] = mv[u].z > 0.f; mk[3] = mv[u].w > 0.f; }
+    }
+    float o[4], gmv[4];
+    float sgu = 0.f, sbu = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = fmaf(xr[e], s, t);
+      const float m = (relu && !MASK) ? (z > 0.f ? 1.f : 0.f) : mk[e];
+      gmv[e] = g[e] * m;
+      // statistics-loss gradient of the hooked feature: of z (added before the affine map is differentiated) or -- before_norm
+      // hooks, utils/norm_stats_utils.py:185 -- of the RAW input x (added to dx as it is; d gamma / d beta do not see it)
+      const float dz = raw ? gmv[e] : gmv[e] + fmaf(ib, z - mu, ia);
+      sgu += dz * (xr[e] - rm) * rstd;
+      sbu += dz;
+      o[e] = raw ? fmaf(dz, s, fmaf(ib, xr[e] - mu, ia)) : dz * s;
+    }
+    if (on) {
+      sg += sgu;
+      sb += sbu;
+      *reinterpret_cast<float4*>(a.dx + base + p) = make_float4(o[0], o[1], o[2], o[3]);
+      if (a.gm) *reinterpret_cast<float4*>(a.gm + base + p) = make_float4(gmv[0], gmv[1], gmv[2], gmv[3]);
+    }
+  }
+  sg = wave_sum(sg);
+  sb = wave_sum(sb);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    red[0][wave] = sg;
+    red[1][wave] = sb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float g0 = 0.f, b0 = 0.f;
+#pragma unroll
+    for (int w = 0; w < VITTA_BLOCK / VITTA_WAVE; ++w) {
+      g0 += red[0][w];
+      b0 += red[1][w];
+    }
+    if (a.dgamma) atomicAdd(a.dgamma + c, g0);
+    if (a.dbeta) atomicAdd(a.dbeta + c, b0);
+  }
 }
 
 // ---- head: global average pooling and its backward ----------------------------------------------------------------------
@@ -250,8 +450,7 @@ int vitta_tam_agg_fwd_cm_f32(const float* d_x, const float* const* h_bn, float e
   if (!d_x || !bn_ok(h_bn) || !d_gate || !d_kern || !d_out || bad(C, N, T, HW)) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BN bn{h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps};
-  const AggFwd g{d_x, bn, d_gate, d_kern, (int)C, (int)N, (int)T, (int)HW, d_out};
-  CM_DISPATCH(agg_fwd_kernel, (int64_t)C * N * T, HW, st, g);
+  CM_DISPATCH(agg_fwd_kernel, (int64_t)C * N * T, HW, st, d_x, bn, d_gate, d_kern, (int)C, (int)N, (int)T, (int)HW, d_out);
   return VITTA_OK;
 }
 
@@ -266,14 +465,15 @@ int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* con
   const BN bn{h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps};
   float* dots = d_ggate + (int64_t)N * C * T;  // the caller gives d_ggate room for N*C*T*4 floats
   const int64_t rows = (int64_t)C * N * T;
-  const AggBwd gb{d_x, bn, d_gate, d_kern, d_gout, (int)C, (int)N, (int)T, (int)HW, xld, d_ga, d_ggate, d_gkern};
   // whole (c, n) groups per workgroup -> d gate / d K finished in the same launch (T = 8: 32 or 16 lanes per row)
   if (HW > 256 && (VITTA_BLOCK / 32) % T == 0) {
-    VITTA_LAUNCH((agg_bwd_fin_kernel<32>), dim3(row_grid(rows, 32)), dim3(VITTA_BLOCK), 0, st, gb);
+    VITTA_LAUNCH((agg_bwd_kernel<32, true>), dim3(row_grid(rows, 32)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
     return VITTA_OK;
   }
   if (HW <= 256 && (VITTA_BLOCK / 16) % T == 0) {
-    VITTA_LAUNCH((agg_bwd_fin_kernel<16>), dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, gb);
+    VITTA_LAUNCH((agg_bwd_kernel<16, true>), dim3(row_grid(rows, 16)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
     return VITTA_OK;
   }
   if (HW > 256)

@@ -62,10 +62,6 @@ POOL_FOLD = os.environ.get("VITTA_TRUNK_POOL_FOLD", "1") != "0"
 # 4p-channel tensor fewer per backward.  (Measured slower on the round-2 fp32 kernels, 79.8 vs 57.7 us + the pass; re-measured on
 # conv_b3.hip in round 5.)  "0": the stand-alone pass.
 BN3_FOLD = os.environ.get("VITTA_TRUNK_BN3_FOLD", "1") != "0"
-# the TAM of a block as ONE launch per direction (branch workgroups first, the row workgroups of the element passes behind them, waiting
-# on arrival words inside the launch): forward branches + aggregation, backward aggregation + branches + bn1's backward; "0": the
-# separate launches (vitta_tam_branch_*_fused_f32, vitta_tam_agg_*_cm_f32, vitta_bn_bwd_cm_ld_f32).  32 + 32 launches fewer per step.
-TAM_MERGE = os.environ.get("VITTA_TRUNK_TAM_MERGE", "0") != "0"
 _side_streams = {}
 _side_pool = {}
 
@@ -112,7 +108,7 @@ _sync_bufs = {}
 def _sync(device):
     """Meeting counters of the fused TAM branch launches on the CURRENT stream (zero at rest; one buffer per stream: launches
     on different streams may overlap)."""
-    return CV.zeroed_per_stream(_sync_bufs, device, 32768, spares=4)  # (never zero-filled inside a graph capture)
+    return CV.zeroed_per_stream(_sync_bufs, device, 1024, spares=4)  # (never zero-filled inside a graph capture)
 
 
 def _bn_ptrs(bn):
@@ -592,19 +588,7 @@ class TrunkRunner:
         kern, gate, hpre = torch.empty(nb * p, 3, **f), torch.empty(nb, p, t, **f), torch.empty(2, nb, p // 4, t, **f)
         from .ops import _ptr4
         from .ops import tam_branch_fused_supported
-        a1 = torch.empty(p, P, **f)
-        rc = _lib.VITTA_ERR_UNSUPPORTED
-        if TAM_MERGE and tam_branch_fused_supported(nb, p, t):  # branches + aggregation pass as ONE launch (tam_branch.hip, "merged launches")
-            rc = L.vitta_tam_fwd_agg_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                         _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), _p(_sync(dev)), ptc,
-                                         _p(x1), bn1p, float(net.bn1.eps), h * w, _p(a1), st)
-            if rc != _lib.VITTA_ERR_UNSUPPORTED:
-                check(rc, "vitta_tam_fwd_agg_f32")
-        if rc != _lib.VITTA_ERR_UNSUPPORTED:
-            pass
-        elif tam_branch_fused_supported(nb, p, t):  # every workgroup of the one-launch form resident (also beside the other stream's)
+        if tam_branch_fused_supported(nb, p, t):  # every workgroup of the one-launch form resident (also beside the other stream's)
             check(L.vitta_tam_branch_fwd_fused_f32(_p(pooled), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                                    _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
@@ -615,9 +599,9 @@ class TrunkRunner:
                                              float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                              _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
                                              _p(tam.L[3].weight), nb, p, t, _p(kern), _p(gate), _p(hpre), ptc, st), "vitta_tam_branch_fwd_f32")
-        if rc == _lib.VITTA_ERR_UNSUPPORTED:
-            check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
-                  "vitta_tam_agg_fwd_cm_f32")
+        a1 = torch.empty(p, P, **f)
+        check(L.vitta_tam_agg_fwd_cm_f32(_p(x1), bn1p, float(net.bn1.eps), _p(gate), _p(kern), p, nb, t, h * w, _p(a1), st),
+              "vitta_tam_agg_fwd_cm_f32")
         # conv2 -> a2 = relu(bn2(x2)) (+ x2 raw for the backward): the activation is applied ONCE in this epilogue -- as a
         # prologue of conv3 it sits in the slab loop (two VALU instructions per staged element beside the MFMAs: the
         # 1024 -> 256 pointwise launch 43 us against 26 us plain, tools/debug/conv_epilogue_probe.py)
@@ -779,6 +763,9 @@ class TrunkRunner:
         ga = torch.empty(p, P, **f)
         ggate = torch.empty(nb * p * t * 4, **f)
         gkern = torch.empty(nb * p, 3, **f)
+        check(L.vitta_tam_agg_bwd_cm_ld_f32(_p(sv["x1"]), ldP, bn1p, float(net.bn1.eps), _p(sv["gate"]), _p(sv["kern"]), _p(ga1), p, nb,
+                                            t, h * w, _p(ga), _p(ggate), _p(gkern), st), "vitta_tam_agg_bwd_cm_ld_f32")
+        del ga1
         bg, bl = tam.G[1], tam.L[1]
         from .ops import _ptr4
         gbuf = torch.empty(nb * p * t + nb * (p // 4) * t, **f)  # d pooled | scratch
@@ -796,29 +783,7 @@ class TrunkRunner:
                 C.c_void_p(gbuf.data_ptr() + 4 * nb * p * t), nb, p, t, _p(dw0), _p(dw3), _stream()), "vitta_tam_branch_wgrad_f32"))
         else:
             w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), dw0, dw3)
-        rc = _lib.VITTA_ERR_UNSUPPORTED
-        dx1 = None
-        if TAM_MERGE and tam_branch_fused_supported(nb, p, t):  # aggregation backward + branches + bn1 backward as ONE launch
-            dx1 = torch.empty(p, P, **f)
-            inj1 = s1.inj if s1 else (None, None, None, None)
-            rc = L.vitta_tam_bwd_all_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
-                                         float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
-                                         _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                         _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
-                                         _p(ggate), _p(gbuf), bn_sinks, w_sinks, _p(_sync(dev)), sv["ptc"],
-                                         _p(sv["x1"]), ldP, bn1p, float(net.bn1.eps), _p(ga1), h * w, _p(ga),
-                                         _p(inj1[0]), _p(inj1[1]), _p(inj1[2]), _p(inj1[3]),
-                                         1 | (_lib.BN_BWD_INJ_RAW if (s1 and s1.raw) else 0), _p(dx1),
-                                         _p(sink(net.bn1.weight)), _p(sink(net.bn1.bias)), st)
-            if rc != _lib.VITTA_ERR_UNSUPPORTED:
-                check(rc, "vitta_tam_bwd_all_f32")
-        if rc == _lib.VITTA_ERR_UNSUPPORTED:
-            check(L.vitta_tam_agg_bwd_cm_ld_f32(_p(sv["x1"]), ldP, bn1p, float(net.bn1.eps), _p(sv["gate"]), _p(sv["kern"]), _p(ga1), p, nb,
-                                                t, h * w, _p(ga), _p(ggate), _p(gkern), st), "vitta_tam_agg_bwd_cm_ld_f32")
-        del ga1
-        if rc != _lib.VITTA_ERR_UNSUPPORTED:
-            pass
-        elif tam_branch_fused_supported(nb, p, t):
+        if tam_branch_fused_supported(nb, p, t):
             check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                                    _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
@@ -832,8 +797,7 @@ class TrunkRunner:
                                              _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
                                              _p(ggate), _p(gbuf), bn_sinks, w_sinks, sv["ptc"], st), "vitta_tam_branch_bwd_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
-        if rc == _lib.VITTA_ERR_UNSUPPORTED:
-            dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w, ld=ldP)
+        dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w, ld=ldP)
         del ga
         if net.conv1.weight.requires_grad:
             wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p, x_ld=ldP)
