@@ -88,6 +88,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--no-streaming", action="store_true")
+    p.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) repetition of the timed steps")
     p.add_argument("--no-sgd-all", action="store_true", help="skip the second (SGD over all parameters) timing")
     p.add_argument("--no-swin", action="store_true", help="skip the Video Swin-B legs (configs 3 and 5)")
     p.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed")
@@ -308,6 +309,42 @@ def run_gpu(opt, rank, world, device):
         f"({'hipGraph replay' if use_graph else 'eager'})")
     eager_elapsed = float("nan")
     run_gpu.conv = None
+    run_gpu.host_fed = None
+    if rank == 0 and world == 1 and not opt.timed_only and not opt.sequential and not opt.no_host_fed:
+        # the same K steps with every video coming from (pinned) HOST memory: `value` above has its inputs resident in HBM; this is the
+        # PCIe-inclusive rate -- (a) vitta_amd/prefetch.py, the next video's copies on a copy stream beside the current step (what
+        # tta_standard does), (b) the reference's way, the upload in the compute stream in front of the step (corpus/basics.py:612-623)
+        from vitta_amd.prefetch import DevicePrefetcher
+        nv = min(n_videos, 4)
+        hx = [tta_set[i][0].unsqueeze(0).cpu().pin_memory() for i in range(nv)]
+        he = [eval_set[i][0].unsqueeze(0).cpu().pin_memory() for i in range(nv)]
+        res = {"mb_per_video": round((hx[0].numel() * hx[0].element_size() + he[0].numel() * he[0].element_size()) / 1e6, 2)}
+        for mode in ("prefetch", "upload_in_stream"):
+            times = []
+            for rep in range(3):
+                if mode == "prefetch":
+                    pt = DevicePrefetcher(((hx[i % nv],) for i in range(opt.steps)), device)
+                    pe = DevicePrefetcher(((he[(i - 1) % nv],) for i in range(opt.steps)), device)
+                    pt.ahead(), pe.ahead()
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(opt.steps):
+                    if mode == "prefetch":
+                        (x,), (ev,) = next(pt), next(pe)
+                    else:
+                        x, ev = hx[i % nv].to(device, non_blocking=True), he[(i - 1) % nv].to(device, non_blocking=True)
+                    adapter.set_adapt_mode()
+                    adapter.step(adapter.shape_tta_input(x), adapter.shape_eval_input(ev))
+                    if mode == "prefetch":
+                        pt.ahead(), pe.ahead()
+                barrier()
+                times.append((time.perf_counter() - t0) / opt.steps)
+            res["ms_per_step_" + mode] = round(1e3 * float(np.median(times)), 4)
+        res["videos_per_s"] = round(1e3 / res["ms_per_step_prefetch"], 2)
+        res["note"] = ("every video from pinned host memory; prefetch = next video's copies on a copy stream beside the current step "
+                       "(vitta_amd/prefetch.py, what tta_standard does); upload_in_stream = copies in the compute stream in front of the step")
+        run_gpu.host_fed = res
+        log(f"host-fed steps: {res}")
     if opt.timed_only:
         run_gpu.mode, run_gpu.eager_ms = ("hipGraph replay" if use_graph else "eager launches"), None
         return elapsed, float("nan"), float("nan"), None, adapter
@@ -852,7 +889,7 @@ def main():
                    "schedule": "sequential: adapt(i); eval(i)" if opt.sequential else
                                "overlapped: eval(i-1) on a second stream beside adapt(i), optimizer update after both "
                                "(same weights and results as the sequential order)"},
-        "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "launch_mode": mode, "eager_ms_per_step": eager_ms,
+        "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "host_fed": getattr(run_gpu, "host_fed", None), "launch_mode": mode, "eager_ms_per_step": eager_ms,
         "roofline": roofline, "ranks": ranks, "dp_graph": dp_graph,
     }
     if opt.arch == "swin":

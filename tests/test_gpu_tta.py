@@ -469,3 +469,31 @@ def test_swin_row_mapped_attention_equals_roll_and_partition_copies_on_gpu():
         assert_logits_close(outs[0][0], outs[1][0], 1e-4)
         for a, b in zip(outs[0][1:], outs[1][1:]):
             assert (a - b).abs().max().item() <= 1e-3 * b.abs().max().item() + 1e-9
+
+
+def test_device_prefetcher_uploads_one_batch_ahead_on_its_own_stream():
+    """vitta_amd/prefetch.py (the reference's loop uploads with a blocking .cuda() in front of each step, corpus/basics.py:612-623):
+    the batches arrive on the device unchanged and in order, whether the loop calls `ahead()` after issuing its step or not, from pinned
+    and from pageable host memory; the copy stream is not the consumer's stream, the consumer's stream waits for the copy (a kernel
+    launched right after `next()` reads the uploaded values); StopIteration at the end, also after an `ahead()` that found the loader empty."""
+    from vitta_amd.prefetch import DevicePrefetcher
+    d = _dev()
+    g = torch.Generator().manual_seed(3)
+    host = [(torch.randn(2, 8, 3, 64, 64, generator=g), torch.tensor([i, 2 * i])) for i in range(5)]
+    host[1] = (host[1][0].pin_memory(), host[1][1].pin_memory())
+    for use_ahead in (True, False):
+        pf = DevicePrefetcher(iter(host), d)
+        assert pf.stream != torch.cuda.current_stream(d)
+        sums = []
+        for i in range(5):
+            x, y = next(pf)
+            assert x.is_cuda and y.is_cuda
+            sums.append((x.double().sum() + y.sum()))  # consumer kernels on the current stream, no host synchronisation in between
+            if use_ahead:
+                pf.ahead()
+                assert len(pf.queue) == (1 if i < 4 else 0)
+        with pytest.raises(StopIteration):
+            next(pf)
+        assert pf.uploads == 5
+        want = [float(a.double().sum() + b.sum()) for a, b in host]
+        assert [float(s) for s in sums] == want

@@ -83,7 +83,7 @@ def test_opts_surface_matches_reference():
     from vitta_amd.opts import get_opts
     ref = json.load(open(H.GOLDEN_DIR + "/opts_defaults.json"))
     mine = {k: repr(v) for k, v in vars(get_opts([])).items()}
-    extensions = {"hip_graph", "overlap_eval", "device_preprocess", "wmsa_bf16", "dense_bf16"}  # flags this build adds on top of the reference surface
+    extensions = {"hip_graph", "overlap_eval", "device_preprocess", "wmsa_bf16", "dense_bf16", "prefetch_input"}  # flags this build adds on top of the reference surface
     assert set(mine) - set(ref) == extensions
     mine = {k: v for k, v in mine.items() if k not in extensions}
     assert set(ref) == set(mine)
@@ -332,3 +332,20 @@ def test_reference_import_paths_resolve():
         m = importlib.import_module(mod)
         for n in names:
             assert hasattr(m, n), (mod, n)
+
+
+def test_device_prefetcher_on_a_cpu_device_is_the_plain_iterator():
+    """vitta_amd/prefetch.py: same batches, same order, same StopIteration; `ahead()` is a no-op without a GPU."""
+    import torch
+    from vitta_amd.prefetch import DevicePrefetcher
+    batches = [(torch.full((2, 3), float(i)), torch.tensor([i, i + 1])) for i in range(4)]
+    pf = DevicePrefetcher(iter(batches), torch.device("cpu"))
+    got = []
+    for _ in range(4):
+        got.append(next(pf))
+        pf.ahead()
+    assert all(a is b for ga, ba in zip(got, batches) for a, b in zip(ga, ba))
+    import pytest
+    with pytest.raises(StopIteration):
+        next(pf)
+    assert pf.uploads == 0

@@ -13,6 +13,8 @@
   accumulation; BASELINE config 5's recipe), vitta_amd/csrc/wmsa_bf16.hip.
 * `--device_preprocess` (extension, default False) uploads the decoded uint8 frames and runs crop / resize / normalise
   of the TANet pipeline in one HIP launch (bit-identical to the PIL path, vitta_amd/frames.py).
+* `--prefetch_input` (extension, default True) uploads the next video on a copy stream while the current one is adapted
+  (vitta_amd/prefetch.py); False: the reference's upload in front of each step.
 """
 import argparse
 
@@ -104,6 +106,9 @@ _FLAGS = [
     (("--overlap_eval",), dict(type=_bool, default=True,
                                help="(extension) evaluate video i on a second stream beside the adaptation forward of "
                                     "video i+1 (same weights, same results)")),
+    (("--prefetch_input",), dict(type=_bool, default=True,
+                                 help="(extension) upload the next video on a copy stream beside the current step "
+                                      "(vitta_amd/prefetch.py; the reference uploads in front of each step)")),
     (("--device_preprocess",), dict(type=_bool, default=False,
                                     help="(extension) TANet real-video pipeline: crop + PIL-BILINEAR resize + normalise on "
                                          "the GPU from the uploaded uint8 frames (bit-identical to the host PIL path)")),

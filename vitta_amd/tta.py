@@ -967,7 +967,13 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
     tta_loader, eval_loader = _loader(tta_set, args), _loader(eval_set, args)
     if world == 1:
         n_steps = len(tta_loader)
-    tta_iter, eval_iter = iter(tta_loader), iter(eval_loader)
+    # (extension, --prefetch_input, default on: the next video's host -> device copies run on a copy stream beside the current step;
+    # the reference's loop uploads with a blocking .cuda() in front of each step, basics.py:612-623)
+    from .prefetch import DevicePrefetcher
+    pf = device.type == "cuda" and bool(getattr(args, "prefetch_input", True))
+    tta_iter = DevicePrefetcher(tta_loader, device) if pf else iter(tta_loader)
+    eval_iter = DevicePrefetcher(eval_loader, device) if pf else iter(eval_loader)
+    ahead = (lambda it: it.ahead()) if pf else (lambda it: None)
 
     log = DeferredLog(device, logger, n_steps, args.verbose)
     adapter = None
@@ -1018,6 +1024,7 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
         else:
             for _ in range(args.n_gradient_steps):
                 output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
+        ahead(tta_iter)  # the step is issued: the next video's upload goes out beside it
         if has_video:
             row[0] = loss_reg.detach()
             if loss_consis is not None:
@@ -1032,6 +1039,7 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
                 ev_input, ev_target = next(eval_iter)
                 waiting = (batch_id, row, actual_bz, adapter.shape_eval_input(ev_input.to(device, non_blocking=True)),
                            ev_target.to(device, non_blocking=True))
+                ahead(eval_iter)
             end = now
             continue
         adapter.close_hooks()
@@ -1040,6 +1048,7 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
             ev_input = adapter.shape_eval_input(ev_input.to(device, non_blocking=True))
             ev_target = ev_target.to(device, non_blocking=True)
             output = adapter.evaluate(ev_input)
+            ahead(eval_iter)
             prec1, prec5 = accuracy(output.data, ev_target, topk=(1, 5))
             row[3], row[4] = prec1, prec5
         if args.if_tta_standard == "tta_online":
