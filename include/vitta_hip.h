@@ -166,13 +166,15 @@ int vitta_moments_nhwc_bf16(const uint16_t* d_x, int64_t rows, int32_t C, float*
  *   d_total_loss [1]        out  sum over layers (loss_reg, corpus/basics.py:658-661)
  *   d_mu   [total_channels] out  batch mean mu_c (needed by the backward)
  *   d_coef_a,d_coef_b       out  dL/dx[i,c] = a_c + b_c * (x[i,c] - mu_c)
+ *   d_zero_word [1] or NULL out  one more device float set to 0 by the launch (the engine's gradient scale, reset once per step)
+ * ONE launch (round 5): a workgroup per layer, the last to arrive (counter in the plan's uploaded tables, zero at rest) adds the
+ * layers in layer order.  Not re-entrant per plan: one alignment launch of a plan at a time (they are issued on one stream).
  * -------------------------------------------------------------------------- */
 int vitta_stat_align_fwd_f32(const vitta_plan* plan, const float* d_shift, const float* d_cnt,
                              const float* d_s1, const float* d_s2, float* d_ema_mean,
                              float* d_ema_var, const float* d_src_mean, const float* d_src_var,
                              float momentum, int reg_type, float* d_layer_loss, float* d_total_loss,
-                             float* d_mu, float* d_coef_a, float* d_coef_b, void* d_workspace,
-                             size_t workspace_bytes, void* stream);
+                             float* d_mu, float* d_coef_a, float* d_coef_b, float* d_zero_word, void* stream);
 
 /* --------------------------------------------------------------------------
  * A6 — backward of A1-A4 w.r.t. the hooked feature:
@@ -381,7 +383,9 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv, const float* d_table, int32_t 
  * A7 -- optimizer update on the flat parameter arena, one launch.
  * Replaces optimizer.step() of corpus/basics.py:671 for the optimizers built at corpus/basics.py:547-560 (torch.optim.Adam over the affine tensors /
  * torch.optim.SGD over every parameter), same element-wise arithmetic as torch's single-tensor formulation.
- *   vitta_adam_step_f32: t = *d_step + 1 (device scalar, incremented by the call, so a captured graph advances it);
+ *   vitta_adam_step_f32: t = d_step[0] + 1 (device scalar, incremented by the call, so a captured graph advances it; d_step is TWO
+ *                        words: d_step[1] is the launch's arrival counter, zero when first used and left zero -- the last
+ *                        workgroup to arrive writes the new step, ONE launch);
  *                        g' = g + wd p; m = lerp(m, g', 1-b1); v = b2 v + (1-b2) g'^2;
  *                        p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  m, v, *d_step start at 0.
  *   vitta_sgd_step_f32:  d = g + wd p; buf = momentum buf + d (buf starts at 0); p -= lr buf.
@@ -763,9 +767,10 @@ int vitta_tanet_head_fwd_f32(const float* d_y, const float* d_w, const float* d_
 int vitta_tanet_head_bwd_f32(const float* d_gradc, const float* d_g_loss, const float* d_g_out, const float* d_w, const void* d_mask,
                              float scale, int32_t B, int32_t V, int32_t T, int32_t K, int32_t D, float* d_dfeat, const float* d_ybar,
                              float* d_dl, float* d_dw, float* d_db, void* stream);
-/* total loss of a step, corpus/basics.py:668: d_out[0] = la * d_a[0] + lb * d_b[0] (d_b NULL: 0); its backward in one launch:
- * d_ga[0] = la * g, d_gb[0] = lb * g (d_g NULL: g = 1; d_gb NULL: skipped). */
-int vitta_loss_axpby_f32(const float* d_a, const float* d_b, float la, float lb, float* d_out, void* stream);
+/* total loss of a step, corpus/basics.py:668: d_out[0] = la * d_a[0] + lb * d_b[0] (d_b NULL: 0); the same launch leaves the two
+ * upstream gradients for d out = 1 in d_ga1[0] = la, d_gb1[0] = lb (NULL: skipped) -- `loss.backward()` then needs no launch here.
+ * Its backward for any other d out in one launch: d_ga[0] = la * g, d_gb[0] = lb * g (d_g NULL: g = 1; d_gb NULL: skipped). */
+int vitta_loss_axpby_f32(const float* d_a, const float* d_b, float la, float lb, float* d_out, float* d_ga1, float* d_gb1, void* stream);
 int vitta_loss_axpby_bwd_f32(const float* d_g, float la, float lb, float* d_ga, float* d_gb, void* stream);
 
 /* --------------------------------------------------------------------------

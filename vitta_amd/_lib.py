@@ -91,7 +91,7 @@ SIGNATURES = {
     "vitta_moments_nchw_bf16": (C.c_int, [_p, _i64, _i32, _i64, _p, _p, _p, _sz, _p]),
     "vitta_moments_nhwc_bf16": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _sz, _p]),
     "vitta_stat_align_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, C.c_int,
-                                           _p, _p, _p, _p, _p, _p, _sz, _p]),
+                                           _p, _p, _p, _p, _p, _p, _p]),
     "vitta_stat_align_bwd_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i32, _p, _p, _p, _p, _p]),
     "vitta_pred_consis_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "vitta_tam_pool_f32": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
@@ -159,7 +159,7 @@ SIGNATURES = {
     "vitta_tanet_head_lds_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vitta_tanet_head_fwd_f32": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "vitta_tanet_head_bwd_f32": (C.c_int, [_p, _p, _p, _p, _p, C.c_float, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p]),
-    "vitta_loss_axpby_f32": (C.c_int, [_p, _p, C.c_float, C.c_float, _p, _p]),
+    "vitta_loss_axpby_f32": (C.c_int, [_p, _p, C.c_float, C.c_float, _p, _p, _p, _p]),
     "vitta_loss_axpby_bwd_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p, _p]),
     "vitta_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "vitta_gemm_nt_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),

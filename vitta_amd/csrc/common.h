@@ -101,14 +101,15 @@ struct vitta_plan {
   int n_blocks_nchw = 0, n_blocks_nhwc = 0;
   bool nt_loads = false;
   vitta::LayerInfo h_info[VITTA_MAX_LAYERS];
-  // host image of the device tables: [LayerInfo x L | BlockEnt nchw | BlockEnt nhwc | chan2layer]
+  // host image of the device tables: [LayerInfo x L | BlockEnt nchw | BlockEnt nhwc | chan2layer | ticket]
   void* h_tables = nullptr;
-  size_t table_bytes = 0, off_nchw = 0, off_nhwc = 0, off_c2l = 0;
+  size_t table_bytes = 0, off_nchw = 0, off_nhwc = 0, off_c2l = 0, off_ticket = 0;
   // device tables: views into the CALLER-OWNED buffer handed to vitta_plan_upload (never freed here)
   vitta::LayerInfo* d_info = nullptr;
   vitta::BlockEnt* d_tab_nchw = nullptr;
   vitta::BlockEnt* d_tab_nhwc = nullptr;
   int32_t* d_chan2layer = nullptr;
+  unsigned* d_ticket = nullptr;  // arrival counter of the alignment launch (uploaded zero, zero at rest)
 };
 
 // hipGetLastError() is sticky per host thread: an unrelated earlier runtime call (e.g. a probing call

@@ -304,8 +304,12 @@ __global__ __launch_bounds__(256) void tanet_head_bwd_w_kernel(const float* __re
 }
 
 // out = la * a + lb * b (the step's total loss, corpus/basics.py:668);  backward: ga = la * g, gb = lb * g in one launch
-__global__ void loss_axpby_kernel(const float* a, const float* b, float la, float lb, float* out) {
-  if (threadIdx.x == 0) out[0] = la * a[0] + lb * (b ? b[0] : 0.f);
+__global__ void loss_axpby_kernel(const float* a, const float* b, float la, float lb, float* out, float* ga, float* gb) {
+  if (threadIdx.x == 0) {
+    out[0] = la * a[0] + lb * (b ? b[0] : 0.f);
+    if (ga) ga[0] = la;  // the two upstream gradients for d out = 1 (what `loss.backward()` starts from): no backward launch then
+    if (gb) gb[0] = lb;
+  }
 }
 __global__ void loss_axpby_bwd_kernel(const float* g, float la, float lb, float* ga, float* gb) {
   if (threadIdx.x == 0) {
@@ -380,9 +384,9 @@ int vitta_tanet_head_bwd_f32(const float* d_gradc, const float* d_g_loss, const 
   return VITTA_OK;
 }
 
-int vitta_loss_axpby_f32(const float* d_a, const float* d_b, float la, float lb, float* d_out, void* stream) {
+int vitta_loss_axpby_f32(const float* d_a, const float* d_b, float la, float lb, float* d_out, float* d_ga1, float* d_gb1, void* stream) {
   if (!d_a || !d_out) return VITTA_ERR_INVALID_ARG;
-  VITTA_LAUNCH(loss_axpby_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_a, d_b, la, lb, d_out);
+  VITTA_LAUNCH(loss_axpby_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_a, d_b, la, lb, d_out, d_ga1, d_gb1);
   return VITTA_OK;
 }
 

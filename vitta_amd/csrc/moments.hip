@@ -454,7 +454,8 @@ int vitta_plan_create_split(const vitta_layer_shape* h_shapes, int n_layers, int
   p->off_nchw = pad(sizeof(LayerInfo) * n_layers);
   p->off_nhwc = p->off_nchw + pad(sizeof(BlockEnt) * tab_nchw.size());
   p->off_c2l = p->off_nhwc + pad(sizeof(BlockEnt) * tab_nhwc.size());
-  p->table_bytes = p->off_c2l + pad(sizeof(int32_t) * (size_t)coff);
+  p->off_ticket = p->off_c2l + pad(sizeof(int32_t) * (size_t)coff);
+  p->table_bytes = p->off_ticket + 256;
   p->h_tables = calloc(1, p->table_bytes);
   if (!p->h_tables) { delete p; return VITTA_ERR_ALLOC; }
   char* h = static_cast<char*>(p->h_tables);
@@ -485,6 +486,7 @@ int vitta_plan_upload(vitta_plan* p, void* d_tables, size_t bytes, void* stream)
   p->d_tab_nchw = reinterpret_cast<BlockEnt*>(d + p->off_nchw);
   p->d_tab_nhwc = reinterpret_cast<BlockEnt*>(d + p->off_nhwc);
   p->d_chan2layer = reinterpret_cast<int32_t*>(d + p->off_c2l);
+  p->d_ticket = reinterpret_cast<unsigned*>(d + p->off_ticket);
   return VITTA_OK;
 }
 

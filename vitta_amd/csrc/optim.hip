@@ -15,7 +15,7 @@ namespace {
 //   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(VITTA_BLOCK) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
-                                                                const float* __restrict__ step, float lr, float b1,
+                                                                float* step, float lr, float b1,
                                                                 float b2, float eps, float wd, int64_t n) {
   const double t = (double)*step + 1.0;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
@@ -23,7 +23,6 @@ __global__ __launch_bounds__(VITTA_BLOCK) void adam_step_kernel(float* __restric
   const float step_size = lr / bc1;
   const float w1 = 1.f - b1, w2 = 1.f - b2;
   const int64_t i0 = ((int64_t)blockIdx.x * VITTA_BLOCK + threadIdx.x) * 4;
-  if (i0 >= n) return;
   if (i0 + 4 <= n) {
     float4 pp = *reinterpret_cast<float4*>(p + i0);
     const float4 gg = *reinterpret_cast<const float4*>(g + i0);
@@ -49,9 +48,18 @@ __global__ __launch_bounds__(VITTA_BLOCK) void adam_step_kernel(float* __restric
       p[i] = p[i] - step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
     }
   }
+  // step += 1 once every workgroup has read it: the last one to arrive (step[1]: arrival counter, zero at rest) writes it.
+  // (Rounds 1-4: a second one-thread launch.)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *step = (float)t;
+    }
+  }
 }
-
-__global__ void bump_step_kernel(float* step) { *step += 1.f; }
 
 // torch.optim.SGD (dampening 0, no nesterov): d = g + wd p; buf = mu buf + d (buf starts at 0, so the first step
 // gives buf = d like torch's clone); p -= lr buf.  mu == 0: p -= lr d, buf untouched (may be NULL).
@@ -105,7 +113,6 @@ int vitta_adam_step_f32(float* d_param, const float* d_grad, float* d_exp_avg, f
   const int64_t grid = (n + 4 * VITTA_BLOCK - 1) / (4 * VITTA_BLOCK);
   VITTA_LAUNCH(adam_step_kernel, dim3((unsigned)grid), dim3(VITTA_BLOCK), 0, st, d_param, d_grad, d_exp_avg, d_exp_avg_sq,
                d_step, lr, beta1, beta2, eps, weight_decay, n);
-  VITTA_LAUNCH(bump_step_kernel, dim3(1), dim3(1), 0, st, d_step);
   return VITTA_OK;
 }
 

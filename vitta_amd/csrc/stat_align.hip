@@ -17,80 +17,102 @@ namespace {
 
 __device__ __forceinline__ float sgn(float v) { return (float)((v > 0.f) - (v < 0.f)); }
 
-// One lane per packed channel: finish the moments, update both EMAs, emit the loss
-// term of the channel and the backward coefficients.
+// One workgroup per hooked layer: finish the moments of its channels, update both EMAs, emit the backward coefficients and the
+// layer's loss (fixed-order tree sum of the channel terms -> r_feature[l]); the LAST workgroup to arrive adds the layers in layer
+// order (= the reference's `loss_reg += hook.r_feature`) and, if asked, zeroes one more device word (the engine's gradient
+// scale, which a step resets here).  (Rounds 1-4: three dependent launches -- channels, layers, total -- ~15 us of the chain.)
 __global__ __launch_bounds__(VITTA_BLOCK) void stat_align_kernel(
-    const LayerInfo* __restrict__ linfo, const int32_t* __restrict__ chan2layer, int64_t total_c,
+    const LayerInfo* __restrict__ linfo, int n_layers,
     const float* __restrict__ shift, const float* __restrict__ cnt, const float* __restrict__ s1,
     const float* __restrict__ s2, float* __restrict__ ema_mean, float* __restrict__ ema_var,
     const float* __restrict__ src_mean, const float* __restrict__ src_var, float momentum, int reg_type,
-    float* __restrict__ term, float* __restrict__ mu_out, float* __restrict__ coef_a,
-    float* __restrict__ coef_b) {
-  const int64_t g = (int64_t)blockIdx.x * VITTA_BLOCK + threadIdx.x;
-  if (g >= total_c) return;
-  const int l = chan2layer[g];
-  const float C = (float)linfo[l].C;
-  const double n = (double)cnt[l];
-  const double k = shift ? (double)shift[g] : 0.0;
-  const double m1 = n > 0.0 ? (double)s1[g] / n : 0.0;
-  const double m2 = n > 0.0 ? (double)s2[g] / n : 0.0;
-  const float mu = (float)(k + m1);
-  double vd = m2 - m1 * m1;
-  const float var = (float)(vd > 0.0 ? vd : 0.0);
-
-  const float em = momentum * mu + (1.f - momentum) * ema_mean[g];
-  const float ev = momentum * var + (1.f - momentum) * ema_var[g];
-  ema_mean[g] = em;
-  ema_var[g] = ev;
-
-  const float sm = src_mean[g], sv = src_var[g];
-  float t, gm, gv;  // loss term, dL/d(ema_mean), dL/d(ema_var)
-  if (reg_type == VITTA_REG_L1) {
-    t = (fabsf(sv - ev) + fabsf(sm - em)) / C;
-    gm = sgn(em - sm) / C;
-    gv = sgn(ev - sv) / C;
-  } else if (reg_type == VITTA_REG_MSE) {
-    const float dm = em - sm, dv = ev - sv;
-    t = (dv * dv + dm * dm) / C;
-    gm = 2.f * dm / C;
-    gv = 2.f * dv / C;
-  } else {  // KLD: 0.5 log(ev/sv) + (sv + (sm-em)^2) / (2 ev) - 0.5, summed over channels
-    const float dm = sm - em;
-    t = 0.5f * logf(ev / sv) + (sv + dm * dm) / (2.f * ev) - 0.5f;
-    gm = -dm / ev;
-    gv = 0.5f / ev - (sv + dm * dm) / (2.f * ev * ev);
-  }
-  term[g] = t;
-  mu_out[g] = mu;
-  const float inv_n = n > 0.0 ? (float)(1.0 / n) : 0.f;
-  coef_a[g] = momentum * gm * inv_n;
-  coef_b[g] = 2.f * momentum * gv * inv_n;
-}
-
-// One workgroup per layer: fixed-order tree sum of the channel terms -> r_feature[l].
-__global__ __launch_bounds__(VITTA_BLOCK) void layer_loss_kernel(const LayerInfo* __restrict__ linfo,
-                                                                 const float* __restrict__ term,
-                                                                 float* __restrict__ layer_loss) {
+    float* __restrict__ mu_out, float* __restrict__ coef_a, float* __restrict__ coef_b, float* layer_loss,
+    float* __restrict__ total, unsigned* ticket, float* __restrict__ zero_word) {
   __shared__ float red[VITTA_BLOCK / VITTA_WAVE];
-  const LayerInfo L = linfo[blockIdx.x];
+  __shared__ int last_flag;
+  const int l = blockIdx.x;
+  const LayerInfo L = linfo[l];
+  const float C = (float)L.C;
+  const double n = (double)cnt[l];
+  const float inv_n = n > 0.0 ? (float)(1.0 / n) : 0.f;
   float acc = 0.f;
-  for (int c = threadIdx.x; c < L.C; c += VITTA_BLOCK) acc += term[L.chan_off + c];
+  constexpr int U = 4;  // channels per thread whose operands are in flight together (a thread walks c = tid, tid + 256, ...)
+  for (int c0 = threadIdx.x; c0 < L.C; c0 += U * VITTA_BLOCK) {
+    float a1[U], a2[U], ak[U], aem[U], aev[U], asm_[U], asv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * VITTA_BLOCK;
+      const int64_t g = L.chan_off + (c < L.C ? c : c0);
+      a1[u] = s1[g]; a2[u] = s2[g]; ak[u] = shift ? shift[g] : 0.f;
+      aem[u] = ema_mean[g]; aev[u] = ema_var[g]; asm_[u] = src_mean[g]; asv[u] = src_var[g];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * VITTA_BLOCK;
+      if (c >= L.C) continue;
+      const int64_t g = L.chan_off + c;
+      const double m1 = n > 0.0 ? (double)a1[u] / n : 0.0;
+      const double m2 = n > 0.0 ? (double)a2[u] / n : 0.0;
+      const float mu = (float)((double)ak[u] + m1);
+      double vd = m2 - m1 * m1;
+      const float var = (float)(vd > 0.0 ? vd : 0.0);
+
+      const float em = momentum * mu + (1.f - momentum) * aem[u];
+      const float ev = momentum * var + (1.f - momentum) * aev[u];
+      ema_mean[g] = em;
+      ema_var[g] = ev;
+
+      const float sm = asm_[u], sv = asv[u];
+      float t, gm, gv;  // loss term, dL/d(ema_mean), dL/d(ema_var)
+      if (reg_type == VITTA_REG_L1) {
+        t = (fabsf(sv - ev) + fabsf(sm - em)) / C;
+        gm = sgn(em - sm) / C;
+        gv = sgn(ev - sv) / C;
+      } else if (reg_type == VITTA_REG_MSE) {
+        const float dm = em - sm, dv = ev - sv;
+        t = (dv * dv + dm * dm) / C;
+        gm = 2.f * dm / C;
+        gv = 2.f * dv / C;
+      } else {  // KLD: 0.5 log(ev/sv) + (sv + (sm-em)^2) / (2 ev) - 0.5, summed over channels
+        const float dm = sm - em;
+        t = 0.5f * logf(ev / sv) + (sv + dm * dm) / (2.f * ev) - 0.5f;
+        gm = -dm / ev;
+        gv = 0.5f / ev - (sv + dm * dm) / (2.f * ev * ev);
+      }
+      acc += t;
+      mu_out[g] = mu;
+      coef_a[g] = momentum * gm * inv_n;
+      coef_b[g] = 2.f * momentum * gv * inv_n;
+    }
+  }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < VITTA_BLOCK / VITTA_WAVE; ++w) t += red[w];
-    layer_loss[blockIdx.x] = t;
+    // the layer's loss reaches the coherence point before the arrival (write-through store, drained); the last arriver reads the
+    // layers with device-scope loads
+    __hip_atomic_store(layer_loss + l, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == (unsigned)n_layers - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = last ? 1 : 0;
   }
-}
-
-__global__ void total_loss_kernel(const float* __restrict__ layer_loss, int n_layers, float* __restrict__ total) {
-  // single wave, sequential accumulation in layer order = the reference's `loss_reg += hook.r_feature`
+  __syncthreads();
+  if (!last_flag || threadIdx.x >= VITTA_WAVE) return;
+  // the last workgroup's first wave: one load per lane, then the sum in layer order (= `loss_reg += hook.r_feature`)
+  float tot = 0.f;
+  for (int base = 0; base < n_layers; base += VITTA_WAVE) {
+    const int i = base + (int)threadIdx.x;
+    const float v = i < n_layers ? __hip_atomic_load(layer_loss + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    const int m = min(VITTA_WAVE, n_layers - base);
+    for (int j = 0; j < m; ++j) tot += __shfl(v, j, VITTA_WAVE);
+  }
   if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int l = 0; l < n_layers; ++l) t += layer_loss[l];
-    *total = t;
+    *total = tot;
+    if (zero_word) *zero_word = 0.f;
   }
 }
 
@@ -261,22 +283,15 @@ int vitta_stat_align_fwd_f32(const vitta_plan* p, const float* d_shift, const fl
                              const float* d_s1, const float* d_s2, float* d_ema_mean, float* d_ema_var,
                              const float* d_src_mean, const float* d_src_var, float momentum, int reg_type,
                              float* d_layer_loss, float* d_total_loss, float* d_mu, float* d_coef_a,
-                             float* d_coef_b, void* d_ws, size_t ws_bytes, void* stream) {
+                             float* d_coef_b, float* d_zero_word, void* stream) {
   if (!p || !d_cnt || !d_s1 || !d_s2 || !d_ema_mean || !d_ema_var || !d_src_mean || !d_src_var ||
       !d_layer_loss || !d_total_loss || !d_mu || !d_coef_a || !d_coef_b)
     return VITTA_ERR_INVALID_ARG;
-  if (reg_type < VITTA_REG_L1 || reg_type > VITTA_REG_KLD || !p->d_info) return VITTA_ERR_INVALID_ARG;
-  if (!d_ws || ws_bytes < vitta_plan_workspace_bytes(p)) return VITTA_ERR_WORKSPACE;
+  if (reg_type < VITTA_REG_L1 || reg_type > VITTA_REG_KLD || !p->d_info || !p->d_ticket) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  float* term = static_cast<float*>(d_ws) + 3 * (size_t)p->ws_triples;
-  const int grid = (int)((p->total_channels + VITTA_BLOCK - 1) / VITTA_BLOCK);
-  VITTA_LAUNCH(stat_align_kernel, dim3(grid), dim3(VITTA_BLOCK), 0, st, p->d_info, p->d_chan2layer,
-                     p->total_channels, d_shift, d_cnt, d_s1, d_s2, d_ema_mean, d_ema_var, d_src_mean,
-                     d_src_var, momentum, reg_type, term, d_mu, d_coef_a, d_coef_b);
-  VITTA_LAUNCH(layer_loss_kernel, dim3(p->n_layers), dim3(VITTA_BLOCK), 0, st, p->d_info, term,
-                     d_layer_loss);
-  VITTA_LAUNCH(total_loss_kernel, dim3(1), dim3(VITTA_WAVE), 0, st, d_layer_loss, p->n_layers,
-                     d_total_loss);
+  VITTA_LAUNCH(stat_align_kernel, dim3(p->n_layers), dim3(VITTA_BLOCK), 0, st, p->d_info, p->n_layers, d_shift, d_cnt, d_s1, d_s2,
+               d_ema_mean, d_ema_var, d_src_mean, d_src_var, momentum, reg_type, d_mu, d_coef_a, d_coef_b, d_layer_loss,
+               d_total_loss, p->d_ticket, d_zero_word);
   return VITTA_OK;
 }
 

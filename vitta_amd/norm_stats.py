@@ -160,7 +160,8 @@ class FusedLNSite:
         if (rows, c) != (outer * inner, pc):
             raise RuntimeError("fused statistics pass: feature shape differs from the planned one")
         if not e._fused_seen:  # first fused layer of the step: the column sums ADD into [s1 | s2]
-            plan.stats.zero_()
+            e._zero_stats(plan)
+            plan.cnt_src = None
         e._fused_seen.add(self.index)
         e._fused_direct = True
         sl = plan.channel_slice(self.index)
@@ -191,10 +192,12 @@ class _LossReg(torch.autograd.Function):
     before any of them."""
 
     @staticmethod
-    def forward(ctx, anchor, engine, value, tie=None):
+    def forward(ctx, anchor, engine, value, tie=None, fresh=False):
         ctx.engine = engine
         ctx.tie = None if tie is None else (tie.shape, tie.dtype, tie.device)
-        return value.clone()
+        # (no copy: the HIP plan hands out a tensor of its own per alignment launch -- ops.Plan.align; other backends' totals are
+        # cloned, they may be views of state the next step overwrites)
+        return value.view_as(value) if fresh else value.clone()
 
     @staticmethod
     def backward(ctx, g):
@@ -204,7 +207,7 @@ class _LossReg(torch.autograd.Function):
         # `tie` (the model output) receives a zero gradient: its only purpose is to make this backward walk the model's
         # graph -- the injection nodes hang off it -- when loss_reg is the WHOLE loss (no consistency term)
         gt = None if ctx.tie is None else torch.zeros(ctx.tie[0], dtype=ctx.tie[1], device=ctx.tie[2])
-        return None, None, None, gt
+        return None, None, None, gt, None
 
 
 class StatAlignEngine:
@@ -220,6 +223,7 @@ class StatAlignEngine:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size(process_group) > 1
         self.distributed = distributed
+        self.zero_pool = None  # tta.FlatArena (or anything with reserve_zeroed): its per-step fill then covers the statistics
         self.hooks = []
         self._src = []
         self._plans = {}
@@ -292,8 +296,11 @@ class StatAlignEngine:
         if getattr(plan, "_direct_cnt", None) is None:
             plan._direct_cnt = torch.tensor([float(o * i) for o, _, i, _ in shapes], dtype=torch.float32, device=self.device)
         self.plan = plan
-        plan.stats.zero_()
-        plan.cnt.copy_(plan._direct_cnt)
+        self._zero_stats(plan)
+        if self.distributed or not hasattr(plan, "cnt_src"):
+            plan.cnt.copy_(plan._direct_cnt)  # (the counts take part in the ranks' sum)
+        else:
+            plan.cnt_src = plan._direct_cnt   # one rank: constants of the plan, read in place by the alignment launch
         self._fused_seen = set(range(len(self.hooks)))
         self._fused_direct = True
         return plan
@@ -345,6 +352,20 @@ class StatAlignEngine:
         nodes of the MODEL's graph, which a backward from loss_reg reaches only through that output."""
         return self._align_and_wrap(self.plan, tie)
 
+    def _zero_stats(self, plan):
+        """[cnt | s1 | s2] of the step to zero: inside the step's ONE fill where an arena offers its zeroed tail (zero_pool =
+        tta.FlatArena: the plan's statistics move there on first use), by a launch of their own otherwise."""
+        z = getattr(plan, "_zeroed", None)
+        if z is None and self.zero_pool is not None and hasattr(plan, "rebind_stats") and not getattr(plan, "_zeroed_tried", False):
+            plan._zeroed_tried = True
+            z = self.zero_pool.reserve_zeroed(plan.stats.numel() * 4)
+            if z is not None:  # (a fresh slice of the tail is zero: nothing has written there)
+                plan.rebind_stats(z.tensor)
+                plan._zeroed = z
+        if z is not None and z.fresh():
+            return
+        plan.stats.zero_()
+
     def reduce_local(self):
         """This rank's additive statistics of the step into plan.stats (no communication)."""
         n = len(self.hooks)
@@ -376,16 +397,18 @@ class StatAlignEngine:
         self._feats, self._kinds = {}, {}
 
     def _align_and_wrap(self, plan, tie=None):
+        in_launch = getattr(plan, "zeroes_in_align", False)  # (the HIP plan resets the gradient scale inside the alignment launch)
         total, layer = plan.align(self.src_mean, self.ema_mean, self.ema_var, self.src_mean, self.src_var,
-                                  self.momentum, self.reg_type)
+                                  self.momentum, self.reg_type, **({"zero": self.gscale} if in_launch else {}))
         for i, h in enumerate(self.hooks):
             h.r_feature = layer[i]
         self._feats, self._kinds = {}, {}
-        self.gscale.zero_()
+        if not in_launch:
+            self.gscale.zero_()
         self._gscale_set = False
         if tie is not None and not tie.requires_grad:
             tie = None
-        return _LossReg.apply(self._anchor, self, total[0], tie)
+        return _LossReg.apply(self._anchor, self, total[0], tie, bool(getattr(total, "_vitta_fresh", False)))
 
     def finish_empty(self):
         """Ragged tail of a data-parallel run: this rank has no video in the step but still joins the

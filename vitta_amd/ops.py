@@ -206,6 +206,7 @@ class StatPlan:
         """feats: list of contiguous CUDA tensors (one per layer), all fp32 or all bfloat16 -> fills cnt/s1/s2.
         `events`: a KernelEventPair attached to the dispatch of the streaming (partials) kernel -- bench.py's
         live kernel timing."""
+        self.cnt_src = None  # (this launch writes the counts)
         if len(feats) != self.n_layers:
             raise ValueError("one feature per planned layer expected")
         bf16 = len(feats) > 0 and feats[0].dtype == torch.bfloat16
@@ -255,6 +256,7 @@ class StatPlan:
 
     def finalize(self, shift=None):
         """Second stage only: the partial triples were written by fused BN passes (vitta_bn_act_fwd_f32)."""
+        self.cnt_src = None
         check(lib().vitta_moments_finalize_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2), _p(self.ws),
                                                self.ws_bytes, _stream()), "vitta_moments_finalize_f32")
         return self.cnt, self.s1, self.s2
@@ -266,12 +268,27 @@ class StatPlan:
                                                  _p(mean), _p(var), _stream()), "vitta_moments_to_meanvar_f32")
         return mean, var
 
-    def align(self, shift, ema_mean, ema_var, src_mean, src_var, momentum, reg_type):
-        check(lib().vitta_stat_align_fwd_f32(self._h, _p(shift), _p(self.cnt), _p(self.s1), _p(self.s2),
+    zeroes_in_align = True  # align(..., zero=t) resets the one-element tensor t inside its launch
+    cnt_src = None          # per-layer counts for align() when they are constants of the plan (the direct path of a single rank)
+
+    def rebind_stats(self, t):
+        """Move [cnt | s1 | s2] into the caller's storage `t` (>= n_layers + 2 total_channels floats, e.g. a slice that the
+        step's one fill zeroes: tta.FlatArena.reserve_zeroed)."""
+        n, tc = self.n_layers, self.total_channels
+        if t.dtype != torch.float32 or t.numel() < n + 2 * tc or not t.is_contiguous():
+            raise VittaHipError("rebind_stats: a contiguous float32 tensor of n_layers + 2 * total_channels elements is needed")
+        self.stats = t[:n + 2 * tc]
+        self.cnt, self.s1, self.s2 = self.stats[:n], self.stats[n:n + tc], self.stats[n + tc:]
+
+    def align(self, shift, ema_mean, ema_var, src_mean, src_var, momentum, reg_type, zero=None):
+        # (a tensor of its own per launch: norm_stats._LossReg hands it on without a copy)
+        self.total_loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        self.total_loss._vitta_fresh = True
+        check(lib().vitta_stat_align_fwd_f32(self._h, _p(shift), _p(self.cnt if self.cnt_src is None else self.cnt_src), _p(self.s1), _p(self.s2),
                                              _p(ema_mean), _p(ema_var), _p(src_mean), _p(src_var),
                                              float(momentum), REG_TYPES[reg_type], _p(self.layer_loss),
                                              _p(self.total_loss), _p(self.mu), _p(self.coef_a), _p(self.coef_b),
-                                             _p(self.ws), self.ws_bytes, _stream()), "vitta_stat_align_fwd_f32")
+                                             _p(zero), _stream()), "vitta_stat_align_fwd_f32")
         return self.total_loss, self.layer_loss
 
 
@@ -925,34 +942,73 @@ class TanetHead(torch.autograd.Function):
         return (dfeat if ctx.needs_input_grad[0] else None), r_w, r_b, None, None, None, None
 
 
+def tanet_head_eval(feat, weight, bias, b, v, t):
+    """Video logits [B, K] of an evaluation pass from the pooled frame features [B V T, D] (no dropout in eval()): new_fc -> segment
+    consensus -> mean over the V crops x clips (models/tanet_models/tanet.py:243-251, corpus/basics.py:700-705) with the forward
+    launch of TanetHead (its consistency outputs go to scratch nobody reads)."""
+    _require_cuda_f32(feat, "feat")
+    feat = feat.contiguous()
+    f, d = feat.shape
+    k = weight.shape[0]
+    if b * v * t != f:
+        raise VittaHipError(f"tanet_head_eval: {f} frame rows are not {b} x {v} views x {t} segments")
+    dev = feat.device
+    e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    lv, out, loss, gradc = e(b * v, k), e(b, k), e(1), e(b * v, k)
+    from . import conv as CV
+    ticket = CV.zeroed_per_stream(_tickets, dev, 64, spares=4)
+    check(lib().vitta_tanet_head_fwd_f32(_p(feat), _p(weight), _p(bias), b, v, t, k, d, None, _p(lv), _p(ticket), _p(out), _p(loss),
+                                         _p(gradc), _stream()), "vitta_tanet_head_fwd_f32")
+    return out
+
+
 def tanet_head_supported(feat, linear, b, v):
     return (feat.is_cuda and feat.dtype == torch.float32 and feat.dim() == 2 and feat.shape[1] % 4 == 0 and b * v <= 8
             and linear.weight.dtype == torch.float32 and not linear._forward_hooks and not linear._forward_pre_hooks
             and int(lib().vitta_tanet_head_lds_bytes(b, v, linear.weight.shape[0], feat.shape[1])) <= 128 * 1024)
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """A cached scalar 1.0 on `device`: `loss.backward(gradient=unit_gradient(dev))` spares autograd's ones_like launch, and
+    WeightedLoss.backward recognises it (its two upstream gradients for d loss = 1 were written by the forward launch).  Created
+    on first use -- outside any graph capture (the eager warm-up steps come first)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1))
+    t = _UNIT.get(key)
+    if t is None:
+        t = _UNIT[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 class WeightedLoss(torch.autograd.Function):
-    """total = la * loss_a + lb * loss_b (corpus/basics.py:668) as one launch, its backward as one launch that writes BOTH upstream
-    gradients -- the first one into `slot` (the statistics engine's device scalar `gscale`, which the injection kernels read:
-    norm_stats._LossReg then finds its gradient already in place)."""
+    """total = la * loss_a + lb * loss_b (corpus/basics.py:668) as one launch that also leaves BOTH upstream gradients for d total = 1
+    -- the first one in `slot` (the statistics engine's device scalar `gscale`, which the injection kernels read: norm_stats._LossReg
+    then finds its gradient already in place).  Backward: nothing to launch when the incoming gradient is ops.unit_gradient (what the
+    adapter's `backward` call passes); one launch otherwise."""
 
     @staticmethod
     def forward(ctx, loss_a, loss_b, la, lb, slot):
         _require_cuda_f32(loss_a, "loss_a")
         ctx.set_materialize_grads(False)
-        out = torch.empty(1, dtype=torch.float32, device=loss_a.device)
+        dev = loss_a.device
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        ga = slot if slot is not None else torch.empty(1, dtype=torch.float32, device=dev)
+        gb = torch.empty(1, dtype=torch.float32, device=dev) if loss_b is not None else None
         check(lib().vitta_loss_axpby_f32(_p(loss_a.reshape(1)), _p(None if loss_b is None else loss_b.reshape(1)), float(la), float(lb), _p(out),
-                                         _stream()), "vitta_loss_axpby_f32")
-        ctx.la, ctx.lb, ctx.slot, ctx.has_b = float(la), float(lb), slot, loss_b is not None
+                                         _p(ga), _p(gb), _stream()), "vitta_loss_axpby_f32")
+        ctx.la, ctx.lb, ctx.ga, ctx.gb = float(la), float(lb), ga, gb
         return out.reshape(())
 
     @staticmethod
     def backward(ctx, g):
-        dev = ctx.slot.device if ctx.slot is not None else g.device
-        ga = ctx.slot if ctx.slot is not None else torch.empty(1, dtype=torch.float32, device=dev)
-        gb = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_b else None
-        check(lib().vitta_loss_axpby_bwd_f32(_p(None if g is None else g.reshape(1)), ctx.la, ctx.lb, _p(ga), _p(gb), _stream()),
-              "vitta_loss_axpby_bwd_f32")
+        ga, gb = ctx.ga, ctx.gb
+        unit = _UNIT.get((ga.device.type, ga.device.index))
+        if g is None or unit is None or g.data_ptr() != unit.data_ptr():
+            check(lib().vitta_loss_axpby_bwd_f32(_p(None if g is None else g.reshape(1)), ctx.la, ctx.lb, _p(ga), _p(gb), _stream()),
+                  "vitta_loss_axpby_bwd_f32")
         return ga.reshape(()), (gb.reshape(()) if gb is not None else None), None, None, None
 
 

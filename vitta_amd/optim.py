@@ -38,7 +38,8 @@ class FlatAdam(_FlatOptimizer):
     def __init__(self, arena, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(arena, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         flat = arena.flat_param
-        self.state = {"step": torch.zeros(1, dtype=torch.float32, device=flat.device),
+        self._step2 = torch.zeros(2, dtype=torch.float32, device=flat.device)  # [step, arrival counter of the launch (zero at rest)]
+        self.state = {"step": self._step2[:1],
                       "exp_avg": torch.zeros_like(flat), "exp_avg_sq": torch.zeros_like(flat)}
 
     @torch.no_grad()

@@ -220,6 +220,10 @@ class TrunkRunner:
         # evaluation reads the adaptation set's forward packs
         self.prepacked = False
         self.after_block = None  # callable(block index) run after each block's backward (tta: bucketed gradient exchange)
+        # tta.FlatArena of the adapter driving this trunk (or None): the adaptation pass's fixed-point pooling sums then live in the
+        # arena's zeroed tail -- the step's ONE fill covers them (FlatArena.Zeroed.fresh() tells whether it has, else zeroed here)
+        self.zero_pool = None
+        self._pool_zeroed = {}
 
     # -- structure ---------------------------------------------------------------------------------------------
     def blocks(self):
@@ -656,7 +660,20 @@ class TrunkRunner:
         tape = []
         blocks = self.blocks()
         # one zeroed buffer for the pooled means of every block of this pass (conv1's epilogue ADDS into it)
-        pool = [torch.zeros(n * sum(b.net.conv1.out_channels for b in blocks), dtype=torch.int64, device=x.device), 0] if POOL_FOLD else None
+        pool = None
+        if POOL_FOLD:
+            npool, buf = n * sum(b.net.conv1.out_channels for b in blocks), None
+            if keep and self.zero_pool is not None:  # the adaptation pass: a slice of the arena tail that the step's ONE fill zeroes
+                if npool not in self._pool_zeroed:  # (a fresh slice of the tail is zero: nothing has written there)
+                    self._pool_zeroed[npool] = self.zero_pool.reserve_zeroed(npool * 8)
+                z = self._pool_zeroed[npool]
+                if z is not None and z.tensor.device == x.device:
+                    buf = z.tensor.view(torch.int64)[:npool]
+                    if not z.fresh():
+                        buf.zero_()
+            if buf is None:
+                buf = torch.zeros(npool, dtype=torch.int64, device=x.device)
+            pool = [buf, 0]
         for b in blocks:
             cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng, pool)
             tape.append(saved)

@@ -169,6 +169,23 @@ class FlatArena:
     partial derivatives add."""
 
     ALIGN = 64  # floats: every tensor starts on a 256-byte boundary (the HIP kernels use 16-byte loads on weights)
+    # floats behind the gradients that the SAME fill zeroes: what a step needs zeroed before its forward besides the gradients (the
+    # statistics engine's additive sums, the trunk's fixed-point pooling sums) lives there instead of being filled by launches of its
+    # own (reserve_zeroed).  1 MiB: the fill of the Adam-affine arena (58 K floats) stays a few microseconds.
+    ZERO_SLACK = 1 << 18
+
+    class Zeroed:
+        """A slice of the arena's zeroed tail.  fresh(): True once after every fill of the arena (zero_grad) -- the slice may then be
+        used as zeroed; False: no fill since the last use, the user zeroes it itself."""
+
+        def __init__(self, arena, tensor):
+            self.arena, self.tensor, self._seen = arena, tensor, -1
+
+        def fresh(self):
+            e = self.arena._fills
+            ok = e != self._seen
+            self._seen = e
+            return ok
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -177,7 +194,9 @@ class FlatArena:
         dev = self.params[0].device
         # the gaps stay zero in both buffers: a zero gradient on a zero weight is a fixed point of SGD and Adam
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._grad_all = torch.zeros(n + self.ZERO_SLACK, dtype=torch.float32, device=dev)
+        self.grad = self._grad_all[:n]
+        self._tail, self._fills = n, 0
         off = 0
         self._all_views, self._learnt = [], False
         self.ranges = {}  # id(param) -> (first float, end) in the arena
@@ -196,7 +215,17 @@ class FlatArena:
         self.flat_param.grad = self.grad
 
     def zero_grad(self):
-        self.grad.zero_()
+        self._grad_all.zero_()  # gradients + everything reserved behind them: ONE fill per step
+        self._fills += 1
+
+    def reserve_zeroed(self, nbytes):
+        """A FlatArena.Zeroed over `nbytes` (256-byte aligned) of the tail that zero_grad() fills, or None when the tail is full."""
+        k = -(-int(nbytes) // 256) * 64
+        if self._tail + k > self._grad_all.numel():
+            return None
+        z = FlatArena.Zeroed(self, self._grad_all[self._tail:self._tail + k])
+        self._tail += k
+        return z
 
     # Gradients our backward kernels do not write themselves (every weight in SGD-all mode, norm layers on the torch
     # fallback) reach a parameter through autograd's AccumulateGrad.  With a live `.grad` view that is one in-place add
@@ -387,6 +416,14 @@ class ViTTAAdapter:
         self.backend = engine_backend
         self.engine = StatAlignEngine(args.reg_type, args.momentum_mvg, backend=engine_backend,
                                       distributed=True if FORCE_EXCHANGES else None) if use_engine else None
+        if self.device.type == "cuda":  # what the step needs zeroed besides the gradients joins the arena's one fill per step
+            if self.engine is not None:
+                self.engine.zero_pool = self.arena
+            base = getattr(self._net(), "base_model", None)
+            if args.arch == "tanet" and base is not None:
+                from . import trunk
+                r = trunk.runner_of(base)
+                r.zero_pool, r._pool_zeroed = self.arena, {}
         self.hooked = select_hooked(args, self.chosen_layers)
         self.stat_reg_hooks = [
             CombineNormStatsRegHook_onereg(layer, clip_len=args.clip_length,
@@ -515,6 +552,38 @@ class ViTTAAdapter:
             return None
         fc = net.base_model.fc
         return ops.TanetHead.apply(feat, net.new_fc.weight, net.new_fc.bias, float(fc.p), bool(fc.training), T, self.n_views)
+
+    def _fused_eval_head(self, input, bz, nv):
+        """Video logits [bz, K] of an EVALUATION pass through the same forward launch as the adaptation head (new_fc -> segment consensus
+        -> mean over the nv crops x clips; no dropout in eval()): global pool + ONE launch instead of pool + linear + two reductions.
+        None: not applicable (the caller takes the module chain)."""
+        if not FUSED_HEAD or self.device.type != "cuda" or torch.is_grad_enabled():
+            return None
+        net = self._net()
+        if not (hasattr(net, "fused_head_ok") and net.fused_head_ok()) or net.training or self.model is not net and (
+                self.model._forward_hooks or self.model._forward_pre_hooks):
+            return None
+        from . import fused_bn, ops
+        if not fused_bn.ENABLED:
+            return None
+        T = net.num_segments
+        frames = input.view((-1, 3 * net.new_length) + input.size()[-2:]).shape[0]
+        if frames != bz * nv * T or not ops.tanet_head_supported(
+                torch.empty(0, net.new_fc.in_features, dtype=torch.float32, device=self.device), net.new_fc, bz, nv):
+            return None
+        feat = net.trunk_features(input)
+        if feat is None:
+            return None
+        return ops.tanet_head_eval(feat, net.new_fc.weight, net.new_fc.bias, bz, nv, T)
+
+    @staticmethod
+    def _backward(loss):
+        """loss.backward() from a cached unit gradient (no ones_like launch; ops.WeightedLoss.backward recognises it)."""
+        if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
+            from . import ops
+            loss.backward(gradient=ops.unit_gradient(loss.device))
+        else:
+            loss.backward()
 
     def total_loss(self, loss_reg, loss_consis):
         a = self.args
@@ -764,7 +833,7 @@ class ViTTAAdapter:
             output, loss_reg, loss_consis = self.forward_losses(input, actual_bz, rider)
             self.arena.before_backward()
             self._exchange_begin()
-            self.total_loss(loss_reg, loss_consis).backward()
+            self._backward(self.total_loss(loss_reg, loss_consis))
             self.arena.after_backward()
         else:
             if self.engine is None:
@@ -813,7 +882,7 @@ class ViTTAAdapter:
         with torch.cuda.graph(g["seg_bwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
             loss_reg = self.engine.finish_global(tie=None if self.if_pred_consistency else output)
             self.arena.before_backward()
-            self.total_loss(loss_reg, loss_consis).backward()
+            self._backward(self.total_loss(loss_reg, loss_consis))
             self.arena.after_backward()
         g["seg_opt"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_opt"], pool=pool, capture_error_mode=CAPTURE_MODE):
@@ -922,8 +991,13 @@ class ViTTAAdapter:
         self.model.eval()
         a = self.args
         if a.arch == "tanet":
-            bz = input.shape[0] // (a.test_crops * self.n_clips)
-            return self.model(input).reshape(bz, a.test_crops * self.n_clips, -1).mean(1)
+            nv = a.test_crops * self.n_clips
+            bz = input.shape[0] // nv
+            out = self._fused_eval_head(input, bz, nv)
+            if out is not None:
+                return out
+            out = self.model(input).reshape(bz, nv, -1)
+            return out[:, 0] if nv == 1 else out.mean(1)  # (a mean over one element is still a launch)
         output, _ = self.model(input)
         return output
 
