@@ -34,7 +34,7 @@ Extra objects on the JSON line:
                 v_mfma_f32_32x32x2_f32 (157.3 TFLOP/s).  `peak` = the flop-weighted peak of the step's launches, `frac` =
                 (sum over launches of flops / that launch's peak) / (sum of durations); `frac_of_fp32_matrix_peak` =
                 achieved / 157.3, the yardstick of the exact-fp32 rounds.
-  swin, swin_c5_bf16   the same per-video iteration on Video Swin-B: BASELINE config 3's shape (2 views x 16 frames x
+  swin, swin_c5_bf16 (, swin_sgd_all, swin_c5_bf16_sgd_all)   the same per-video iteration on Video Swin-B: BASELINE config 3's shape (2 views x 16 frames x
                 224^2, window (8,7,7), exact-fp32 kernels) and config 5's (4 views x 32 frames x 224^2, window (16,7,7), the
                 bf16-operand attention + dense kernels), each with the achieved TFLOP/s of its dense (gemm.hip) and window
                 attention launches against the matrix peak of the instruction they issue (157.3 / 2500).
@@ -928,7 +928,10 @@ def main():
         # the other half of north_star: Video Swin-B at BASELINE config 3's and config 5's shapes, in the same run
         for key, cfg in (("swin", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=8)),
                          ("swin_c5_bf16", dict(views=4, frames=32, window_depth=16, classes=174, bf16=True, steps=4)),
-                         ("swin_sgd_all", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=6, sgd_all=True))):
+                         ("swin_sgd_all", dict(views=2, frames=16, window_depth=8, classes=101, bf16=False, steps=6, sgd_all=True)),
+                         # config 5's shape under the reference's DEFAULT optimizer: every table, weight and bias trains -- the bf16
+                         # attention bins the relative-position table's gradient in LDS (round 5; before: the fp32 kernels)
+                         ("swin_c5_bf16_sgd_all", dict(views=4, frames=32, window_depth=16, classes=174, bf16=True, steps=3, sgd_all=True))):
             try:
                 log(f"Video Swin-B leg {key} ...")
                 line[key] = swin_leg(device, **cfg)

@@ -377,7 +377,11 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv, const float* d_table, int32_t 
                                const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                                float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                                const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dqkv,
-                               int32_t io_bf16, void* stream);
+                               float* d_dtable, int32_t io_bf16, void* stream);
+/* d_dtable [T, nH] fp32 or NULL: the gradient of the relative-position table is ADDED to it (swin_transformer.py:110-151 under
+ * SGD over all parameters) -- by the one-pass backward only (binned in LDS per (window, head), one global atomic per entry);
+ * VITTA_ERR_UNSUPPORTED where that form does not apply (vitta_wmsa_bf16_dtable_supported says so beforehand). */
+int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_rows);
 
 /* --------------------------------------------------------------------------
  * A7 -- optimizer update on the flat parameter arena, one launch.

@@ -424,6 +424,70 @@ def test_wmsa_bf16_operand_variant(ws, clamp, B, nh, shift, rowmap, io16, bwd_fo
         assert err <= 3e-2 * gr[:, :, sel].abs().max().item(), (name, err, gr[:, :, sel].abs().max().item())
 
 
+@pytest.mark.parametrize("ws,clamp,nh,shift", [((16, 7, 7), (16, 7, 7), 4, True), ((8, 7, 7), (8, 7, 7), 4, False), ((16, 7, 7), (9, 7, 7), 8, True)])
+@pytest.mark.parametrize("io16", [False, True])
+def test_wmsa_bf16_relative_position_table_gradient(ws, clamp, nh, shift, io16):
+    """A TRAINABLE relative-position table (SGD over all parameters, the reference's default optimizer: corpus/basics.py:547-560,
+    swin_transformer.py:110-151) on the bf16-operand attention: the one-pass backward bins d bias = dS by relative position in LDS
+    and ADDS the (window, head) pair's column to table.grad.  Against the fp64 composed reference on the bf16-rounded operands: 3e-2
+    of the gradient's maximum (the bound of dq / dk / dv); a gradient already in table.grad stays (accumulation); the qkv gradient
+    keeps its bound.  Until round 5 a trainable table silently took the fp32 kernels."""
+    from vitta_amd import _lib, ops, swin
+    g = torch.Generator().manual_seed(31)
+    N = clamp[0] * clamp[1] * clamp[2]
+    C = nh * 32
+    T = (2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    assert _lib.lib().vitta_wmsa_bf16_dtable_supported(N, 32, T) == 1
+    table = torch.randn(T, nh, generator=g) * 0.5
+    index = swin.relative_position_index(ws)[:N, :N]
+    code, off = swin.relative_position_code(ws)
+    nW, B = 4, 1
+    region = torch.randint(0, 4, (nW, N), generator=g, dtype=torch.int32) if shift else None
+    mask = torch.where(region.unsqueeze(1) != region.unsqueeze(2), torch.tensor(-100.0), torch.tensor(0.0)) if shift else None
+    B_ = B * nW
+    scale = 32 ** -0.5
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    qkv = torch.randn(B_, N, 3 * C, generator=g)
+    gout = torch.randn(B_, N, C, generator=g)
+    if io16:
+        qkv, gout = rb(qkv), rb(gout)
+    q, k, v = qkv.view(B_, N, 3, C).unbind(2)
+    qkv_r = torch.stack([rb(q * scale) / scale, rb(k), rb(v)], 2).reshape(B_, N, 3 * C)
+    qr = qkv_r.double().requires_grad_(True)
+    tabd = table.double().requires_grad_(True)
+    bias = tabd[index.reshape(-1)].view(N, N, nh).permute(2, 0, 1)
+    ref = _wmsa_reference(qr, bias, mask.double() if mask is not None else None, scale, nh)
+    ref.backward(rb(gout).double())
+    d = _dev()
+    old = ops.WMSA_BF16
+    ops.WMSA_BF16 = True
+    try:
+        io_t = torch.bfloat16 if io16 else torch.float32
+        qd = qkv.to(d, io_t).requires_grad_(True)
+        td = table.to(d).requires_grad_(True)
+        td.grad = torch.full_like(td, 0.25)  # live storage: the kernel adds into it
+        calls = {}
+        _lib.CALL_COUNTS = calls
+        out = ops.WindowAttentionRel.apply(qd, td, code[:N].to(d), off, region.to(d) if shift else None, scale, nh, None)
+        out.backward(gout.to(d, io_t))
+        torch.cuda.synchronize()
+    finally:
+        ops.WMSA_BF16 = old
+        _lib.CALL_COUNTS = None
+    assert calls.get("vitta_wmsa_rel_bwd_bf16", 0) == 1 and "vitta_wmsa_rel_bwd_f32" not in calls, calls
+    gt = td.grad.cpu().double() - 0.25
+    err = (gt - tabd.grad).abs().max().item()
+    assert err <= 3e-2 * tabd.grad.abs().max().item(), (err, tabd.grad.abs().max().item())
+    # entries no (query, key) pair of the clamped window reaches stay untouched
+    reached = torch.zeros(T, dtype=torch.bool)
+    reached[index.reshape(-1)] = True
+    assert (gt[~reached] == 0).all()
+    gr = qr.grad.view(B_, N, 3, C)
+    gk = qd.grad.float().cpu().double().view(B_, N, 3, C)
+    for sel in range(3):
+        assert (gk[:, :, sel] - gr[:, :, sel]).abs().max().item() <= 3e-2 * gr[:, :, sel].abs().max().item()
+
+
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("shape", [(16, 64, 14, 14), (16, 512, 7, 7), (8, 24, 5, 4)])
 def test_fused_bn_act_matches_torch(shape, relu, res):

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--heads", type=int, default=4)
     ap.add_argument("--shift", action="store_true")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--fp32", action="store_true", help="the fp32 kernels (wmsa.hip) on an fp32 qkv")
+    ap.add_argument("--table-grad", action="store_true", help="a trainable relative-position table (its gradient binned in LDS by the one-pass backward)")
     opt = ap.parse_args()
     d = torch.device("cuda:0")
     ws = (16, 7, 7)
@@ -28,12 +30,16 @@ def main():
     g = torch.Generator().manual_seed(0)
     t_rows = (2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1)
     table = (torch.randn(t_rows, nh, generator=g) * 0.5).to(d)
+    if opt.table_grad:
+        table.requires_grad_(True)
+        table.grad = torch.zeros_like(table)
     code, off = swin.relative_position_code(ws)
     code = code[:n].to(d)
     region = torch.randint(0, 4, (4, n), generator=g, dtype=torch.int32).to(d) if opt.shift else None
-    qkv = torch.randn(opt.windows, n, 3 * c, generator=g).to(d, torch.bfloat16).requires_grad_(True)
-    gout = torch.randn(opt.windows, n, c, generator=g).to(d, torch.bfloat16)
-    ops.WMSA_BF16 = True
+    io_t = torch.float32 if opt.fp32 else torch.bfloat16
+    qkv = torch.randn(opt.windows, n, 3 * c, generator=g).to(d, io_t).requires_grad_(True)
+    gout = torch.randn(opt.windows, n, c, generator=g).to(d, io_t)
+    ops.WMSA_BF16 = not opt.fp32
     flops_f = 4.0 * n * n * 32 * opt.windows * nh
 
     def timed(fn):
@@ -54,7 +60,7 @@ def main():
 
     tf = timed(fwd)
     print(f"forward            {tf:8.1f} us  {flops_f / tf / 1e6:6.1f} TF")
-    for form in ("two", "one"):
+    for form in (("one",) if (opt.table_grad or opt.fp32) else ("two", "one")):
         os.environ["VITTA_WMSA_BF16_BWD"] = form
 
         def fb():

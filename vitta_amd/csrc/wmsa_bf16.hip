@@ -498,27 +498,29 @@ constexpr int TSP = 20;        // pitch of the per-wave turn-around tile in bf16
 
 struct Carve1 {
   unsigned short *kb, *qb, *gb, *tscr;
-  float *dq, *l, *dl, *tab;
+  float *dq, *l, *dl, *tab, *dtab;
   int *cr, *rows;
 };
-__host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T) {
-  const size_t qrows = 16 * (size_t)qc;
-  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + 8 * 16 * TSP) + 4 * (qrows * DQP + 2 * qrows + ((T + 3) & ~3) + 2 * 16 * (size_t)nt) + 64;
+// qc = query tiles of the largest chunk; dtab: room for the table gradient of the (window, head) pair (T floats)
+__host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T, bool dtab) {
+  const size_t qrows = 16 * (size_t)qc, tp = (size_t)((T + 3) & ~3);
+  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + 8 * 16 * TSP) + 4 * (qrows * DQP + 2 * qrows + tp * (dtab ? 2 : 1) + 2 * 16 * (size_t)nt) + 64;
 }
-// query tiles per chunk: the largest of 13 / 10 that fits LDS, balanced over the chunks; 0: no admissible chunking (< 8 tiles somewhere)
-inline int bwd1_chunks(int nt, int T, int* nchunks) {
-  for (int cap = 13; cap >= 8; --cap) {
-    const int nc = (nt + cap - 1) / cap, qc = (nt + nc - 1) / nc;
-    if (bwd1_lds_bytes(nt, qc, T) > 160 * 1024) continue;
-    if (nt - (nc - 1) * qc < 8) continue;  // the last chunk
+// chunks of query tiles: the fewest that fit LDS, BALANCED (chunk c = tiles [c nt / nc, (c + 1) nt / nc)), every chunk >= 8 tiles (the
+// step-synchronous rotation puts the eight waves on eight distinct tiles); returns the largest chunk, 0: no admissible chunking
+inline int bwd1_chunks(int nt, int T, bool dtab, int* nchunks) {
+  for (int nc = (nt + 12) / 13; nc <= nt; ++nc) {
+    if (nt / nc < 8) break;
+    const int qc = (nt + nc - 1) / nc;
+    if (bwd1_lds_bytes(nt, qc, T, dtab) > 160 * 1024) continue;
     *nchunks = nc;
     return qc;
   }
   return 0;
 }
-__device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, int T) {
+__device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, int T, bool dtab) {
   Carve1 c;
-  const int qrows = 16 * qc;
+  const int qrows = 16 * qc, tp = (T + 3) & ~3;
   c.kb = reinterpret_cast<unsigned short*>(smem);
   c.qb = c.kb + 16 * nt * RP;
   c.gb = c.qb + qrows * RP;
@@ -527,18 +529,25 @@ __device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, in
   c.l = c.dq + qrows * DQP;
   c.dl = c.l + qrows;
   c.tab = c.dl + qrows;
-  c.cr = reinterpret_cast<int*>(c.tab + ((T + 3) & ~3));
+  c.dtab = c.tab + tp;
+  c.cr = reinterpret_cast<int*>(c.dtab + (dtab ? tp : 0));
   c.rows = c.cr + 16 * nt;
   return c;
 }
 
-template <bool REG, bool TAIL>
+// DTAB: the gradient of the relative-position table (swin_transformer.py:110-151, trainable under SGD over all parameters): d bias =
+// dS, binned by code[q] - code[k] + off into an LDS column of T floats (ds_add_f32; different waves hold different key tiles, i.e.
+// mostly different relative positions), added to dtable [T, nH] with one global atomic per non-zero entry at the end
+template <bool REG, bool TAIL, bool DTAB>
 __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args a, const float* __restrict__ out,
                                                                       const float* __restrict__ dout, const float* __restrict__ lse,
-                                                                      float* __restrict__ delta, float* __restrict__ dqkv, int qc) {
+                                                                      float* __restrict__ delta, float* __restrict__ dqkv, int qc, int nchunks,
+                                                                      float* __restrict__ dtable) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
-  const Carve1 cv = carve1(smem, nt, qc, a.T);
+  const Carve1 cv = carve1(smem, nt, qc, a.T, DTAB);
+  if (DTAB)
+    for (int t = threadIdx.x; t < a.T; t += TH_BWD1) cv.dtab[t] = 0.f;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int64_t rs = 3 * (int64_t)nH * HD;
@@ -564,9 +573,8 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
     load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va[j], vb[j], vf_);
   }
   const bool kvalid_all = !TAIL;
-  const int nchunks = (nt + qc - 1) / qc;
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int qt0 = ch * qc, qtn = min(qc, nt - qt0), qrows = 16 * qtn;
+    const int qt0 = ch * nt / nchunks, qtn = (ch + 1) * nt / nchunks - qt0, qrows = 16 * qtn;
     __syncthreads();  // (the previous chunk's readers are done)
     // ---- stage the chunk: scaled Q rows, dO rows (bf16), lse, delta = sum_d dO O (also stored for the record), zero the dQ tile ----
     for (int it = threadIdx.x; it < qrows * 8; it += TH_BWD1) {
@@ -644,6 +652,9 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
             const float sv = (!TAIL || (q0 + r < N && kvalid)) ? sacc[r] + term : -INFINITY;
             p[r] = __expf(sv - lv[r]);
             ds[r] = p[r] * (dp[r] - dv[r]);
+            if (DTAB) {
+              if (!TAIL || (q0 + r < N && kvalid)) atomicAdd(cv.dtab + (qcd[r] - ckey_j + a.off), ds[r]);
+            }
           }
           const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
           dv0[j] = mfma(pa, gq0, dv0[j]);
@@ -677,6 +688,12 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       } else {
         *reinterpret_cast<float4*>(dqkv + o) = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
       }
+    }
+  }
+  if (DTAB) {  // (the last step's barrier is behind every ds_add)
+    for (int t = threadIdx.x; t < a.T; t += TH_BWD1) {
+      const float v = cv.dtab[t];
+      if (v != 0.f) atomicAdd(dtable + (int64_t)t * nH + h, v);
     }
   }
   // ---- dK, dV of the wave's key tiles ----
@@ -733,6 +750,13 @@ int vitta_wmsa_bf16_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
   return (f <= 160 * 1024 && b1 <= 160 * 1024 && b2 <= 160 * 1024) ? 1 : 0;
 }
 
+int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
+  if (!vitta_wmsa_bf16_supported(N, head_dim, table_rows)) return 0;
+  const int nt = (N + 15) / 16;
+  int nc = 0;
+  return (nt <= 8 * KT_MAX && bwd1_chunks(nt, table_rows, true, &nc) > 0) ? 1 : 0;
+}
+
 int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
                             const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                             float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
@@ -780,14 +804,14 @@ int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
                             const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
                             void* stream) {
   return vitta_wmsa_rel_bwd_bf16_io(d_qkv, d_table, T, d_code, code_off, d_region, nW, B_, N, nH, head_dim, scale, d_rowmap, map_windows,
-                                    tokens_per_sample, d_out, d_dout, d_lse, d_delta, d_dqkv, 0, stream);
+                                    tokens_per_sample, d_out, d_dout, d_lse, d_delta, d_dqkv, nullptr, 0, stream);
 }
 
 int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
                                const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                                float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                                const void* d_out_, const void* d_dout_, const float* d_lse, float* d_delta, void* d_dqkv_,
-                               int32_t io_bf16, void* stream) {
+                               float* d_dtable, int32_t io_bf16, void* stream) {
   const float* d_qkv = static_cast<const float*>(d_qkv_);
   const float* d_out = static_cast<const float*>(d_out_);
   const float* d_dout = static_cast<const float*>(d_dout_);
@@ -806,17 +830,24 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const char* form = std::getenv("VITTA_WMSA_BF16_BWD");
   const bool force_one = form && form[0] == 'o', force_two = form && form[0] == 't';
   int nchunks1 = 0;
-  const int qc1 = bwd1_chunks(nt, T, &nchunks1);
-  const size_t lf = qc1 ? bwd1_lds_bytes(nt, qc1, T) : 0;
-  if (!force_two && (qs == 1 || force_one) && qc1 > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
-#define WMSA_BWD1(R, TL)                                                                                                              \
+  const bool dtab = d_dtable != nullptr;  // the table gradient exists in the one-pass kernel only
+  const int qc1 = bwd1_chunks(nt, T, dtab, &nchunks1);
+  const size_t lf = qc1 ? bwd1_lds_bytes(nt, qc1, T, dtab) : 0;
+  if (dtab && (qc1 <= 0 || nt > 8 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
+  if ((dtab || (!force_two && (qs == 1 || force_one))) && qc1 > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
+#define WMSA_BWD1(R, TL, DT)                                                                                                          \
   do {                                                                                                                                \
-    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL>, lf)) return VITTA_ERR_LAUNCH;                                                       \
-    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf, st, a, d_out, d_dout, d_lse, d_delta, \
-                 d_dqkv, qc1);                                                                                                        \
+    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT>, lf)) return VITTA_ERR_LAUNCH;                                                   \
+    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf, st, a, d_out, d_dout, d_lse,    \
+                 d_delta, d_dqkv, qc1, nchunks1, d_dtable);                                                                           \
   } while (0)
-    if (reg) { if (tail) WMSA_BWD1(true, true); else WMSA_BWD1(true, false); }
-    else { if (tail) WMSA_BWD1(false, true); else WMSA_BWD1(false, false); }
+    if (dtab) {
+      if (reg) { if (tail) WMSA_BWD1(true, true, true); else WMSA_BWD1(true, false, true); }
+      else { if (tail) WMSA_BWD1(false, true, true); else WMSA_BWD1(false, false, true); }
+    } else {
+      if (reg) { if (tail) WMSA_BWD1(true, true, false); else WMSA_BWD1(true, false, false); }
+      else { if (tail) WMSA_BWD1(false, true, false); else WMSA_BWD1(false, false, false); }
+    }
 #undef WMSA_BWD1
     return VITTA_OK;
   }

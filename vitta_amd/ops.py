@@ -485,7 +485,9 @@ class WindowAttentionRel(torch.autograd.Function):
             out = torch.empty(bsz, tokens, c, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(b_, num_heads, n, dtype=torch.float32, device=qkv.device)
         nw = region.shape[0] if region is not None else 1
-        bf16 = bool(WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0]))
+        # (a trainable table -- SGD over all parameters -- needs the one-pass backward, which bins its gradient in LDS)
+        bf16 = bool(WMSA_BF16 and lib().vitta_wmsa_bf16_supported(n, hd, table.shape[0])
+                    and (not table.requires_grad or lib().vitta_wmsa_bf16_dtable_supported(n, hd, table.shape[0])))
         if io16 and not bf16:
             raise _lib.VittaHipError("a bfloat16 qkv needs the bf16-operand attention kernels (ops.wmsa_io16_ok)")
         tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 4.0 * n * n * hd * b_ * num_heads, 8.0 * n * n * b_ * num_heads) if KTIMING is not None else None
@@ -515,14 +517,14 @@ class WindowAttentionRel(torch.autograd.Function):
         # algorithmic flops of the backward: S, dP, dV, dK, dQ once each = 10 N^2 d (until round 4 the line counted the 14 N^2 d the two-kernel
         # form executes: S and dP twice); vector lane-operations per score: ~8 forward, ~10 backward (bias / mask terms, exp, dS, packing)
         tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 10.0 * n * n * hd * b_ * nh, 10.0 * n * n * b_ * nh) if KTIMING is not None else None
+        dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         if bf16:
             check(lib().vitta_wmsa_rel_bwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                                    hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
-                                                   _p(dqkv), int(qkv.dtype == torch.bfloat16), _stream()), "vitta_wmsa_rel_bwd_bf16")
+                                                   _p(dqkv), _p(dtable), int(qkv.dtype == torch.bfloat16), _stream()), "vitta_wmsa_rel_bwd_bf16")
             if tm is not None:
                 tm.stop()
-            return dqkv, None, None, None, None, None, None, None
-        dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
+            return dqkv, r_table, None, None, None, None, None, None
         check(lib().vitta_wmsa_rel_bwd_f32(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                            hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
                                            _p(dqkv), _p(dtable), _stream()), "vitta_wmsa_rel_bwd_f32")
@@ -1306,8 +1308,9 @@ def dense_supported(x, *linears):
 
 def wmsa_io16_ok(n_tok, head_dim, table):
     """True when the window attention takes a bfloat16 qkv and returns a bfloat16 context (bf16 data flow on, the bf16-operand
-    kernels enabled and covering the window, the bias table frozen)."""
-    return bool(bf16_flow() and WMSA_BF16 and not table.requires_grad and lib().vitta_wmsa_bf16_supported(int(n_tok), int(head_dim), table.shape[0]))
+    kernels enabled and covering the window; a trainable bias table where the one-pass backward carries its gradient)."""
+    return bool(bf16_flow() and WMSA_BF16 and lib().vitta_wmsa_bf16_supported(int(n_tok), int(head_dim), table.shape[0])
+                and (not table.requires_grad or lib().vitta_wmsa_bf16_dtable_supported(int(n_tok), int(head_dim), table.shape[0])))
 
 
 def bf16_dense_ok(rows, *linears):

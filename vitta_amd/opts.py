@@ -114,7 +114,8 @@ _FLAGS = [
                                          "the GPU from the uploaded uint8 frames (bit-identical to the host PIL path)")),
     (("--wmsa_bf16",), dict(type=_bool, default=False,
                             help="(extension) Video Swin-B: window attention with bf16 MFMA operands, fp32 softmax / accumulation "
-                                 "(windows up to 800 tokens in one pass; the relative-position table must be frozen)")),
+                                 "(windows up to 800 tokens in one pass; a trainable relative-position table takes the one-pass "
+                                 "backward, which bins its gradient in LDS)")),
     (("--dense_bf16",), dict(type=_bool, default=False,
                              help="(extension) Video Swin-B: qkv / proj / MLP / patch-merging products with bf16 MFMA operands, "
                                   "fp32 accumulation and epilogues (vitta_gemm_nt_bf16w_f32); default: exact fp32 MFMA")),
