@@ -173,12 +173,14 @@ def test_swin_forward_matches_reference_on_gpu():
     torch.testing.assert_close(torch.cat([h.batch_var for h in hooks]).cpu(), torch.from_numpy(g["vars"]), rtol=5e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("mode,use_engine", [("sgd", True), ("adam", True), ("sgd", False)])
-def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine, abi_calls):
+@pytest.mark.parametrize("mode,use_engine,strict", [("sgd", True, False), ("adam", True, False), ("sgd", False, False), ("adam", True, True)])
+def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine, strict, abi_calls):
+    """strict: the exact-fp32 kernels of the Swin path with NO outlier allowance -- every sampled tensor under its own
+    bound on every step, as the TANet test does with arith = f32."""
     from test_swin_cpu import run_product_tta_swin
     g = H.golden("tta3_swin.npz")
     recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
-    check_tta_records(g, mode, recs, BASE_GPU, outliers=OUTLIERS)
+    check_tta_records(g, mode, recs, BASE_GPU, outliers=None if strict else OUTLIERS)
     abi_calls.assert_swin_kernels()
 
 
