@@ -678,6 +678,15 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
         const f32x4 v = {acc[y][4 * qd], acc[y][4 * qd + 1], acc[y][4 * qd + 2], acc[y][4 * qd + 3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((y * 4 + qd) * NTHR + tid) * 16, kz * tile_bytes, 16);
       }
+    // (A 16-byte store reads its data registers a few cycles AFTER it issues.  The accumulators are dead behind this loop, and in
+    // one build of this file -- round 5, a different tail behind these stores -- the register allocator handed the first data
+    // register of each store to the NEXT store's address: `buffer_store_dwordx4 v[18:21], ...` directly followed by `v_or_b32 v18,
+    // 0x1000, v34`, with no wait state from this compiler for gfx950.  The first float of a piece then went out corrupted now and
+    // then: O(1) errors in a few elements of a split tile (tools/debug/dist_probe.py found them, tools/isa_store_hazard.py finds the
+    // pattern in the assembly).  The accumulators therefore stay live across the stores and a few idle cycles: the address
+    // temporaries get other registers.)
+    asm volatile("s_nop 7" ::: "memory");
+    asm volatile("" ::"v"(acc[0]), "v"(acc[1]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     B3_STAMP(5);
