@@ -252,13 +252,16 @@ def test_config5_swin_at_full_size_bf16_recipe_agrees_with_fp32(tmp_path, abi_ca
     (recognizer3d.py:36-40).  The CPU oracle path is out of reach at this size (5 TFLOP per step), so the check is between
     the product's arithmetic forms: the exact-fp32 kernels (pinned to the oracle at 112^2 by
     test_swin_config5_shape_gpu_equals_cpu_oracle_path) against the bf16-operand attention and dense kernels of the
-    recipe -- finite everywhere, statistics loss rel 1e-3, consistency loss rel 2e-2, whole-gradient cosine >= 0.999, per-tensor
-    max error / max|g| median <= 2e-2 and 95th percentile <= 2e-1, evaluation logits within 2e-2 of their maximum and the
-    SAME top-1."""
+    recipe -- finite everywhere, statistics loss rel 1e-4, consistency loss rel 2e-3, whole-gradient cosine >= 0.9999, per-tensor
+    max error / max|g| median <= 1.2e-2, 95th percentile <= 1.5e-1, worst <= 0.5, evaluation logits within 1e-2 of their maximum
+    and the SAME top-1 (bounds re-measured in round 5 for the bf16 data flow)."""
     from vitta_amd import data, ops, scripts, tta
     from vitta_amd.bns_utils import choose_layers
     T, size, views, K = 32, 224, 4, 174
-    Q50, Q95 = 2e-2, 2e-1  # measured (r3): median 6.0e-3, 95 % 9.3e-2 (worst tensor 0.36: layers.3.blocks.0.norm2.bias), cosine 0.99998
+    # re-measured for the bf16 DATA FLOW of rounds 4-5 (2-byte activations between LayerNorm / dense / attention, one-pass attention
+    # backward), identical over repeated runs: median 6.2e-3, 95 % 9.7e-2, worst tensor 0.364 (layers.3.blocks.0.norm2.bias), cosine
+    # 0.999982, logits 3.9e-3 of their maximum, loss_reg rel 1.6e-6, loss_consis rel 3.5e-4.  Bounds = 1.5-2x those.
+    Q50, Q95, WORST, COS, LOGIT = 1.2e-2, 1.5e-1, 0.5, 0.9999, 1e-2
 
     def build():
         m = H.build_swin(K, 0, window_size=(16, 7, 7), drop_path_rate=0.0)
@@ -307,6 +310,6 @@ def test_config5_swin_at_full_size_bf16_recipe_agrees_with_fp32(tmp_path, abi_ca
     lerr = ((b[3] - f[3]).abs().max() / f[3].abs().max()).item()
     print("config 5 at 224^2: loss_reg", f[0], b[0], "loss_consis", f[1], b[1], "gradient cosine", cos, "per-tensor max error / max|g|: median", q50,
           "95 %", q95, "worst", worst, "logits", lerr)
-    assert b[0] == pytest.approx(f[0], rel=1e-3) and b[1] == pytest.approx(f[1], rel=2e-2, abs=1e-6)
-    assert cos >= 0.999 and q50 <= Q50 and q95 <= Q95, (cos, q50, q95, worst)
-    assert lerr <= 2e-2 and int(b[3].argmax()) == int(f[3].argmax())
+    assert b[0] == pytest.approx(f[0], rel=1e-4) and b[1] == pytest.approx(f[1], rel=2e-3, abs=1e-6)
+    assert cos >= COS and q50 <= Q50 and q95 <= Q95 and worst[0] <= WORST, (cos, q50, q95, worst)
+    assert lerr <= LOGIT and int(b[3].argmax()) == int(f[3].argmax())

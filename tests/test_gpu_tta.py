@@ -252,8 +252,8 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
         assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
 
 
-@pytest.mark.parametrize("bf16", [False, True, "dense"])
-def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
+@pytest.mark.parametrize("bf16,sgd", [(False, False), (True, False), ("dense", False), (True, True)])
+def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16, sgd):
     """BASELINE config 5 shape in small: Video Swin-B, window (16,7,7), 4 views x 32 frames.  N = 784 tokens per
     window at the first stages: the CHUNKED W-MSA kernels (keys / queries walked in chunks of 400, online softmax)
     run there -- asserted below by spying on the C-ABI entry --, the single-pass kernels at the clamped later stages;
@@ -261,7 +261,10 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     bf16: the bf16-OPERAND attention kernels (ops.WMSA_BF16, BASELINE config 5's "bf16 MFMA W-MSA"; 784 tokens in one
     pass) against the same fp32 CPU path at the tolerance 8-bit operand mantissas allow through 24 blocks: statistics loss
     rel 1e-4, consistency loss rel 2e-3, sampled gradients 3e-2 of their maximum (dense: 1e-4 / 5e-3 / 5e-2).  "dense": the bf16-operand dense layers
-    as well (ops.DENSE_BF16, vitta_gemm_nt_bf16w_f32): every matrix product of the backbone on bf16 operands."""
+    as well (ops.DENSE_BF16, vitta_gemm_nt_bf16w_f32): every matrix product of the backbone on bf16 operands.
+    sgd (round 5): SGD over ALL parameters, the reference's default optimizer (corpus/basics.py:547-560) -- the relative-position
+    tables train, and the bf16 attention produces their gradient itself (one-pass backward, binned in LDS): the gradients of two
+    784-token stages' tables against the CPU path at the attention bound, and no fp32 relative-position attention launch."""
     import numpy as np
     from oracle.oracle_backend import OracleBackend
     from vitta_amd import data, scripts, tta
@@ -283,10 +286,14 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
     args.clip_length, args.n_augmented_views, args.window_size = T, views, (16, 7, 7)
     args.input_size, args.scale_size, args.workers, args.verbose, args.result_dir = size, size, 0, False, str(tmp_path)
     args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
-    args.update_only_bn_affine, args.lr = True, 1e-4
+    args.update_only_bn_affine, args.lr = (not sgd), 1e-4
     x = data.SyntheticVideoDataset(1, views, T, size, 174, "swin", seed0=40)[0][0].unsqueeze(0)
     res = {}
     from vitta_amd import _lib, ops
+    extra = ["module.backbone.layers.0.blocks.1.attn.relative_position_bias_table",
+             "module.backbone.layers.2.blocks.5.attn.relative_position_bias_table"] if sgd else []
+    calls = {}
+    _lib.CALL_COUNTS = calls if sgd else None
     L = _lib.lib()
     entry = "vitta_wmsa_rel_fwd_bf16_io" if bf16 else "vitta_wmsa_rel_fwd_f32"
     orig, seen = getattr(L, entry), []
@@ -306,12 +313,16 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16):
             named = dict(adapter.model.named_parameters())
             res[dev.type] = (float(loss_reg), float(loss_consis),
                              named["module.backbone.layers.2.blocks.4.norm1.weight"].grad.cpu().clone(),
-                             named["module.backbone.norm.bias"].grad.cpu().clone())
+                             named["module.backbone.norm.bias"].grad.cpu().clone()) + tuple(named[k].grad.cpu().clone() for k in extra)
     finally:
+        _lib.CALL_COUNTS = None
         setattr(L, entry, orig)
         ops.WMSA_BF16 = old_flag
         ops.DENSE_BF16 = old_dense
     assert seen.count(784) == 22, sorted(set(seen))  # stages 1-3 (2 + 2 + 18 blocks): N = 784 (fp32: the chunked kernels)
+    if sgd:  # every 784-token attention backward of the GPU step on the bf16 kernels (22 blocks; the last stage's window is clamped to
+        # the 4 x 4 plane at this input size and takes the dense-bias kernels), none on the fp32 relative-position kernels
+        assert calls.get("vitta_wmsa_rel_bwd_bf16", 0) == 22 and "vitta_wmsa_rel_bwd_f32" not in calls, {k: v for k, v in calls.items() if "wmsa" in k}
     c, gdev = res["cpu"], res["cuda"]
     # measured (r2k): fp32 9e-8 / 2e-7 / 4e-6; bf16 attention 9e-8 / 3e-5 / 3e-3; bf16 attention + dense 2e-6 / 1.3e-4 / 8e-3
     r0, r1, rg = (1e-4, 5e-3, 5e-2) if bf16 == "dense" else (1e-4, 2e-3, 3e-2) if bf16 else (2e-5, 1e-3, 2e-2)
