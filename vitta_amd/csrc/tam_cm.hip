@@ -31,9 +31,9 @@ struct Row {
 };
 
 // rows are enumerated (c, n, t) with t fastest == memory order
-template <int LPR>
+template <int LPR, int BLOCK = VITTA_BLOCK>
 __device__ __forceinline__ Row row_of(int C, int N, int T, int* sub) {
-  constexpr int RPB = VITTA_BLOCK / LPR;
+  constexpr int RPB = BLOCK / LPR;
   const int F = N * T;
   *sub = threadIdx.x % LPR;
   const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -138,16 +138,18 @@ __global__ __launch_bounds__(VITTA_BLOCK) void agg_fwd_kernel(const float* __res
 
 // FIN: the block holds whole (c, n) groups of T rows (rows per block % T == 0): d gate / d K of its groups are finished here
 // from LDS (the arithmetic of finish_kernel, same order) instead of by a second launch
-template <int LPR, bool FIN>
-__global__ __launch_bounds__(VITTA_BLOCK) void agg_bwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
+// BLOCK: threads per workgroup -- 512 at 56 x 56 (64 lanes per row and still whole (c, n) groups of T = 8 rows per workgroup: 128
+// workgroups of EIGHT waves; with 32 lanes per row and four waves the launch was 128 workgroups on 256 CUs, 14 us for 38 MB)
+template <int LPR, bool FIN, int BLOCK = VITTA_BLOCK>
+__global__ __launch_bounds__(BLOCK) void agg_bwd_kernel(const float* __restrict__ x, BN bn, const float* __restrict__ gate,
                                                               const float* __restrict__ kern, const float* __restrict__ gout,
                                                               int C, int N, int T, int HW, int64_t xld, float* __restrict__ ga,
                                                               float* __restrict__ dots, float* __restrict__ ggate,
                                                               float* __restrict__ gkern) {
-  constexpr int RPB = VITTA_BLOCK / LPR;
+  constexpr int RPB = BLOCK / LPR;
   __shared__ float sd[FIN ? RPB * 3 : 1];
   int sub;
-  const Row r = row_of<LPR>(C, N, T, &sub);
+  const Row r = row_of<LPR, BLOCK>(C, N, T, &sub);
   float d0 = 0.f, d1 = 0.f, d2 = 0.f;
   if (r.ok) {
     float s, sh;
@@ -466,6 +468,11 @@ int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* con
   float* dots = d_ggate + (int64_t)N * C * T;  // the caller gives d_ggate room for N*C*T*4 floats
   const int64_t rows = (int64_t)C * N * T;
   // whole (c, n) groups per workgroup -> d gate / d K finished in the same launch (T = 8: 32 or 16 lanes per row)
+  if (HW > 256 && (512 / 64) % T == 0 && (HW & 3) == 0) {
+    VITTA_LAUNCH((agg_bwd_kernel<64, true, 512>), dim3((unsigned)((rows + 7) / 8)), dim3(512), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
+                 (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
+    return VITTA_OK;
+  }
   if (HW > 256 && (VITTA_BLOCK / 32) % T == 0) {
     VITTA_LAUNCH((agg_bwd_kernel<32, true>), dim3(row_grid(rows, 32)), dim3(VITTA_BLOCK), 0, st, d_x, bn, d_gate, d_kern, d_gout, (int)C,
                  (int)N, (int)T, (int)HW, xld, d_ga, dots, d_ggate, d_gkern);
