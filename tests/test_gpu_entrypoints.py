@@ -360,3 +360,37 @@ def test_swin_buckets_leave_from_inside_the_backward_on_gpu(tmp_path):
         assert float(res[4][0][f"step{i}_loss_reg"]) == pytest.approx(float(res[1][0][f"step{i}_loss_reg"]), rel=1e-4 if i == 0 else 5e-3)
     a, b = res[4][0]["step0_grad"], res[1][0]["step0_grad"]
     assert np.abs(a - b).max() <= 2e-4 * np.abs(b).max() + 1e-9
+
+
+def test_bench_line_keeps_the_contract_on_one_gpu():
+    """`python bench.py` as the driver runs it for N = 1 (fewer steps, no Swin / SGD-all legs, two CPU-baseline steps: seconds):
+    ONE JSON line alone on stdout with the contract's fields -- metric / value / unit / n_gpus / steps / warmup / ms_per_step /
+    higher_is_better / scaling / vs_baseline / dtype / data / config.workload --, the `roofline` object (bound, achieved, peak, unit,
+    frac, traffic) of the dominant kernel family, the `cpu_baseline` object (value, unit, cores, kind, sample), and the host-fed
+    (PCIe-inclusive) repetition of the timed steps."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "4", "--no-swin", "--no-sgd-all", "--cpu-steps", "2",
+           "--min-seconds", "0.05"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-500:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "host_fed"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 4 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "videos/s" and d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-6 * max(1.0, r["frac"])
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0
+    h = d["host_fed"]
+    assert h["videos_per_s"] > 0 and h["ms_per_step_prefetch"] > 0 and h["ms_per_step_upload_in_stream"] > 0
