@@ -263,11 +263,9 @@ int vitta_tam_branch_fwd_f32(const float* d_pooled, const float* d_wg1, const fl
                              float* d_hpre, int32_t pooled_tc, void* stream);
 int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                             const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
+                             const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                              float* d_gpooled, float* const* h_dbn, float* const* h_dw, int32_t pooled_tc, void* stream);
-/* N_saved >= N: clips of the forward launch that wrote d_hpre (its second plane starts N_saved * (C/4) * T floats in); the
- * backward covers the first N of them (d_pooled / d_kern / d_gate are clip-major, so their first N clips are a prefix). */
 /* The same two passes with their two launches each fused into ONE (F1 -> F2, B1 -> B2): the workgroups of a clip meet on a
  * device-scope counter inside the launch (the second half's staging -- and in the backward the whole G branch -- runs while
  * the first half's tiles finish).  d_sync: >= 2 * N uint32, ZERO when first used (the kernels leave it zero), not shared by
@@ -280,7 +278,7 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
 int vitta_tam_branch_fused_supported(int32_t N, int32_t C, int32_t T);
 /* The L branch's weight gradients as their own launch (the backward entry points called with NULL dw0 / dw3 leave them out):
  * d_dw0 [C/4, C, 3] += sum over clips and t of dpre[n, o, t] pooled[n, c, t + j - 1];  d_dw3 [C, C/4] += sum of
- * (d gate * gate * (1 - gate))[n, c, t] h[n, o, t].  d_hact = the SECOND half of the forward's d_hpre (after N_saved * C/4 * T floats),
+ * (d gate * gate * (1 - gate))[n, c, t] h[n, o, t].  d_hact = the SECOND half of the forward's d_hpre (after N * C/4 * T floats),
  * d_dpre = the scratch behind d_gpooled's first N * C * T floats that the backward left.  Single writer per element (plain
  * read-modify-write): may run on another stream than the backward, after it. */
 int vitta_tam_branch_wgrad_f32(const float* d_pooled, int32_t pooled_tc, const float* d_gate, const float* d_ggate, const float* d_hact,
@@ -291,7 +289,7 @@ int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, co
                                    float* d_hpre, void* d_sync, int32_t pooled_tc, void* stream);
 int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                                   const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                                    float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc, void* stream);
 
@@ -510,13 +508,6 @@ typedef struct vitta_conv_desc {
    * accumulation; error of the fp32-roundoff class, see conv_b3.hip); `w` is then not read.  NULL: exact fp32 MFMA. */
   const void* w_b3;
   int8_t cls_ntaps[4]; /* VITTA_CONV_PARITY4: taps of class 0..3 (sum = ntaps) */
-  /* A pass over the FIRST frames of tensors that hold more frames per channel row (the adaptation backward of a forward that
-   * also carried the evaluation clip, vitta_amd/trunk.py): pixels between consecutive channel rows, 0 = compact.
-   *   bwd_ld  rows of `bwd_x` / `bwd_mask` (VITTA_CONV_BWD_BN)        (vitta_wgrad_desc::x_ld is the same for wgrad's x)
-   * and the converse for the forward of such a batch:
-   *   stat_m  VITTA_CONV_STATS counts, and y_raw is written for, output pixels m < stat_m only (0 = all; a multiple of 4;
-   *           contiguous forward outputs). */
-  int64_t bwd_ld, stat_m;
   void* pool;        /* VITTA_CONV_POOL: int64 [N][K], 32 fractional bits, accumulated */
   float pool_scale;  /* 1 / (Hy * Wy) */
 } vitta_conv_desc;
@@ -575,7 +566,6 @@ typedef struct vitta_wgrad_desc {
    * added to grad_w with atomics (thousands of adds per weight on the small early layers) */
   void* workspace;
   int64_t workspace_bytes;
-  int64_t x_ld; /* pixels between consecutive channel rows of x when it holds more than N frames per row; 0 = compact */
 } vitta_wgrad_desc;
 int vitta_conv_wgrad_f32(const vitta_wgrad_desc* h_desc, void* stream);
 /* VITTA_WGRAD_DEFER_REDUCE in flags: vitta_conv_wgrad_f32 leaves its partial tiles in `workspace` and skips the second launch;
@@ -642,17 +632,6 @@ int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, c
                         float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
                         const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
                         float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream);
-/* The same two passes over the FIRST N * T frames of saved tensors whose channel rows hold more frames (the adaptation backward
- * after a forward that also carried the evaluation clip): x_ld = pixels between consecutive channel rows of d_x (and d_mask),
- * 0 = compact.  Gradient tensors (d_g, d_gout, d_dx, d_ga, d_gm) are compact [C][N * T * HW]. */
-int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* const* h_bn, float eps, const float* d_gate,
-                                const float* d_kern, const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga,
-                                float* d_ggate, float* d_gkern, void* stream);
-int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, int64_t x_ld,
-                           const float* d_rowadd, float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu,
-                           const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx,
-                           float* d_gm, float* d_dgamma, float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW,
-                           void* stream);
 int vitta_avgpool_cm_f32(const float* d_x, int32_t C, int32_t F, int32_t HW, float* d_feat, void* stream);
 int vitta_avgpool_cm_bwd_f32(const float* d_gfeat, int32_t C, int32_t F, int32_t HW, float* d_gx, void* stream);
 

@@ -378,64 +378,6 @@ def test_non_finite_inputs_stay_where_fp32_arithmetic_puts_them(n, c, k, h, ksz,
         assert torch.equal(torch.isnan(got), torch.isnan(ref)) and torch.equal(got[torch.isinf(ref)], ref[torch.isinf(ref)])
 
 
-@pytest.mark.parametrize("n,ng,c,k,h,ksz", [(12, 8, 256, 1024, 14, 1), (6, 4, 64, 64, 28, 3), (24, 16, 512, 2048, 7, 1)])
-def test_leading_frames_only_statistics_raw_output_and_pitched_backward_inputs(n, ng, c, k, h, ksz):
-    """A forward over n frames of which only the first ng are the adaptation batch (trunk.py: the evaluation clip rides
-    along): `stat_m` limits the hooked statistics and the raw copy to those frames, the output covers all of them; and a
-    data gradient / weight gradient over ng frames reads its saved inputs (bwd_x; wgrad's x) from rows that hold n frames
-    (`bwd_ld`, `x_ld`) -- each equal to the same launch on compact ng-frame tensors."""
-    from vitta_amd import conv as CV
-    gen = torch.Generator().manual_seed(n * 131 + c + k + h)
-    d = _dev()
-    x, w = torch.randn(n, c, h, h, generator=gen).to(d), (torch.randn(k, c, ksz, ksz, generator=gen) * (c * ksz * ksz) ** -0.5).to(d)
-    bn = [t.to(d) for t in _bn(k, gen)]
-    shift = (torch.randn(k, generator=gen) * 0.1).to(d)
-    pad = ksz // 2
-    geo, geo_g = CV.Geometry.forward(n, h, h, ksz, 1, pad), CV.Geometry.forward(ng, h, h, ksz, 1, pad)
-    P, Pg = n * h * h, ng * h * h
-    wp = CV.pack_fwd(w)
-
-    def fwd(g, xx, stat_m):
-        frames = xx.shape[0]
-        y, raw = torch.empty(k, frames * h * h, device=d), torch.full((k, frames * h * h), -7.0, device=d)
-        s1, s2 = torch.zeros(k, device=d), torch.zeros(k, device=d)
-        CV.launch(g, CV.to_cm(xx), wp, y, c, k, flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_STATS, y_raw=raw, epi_bn=bn,
-                  stats=(shift, s1, s2), stat_m=stat_m)
-        torch.cuda.synchronize()
-        return y, raw, s1, s2
-    y, raw, s1, s2 = fwd(geo, x, Pg)
-    y_all, _, _, _ = fwd(geo, x, 0)
-    y_g, raw_g, s1_g, s2_g = fwd(geo_g, x[:ng].contiguous(), 0)
-    assert torch.equal(y, y_all)                                     # the output does not depend on stat_m
-    # raw copy: leading frames only (a launch over fewer frames may split its K ranges elsewhere: round-off, not bits)
-    assert (raw[:, :Pg] - raw_g).abs().max().item() <= 1e-5 * raw_g.abs().max().item() and bool((raw[:, Pg:] == -7.0).all())
-    for a, b in ((s1, s1_g), (s2, s2_g)):                            # sums: same values, another atomic order
-        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-6
-    # backward over ng frames with saved tensors of n frames
-    g = torch.randn(k, Pg, generator=gen).to(d)
-    wb = CV.pack_bwd(w)
-    gb = CV.Geometry.dgrad(ng, h, h, ksz, 1, pad)[0]
-    xsave = torch.randn(c, P, generator=gen).to(d)
-    bnb = [t.to(d) for t in _bn(c, gen)]
-
-    def dgrad(bx, ld):
-        dx, dg, db = torch.empty(c, Pg, device=d), torch.zeros(c, device=d), torch.zeros(c, device=d)
-        CV.launch(gb, g, wb, dx, k, c, flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU, bwd_bn=bnb, bwd_x=bx, dgamma=dg, dbeta=db, bwd_ld=ld)
-        torch.cuda.synchronize()
-        return dx, dg, db
-    pitched, compact = dgrad(xsave, P), dgrad(xsave[:, :Pg].contiguous(), 0)
-    assert torch.equal(pitched[0], compact[0])
-    for a, b in zip(pitched[1:], compact[1:]):
-        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-6
-    if c % 64 == 0 and k % 64 == 0:
-        xcm = CV.to_cm(x)
-        gw_p, gw_c = torch.zeros_like(w), torch.zeros_like(w)
-        CV.wgrad(geo_g, xcm, g, gw_p, c, k, x_ld=P)
-        CV.wgrad(geo_g, xcm[:, :Pg].contiguous(), g, gw_c, c, k)
-        torch.cuda.synchronize()
-        assert (gw_p - gw_c).abs().max().item() <= 1e-5 * gw_c.abs().max().item() + 1e-7
-
-
 def test_deferred_weight_gradient_reductions_of_a_group_equal_the_immediate_ones():
     """vitta_conv_wgrad_f32 with VITTA_WGRAD_DEFER_REDUCE + ONE vitta_conv_wgrad_reduce_f32 over the group (the convolutions of a
     bottleneck, trunk.py) == the same launches each followed by its own reduction, accumulated onto non-zero buffers."""

@@ -977,7 +977,7 @@ def test_tam_branch_single_launch_forms_equal_the_two_launch_forms(c, t, n):
         gbuf = torch.empty(n * c * t + n * o * t, device=d)
         dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
         dw = [torch.zeros_like(wg1), torch.zeros_like(wg3), torch.zeros_like(w0), torch.zeros_like(w3)]
-        bargs = args + (n, _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
+        bargs = args + (_p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), _ptr4(*dw))
         if fused:
             _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), tc, _stream()), "bwd fused")
         else:
@@ -1049,7 +1049,7 @@ def test_tam_branch_launches_of_different_grids_share_one_meeting_buffer():
             gbuf = torch.empty(n * c * t + n * o * t, device=d)
             dbn = [torch.zeros(2 * t, device=d), torch.zeros(2 * t, device=d), torch.zeros(o, device=d), torch.zeros(o, device=d)]
             args = (_p(st["pooled"]), _p(st["wg1"]), _ptr4(*st["bng"]), 1e-5, _p(st["wg3"]), _p(st["w0"]), _ptr4(*st["bnl"]), 1e-5, _p(st["w3"]), n, c, t)
-            bargs = args + (n, _p(st["kern"]), _p(st["gate"]), _p(st["hpre"]), _p(st["gkern"]), _p(st["ggate"]), _p(gbuf), _ptr4(*dbn), None)
+            bargs = args + (_p(st["kern"]), _p(st["gate"]), _p(st["hpre"]), _p(st["gkern"]), _p(st["ggate"]), _p(gbuf), _ptr4(*dbn), None)
             if fused:
                 _lib.check(L.vitta_tam_branch_bwd_fused_f32(*bargs, _p(sync), 0, _stream()), "bwd fused")
             else:

@@ -77,7 +77,7 @@ def test_adapt_step_equals_module_path(tmp_path, size, over, abi_calls):
             _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
             if fast is True:  # the node ran (before_norm hooks included: raw-output statistics, raw injection)
                 assert abi_calls.abi.get("vitta_conv_f32", 0) > calls0.get("vitta_conv_f32", 0)
-                assert abi_calls.abi.get("vitta_bn_bwd_cm_ld_f32", 0) > calls0.get("vitta_bn_bwd_cm_ld_f32", 0)
+                assert abi_calls.abi.get("vitta_bn_bwd_cm_f32", 0) > calls0.get("vitta_bn_bwd_cm_f32", 0)
             grads = {k: v.grad.detach().clone() for k, v in adapter.model.named_parameters() if v.requires_grad}
             adapter.close_hooks()
             ev = adapter.evaluate(adapter.shape_eval_input(H.seeded_randn((1, T * 3, size, size), 8).to(_dev()))).clone()

@@ -51,7 +51,7 @@ def main():
                 _lib.check(L.vitta_tam_branch_fwd_fused_f32(*args, _p(kern), _p(gate), _p(hpre), _p(sync), 1, _stream()), "fwd fused")
 
         def bwd():
-            bargs = args + (n, _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), nul)
+            bargs = args + (_p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf), _ptr4(*dbn), nul)
             if opt.two_launch:
                 _lib.check(L.vitta_tam_branch_bwd_f32(*bargs, 1, _stream()), "bwd")
             else:

@@ -30,7 +30,7 @@ class WgradDesc(C.Structure):
                 ("Hs", C.c_int32), ("Ws", C.c_int32), ("Hg", C.c_int32), ("Wg", C.c_int32), ("sstride", C.c_int32),
                 ("ntaps", C.c_int32), ("wtaps", C.c_int32),
                 ("dh", C.c_int8 * 9), ("dw", C.c_int8 * 9), ("wt", C.c_int8 * 9), ("flags", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("x_ld", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 CONV_PRO_BN_RELU, CONV_EPI_APPLY, CONV_EPI_RELU, CONV_STATS = 1, 2, 4, 8
 CONV_RES, CONV_RES_HALF, CONV_BWD_BN, CONV_BWD_RELU, CONV_PARITY4, CONV_STATS_RAW, CONV_INJ_RAW, CONV_POOL = 16, 32, 64, 128, 256, 512, 1024, 2048
 BN_BWD_INJ_RAW = 2
@@ -55,7 +55,7 @@ class ConvDesc(C.Structure):
                 ("dh", C.c_int8 * CONV_MAX_TAPS), ("dw", C.c_int8 * CONV_MAX_TAPS), ("wt", C.c_int8 * CONV_MAX_TAPS),
                 ("flags", C.c_int32), ("tile", C.c_int32),
                 ("ksplit", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("w_b3", C.c_void_p),
-                ("cls_ntaps", C.c_int8 * 4), ("bwd_ld", C.c_int64), ("stat_m", C.c_int64),
+                ("cls_ntaps", C.c_int8 * 4),
                 ("pool", C.c_void_p), ("pool_scale", C.c_float)]
 
 
@@ -103,11 +103,11 @@ SIGNATURES = {
     "vitta_tam_branch_wgrad_f32": (C.c_int, [_p, _i32, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
     "vitta_tam_branch_fwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                            _p, _p, _p, _i32, _p]),
-    "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
+    "vitta_tam_branch_bwd_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                            _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _i32, _p]),
     "vitta_tam_branch_fwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                                  _p, _p, _p, _p, _i32, _p]),
-    "vitta_tam_branch_bwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32, _i32,
+    "vitta_tam_branch_bwd_fused_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _p, _p, C.POINTER(_p), _f32, _p, _i32, _i32, _i32,
                                                  _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _i32, _p]),
     "vitta_bn_act_partial_floats": (_sz, [_i64, _i32, _i64, _i32]),
     "vitta_bn_act_fwd_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i64, _i32, _i32, _p, _p]),
@@ -170,9 +170,6 @@ SIGNATURES = {
     "vitta_tam_agg_bwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "vitta_bn_bwd_cm_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, C.POINTER(_p), _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p,
                                       _i32, _i32, _i32, _i32, _p]),
-    "vitta_tam_agg_bwd_cm_ld_f32": (C.c_int, [_p, _i64, C.POINTER(_p), _f32, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
-    "vitta_bn_bwd_cm_ld_f32": (C.c_int, [_p, _p, _p, _p, _i64, _p, _f32, C.POINTER(_p), _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p,
-                                         _i32, _i32, _i32, _i32, _p]),
     "vitta_avgpool_cm_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "vitta_avgpool_cm_bwd_f32": (C.c_int, [_p, _i32, _i32, _i32, _p, _p]),
     "vitta_ln_supported": (C.c_int, [_i32]),

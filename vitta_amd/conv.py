@@ -236,10 +236,9 @@ def workspace(device):
 
 
 def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi_bn=None, bwd_bn=None, eps=1e-5,
-           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0, bwd_ld=0, stat_m=0, pool=None):
+           stats=None, bwd_x=None, bwd_mask=None, inj=None, dgamma=None, dbeta=None, tile=0, ksplit=0, pool=None):
     """One `vitta_conv_f32` launch on the current stream.  x [C, *], wp packed [taps][C][K] (fp32 tensor or Pack), y [K, *].
-    stats = (shift, s1, s2); inj = (mu, a, b, gscale).  bwd_ld: pixels per channel row of bwd_x / bwd_mask when they hold
-    more frames than this pass covers; stat_m: the statistics count output pixels below it only (0: all).
+    stats = (shift, s1, s2); inj = (mu, a, b, gscale).
     pool: a zeroed int64 [frames, K] tensor the per-(frame, channel) means of relu(epi_bn(raw output)) are ADDED to as
     fixed-point numbers with 32 fractional bits (CONV_POOL)."""
     if isinstance(wp, Pack):
@@ -259,7 +258,6 @@ def launch(geom, x, wp, y, c, k, flags=0, y_raw=None, res=None, pro_bn=None, epi
     if stats is not None:
         d.st_shift, d.st_s1, d.st_s2 = (t.data_ptr() for t in stats)
     d.bwd_x, d.bwd_mask = _ptr(bwd_x), _ptr(bwd_mask)
-    d.bwd_ld, d.stat_m = int(bwd_ld), int(stat_m)
     if inj is not None:
         d.inj_mu, d.inj_a, d.inj_b, d.inj_gscale = (_ptr(t) for t in inj)
     d.dgamma, d.dbeta = _ptr(dgamma), _ptr(dbeta)
@@ -333,7 +331,7 @@ def wgrad_reduce(descs):
           "vitta_conv_wgrad_reduce_f32")
 
 
-def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, x_ld=0, defer=None):
+def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, defer=None):
     """grad_w [K, C, kh, kw] += weight gradient of the convolution with FORWARD geometry `geom` (Geometry.forward):
     x [C, *] its input planes (raw, with pro_bn = the BatchNorm whose relu(bn(.)) the forward applied on load),
     dy [K, *] the gradient of its raw output (`vitta_conv_wgrad_f32`).  defer = slot 0..3: leave the partial tiles in that
@@ -346,7 +344,6 @@ def wgrad(geom, x, dy, grad_w, c, k, pro_bn=None, eps=1e-5, x_ld=0, defer=None):
     _bn4(d.pro_bn, pro_bn)
     d.pro_eps = float(eps)
     d.flags = CONV_PRO_BN_RELU if pro_bn is not None else 0
-    d.x_ld = int(x_ld)  # x holds more frames per channel row than geom.n (pixels between rows; 0: compact)
     d.C, d.K, d.N = int(c), int(k), geom.n
     d.Hs, d.Ws, d.Hg, d.Wg, d.sstride = geom.hs, geom.ws, geom.hg, geom.wg, geom.sstride
     d.ntaps, d.wtaps = len(geom.taps), grad_w.shape[2] * grad_w.shape[3]

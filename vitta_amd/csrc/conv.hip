@@ -453,11 +453,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
             }
           }
           if (BWD) {
-            const float4 xr = *reinterpret_cast<const float4*>(d.bwd_x + (int64_t)k * a.bP + m);
+            const float4 xr = *reinterpret_cast<const float4*>(d.bwd_x + (int64_t)k * a.yP + m);
             const float xv[4] = {xr.x, xr.y, xr.z, xr.w};
             float mk[4] = {1.f, 1.f, 1.f, 1.f};
             if (BRELU && d.bwd_mask) {
-              const float4 mr = *reinterpret_cast<const float4*>(d.bwd_mask + (int64_t)k * a.bP + m);
+              const float4 mr = *reinterpret_cast<const float4*>(d.bwd_mask + (int64_t)k * a.yP + m);
               mk[0] = mr.x > 0.f; mk[1] = mr.y > 0.f; mk[2] = mr.z > 0.f; mk[3] = mr.w > 0.f;
             }
             float o[4], gm[4];
@@ -474,12 +474,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(const ConvK a) 
             *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
             if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(gm[0], gm[1], gm[2], gm[3]);
           } else {
-            if (d.y_raw && m < a.statM) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
+            if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
             float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const float z = fmaf(v[e], es, et);
-              if (STATS && m < a.statM) {
+              if (STATS) {
                 const float dd = (RAWST ? v[e] : z) - sh;
                 r1 += dd;
                 r2 = fmaf(dd, dd, r2);
@@ -677,10 +677,6 @@ int fill(const vitta_conv_desc* h, ConvK& a) {
   const int64_t M = (int64_t)d.N * d.Hg * d.Wg;
   if (M >= (1ll << 31) || a.xP % 4 || a.yP % 4 || M % 4) return VITTA_ERR_UNSUPPORTED;
   a.Mtot = (int)M;
-  if (d.bwd_ld < 0 || d.stat_m < 0 || d.stat_m % 4 || (d.bwd_ld && (d.bwd_ld < a.yP || d.bwd_ld % 4)))
-    return VITTA_ERR_INVALID_ARG;
-  a.bP = d.bwd_ld ? d.bwd_ld : a.yP;
-  a.statM = (d.stat_m && d.stat_m < M) ? (int)d.stat_m : (int)M;
   a.contig = (d.ostride == 1 && d.oa == 0 && d.ob == 0 && d.Hg == d.Hy && d.Wg == d.Wy) ? 1 : 0;
   a.rP = (d.flags & VITTA_CONV_RES_HALF) ? (int64_t)d.N * ((d.Hy + 1) / 2) * ((d.Wy + 1) / 2) : a.yP;
   if (!a.contig && (d.flags & (VITTA_CONV_BWD_BN | VITTA_CONV_STATS | VITTA_CONV_RES | VITTA_CONV_RES_HALF | VITTA_CONV_EPI_APPLY |

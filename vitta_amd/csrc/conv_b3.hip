@@ -146,7 +146,7 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
   const int r = lane >> 3, q = lane & 7;
   const int m = m0 + 32 * wave + 4 * q;
   const bool live = m < a.Mtot;
-  const bool head = m < a.statM, counted = STATS && head;
+  const bool counted = STATS && live;
   const int HWy = d.Hy * d.Wy;
   PoolSums pool(a, m0 + 32 * wave, POOL);
   float s1v[8], s2v[8];
@@ -163,7 +163,7 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
       x2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       x3[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (BWD) {
-        if (!PRE) x2[j] = *reinterpret_cast<const f32x4*>(d.bwd_x + k * a.bP + mm);
+        if (!PRE) x2[j] = *reinterpret_cast<const f32x4*>(d.bwd_x + k * a.yP + mm);
         if (RES) x3[j] = *reinterpret_cast<const f32x4*>(d.res + k * a.rP + mm);
       } else if (RES && !PRE) {
         x2[j] = *reinterpret_cast<const f32x4*>(d.res + k * a.rP + mm);
@@ -172,7 +172,7 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
     f32x4 mk[4];
     if (BWD && BRELU && d.bwd_mask) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mk[j] = *reinterpret_cast<const f32x4*>(d.bwd_mask + (int64_t)(k0 + 8 * (4 * half + j) + r) * a.bP + (live ? m : a.Mtot - 4));
+      for (int j = 0; j < 4; ++j) mk[j] = *reinterpret_cast<const f32x4*>(d.bwd_mask + (int64_t)(k0 + 8 * (4 * half + j) + r) * a.yP + (live ? m : a.Mtot - 4));
     }
     // ... then the arithmetic of TileEpilogue::body per item
 #pragma unroll
@@ -216,7 +216,7 @@ __device__ __forceinline__ void epilogue_t(const ConvK& a, int m0, int k0, int w
           if (d.y_raw) *reinterpret_cast<f32x4*>(d.y_raw + k * a.yP + m) = f32x4{gm[0], gm[1], gm[2], gm[3]};
         }
       } else {
-        if (live && d.y_raw && head) *reinterpret_cast<f32x4*>(d.y_raw + k * a.yP + m) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+        if (live && d.y_raw) *reinterpret_cast<f32x4*>(d.y_raw + k * a.yP + m) = f32x4{vv[0], vv[1], vv[2], vv[3]};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -566,8 +566,8 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(const ConvK a) {
   epi1.load_consts(L);
   if constexpr (PRE) {  // (the host sets pw_prefetch for contiguous outputs only: BWD_BN -> its input, else the residual)
     const bool bwd = d.flags & VITTA_CONV_BWD_BN;
-    const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + (lane >> 3)) * (bwd ? a.bP : a.rP) + min(m0 + 32 * wave + 4 * (lane & 7), Mtot - 4);
-    const int64_t step = 8 * (bwd ? a.bP : a.rP);
+    const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + (lane >> 3)) * (bwd ? a.yP : a.rP) + min(m0 + 32 * wave + 4 * (lane & 7), Mtot - 4);
+    const int64_t step = 8 * (bwd ? a.yP : a.rP);
 #pragma unroll
     for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const float4*>(row + i * step);
   }

@@ -39,8 +39,6 @@ struct B3Hot {
 struct ConvK {
   vitta_conv_desc d;
   int64_t xP, yP, rP;  // pixels per channel row of x, y, res
-  int64_t bP;          // ... of bwd_x / bwd_mask (yP unless the descriptor gives bwd_ld)
-  int statM;           // VITTA_CONV_STATS counts output pixels below this
   int Mtot;            // N * Hg * Wg
   int nMt, nNt;        // tiles
   int contig;          // 1: output pixel index == M index (float4 epilogue)

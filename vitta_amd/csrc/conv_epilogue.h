@@ -184,12 +184,12 @@ struct TileEpilogue {
       es = c_gam * rsqrtf(c_var + d.epi_eps);
       et = c_bet - c_mean * es;
     }
-    const int64_t yrow = (int64_t)k * a.yP, brow = (int64_t)k * a.bP;
+    const int64_t yrow = (int64_t)k * a.yP, brow = (int64_t)k * a.yP;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       const int m = m0 + wm * (BM >> 1) + 32 * xb + 8 * qd + 4 * lk;
       if (m >= a.Mtot) continue;
-      const bool head = m < a.statM, counted = STATS && head;
+      const bool counted = STATS;
       float v[4] = {acc[4 * qd], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]};
       if (a.contig) {
         float* yp = d.y + yrow + m;
@@ -231,7 +231,7 @@ struct TileEpilogue {
           *reinterpret_cast<float4*>(yp) = make_float4(o[0], o[1], o[2], o[3]);
           if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(gm[0], gm[1], gm[2], gm[3]);
         } else {
-          if (d.y_raw && head) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
+          if (d.y_raw) *reinterpret_cast<float4*>(d.y_raw + yrow + m) = make_float4(v[0], v[1], v[2], v[3]);
           float o[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -313,7 +313,7 @@ __device__ __forceinline__ void tile_prefetch_at(const ConvK& a, int m0, int k0,
                                                  float4& p2, float4& p3, int bm = 64, int xb = 0) {
   const vitta_conv_desc& d = a.d;
   const bool bwd = d.flags & VITTA_CONV_BWD_BN;
-  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + wn * 32 + li) * (bwd ? a.bP : a.rP);
+  const float* row = (bwd ? d.bwd_x : d.res) + (int64_t)(k0 + wn * 32 + li) * (bwd ? a.yP : a.rP);
   const int m = m0 + wm * (bm >> 1) + 32 * xb + 4 * lk, last = a.Mtot - 4;
   p0 = *reinterpret_cast<const float4*>(row + min(m, last));
   p1 = *reinterpret_cast<const float4*>(row + min(m + 8, last));

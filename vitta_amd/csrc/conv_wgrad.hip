@@ -330,10 +330,6 @@ int fill(const vitta_wgrad_desc* h, WgradK& a) {
   if (d.C <= 0 || d.K <= 0 || d.N <= 0 || d.ntaps < 1 || d.ntaps > VITTA_CONV_MAX_TAPS || d.wtaps < d.ntaps || d.sstride < 1)
     return VITTA_ERR_INVALID_ARG;
   a.xP = (int64_t)d.N * d.Hs * d.Ws;
-  if (d.x_ld) {  // the first N frames of rows that hold more
-    if (d.x_ld < a.xP || d.x_ld % 4) return VITTA_ERR_INVALID_ARG;
-    a.xP = d.x_ld;
-  }
   const int64_t P = (int64_t)d.N * d.Hg * d.Wg;
   if (P % 4 || a.xP % 4 || (int64_t)d.C * a.xP * 4 >= (1ll << 31) || (int64_t)d.K * P * 4 >= (1ll << 31)) return VITTA_ERR_UNSUPPORTED;
   if (d.C % 64 || d.K % 64) return VITTA_ERR_UNSUPPORTED;  // row tails would need the scalar offset range-checked

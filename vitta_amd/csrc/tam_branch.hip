@@ -1223,10 +1223,9 @@ int vitta_tam_branch_fwd_fused_f32(const float* d_pooled, const float* d_wg1, co
 
 int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                                    const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                                   const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
+                                   const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                                    const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                                    float* d_gpooled, float* const* h_dbn, float* const* h_dw, void* d_sync, int32_t pooled_tc, void* stream) {
-  if (N_saved < N) return VITTA_ERR_INVALID_ARG;
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn || !d_sync)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T) || N > 32) return VITTA_ERR_UNSUPPORTED;
@@ -1239,7 +1238,7 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
   int nt1, nt2;
   size_t l1, lds;
   if (!fused_geometry(N, C, T, true, nt1, nt2, l1, lds)) return VITTA_ERR_UNSUPPORTED;
-  const float* d_hact = d_hpre + (int64_t)N_saved * O * T;
+  const float* d_hact = d_hpre + (int64_t)N * O * T;
   float* d_dpre = d_gpooled + (int64_t)N * C * T;
   if (use_fast(a, {d_pooled, d_w0, d_w3, d_gate, d_ggate, d_dpre})) {
     auto kfn = a.pooled_tc ? tam_branch_bwd_fast_kernel<true> : tam_branch_bwd_fast_kernel<false>;
@@ -1258,12 +1257,11 @@ int vitta_tam_branch_bwd_fused_f32(const float* d_pooled, const float* d_wg1, co
 
 int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const float* const* h_bn_g, float eps_g,
                              const float* d_wg3, const float* d_w0, const float* const* h_bn_l, float eps_l,
-                             const float* d_w3, int32_t N, int32_t C, int32_t T, int32_t N_saved, const float* d_kern,
+                             const float* d_w3, int32_t N, int32_t C, int32_t T, const float* d_kern,
                              const float* d_gate, const float* d_hpre, const float* d_gkern, const float* d_ggate,
                              float* d_gpooled, float* const* h_dbn /* {dG.w, dG.b, dL.w, dL.b} accumulated into */,
                              float* const* h_dw /* {dwg1, dwg3, dw0, dw3} accumulated into, or NULL entries */, int32_t pooled_tc, void* stream) {
   // d_gpooled doubles as scratch: it must have room for N*C*T + N*(C/4)*T floats (result, then d conv1-output)
-  if (N_saved < N) return VITTA_ERR_INVALID_ARG;
   if (!h_bn_g || !h_bn_l || !d_kern || !d_gate || !d_hpre || !d_gkern || !d_ggate || !d_gpooled || !h_dbn)
     return VITTA_ERR_INVALID_ARG;
   if (!vitta_tam_branch_supported(C, T)) return VITTA_ERR_UNSUPPORTED;
@@ -1274,7 +1272,7 @@ int vitta_tam_branch_bwd_f32(const float* d_pooled, const float* d_wg1, const fl
                    h_dw ? h_dw[2] : nullptr, h_dw ? h_dw[3] : nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int O = C / 4;
-  const float* d_hact = d_hpre + (int64_t)N_saved * O * T;
+  const float* d_hact = d_hpre + (int64_t)N * O * T;
   float* d_dpre = d_gpooled + (int64_t)N * C * T;
   if (!set_lds(tam_branch_b1_kernel, b1_lds(C, T)) || !set_lds(tam_branch_b2_kernel, b2_lds(C, T))) return VITTA_ERR_LAUNCH;
   VITTA_LAUNCH(tam_branch_b1_kernel, dim3(N, (O + OBB - 1) / OBB), dim3(TBW), b1_lds(C, T), st, a, d_gate, d_hpre, d_hact,

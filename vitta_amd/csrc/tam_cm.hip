@@ -456,13 +456,12 @@ int vitta_tam_agg_fwd_cm_f32(const float* d_x, const float* const* h_bn, float e
   return VITTA_OK;
 }
 
-int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* const* h_bn, float eps, const float* d_gate,
-                                const float* d_kern, const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga,
-                                float* d_ggate, float* d_gkern, void* stream) {
+int vitta_tam_agg_bwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
+                             const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga, float* d_ggate,
+                             float* d_gkern, void* stream) {
   if (!d_x || !bn_ok(h_bn) || !d_gate || !d_kern || !d_gout || !d_ga || !d_ggate || !d_gkern || bad(C, N, T, HW))
     return VITTA_ERR_INVALID_ARG;
-  const int64_t xld = x_ld ? x_ld : (int64_t)N * T * HW;
-  if (xld < (int64_t)N * T * HW || ((HW & 3) == 0 && (xld & 3))) return VITTA_ERR_INVALID_ARG;
+  const int64_t xld = (int64_t)N * T * HW;  // pixels per channel row
   hipStream_t st = static_cast<hipStream_t>(stream);
   const BN bn{h_bn[0], h_bn[1], h_bn[2], h_bn[3], eps};
   float* dots = d_ggate + (int64_t)N * C * T;  // the caller gives d_ggate room for N*C*T*4 floats
@@ -495,21 +494,13 @@ int vitta_tam_agg_bwd_cm_ld_f32(const float* d_x, int64_t x_ld, const float* con
   return VITTA_OK;
 }
 
-int vitta_tam_agg_bwd_cm_f32(const float* d_x, const float* const* h_bn, float eps, const float* d_gate, const float* d_kern,
-                             const float* d_gout, int32_t C, int32_t N, int32_t T, int32_t HW, float* d_ga, float* d_ggate,
-                             float* d_gkern, void* stream) {
-  return vitta_tam_agg_bwd_cm_ld_f32(d_x, 0, h_bn, eps, d_gate, d_kern, d_gout, C, N, T, HW, d_ga, d_ggate, d_gkern, stream);
-}
-
-int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, int64_t x_ld,
-                           const float* d_rowadd, float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu,
-                           const float* d_coef_a, const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx,
-                           float* d_gm, float* d_dgamma, float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW,
-                           void* stream) {
+int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, const float* d_rowadd,
+                        float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
+                        const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
+                        float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream) {
   if (!d_g || !d_x || !bn_ok(h_bn) || !d_dx || bad(C, N, T, HW) || C > 65535) return VITTA_ERR_INVALID_ARG;
   const int64_t P = (int64_t)N * T * HW;
   if (P % 4) return VITTA_ERR_UNSUPPORTED;
-  if (x_ld && (x_ld < P || x_ld % 4)) return VITTA_ERR_INVALID_ARG;
   if (d_mu && (!d_coef_a || !d_coef_b)) return VITTA_ERR_INVALID_ARG;
   BnBwd a;
   a.g = d_g; a.g2 = d_g2; a.x = d_x; a.mask = d_mask; a.rowadd = d_rowadd; a.rowadd_scale = rowadd_scale;
@@ -517,7 +508,7 @@ int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x
   a.mu = d_mu; a.ca = d_coef_a; a.cb = d_coef_b; a.gs = d_gscale;
   a.dx = d_dx; a.gm = d_gm; a.dgamma = d_dgamma; a.dbeta = d_dbeta;
   a.C = C; a.N = N; a.T = T; a.HW = HW; a.relu = relu;
-  a.xld = x_ld ? x_ld : P;
+  a.xld = P;
   if (P >= (1ll << 31) - 4) return VITTA_ERR_UNSUPPORTED;
   a.d_hw = vitta_conv::make_fastdiv(HW);
   a.d_t = vitta_conv::make_fastdiv(T);
@@ -537,14 +528,6 @@ int vitta_bn_bwd_cm_ld_f32(const float* d_g, const float* d_g2, const float* d_x
   else BN_BWD_GO(false, false);
 #undef BN_BWD_GO
   return VITTA_OK;
-}
-
-int vitta_bn_bwd_cm_f32(const float* d_g, const float* d_g2, const float* d_x, const float* d_mask, const float* d_rowadd,
-                        float rowadd_scale, const float* const* h_bn, float eps, const float* d_mu, const float* d_coef_a,
-                        const float* d_coef_b, const float* d_gscale, int32_t relu, float* d_dx, float* d_gm, float* d_dgamma,
-                        float* d_dbeta, int32_t C, int32_t N, int32_t T, int32_t HW, void* stream) {
-  return vitta_bn_bwd_cm_ld_f32(d_g, d_g2, d_x, d_mask, 0, d_rowadd, rowadd_scale, h_bn, eps, d_mu, d_coef_a, d_coef_b, d_gscale, relu,
-                                d_dx, d_gm, d_dgamma, d_dbeta, C, N, T, HW, stream);
 }
 
 int vitta_avgpool_cm_f32(const float* d_x, int32_t C, int32_t F, int32_t HW, float* d_feat, void* stream) {

@@ -696,7 +696,7 @@ class TamFused(torch.autograd.Function):
             _grad_sink(v, nd) for v, nd in zip((wg1, wg3, w0, w3), (need[2], need[5], need[6], need[9])))
         gbuf = torch.empty(n * c * t + n * (c // 4) * t, **f)  # d pooled | scratch: d(conv1 output)
         check(lib().vitta_tam_branch_bwd_f32(_p(pooled), _p(wg1), _ptr4(bng_w, bng_b, bng_rm, bng_rv), eps_g, _p(wg3),
-                                             _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), eps_l, _p(w3), n, c, t, n,
+                                             _p(w0), _ptr4(bnl_w, bnl_b, bnl_rm, bnl_rv), eps_l, _p(w3), n, c, t,
                                              _p(kern), _p(gate), _p(hpre), _p(gkern), _p(ggate), _p(gbuf),
                                              _ptr4(dgw, dgb, dlw, dlb), _ptr4(dwg1, dwg3, dw0, dw3), 0, st),
               "vitta_tam_branch_bwd_f32")

@@ -92,16 +92,10 @@ class ResNet(nn.Module):
                 and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) ==
                 (3, 2, 1, 1, False) and y.shape[0] * y.shape[1] <= 65535)
 
-    def forward(self, x, n_grad=None):
+    def forward(self, x):
         # the hand-written trunk (vitta_amd/trunk.py: every convolution is vitta_conv_f32) whenever the configuration
         # allows it; otherwise module by module (library convolutions + the fused BN passes)
         from . import trunk
-        if n_grad is not None:  # frames x[n_grad:] ride along (trunk.ride_along_ok): (head of the adaptation frames, their
-            # plain features -- no dropout, no gradient)
-            feat, rider = trunk.run(self, x, n_grad)
-            with torch.no_grad():  # `fc` as model.eval() would apply it
-                rider = rider if isinstance(self.fc, (nn.Dropout, nn.Identity)) else nn.functional.linear(rider, self.fc.weight, self.fc.bias)
-            return self.fc(feat), rider
         feat = trunk.run(self, x)
         if feat is not None:
             return self.fc(feat)

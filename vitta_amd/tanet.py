@@ -35,18 +35,6 @@ def _noop_hooks_only(module):
     return not module._forward_pre_hooks
 
 
-class _Shape:
-    """What trunk.eligible reads of a tensor, for the concatenation of `like` with more frames (nothing is allocated)."""
-
-    def __init__(self, like, frames):
-        self.shape = (frames,) + tuple(like.shape[1:])
-        self.is_cuda, self.dtype, self.device = like.is_cuda, like.dtype, like.device
-        self.requires_grad = like.requires_grad
-
-    def dim(self):
-        return len(self.shape)
-
-
 def _tam_aggregate_torch(x, gate, kern, t):
     """out[n,t] = K0 g[t-1] x[t-1] + K1 g[t] x[t] + K2 g[t+1] x[t+1] with zero padding in T."""
     nt, c, h, w = x.shape
@@ -226,33 +214,10 @@ class TSN(nn.Module):
             input = input.view((-1, 3 * self.new_length) + input.size()[-2:])
         return trunk.run(self.base_model, input)
 
-    def ride_along_ok(self, input, rider):
-        """True when `forward(input, rider=rider)` can take the evaluation clips `rider` through the trunk inside the
-        adaptation forward of `input` (same weights, every BatchNorm in eval(): the per-frame arithmetic is the same)."""
-        from . import trunk
-        fc = self.base_model.fc
-        if not self.tam or input.dim() < 4 or rider.shape[-2:] != input.shape[-2:] or fc._forward_hooks \
-                or not isinstance(fc, (nn.Dropout, nn.Identity, nn.Linear)):
-            return False
-        a = input.view((-1, 3 * self.new_length) + input.size()[-2:])
-        b = rider.view((-1, 3 * self.new_length) + rider.size()[-2:])
-        if a.device != b.device or a.dtype != b.dtype:
-            return False
-        return trunk.ride_along_ok(self.base_model, _Shape(a, a.shape[0] + b.shape[0]), a.shape[0])
-
-    def forward(self, input, no_reshape=False, rider=None):
-        """rider (tta.py): clips of ANOTHER video to evaluate with the current weights; their frames go through the trunk
-        behind `input`'s in the same launches, their features skip the dropout and take no part in statistics or gradients.
-        Returns (logits of input, logits of rider) then."""
+    def forward(self, input, no_reshape=False):
         if not no_reshape:
             sample_len = 3 * self.new_length
             input = input.view((-1, sample_len) + input.size()[-2:])
-        if rider is not None:
-            rider = rider.view((-1, 3 * self.new_length) + rider.size()[-2:])
-            base_out, feat_r = self.base_model(torch.cat([input, rider]), n_grad=input.shape[0])
-            with torch.no_grad():
-                out_r = self._head(feat_r)
-            return self._head(base_out), out_r
         return self._head(self.base_model(input))
 
     @property

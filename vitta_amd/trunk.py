@@ -540,7 +540,7 @@ class TrunkRunner:
                                                            n, c, h, w, _p(dw), _p(db), _stream()),
               "vitta_stem_bn_relu_pool_bwd_affine_f32")
 
-    def block_forward(self, b, xin, n, h, w, keep, sites, ng=None, pool=None):
+    def block_forward(self, b, xin, n, h, w, keep, sites, pool=None):
         """pool: [zeroed int64 buffer, next offset] of the pass in progress (POOL_FOLD) -- a local of forward(), not runner state."""
         net, tam = b.net, b.tam
         t = b.n_segment
@@ -551,7 +551,6 @@ class TrunkRunner:
         L = lib()
         st = _stream()
         P = n * h * w
-        ng = n if ng is None else ng  # frames of the adaptation batch (a prefix); the rest ride along (evaluation clip)
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
         # identity path (first bottleneck of a stage: 1x1 convolution + BN, beside the main chain)
         xd = None
@@ -566,7 +565,7 @@ class TrunkRunner:
 
             def identity_path():
                 CV.launch(gdn, xin, wd, ident, cin, 4 * p, flags=CV.CONV_EPI_APPLY | _sflags(sd), y_raw=xd,
-                          epi_bn=_bn_t(dbn), eps=dbn.eps, stats=sd.stats if sd else None, stat_m=ng * gdn.hy * gdn.wy if ng != n else 0)
+                          epi_bn=_bn_t(dbn), eps=dbn.eps, stats=sd.stats if sd else None)
             identity_path()
         else:
             ident = xin
@@ -582,7 +581,7 @@ class TrunkRunner:
             pool[1] = off + n * p
         CV.launch(self.geo("f", n, h, w), xin, self.packed(net.conv1, "f", keep), x1, cin, p, flags=_sflags(s1),
                   epi_bn=_bn_t(net.bn1) if (s1 or pooled is not None) else None, eps=net.bn1.eps, stats=s1.stats if s1 else None,
-                  stat_m=ng * h * w if ng != n else 0, pool=pooled)
+                  pool=pooled)
         # TAM on relu(bn1(x1))
         bn1p = _bn_ptrs(net.bn1)
         if pooled is None:
@@ -616,36 +615,29 @@ class TrunkRunner:
         x2 = torch.empty(p, Po, **f) if keep else None
         CV.launch(g2, a1, self.packed(net.conv2, "f", keep), a2, p, p,
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | _sflags(s2), y_raw=x2,
-                  epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None, stat_m=ng * ho * wo if ng != n else 0)
+                  epi_bn=_bn_t(net.bn2), eps=net.bn2.eps, stats=s2.stats if s2 else None)
         # conv3 -> x3 raw, out
         out = torch.empty(4 * p, Po, **f)
         x3 = torch.empty(4 * p, Po, **f) if keep else None
         CV.launch(self.geo("f", n, ho, wo), a2, self.packed(net.conv3, "f", keep), out, p, 4 * p,
                   flags=CV.CONV_EPI_APPLY | CV.CONV_EPI_RELU | CV.CONV_RES | _sflags(s3),
-                  y_raw=x3, res=ident, epi_bn=_bn_t(net.bn3), eps=net.bn3.eps, stats=s3.stats if s3 else None,
-                  stat_m=ng * ho * wo if ng != n else 0)
+                  y_raw=x3, res=ident, epi_bn=_bn_t(net.bn3), eps=net.bn3.eps, stats=s3.stats if s3 else None)
         saved = None
         if keep:
             saved = dict(xin=xin, x1=x1, pooled=pooled, ptc=ptc, kern=kern, gate=gate, hpre=hpre, x2=x2, x3=x3, out=out, xd=xd,
                          a1=a1 if net.conv2.weight.requires_grad else None,
-                         a2=a2 if net.conv3.weight.requires_grad else None, dims=(ng, h, w, ho, wo), frames=n)
+                         a2=a2 if net.conv3.weight.requires_grad else None, dims=(n, h, w, ho, wo))
         return out, ho, wo, saved
 
-    def forward(self, x, keep, pooled_in=None, n_grad=None):
+    def forward(self, x, keep, pooled_in=None):
         """x [N, 3, H, W] -> (features [N, 2048], tape).  keep: save what the backward needs.  pooled_in: the stem's output
-        [N, 64, h, w] computed outside (trainable stem convolution); the tape then ends at it.  n_grad: the first n_grad
-        frames are the adaptation batch (statistics sites, tape, backward); the frames after them ride along -- the
-        evaluation clip of the previous video, which reads the same weights (tta.py) -- and only their features are used."""
+        [N, 64, h, w] computed outside (trainable stem convolution); the tape then ends at it."""
         cur_stream = torch.cuda.current_stream(x.device).cuda_stream
         self._step_packs = {k: v for k, v in self._step_packs.items() if k[2] != cur_stream}  # this stream's packs are stale
         self.refresh_packs(x.device, adapt=keep)
         self._adapt_pass = keep
-        ng = x.shape[0] if n_grad is None else int(n_grad)
-        xg = x if ng == x.shape[0] else x[:ng]
-        sites = self.open_sites(xg) if keep else {}
-        producers = self.open_producer_sites(xg)
-        if ng != x.shape[0] and (not keep or pooled_in is not None or producers or id(self.net.bn1) in sites):
-            raise RuntimeError("vitta_amd.trunk: frames can only ride along an adaptation forward with the stem inside the node")
+        sites = self.open_sites(x) if keep else {}
+        producers = self.open_producer_sites(x)
         if producers:
             if any(k in sites for k in producers):
                 raise RuntimeError("a BatchNorm2d carries both an engine hook and a statistics-producer hook: use the module path")
@@ -675,13 +667,13 @@ class TrunkRunner:
                 buf = torch.zeros(npool, dtype=torch.int64, device=x.device)
             pool = [buf, 0]
         for b in blocks:
-            cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, ng, pool)
+            cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, pool)
             tape.append(saved)
         c = cur.shape[0]
         feat = torch.empty(n, c, dtype=torch.float32, device=x.device)
         check(lib().vitta_avgpool_cm_f32(_p(cur), c, n, h * w, _p(feat), _stream()), "vitta_avgpool_cm_f32")
         if producers:  # source-statistics producer: hand every hook its batch moments
-            shapes = self.feature_shapes(xg)
+            shapes = self.feature_shapes(x)
             for site in producers.values():
                 frames, _, hw, _ = shapes[id(site.bn)]
                 site.finish(frames * hw)
@@ -691,7 +683,7 @@ class TrunkRunner:
             sites = {k: v for k, v in sites.items() if k not in producers}
         return feat, dict(tape=tape, sites=sites, stem=y if (keep and pooled_in is None) else None,
                           x=x if (keep and pooled_in is None and self.net.conv1.weight.requires_grad) else None, pooled_hw=h0w0,
-                          last=(c, ng, h, w))
+                          last=(c, n, h, w))
 
     # -- backward ----------------------------------------------------------------------------------------------
     def block_backward(self, b, sv, G, sites, sink, prev=None):
@@ -710,8 +702,6 @@ class TrunkRunner:
                 wq.append((a, kw))
             else:
                 CV.wgrad(*a, **kw)
-        fr = sv["frames"]  # frames per channel row of the saved tensors (> n when an evaluation clip rode along)
-        ldP, ldPo = (fr * h * w, fr * ho * wo) if fr != n else (0, 0)
         cin, p, s = net.conv1.in_channels, net.conv1.out_channels, net.conv2.stride[0]
         dev = (G[0] if isinstance(G, tuple) else G).device
         f = dict(dtype=torch.float32, device=dev)
@@ -720,15 +710,15 @@ class TrunkRunner:
         P, Po = n * h * w, n * ho * wo
         s1, s2, s3 = sites.get(id(net.bn1)), sites.get(id(net.bn2)), sites.get(id(net.bn3))
 
-        def bn_bwd(g, x, bn, site, relu, mask=None, gm=None, rowadd=None, c=None, hw=None, dx=None, ld=0):
+        def bn_bwd(g, x, bn, site, relu, mask=None, gm=None, rowadd=None, c=None, hw=None, dx=None):
             dx = torch.empty_like(g) if dx is None else dx
             st = _stream()
             dg, db = sink(bn.weight), sink(bn.bias)
             inj = site.inj if site else (None, None, None, None)
-            check(L.vitta_bn_bwd_cm_ld_f32(_p(g), None, _p(x), _p(mask), ld, _p(rowadd), (1.0 / hw) if rowadd is not None else 0.0,
-                                           _bn_ptrs(bn), float(bn.eps), _p(inj[0]), _p(inj[1]), _p(inj[2]), _p(inj[3]),
-                                           int(relu) | (_lib.BN_BWD_INJ_RAW if (site and site.raw) else 0),
-                                           _p(dx), _p(gm), _p(dg), _p(db), c, nb, t, hw, st), "vitta_bn_bwd_cm_ld_f32")
+            check(L.vitta_bn_bwd_cm_f32(_p(g), None, _p(x), _p(mask), _p(rowadd), (1.0 / hw) if rowadd is not None else 0.0,
+                                        _bn_ptrs(bn), float(bn.eps), _p(inj[0]), _p(inj[1]), _p(inj[2]), _p(inj[3]),
+                                        int(relu) | (_lib.BN_BWD_INJ_RAW if (site and site.raw) else 0),
+                                        _p(dx), _p(gm), _p(dg), _p(db), c, nb, t, hw, st), "vitta_bn_bwd_cm_f32")
             return dx
 
         # bn3 (+ identity add + ReLU) backward -- unless the launch that produced G did it (BN3_FOLD)
@@ -737,7 +727,7 @@ class TrunkRunner:
             G = g_id  # (device, shape)
         else:
             g_id = torch.empty_like(G)
-            dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo, ld=ldPo)
+            dx3 = bn_bwd(G, sv["x3"], net.bn3, s3, True, mask=sv["out"], gm=g_id, c=4 * p, hw=ho * wo)
         # identity / downsample path of a stage's first bottleneck, beside the main chain: bn_d backward, its data gradient
         if net.downsample is not None:
             dconv, dbn = net.downsample[0], net.downsample[1]
@@ -748,9 +738,9 @@ class TrunkRunner:
             wdb = self.packed(dconv, "b", True)
 
             def identity_path():
-                bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo, dx=dxd, ld=ldPo)
+                bn_bwd(g_id, sv["xd"], dbn, sd, False, c=4 * p, hw=ho * wo, dx=dxd)
                 if dconv.weight.requires_grad:
-                    wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p, x_ld=ldP)
+                    wgrad(self.geo("f", n, h, w, 1, ds, 0), sv["xin"], dxd, sink(dconv.weight), cin, 4 * p)
                 CV.launch(self.geo("b", n, h, w, 1, ds, 0)[0], dxd, wdb, gd, 4 * p, cin)
             identity_path()
         # conv3 data gradient, epilogue = bn2 (+ReLU) backward
@@ -759,12 +749,12 @@ class TrunkRunner:
         CV.launch(self.geo("b", n, ho, wo)[0], dx3, self.packed(net.conv3, "b", True), dx2, 4 * p, p,
                   flags=CV.CONV_BWD_BN | CV.CONV_BWD_RELU | (CV.CONV_INJ_RAW if (s2 and s2.raw) else 0), bwd_bn=_bn_t(net.bn2),
                   eps=net.bn2.eps, bwd_x=sv["x2"], inj=i2,
-                  dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias), bwd_ld=ldPo)
+                  dgamma=sink(net.bn2.weight), dbeta=sink(net.bn2.bias))
         if net.conv3.weight.requires_grad:
-            wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p, x_ld=ldPo)
+            wgrad(self.geo("f", n, ho, wo), sv["a2"], dx3, sink(net.conv3.weight), p, 4 * p)
         del dx3
         if net.conv2.weight.requires_grad:
-            wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p, x_ld=ldP)
+            wgrad(self.geo("f", n, h, w, 3, s, 1), sv["a1"], dx2, sink(net.conv2.weight), p, p)
         # conv2 data gradient -> d a1
         ga1 = torch.empty(p, P, **f)
         wb2 = self.packed(net.conv2, "b", True)
@@ -780,8 +770,8 @@ class TrunkRunner:
         ga = torch.empty(p, P, **f)
         ggate = torch.empty(nb * p * t * 4, **f)
         gkern = torch.empty(nb * p, 3, **f)
-        check(L.vitta_tam_agg_bwd_cm_ld_f32(_p(sv["x1"]), ldP, bn1p, float(net.bn1.eps), _p(sv["gate"]), _p(sv["kern"]), _p(ga1), p, nb,
-                                            t, h * w, _p(ga), _p(ggate), _p(gkern), st), "vitta_tam_agg_bwd_cm_ld_f32")
+        check(L.vitta_tam_agg_bwd_cm_f32(_p(sv["x1"]), bn1p, float(net.bn1.eps), _p(sv["gate"]), _p(sv["kern"]), _p(ga1), p, nb,
+                                         t, h * w, _p(ga), _p(ggate), _p(gkern), st), "vitta_tam_agg_bwd_cm_f32")
         del ga1
         bg, bl = tam.G[1], tam.L[1]
         from .ops import _ptr4
@@ -796,7 +786,7 @@ class TrunkRunner:
             w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), None, None)
             pooled_sv, gate_sv, hpre_sv, ptc_sv = sv["pooled"], sv["gate"], sv["hpre"], sv["ptc"]
             tq.append(lambda: check(L.vitta_tam_branch_wgrad_f32(
-                _p(pooled_sv), ptc_sv, _p(gate_sv), _p(ggate), C.c_void_p(hpre_sv.data_ptr() + 4 * (fr // t) * (p // 4) * t),
+                _p(pooled_sv), ptc_sv, _p(gate_sv), _p(ggate), C.c_void_p(hpre_sv.data_ptr() + 4 * nb * (p // 4) * t),
                 C.c_void_p(gbuf.data_ptr() + 4 * nb * p * t), nb, p, t, _p(dw0), _p(dw3), _stream()), "vitta_tam_branch_wgrad_f32"))
         else:
             w_sinks = _ptr4(sink(tam.G[0].weight), sink(tam.G[3].weight), dw0, dw3)
@@ -804,20 +794,20 @@ class TrunkRunner:
             check(L.vitta_tam_branch_bwd_fused_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                                    float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                                    _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                                   _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                                   _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
                                                    _p(ggate), _p(gbuf), bn_sinks, w_sinks, _p(_sync(dev)), sv["ptc"], st),
                   "vitta_tam_branch_bwd_fused_f32")
         else:
             check(L.vitta_tam_branch_bwd_f32(_p(sv["pooled"]), _p(tam.G[0].weight), _ptr4(bg.weight, bg.bias, bg.running_mean, bg.running_var),
                                              float(bg.eps), _p(tam.G[3].weight), _p(tam.L[0].weight),
                                              _ptr4(bl.weight, bl.bias, bl.running_mean, bl.running_var), float(bl.eps),
-                                             _p(tam.L[3].weight), nb, p, t, fr // t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
+                                             _p(tam.L[3].weight), nb, p, t, _p(sv["kern"]), _p(sv["gate"]), _p(sv["hpre"]), _p(gkern),
                                              _p(ggate), _p(gbuf), bn_sinks, w_sinks, sv["ptc"], st), "vitta_tam_branch_bwd_f32")
         # bn1 (+ReLU) backward with the pooling gradient added per (n, c, t) row
-        dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w, ld=ldP)
+        dx1 = bn_bwd(ga, sv["x1"], net.bn1, s1, True, rowadd=gbuf, c=p, hw=h * w)
         del ga
         if net.conv1.weight.requires_grad:
-            wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p, x_ld=ldP)
+            wgrad(self.geo("f", n, h, w), sv["xin"], dx1, sink(net.conv1.weight), cin, p)
         # join the identity / downsample path
         gin = torch.empty(cin, P, **f)
         if net.downsample is not None:
@@ -825,7 +815,7 @@ class TrunkRunner:
         else:
             res, rflag = g_id, CV.CONV_RES
         fold = None
-        if BN3_FOLD and prev is not None and fr == n and prev[1]["frames"] == prev[1]["dims"][0]:
+        if BN3_FOLD and prev is not None:
             pnet, psv = prev[0].net, prev[1]
             ps3 = sites.get(id(pnet.bn3))
             g_idp = torch.empty(cin, P, **f)  # the masked gradient: the previous block's identity path reads it
@@ -860,9 +850,9 @@ class TrunkRunner:
             self._wgrad_pending = []
 
     def backward(self, ctxd, gfeat, sink):
-        c, n, h, w = ctxd["last"]  # n: frames of the adaptation batch (frames that rode along have no backward)
+        c, n, h, w = ctxd["last"]
         G = torch.empty(c, n * h * w, dtype=torch.float32, device=gfeat.device)
-        check(lib().vitta_avgpool_cm_bwd_f32(_p(gfeat[:n].contiguous()), c, n, h * w, _p(G), _stream()), "vitta_avgpool_cm_bwd_f32")
+        check(lib().vitta_avgpool_cm_bwd_f32(_p(gfeat.contiguous()), c, n, h * w, _p(G), _stream()), "vitta_avgpool_cm_bwd_f32")
         blocks = self.blocks()
         try:
             for i in range(len(blocks) - 1, -1, -1):
@@ -880,7 +870,7 @@ class TrunkRunner:
             return CV.from_cm(G, n, h0, w0)
         # stem: bn1 affine gradients through the fused BN + ReLU + max-pool pass (the 7x7 convolution is frozen)
         x0 = ctxd.get("x")
-        self.stem_backward(ctxd["stem"][:n], G, (n, h0, w0), sink, x=None if x0 is None else x0[:n])
+        self.stem_backward(ctxd["stem"], G, (n, h0, w0), sink, x=x0)
         return None
 
 
@@ -889,22 +879,18 @@ class TrunkFunction(torch.autograd.Function):
     schedules this node); their gradients are written by the kernels straight into `.grad` storage where it exists."""
 
     @staticmethod
-    def forward(ctx, x, runner, pooled, n_grad, *params):
+    def forward(ctx, x, runner, pooled, *params):
         ctx.set_materialize_grads(False)
-        feat, tape = runner.forward(x, True, pooled_in=pooled, n_grad=n_grad)
+        feat, tape = runner.forward(x, True, pooled_in=pooled)
         ctx.runner, ctx.tape, ctx.params = runner, tape, params
-        if n_grad is None:
-            return feat
-        rider = feat[n_grad:]  # features of the frames that rode along: no gradient
-        ctx.mark_non_differentiable(rider)
-        return feat[:n_grad], rider
+        return feat
 
     @staticmethod
-    def backward(ctx, gfeat, grider=None):
+    def backward(ctx, gfeat):
         from . import ops
         runner, params = ctx.runner, ctx.params
         if gfeat is None:
-            return (None, None, None, None) + tuple(None for _ in params)
+            return (None, None, None) + tuple(None for _ in params)
         bufs = {}
 
         def sink(param):
@@ -922,7 +908,7 @@ class TrunkFunction(torch.autograd.Function):
         for p in params:
             hit = bufs.get(id(p))
             grads.append(hit[1] if hit is not None else None)
-        return (None, None, gpooled, None) + tuple(grads)
+        return (None, None, gpooled) + tuple(grads)
 
 
 def runner_of(resnet):
@@ -933,31 +919,9 @@ def runner_of(resnet):
     return runner
 
 
-def ride_along_ok(resnet, x, n_grad):
-    """True when `run(resnet, x, n_grad)` takes frames x[n_grad:] along an adaptation forward of x[:n_grad] (tta.py: the
-    evaluation clip of the previous video inside the adaptation forward of the next, one launch sequence for both)."""
+def run(resnet, x):
+    """features [N, 2048] of the trunk on the hand-written path, or None if the configuration needs the module path."""
     runner = runner_of(resnet)
-    if not (torch.is_grad_enabled() and runner.eligible(x) and 0 < n_grad < x.shape[0]):
-        return False
-    t = runner.blocks()[0].n_segment
-    hh, ww = CV.out_size(CV.out_size(x.shape[2], 7, 2, 3), 3, 2, 1), CV.out_size(CV.out_size(x.shape[3], 7, 2, 3), 3, 2, 1)
-    for _ in range(4):  # the adaptation frames alone keep every pixel count a multiple of four, too
-        if (n_grad * hh * ww) % 4:
-            return False
-        hh, ww = CV.out_size(hh, 3, 2, 1), CV.out_size(ww, 3, 2, 1)
-    y_w = (x.shape[3] - 1) // 2 + 1
-    if resnet.conv1.weight.requires_grad and (y_w % 4 or y_w > 256):  # the stem would run outside the node
-        return False
-    return n_grad % t == 0 and _engine_hook(resnet.bn1)[1] is None and not _producer_hooks(resnet.bn1) \
-        and not any(_producer_hooks(m) for m in runner.bn2d_modules())
-
-
-def run(resnet, x, n_grad=None):
-    """features [N, 2048] of the trunk on the hand-written path, or None if the configuration needs the module path.
-    n_grad (see ride_along_ok): returns (features of x[:n_grad] under autograd, features of x[n_grad:] detached)."""
-    runner = runner_of(resnet)
-    if n_grad is not None and not ride_along_ok(resnet, x, n_grad):
-        raise RuntimeError("vitta_amd.trunk: this configuration cannot take frames along (ask ride_along_ok first)")
     if not runner.eligible(x):
         return None
     params = [p for m in runner.bn2d_modules() for p in (m.weight, m.bias)]
@@ -980,7 +944,7 @@ def run(resnet, x, n_grad=None):
             params = [p for p in params if id(p) not in stem_params]
         if pooled is None and resnet.conv1.weight.requires_grad:
             params = params + [resnet.conv1.weight]
-        return TrunkFunction.apply(x, runner, pooled, n_grad, *[p for p in params if p.requires_grad])
+        return TrunkFunction.apply(x, runner, pooled, *[p for p in params if p.requires_grad])
     with torch.no_grad():
         feat, _ = runner.forward(x, False)
-    return feat if n_grad is None else (feat[:n_grad], feat[n_grad:])
+    return feat

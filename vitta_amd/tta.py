@@ -42,13 +42,6 @@ GRAPH_AFTER_STEPS = 3
 CAPTURE_MODE = "thread_local"
 # the TANet head of the adaptation pass + the loss combination as our own launches (ops.TanetHead, ops.WeightedLoss); "0": module chain
 FUSED_HEAD = os.environ.get("VITTA_FUSED_HEAD", "1") != "0"
-# the evaluation clip of the previous video inside the adaptation forward of the next (ViTTAAdapter.ride_along_ok): one launch
-# sequence over 24 frames instead of 16 + 8 on two streams.  Measured on MI355X (round 3, same box, hipGraph replay): 104
-# instead of 156 convolution launches per video and 4.38 instead of 4.57 ms of convolution kernel time, but 6.20 ms per video
-# against 5.75 -- at 16 frames the launches already fill the chip (a 24-frame launch takes 1.5x a 16-frame one), so the
-# evaluation on its own stream hides in the adaptation pass's idle slots while riding along lengthens the critical path.
-# Opt-in.
-RIDE_ALONG = os.environ.get("VITTA_EVAL_RIDE_ALONG", "0") != "0"
 # overlapped step with trainable convolution weights: pack them once per step, not once per pass (ViTTAAdapter._prepacked)
 PREPACK = os.environ.get("VITTA_PREPACK", "1") != "0"
 
@@ -392,7 +385,6 @@ class ViTTAAdapter:
         self.n_views = args.test_crops * (args.n_augmented_views if args.if_sample_tta_aug_views else self.n_clips)
         self._graph = None
         self._side_stream = None
-        self._rider_out = None
         self.engine = None
         if args.stat_reg == "BNS":
             # regularise the BN INPUT statistics towards the layer's own running statistics (basics.py:588-599)
@@ -475,9 +467,9 @@ class ViTTAAdapter:
             return input.view(bz * a.test_crops * self.n_clips, a.clip_length, 3, input.size(2), input.size(3))
         return input
 
-    def forward_losses(self, input, actual_bz, rider=None):
+    def forward_losses(self, input, actual_bz):
         """Adaptation forward: (video logits, loss_reg, loss_consis or None)."""
-        output, loss_consis = self.forward_local(input, actual_bz, rider)
+        output, loss_consis = self.forward_local(input, actual_bz)
         if self.engine is not None:
             self.engine.exchange()
             loss_reg = self.engine.finish_global(tie=None if self.if_pred_consistency else output)
@@ -487,30 +479,12 @@ class ViTTAAdapter:
                 loss_reg = loss_reg + h.r_feature.to(output.device)
         return output, loss_reg, loss_consis
 
-    def ride_along_ok(self, tta_input, eval_input):
-        """The evaluation clip of the previous video can go through the trunk INSIDE the adaptation forward of this one
-        (TANet on the hand-written trunk, adaptation mode = every BatchNorm in eval()): both read the weights left by
-        the previous update, so one launch sequence over adaptation + evaluation frames gives the overlapped schedule's
-        results with a third fewer launches (VITTA_EVAL_RIDE_ALONG=1; see RIDE_ALONG for why it is not the default)."""
-        net = self.model.module if isinstance(self.model, SingleDeviceParallel) else self.model
-        return (RIDE_ALONG and self.args.arch == "tanet" and self.device.type == "cuda" and eval_input is not None
-                and hasattr(net, "ride_along_ok") and net.training and net.ride_along_ok(tta_input, eval_input))
-
-    def forward_local(self, input, actual_bz, rider=None):
+    def forward_local(self, input, actual_bz):
         """Everything of the adaptation forward that needs no communication: model forward, view
-        consistency, this rank's additive moments.  rider: evaluation clips taken along (ride_along_ok); their video
-        logits are left in self._rider_out."""
+        consistency, this rank's additive moments."""
         a = self.args
         loss_consis = None
-        if a.arch == "tanet" and rider is not None:
-            output, out_r = self.model(input, rider=rider)
-            bz = rider.shape[0] // (a.test_crops * self.n_clips)
-            self._rider_out = out_r.detach().reshape(bz, a.test_crops * self.n_clips, -1).mean(1)
-            output = output.reshape(actual_bz, self.n_views, -1)
-            if self.if_pred_consistency:
-                loss_consis = compute_pred_consis(output)
-            output = output.mean(1)
-        elif a.arch == "tanet":
+        if a.arch == "tanet":
             fused = self._fused_head(input, actual_bz)
             if fused is not None:
                 output, loss_consis = fused
@@ -670,9 +644,6 @@ class ViTTAAdapter:
             self.add_hooks_back()
             self.set_adapt_mode()
             return self._adapt_step_eager(tta_input, has_video), ev
-        if has_video and self.ride_along_ok(tta_input, eval_input):
-            out = self._adapt_step_eager(tta_input, True, rider=eval_input)
-            return out, self._rider_out
         with self._prepacked():
             ev, side = self._fork_eval(eval_input)
             out = self._adapt_step_eager(tta_input, has_video, join=side)
@@ -824,13 +795,13 @@ class ViTTAAdapter:
             return g["adapt_out"]
         return self._adapt_step_eager(input, has_video)
 
-    def _adapt_step_eager(self, input, has_video=True, join=None, rider=None):
+    def _adapt_step_eager(self, input, has_video=True, join=None):
         a = self.args
         self.arena.zero_grad()
         output = loss_reg = loss_consis = None
         if has_video:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
-            output, loss_reg, loss_consis = self.forward_losses(input, actual_bz, rider)
+            output, loss_reg, loss_consis = self.forward_losses(input, actual_bz)
             self.arena.before_backward()
             self._exchange_begin()
             self._backward(self.total_loss(loss_reg, loss_consis))
@@ -866,17 +837,13 @@ class ViTTAAdapter:
         actual_bz = x.shape[0] // self.n_views if a.arch == "tanet" else x.shape[0]
         pool = torch.cuda.graph_pool_handle()
         g["seg_fwd"] = torch.cuda.CUDAGraph()
-        ride = overlap_eval and self.ride_along_ok(x, g["eval_in"])
-        g["ride_along"] = ride
         with torch.cuda.graph(g["seg_fwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
-            with self._prepacked() if (overlap_eval and not ride) else contextlib.nullcontext():
-                if overlap_eval and not ride:  # the evaluation of the previous video rides beside the adaptation forward
+            with self._prepacked() if overlap_eval else contextlib.nullcontext():
+                if overlap_eval:  # the evaluation of the previous video runs beside the adaptation forward
                     g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
                 self.arena.zero_grad()
-                output, loss_consis = self.forward_local(x, actual_bz, g["eval_in"] if ride else None)
-            if ride:  # ... or inside it
-                g["eval_out_overlapped"] = self._rider_out
-            elif overlap_eval:
+                output, loss_consis = self.forward_local(x, actual_bz)
+            if overlap_eval:
                 torch.cuda.current_stream().wait_stream(side)
         g["seg_bwd"] = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g["seg_bwd"], pool=pool, capture_error_mode=CAPTURE_MODE):
@@ -961,16 +928,10 @@ class ViTTAAdapter:
                 g["step"] = None  # step() replays the three segments
         elif overlap_eval:
             g["step"] = torch.cuda.CUDAGraph()
-            ride = self.ride_along_ok(g["tta_in"], g["eval_in"])
             with torch.cuda.graph(g["step"], capture_error_mode=CAPTURE_MODE):
-                if ride:
-                    g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, rider=g["eval_in"])
-                    g["eval_out_overlapped"] = self._rider_out
-                else:
-                    with self._prepacked():
-                        g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
-                        g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
-            g["ride_along"] = ride
+                with self._prepacked():
+                    g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
+                    g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
         else:
             g["adapt"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["adapt"], capture_error_mode=CAPTURE_MODE):
