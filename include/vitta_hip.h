@@ -678,6 +678,19 @@ int vitta_ln_bwd_mixed(const void* d_gy, const float* d_gxnew, const float* d_x,
                        void* stream);
 int vitta_colsum2_f32(const float* d_partial, int64_t n_partials, int32_t C, float* d_out_a, float* d_out_b, float* d_cnt,
                       float cnt_value, void* stream);
+/* The same sums for n_items partial matrices (a HOST array of items, read during the call) in one launch per 32 items: the
+ * column sums of a pass's LayerNorm sites, deferred to the point where their results are first read (vitta_amd/ops.py:
+ * ColsumQueue).  Items may share outputs (the sums are atomic adds). */
+typedef struct {
+  const float* d_partial; /* [n_partials][2][C] */
+  int64_t n_partials;
+  int32_t C;
+  float cnt_value;
+  float* d_out_a; /* [C] += */
+  float* d_out_b; /* [C] += */
+  float* d_cnt;   /* optional: <- cnt_value */
+} vitta_colsum_item;
+int vitta_colsum2_multi_f32(const vitta_colsum_item* h_items, int32_t n_items, void* stream);
 
 /* --------------------------------------------------------------------------
  * A8 -- ResNet stem tail in one pass: eval BatchNorm -> ReLU -> MaxPool2d(3, stride 2, pad 1) over the 7x7 convolution's

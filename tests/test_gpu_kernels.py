@@ -849,6 +849,67 @@ def test_batchnorm_backward_on_channel_major_planes(c, nb, t, hw, relu, mask, ro
     assert (gm.cpu().double() - mref).abs().max().item() <= 1e-6 * mref.abs().max().item()
 
 
+def test_batched_column_sums_equal_the_per_site_launches():
+    """vitta_colsum2_multi_f32 (the deferred column sums of a pass's LayerNorm sites: one launch per 32 items) == one
+    vitta_colsum2_f32 per item: 40 items (two launches), ragged partial counts, every supported width, outputs that already hold
+    values, two items sharing one output pair, the optional count word -- and through ops.ColsumQueue."""
+    from vitta_amd import _lib, ops
+    from vitta_amd.ops import _p, _stream
+    L, d = _lib.lib(), _dev()
+    gen = torch.Generator().manual_seed(5)
+    items, ref = [], []
+    shared = None
+    for i in range(40):
+        c = (128, 256, 512, 1024, 2048)[i % 5]
+        nb = (1, 7, 32, 33, 196, 1568)[i % 6]
+        part = torch.randn(nb, 2, c, generator=gen).to(d)
+        if i == 11 and shared is not None:
+            a, b = shared
+            a0, b0 = None, None
+        else:
+            a, b = torch.randn(c, generator=gen).to(d), torch.randn(c, generator=gen).to(d)
+            a0, b0 = a.clone(), b.clone()
+        if i == 6:
+            shared = (a, b)
+        cnt = torch.zeros(1, device=d) if i % 3 == 0 else None
+        items.append((part, nb, c, a, b, cnt, float(i + 1)))
+        ref.append((a0, b0))
+    # expected: fp64 sums on top of the initial values (item 11 adds to item 6's outputs)
+    exp = {}
+    for i, (part, nb, c, a, b, cnt, cv) in enumerate(items):
+        key = 6 if i == 11 else i
+        a0, b0 = ref[key]
+        ea, eb = exp.get(key, (a0.double().cpu(), b0.double().cpu()))
+        exp[key] = (ea + part[:, 0].double().sum(0).cpu(), eb + part[:, 1].double().sum(0).cpu())
+    q = ops.ColsumQueue()
+    for it in items:
+        q.add(*it)
+    q.flush()
+    assert not q.items
+    torch.cuda.synchronize()
+    for i, (part, nb, c, a, b, cnt, cv) in enumerate(items):
+        if i == 11:
+            continue
+        ea, eb = exp[i]
+        tol = 1e-5 * max(1.0, float(part.abs().sum(0).max()))
+        assert (a.double().cpu() - ea).abs().max().item() <= tol and (b.double().cpu() - eb).abs().max().item() <= tol, i
+        if cnt is not None:
+            assert cnt.item() == cv
+    # the per-site entry point on the same partial rows gives the same sums (another order of the atomic adds)
+    part, nb, c = items[5][0], items[5][1], items[5][2]
+    a1, b1 = torch.zeros(c, device=d), torch.zeros(c, device=d)
+    a2, b2 = torch.zeros(c, device=d), torch.zeros(c, device=d)
+    _lib.check(L.vitta_colsum2_f32(_p(part), nb, c, _p(a1), _p(b1), None, 0.0, _stream()), "colsum2")
+    q.add(part, nb, c, a2, b2)
+    q.flush()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a1, a2, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(b1, b2, rtol=1e-5, atol=1e-4)
+    arr = (_lib.ColsumItem * 1)()
+    assert L.vitta_colsum2_multi_f32(arr, 1, _stream()) != 0  # null pointers: VITTA_ERR_INVALID_ARG
+    assert L.vitta_colsum2_multi_f32(arr, 0, _stream()) != 0
+
+
 @pytest.mark.parametrize("c", [128, 512, 1024])
 def test_fused_layernorm_passthrough_joins_the_two_gradients_of_its_input(c):
     """FusedLayerNorm(..., passthrough=True) -> (x, y): the returned x stands for the block input's second reader (the residual

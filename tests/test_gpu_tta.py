@@ -182,6 +182,8 @@ def test_three_swin_tta_steps_match_reference_on_gpu(tmp_path, mode, use_engine,
     recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, use_engine=use_engine)
     check_tta_records(g, mode, recs, BASE_GPU, outliers=None if strict else OUTLIERS)
     abi_calls.assert_swin_kernels()
+    if use_engine:  # the column sums of the LayerNorm sites leave in batches (forward statistics, d gamma / d beta)
+        assert abi_calls.abi.get("vitta_colsum2_multi_f32", 0) > 0, abi_calls.abi
 
 
 def test_swin_fused_attention_equals_composed_ops_on_gpu():

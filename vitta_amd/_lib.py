@@ -59,6 +59,12 @@ class ConvDesc(C.Structure):
                 ("pool", C.c_void_p), ("pool_scale", C.c_float)]
 
 
+class ColsumItem(C.Structure):
+    """vitta_colsum_item of include/vitta_hip.h (field for field)."""
+    _fields_ = [("d_partial", C.c_void_p), ("n_partials", C.c_int64), ("C", C.c_int32), ("cnt_value", C.c_float),
+                ("d_out_a", C.c_void_p), ("d_out_b", C.c_void_p), ("d_cnt", C.c_void_p)]
+
+
 _p = C.c_void_p
 _i32 = C.c_int32
 _i64 = C.c_int64
@@ -179,6 +185,7 @@ SIGNATURES = {
     "vitta_ln_fwd_mixed": (C.c_int, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _f32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "vitta_ln_bwd_mixed": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _i32, _p]),
     "vitta_colsum2_f32": (C.c_int, [_p, _i64, _i32, _p, _p, _p, _f32, _p]),
+    "vitta_colsum2_multi_f32": (C.c_int, [C.POINTER(ColsumItem), _i32, _p]),
     "vitta_stem_bn_relu_pool_fwd_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p]),
     "vitta_stem_bn_relu_pool_bwd_affine_f32": (C.c_int, [_p, _p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "vitta_stem_bn_relu_pool_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i64, _i32, _i32, _i32, _p, _p]),

@@ -293,6 +293,39 @@ __global__ __launch_bounds__(VITTA_BLOCK) void colsum2_kernel(const float* __res
   if (cnt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *cnt = cnt_value;
 }
 
+// The same sums for up to CS_BATCH partial matrices in ONE launch (the column sums of a pass's LayerNorm sites, deferred to
+// the point where their results are first read: the statistics alignment after the forward, the exchange / optimizer after the
+// backward -- ~100 five-microsecond launches per Video Swin step leave the dependent chain).  Workgroup w belongs to the item
+// whose range [first[i], first[i + 1]) holds it; inside the item it is the (x, y) workgroup of colsum2_kernel.
+constexpr int CS_BATCH = 32;
+struct ColsumBatch {
+  vitta_colsum_item it[CS_BATCH];
+  int first[CS_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(VITTA_BLOCK) void colsum2_multi_kernel(const ColsumBatch b) {
+  __shared__ float red[4][64];
+  const int w = blockIdx.x;
+  int i = 0;
+  while (i + 1 < b.n && w >= b.first[i + 1]) ++i;
+  const vitta_colsum_item& it = b.it[i];
+  const int C = it.C, n = 2 * C, gx = (n + 63) / 64;
+  const int local = w - b.first[i], bx = local % gx, by = local / gx;
+  const int col = bx * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const int64_t nb = it.n_partials;
+  const int64_t b0 = (int64_t)by * CS_ROWS, b1 = b0 + CS_ROWS < nb ? b0 + CS_ROWS : nb;
+  float s = 0.f;
+  if (col < n)
+    for (int64_t r = b0 + grp; r < b1; r += 4) s += it.d_partial[r * n + col];
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0 && col < n) {
+    const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    atomicAdd(col < C ? it.d_out_a + col : it.d_out_b + (col - C), t);
+  }
+  if (it.d_cnt && local == 0 && threadIdx.x == 0) *it.d_cnt = it.cnt_value;
+}
+
 inline bool ln_shape(int C, int* nv, int* vec) {
   if (C == 128) { *nv = 1; *vec = 2; return true; }
   if (C % 256 == 0 && C >= 256 && C <= 2048 && ((C / 256) & (C / 256 - 1)) == 0) { *nv = C / 256; *vec = 4; return true; }
@@ -406,6 +439,29 @@ int vitta_colsum2_f32(const float* d_partial, int64_t n_partials, int32_t C, flo
   const dim3 grid((2 * C + 63) / 64, (unsigned)((n_partials + CS_ROWS - 1) / CS_ROWS));
   VITTA_LAUNCH(colsum2_kernel, grid, dim3(VITTA_BLOCK), 0, static_cast<hipStream_t>(stream), d_partial, n_partials, (int)C,
                d_out_a, d_out_b, d_cnt, cnt_value);
+  return VITTA_OK;
+}
+
+int vitta_colsum2_multi_f32(const vitta_colsum_item* h_items, int32_t n_items, void* stream) {
+  if (!h_items || n_items <= 0) return VITTA_ERR_INVALID_ARG;
+  for (int32_t i = 0; i < n_items; ++i) {
+    const vitta_colsum_item& it = h_items[i];
+    if (!it.d_partial || !it.d_out_a || !it.d_out_b || it.n_partials <= 0 || it.C <= 0) return VITTA_ERR_INVALID_ARG;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int32_t i0 = 0; i0 < n_items; i0 += CS_BATCH) {
+    ColsumBatch b;
+    b.n = n_items - i0 < CS_BATCH ? n_items - i0 : CS_BATCH;
+    int64_t total = 0;
+    for (int j = 0; j < b.n; ++j) {
+      b.it[j] = h_items[i0 + j];
+      b.first[j] = (int)total;
+      total += (int64_t)((2 * b.it[j].C + 63) / 64) * ((b.it[j].n_partials + CS_ROWS - 1) / CS_ROWS);
+      if (total >= (1ll << 31)) return VITTA_ERR_UNSUPPORTED;
+    }
+    for (int j = b.n; j <= CS_BATCH; ++j) b.first[j] = (int)total;
+    VITTA_LAUNCH(colsum2_multi_kernel, dim3((unsigned)total), dim3(VITTA_BLOCK), 0, st, b);
+  }
   return VITTA_OK;
 }
 

@@ -162,10 +162,21 @@ class FusedLNSite:
         if not e._fused_seen:  # first fused layer of the step: the column sums ADD into [s1 | s2]
             e._zero_stats(plan)
             plan.cnt_src = None
+            if e._colsums is not None:
+                e._colsums.clear()  # (a forward that raised leaves nothing behind)
         e._fused_seen.add(self.index)
         e._fused_direct = True
         sl = plan.channel_slice(self.index)
         return e.src_mean[sl], plan.s1[sl], plan.s2[sl], plan.cnt[self.index:self.index + 1]
+
+    def colsum_queue(self):
+        """ops.ColsumQueue the pass leaves its column sums in (the engine issues them in reduce_local: one launch for all hooked
+        layers), or None: the pass issues its own."""
+        e = self.engine
+        if e._colsums is None:
+            from . import ops
+            e._colsums = ops.ColsumQueue()
+        return e._colsums
 
     coefficients = FusedSite.coefficients
 
@@ -235,6 +246,7 @@ class StatAlignEngine:
         self._gscale_set = False
         self._fused_seen = set()
         self._fused_direct = False
+        self._colsums = None  # ops.ColsumQueue of the fused LayerNorm passes' column sums (FusedLNSite.colsum_queue)
         self._fused_plans = {}
         self.timing_events = None  # bench.py: callable returning (start, stop) events per step
 
@@ -377,6 +389,8 @@ class StatAlignEngine:
             self._fused_seen = set()
             if self._fused_direct:  # fused LayerNorm passes wrote [cnt | s1 | s2] themselves
                 self._fused_direct = False
+                if self._colsums is not None:  # ... or left their column sums for this ONE launch
+                    self._colsums.flush()
             else:
                 self.plan.finalize(self.src_mean)
             return

@@ -5,6 +5,7 @@ Every function here requires CUDA(HIP) tensors and raises if the library is miss
 is no eager fallback for the HIP path.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -738,6 +739,63 @@ def ln_supported(c):
     return bool(lib().vitta_ln_supported(int(c)))
 
 
+class ColsumQueue:
+    """Column sums of LayerNorm partial rows (vitta_colsum2_f32) put off to the point where their results are first read, then
+    issued as ONE launch per 32 sites (vitta_colsum2_multi_f32): ~100 five-microsecond launches per Video Swin step leave the
+    dependent chain.  The queue keeps the partial rows and the outputs alive until flush()."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, partial, nb, c, out_a, out_b, cnt=None, cnt_value=0.0):
+        self.items.append((partial, int(nb), int(c), out_a, out_b, cnt, float(cnt_value)))
+
+    def clear(self):
+        self.items = []
+
+    def flush(self):
+        """Issue the queued sums on the CURRENT stream (the one their partial rows were written on)."""
+        if not self.items:
+            return
+        items, self.items = self.items, []
+        arr = (_lib.ColsumItem * len(items))()
+        for a, (partial, nb, c, out_a, out_b, cnt, cv) in zip(arr, items):
+            a.d_partial, a.n_partials, a.C, a.cnt_value = partial.data_ptr(), nb, c, cv
+            a.d_out_a, a.d_out_b, a.d_cnt = out_a.data_ptr(), out_b.data_ptr(), (cnt.data_ptr() if cnt is not None else None)
+        check(lib().vitta_colsum2_multi_f32(arr, len(items), _stream()), "vitta_colsum2_multi_f32")
+
+
+# d gamma / d beta sums of the LayerNorm backward passes running inside `deferred_grad_colsums()` (tta.ViTTAAdapter._backward):
+# queued while the sink is live `.grad` storage (nothing else adds to it before the flush), flushed when the context ends or a
+# gradient bucket is about to leave (flush_grad_colsums)
+_GRAD_COLSUMS = ColsumQueue()
+_grad_colsums_deferred = False
+DEFER_COLSUMS = os.environ.get("VITTA_DEFER_COLSUMS", "1") != "0"
+
+
+class deferred_grad_colsums:
+    def __enter__(self):
+        global _grad_colsums_deferred
+        self.prev = _grad_colsums_deferred
+        if not self.prev:
+            _GRAD_COLSUMS.clear()  # (a backward that raised leaves nothing behind)
+        _grad_colsums_deferred = DEFER_COLSUMS
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _grad_colsums_deferred
+        _grad_colsums_deferred = self.prev
+        if et is None:
+            _GRAD_COLSUMS.flush()
+        else:
+            _GRAD_COLSUMS.clear()
+        return False
+
+
+def flush_grad_colsums():
+    _GRAD_COLSUMS.flush()
+
+
 class FusedLayerNorm(torch.autograd.Function):
     """y = LayerNorm_C(x') with x' = x + scale_b * branch (branch optional), one pass; a hooked layer (`site`) leaves the
     shifted channel sums of y in the engine's statistics buffer, and its backward adds the statistics-loss gradient.
@@ -777,8 +835,12 @@ class FusedLayerNorm(torch.autograd.Function):
         check(lib().vitta_ln_fwd_mixed(_p(x), _p(branch), _p(scale), rows, rps, c, _p(weight), _p(bias), float(eps), _p(xnew),
                                        _p(y), _p(mean), _p(rstd), _p(shift), _p(partial), flags, _stream()), "vitta_ln_fwd_mixed")
         if site is not None:
-            check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(s1), _p(s2), _p(cnt), float(rows), _stream()),
-                  "vitta_colsum2_f32")
+            q = site.colsum_queue() if (DEFER_COLSUMS and hasattr(site, "colsum_queue")) else None
+            if q is not None:  # the engine issues the sums of all hooked layers in one launch before it reads them
+                q.add(partial, nb, c, s1, s2, cnt, float(rows))
+            else:
+                check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(s1), _p(s2), _p(cnt), float(rows), _stream()),
+                      "vitta_colsum2_f32")
         ctx.save_for_backward(xnew if xnew is not None else x, mean, rstd, weight, bias, scale)
         ctx.meta = (rows, rps, c, site, nb, branch is not None, branch is not None and branch.dtype == torch.bfloat16,
                     passthrough and branch is None)
@@ -816,7 +878,10 @@ class FusedLayerNorm(torch.autograd.Function):
         if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
             dw, r_w = _grad_sink(weight, True)   # live .grad storage, or a zeroed buffer: the column sum adds into it
             db, r_b = _grad_sink(bias, True)
-            check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(dw), _p(db), None, 0.0, _stream()), "vitta_colsum2_f32")
+            if _grad_colsums_deferred and r_w is None and r_b is None:
+                _GRAD_COLSUMS.add(partial, nb, c, dw, db)
+            else:
+                check(lib().vitta_colsum2_f32(_p(partial), nb, c, _p(dw), _p(db), None, 0.0, _stream()), "vitta_colsum2_f32")
             if not ctx.needs_input_grad[3]:
                 r_w = None
             if not ctx.needs_input_grad[4]:

@@ -555,7 +555,9 @@ class ViTTAAdapter:
         """loss.backward() from a cached unit gradient (no ones_like launch; ops.WeightedLoss.backward recognises it)."""
         if loss.is_cuda and loss.dtype == torch.float32 and loss.dim() == 0:
             from . import ops
-            loss.backward(gradient=ops.unit_gradient(loss.device))
+            # (the LayerNorm passes' d gamma / d beta column sums: queued, ONE launch when the backward has been issued)
+            with ops.deferred_grad_colsums():
+                loss.backward(gradient=ops.unit_gradient(loss.device))
         else:
             loss.backward()
 
@@ -728,6 +730,9 @@ class ViTTAAdapter:
         hit = self._armed.get(index)
         if hit is not None and index not in self._launched:
             self._launched.add(index)
+            if self.device.type == "cuda":
+                from . import ops
+                ops.flush_grad_colsums()  # (queued d gamma / d beta sums of the units behind this cut join their bucket)
             self.arena.reduce_range(*hit, async_op=True)
             self.n_from_backward += 1
 
