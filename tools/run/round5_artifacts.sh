@@ -16,6 +16,7 @@ test -n "$DB" && timeout 120 python tools/timeline.py "$DB" $O/${T}_timeline.csv
 rm -rf $O/prof_${T}g
 timeout 100 python tools/bench_tam.py --out $O/${T}_tam_branch_latency.json > /dev/null 2>&1
 timeout 200 python tools/bench_wmsa.py --shift > $O/${T}_wmsa_bf16_stage0.txt 2>&1
+(timeout 200 python tools/bench_ln.py --bf16; timeout 200 python tools/bench_ln.py --views 2 --frames 16) > $O/${T}_ln_passes.txt 2> /dev/null
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_${T}s -o g -- python bench.py --timed-only --steps 128 --no-cpu-baseline --optimizer sgd_all > $O/${T}_timed_only_sgd.json 2>> $O/${T}_prof.err
 DB=$(ls $O/prof_${T}s/*.db $O/prof_${T}s/*/*.db 2>/dev/null | head -1)
 test -n "$DB" && timeout 120 python tools/prof_summary.py "$DB" $O/${T}_sgd_all_graph_replay_kernel_stats.csv 250 > /dev/null
