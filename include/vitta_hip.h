@@ -784,6 +784,15 @@ int vitta_loss_axpby_bwd_f32(const float* d_g, float la, float lb, float* d_ga, 
 int vitta_gemm_nt_supported(int64_t M, int32_t N, int32_t K);
 int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y, float* d_pre,
                       int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream);
+/* The same product (64 x 64 tiles) as a STREAM-K launch of `grid` workgroups (a multiple of the CU count): the K slabs of all
+ * tiles are cut into `grid` equal contiguous ranges, partial tiles meet in the workspace and the last arriver of a tile's ticket
+ * adds them in range order (deterministic) and runs the epilogue.  For products whose tile count quantises badly on 256 CUs
+ * (Swin-B stage 2, N = 512: 392 tiles).  d_workspace: vitta_gemm_nt_sk_workspace_bytes(grid) bytes, 16-byte aligned, its first
+ * 256 KiB ZERO when first used (the kernel leaves them zero), one per stream. */
+int64_t vitta_gemm_nt_sk_workspace_bytes(int32_t grid);
+int vitta_gemm_nt_sk_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y, float* d_pre,
+                         int64_t M, int32_t N, int32_t K, int32_t mode, int32_t grid, void* d_workspace, int64_t workspace_bytes,
+                         void* stream);
 /* The same product on bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation and epilogues; an extension beside
  * BASELINE config 5's bf16 window attention, opt-in because the reference computes in fp32): d_a stays fp32 in memory and
  * is rounded to bf16 (nearest even) while it is staged, d_b_bf16 is the caller's bfloat16 copy of the weight [N][K].

@@ -55,6 +55,73 @@ def test_gemm_modes_vs_fp64(m, n, k, tile):
     _close(y2, lin * dg, rel=4e-5)
 
 
+@pytest.mark.parametrize("grid", [256, 512, 1000])
+@pytest.mark.parametrize("m,n,k", [(3136, 512, 2048), (3136, 512, 1536), (784, 1024, 4096), (12544, 256, 1024), (200, 128, 32),
+                                   (1, 256, 64), (392, 3072, 1024), (3100, 500, 512)])
+def test_gemm_stream_k_vs_fp64_and_deterministic(m, n, k, grid):
+    """vitta_gemm_nt_sk_f32 (the K slabs of all 64 x 64 tiles cut into `grid` equal ranges; partial tiles through the workspace, the
+    last arriver of a tile's ticket adds them in range order): every epilogue against fp64, ragged M / N, ranges shorter and longer
+    than a tile, fewer slabs than workgroups, a grid that is no multiple of eight; two launches give the same bits; the arrival
+    counters are zero afterwards."""
+    from vitta_amd import _lib
+    from vitta_amd.ops import _p, _stream
+    L, d = _lib.lib(), _dev()
+    g = torch.Generator().manual_seed(m + n + k + grid)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * k ** -0.5
+    b = torch.randn(n, generator=g)
+    aux = torch.randn(m, n, generator=g) * 1.5
+    ad, wd, bd, auxd = (t.to(d) for t in (a, w, b, aux))
+    ws = torch.zeros(int(L.vitta_gemm_nt_sk_workspace_bytes(grid)), dtype=torch.uint8, device=d)
+
+    def run(bias, mode, auxt=None, pre=None):
+        y = torch.empty(m, n, device=d)
+        _lib.check(L.vitta_gemm_nt_sk_f32(_p(ad), _p(wd), _p(bias), _p(auxt), _p(y), _p(pre), m, n, k, mode, grid, _p(ws), ws.numel(),
+                                          _stream()), "vitta_gemm_nt_sk_f32")
+        return y
+    y0, y0b = run(bd, 0), run(bd, 0)
+    y0n = run(None, 0)
+    pre = torch.empty(m, n, device=d)
+    y1 = run(bd, 1, pre=pre)
+    y2 = run(None, 2, auxt=auxd)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y0b)
+    assert int(ws[:65536 * 4].view(torch.int32).abs().max()) == 0
+    a64, w64, b64, x64 = a.double(), w.double(), b.double(), aux.double()
+    lin = a64 @ w64.t()
+    _close(y0, lin + b64)
+    _close(y0n, lin)
+    _close(pre, lin + b64)
+    _close(y1, F.gelu(lin + b64))
+    x = x64.clone().requires_grad_(True)
+    (dg,) = torch.autograd.grad(F.gelu(x).sum(), x)
+    _close(y2, lin * dg, rel=4e-5)
+    # what it refuses
+    assert L.vitta_gemm_nt_sk_f32(_p(ad), _p(wd), None, None, _p(y0), None, m, n, k, 0, grid, _p(ws), 1024, _stream()) == -1  # workspace too small
+    assert L.vitta_gemm_nt_sk_f32(_p(ad), _p(wd), None, None, _p(y0), None, m, n, k, 0, 0, _p(ws), ws.numel(), _stream()) == -1
+
+
+def test_gemm_nt_takes_the_stream_k_form_where_the_tile_count_quantises_badly(abi_calls):
+    """ops.gemm_nt: 392 tiles with K = 2048 -> vitta_gemm_nt_sk_f32 (same numbers as the plain launch to round-off); K = 512 or a
+    forced tile -> vitta_gemm_nt_f32."""
+    from vitta_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(1)
+    a, w = torch.randn(3136, 2048, generator=g).to(d), (torch.randn(512, 2048, generator=g) * 2048 ** -0.5).to(d)
+    assert ops.gemm_sk_pays(3136, 512, 2048) and not ops.gemm_sk_pays(3136, 512, 512) and not ops.gemm_sk_pays(3136, 1536, 2048)
+    y = ops.gemm_nt(a, w)
+    assert abi_calls.abi.get("vitta_gemm_nt_sk_f32", 0) == 1 and abi_calls.abi.get("vitta_gemm_nt_f32", 0) == 0
+    ops.GEMM_TILE = 3
+    try:
+        y3 = ops.gemm_nt(a, w)
+    finally:
+        ops.GEMM_TILE = 0
+    assert abi_calls.abi.get("vitta_gemm_nt_f32", 0) == 1
+    assert (y - y3).abs().max().item() <= 1e-5 * y3.abs().max().item()
+    ops.gemm_nt(a[:, :512].contiguous(), w[:, :512].contiguous())
+    assert abi_calls.abi.get("vitta_gemm_nt_f32", 0) == 2
+
+
 def test_gemm_rejects_unsupported_and_host_tensors():
     from vitta_amd import _lib, ops
     assert not ops.gemm_nt_supported(64, 64, 48)

@@ -33,7 +33,7 @@ def test_no_wide_buffer_store_is_followed_by_a_write_of_its_data_registers():
     import subprocess
     import tempfile
     t = _tool()
-    files = ["conv_b3.hip", "conv.hip", "conv_sk.hip", "head.hip", "tam_branch.hip"]
+    files = ["conv_b3.hip", "conv.hip", "conv_sk.hip", "head.hip", "tam_branch.hip", "gemm.hip"]
     for f in files:
         src = os.path.join(ROOT, "vitta_amd", "csrc", f)
         assert "buffer_store" in open(src).read(), f

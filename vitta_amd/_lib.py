@@ -170,6 +170,8 @@ SIGNATURES = {
     "vitta_loss_axpby_bwd_f32": (C.c_int, [_p, C.c_float, C.c_float, _p, _p, _p]),
     "vitta_gemm_nt_supported": (C.c_int, [_i64, _i32, _i32]),
     "vitta_gemm_nt_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
+    "vitta_gemm_nt_sk_workspace_bytes": (C.c_int64, [_i32]),
+    "vitta_gemm_nt_sk_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _i64, _p]),
     "vitta_gemm_nt_bf16w_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
     "vitta_tam_pool_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _i32, _i32, _i32, _i32, _p, _p]),
     "vitta_tam_agg_fwd_cm_f32": (C.c_int, [_p, C.POINTER(_p), _f32, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),

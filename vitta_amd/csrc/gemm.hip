@@ -44,6 +44,10 @@ struct GemmArgs {
   float* pre;          // [M][N] or null (mode 1)
   int M, N, K, mode;
   int nMt, nNt;
+  // stream-K form (gemm_nt_sk_kernel): K slabs per workgroup, arrival counters [tiles] (zero at rest), partial tiles [2 * grid][64 * 64]
+  int sk_per;
+  unsigned* sk_cnt;
+  float* sk_ws;
 };
 
 __device__ __forceinline__ float gelu_f(float h) { return 0.5f * h * (1.f + erff(h * 0.70710678118654752f)); }
@@ -202,6 +206,152 @@ __global__ __launch_bounds__(NTH) void gemm_nt_kernel(const GemmArgs g) {
   }
 
   epilogue<BM, BN, AUX>(g, acc, auxv, m0, n0, wm, wn, li, lk);
+}
+
+// ---- stream-K form of the 64 x 64 kernel ------------------------------------------------------------------------------------
+// The N = 512 products of stage 2 (proj, fc2, and the data gradients of qkv / proj / fc1: 18 of the 24 blocks) are 392 tiles: on
+// 256 CUs 136 CUs hold two workgroups and 120 one, and the launch lasts two tile times for 1.53 tiles of work per CU.  Here the
+// launch is a fixed number of workgroups (a multiple of the CU count) and the unit of work is a K slab of a tile: the tiles' slabs,
+// tile after tile, are cut into equal contiguous ranges, so a workgroup walks the tail of one tile, whole tiles, the head of
+// another.  A whole tile ends in the ordinary epilogue.  A partial tile is written through to the workspace (register order: every
+// store instruction 4 KB contiguous), a ticket on the tile's counter follows, and the workgroup that arrives last adds the tile's
+// partials IN RANGE ORDER (its own from registers: the sum does not depend on who was last), runs the epilogue and leaves the
+// counter zero.  Nobody waits for anybody: no residency requirement.  Slot of workgroup c's partial: 2 c + (it starts at the
+// tile's slab 0) -- a range has at most one partial segment that starts inside a tile (its first) and one that starts a tile (its last).
+template <bool AUX>
+__global__ __launch_bounds__(NTH) void gemm_nt_sk_kernel(const GemmArgs g) {
+  constexpr int BM = 64, BN = 64, A4 = BM * BK / 4 / NTH, B4 = BN * BK / 4 / NTH;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const As = lds;
+  float* const Bs = lds + 2 * BM * LS;
+  __shared__ int flag;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lk = lane >> 5;
+  const int K = g.K, ns = K / BK;
+  const int64_t total = (int64_t)g.nMt * g.nNt * ns;
+  const int me = xcd_remap(blockIdx.x, gridDim.x);  // contiguous ranges per XCD: a token tile's rows stay in one L2
+  int64_t it = (int64_t)me * g.sk_per;
+  const int64_t end = it + g.sk_per < total ? it + g.sk_per : total;
+
+  __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a), 0, (int)((int64_t)g.M * K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, (int)((int64_t)g.N * K * 4), 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(g.sk_ws, 0, (int)((int64_t)gridDim.x * 2 * BM * BN * 4), 0x00020000);
+  constexpr int OOB = (int)0x80000000u;
+  float* const st_a = As + (tid >> 3) * LS + (tid & 7) * 4;
+  float* const st_b = Bs + (tid >> 3) * LS + (tid & 7) * 4;
+  const float* const rd_a = As + (wm * (BM / 2) + li) * LS + 4 * lk;
+  const float* const rd_b = Bs + (wn * (BN / 2) + li) * LS + 4 * lk;
+
+  while (it < end) {
+    const int t = (int)(it / ns), s0 = (int)(it - (int64_t)t * ns);
+    const int s1 = (int64_t)(ns - s0) < end - it ? ns : s0 + (int)(end - it);
+    const int n = s1 - s0;
+    it += n;
+    const int m0 = (t / g.nNt) * BM, n0 = (t % g.nNt) * BN;
+    int voff_a[A4], voff_b[B4];
+#pragma unroll
+    for (int u = 0; u < A4; ++u) {
+      const int r = m0 + (tid >> 3) + u * 32;
+      voff_a[u] = r < g.M ? (r * K + (tid & 7) * 4) * 4 : OOB;
+    }
+#pragma unroll
+    for (int u = 0; u < B4; ++u) {
+      const int r = n0 + (tid >> 3) + u * 32;
+      voff_b[u] = r < g.N ? (r * K + (tid & 7) * 4) * 4 : OOB;
+    }
+    f32x4 ra[A4], rb[B4];
+    auto load_global = [&](int s) __attribute__((always_inline)) {
+      const int so = s * BK * 4;
+#pragma unroll
+      for (int u = 0; u < A4; ++u) ra[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, voff_a[u], so, 0));
+#pragma unroll
+      for (int u = 0; u < B4; ++u) rb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, voff_b[u], so, 0));
+    };
+    auto store_lds = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < A4; ++u) *reinterpret_cast<f32x4*>(st_a + buf * BM * LS + u * 32 * LS) = ra[u];
+#pragma unroll
+      for (int u = 0; u < B4; ++u) *reinterpret_cast<f32x4*>(st_b + buf * BN * LS + u * 32 * LS) = rb[u];
+    };
+    f32x4 fa[2], fb[2];
+    auto read_frag = [&](int buf, int j, int set) __attribute__((always_inline)) {
+      fa[set] = *reinterpret_cast<const f32x4*>(rd_a + buf * BM * LS + 8 * j);
+      fb[set] = *reinterpret_cast<const f32x4*>(rd_b + buf * BN * LS + 8 * j);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+
+    load_global(s0);
+    store_lds(0);
+    if (n > 1) load_global(s0 + 1);
+    __syncthreads();
+    auto slab = [&](int q, int buf) __attribute__((always_inline)) {
+      read_frag(buf, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < 3) read_frag(buf, j + 1, (j + 1) & 1);
+        if (j == 1 && q + 1 < n) store_lds(buf ^ 1);
+        if (j == 2 && q + 2 < n) load_global(s0 + q + 2);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][kk], fb[j & 1][kk], acc, 0, 0, 0);
+      }
+      __syncthreads();
+    };
+    for (int q = 0; q < n; q += 2) {
+      slab(q, 0);
+      if (q + 1 < n) slab(q + 1, 1);
+    }
+
+    if (n < ns) {  // a partial tile: out through the workspace, ticket, the last arriver goes on
+      const int first = (int)(((int64_t)t * ns) / g.sk_per), lastc = (int)(((int64_t)(t + 1) * ns - 1) / g.sk_per);
+      const int slot = 2 * me + (s0 == 0 ? 1 : 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_w, (q * NTH + tid) * 16, slot * (BM * BN * 4), 16);
+      }
+      // (the data registers of a 16-byte store are read a few cycles after it issues -- conv_b3.hip's split-K tail has the story:
+      // the accumulator stays live across the stores and a few idle cycles)
+      asm volatile("s_nop 7" ::: "memory");
+      asm volatile("" ::"v"(acc));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(g.sk_cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = ticket == (unsigned)(lastc - first);
+        if (last) __hip_atomic_store(g.sk_cnt + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag = last ? 1 : 0;
+      }
+      __syncthreads();
+      const bool last = flag != 0;
+      __syncthreads();  // (flag is rewritten by the next partial segment)
+      if (!last) continue;
+      f32x16 sum;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sum[v] = 0.f;
+      for (int c = first; c <= lastc; ++c) {
+        if (c == me) {
+#pragma unroll
+          for (int v = 0; v < 16; ++v) sum[v] += acc[v];
+          continue;
+        }
+        const int so = (2 * c + (c == first ? 1 : 0)) * (BM * BN * 4);
+        f32x4 pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pv[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (q * NTH + tid) * 16, so, 16));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sum[4 * q] += pv[q].x; sum[4 * q + 1] += pv[q].y; sum[4 * q + 2] += pv[q].z; sum[4 * q + 3] += pv[q].w;
+        }
+      }
+      acc = sum;
+    }
+    float auxv[1][1][16];
+    f32x16 accs[1][1] = {{acc}};
+    prefetch_aux<BM, BN, AUX>(g, auxv, m0, n0, wm, wn, li, lk);
+    epilogue<BM, BN, AUX>(g, accs, auxv, m0, n0, wm, wn, li, lk);
+  }
 }
 
 // ---- bf16-operand variant (opt-in, BASELINE config 5's arithmetic: bf16 MFMA operands, fp32 accumulation) ----------------
@@ -385,7 +535,7 @@ extern "C" int vitta_gemm_nt_f32(const float* d_a, const float* d_b, const float
                                  float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream) {
   if (!d_a || !d_b || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux)) return VITTA_ERR_INVALID_ARG;
   if (!vitta_gemm_nt_supported(M, N, K)) return VITTA_ERR_UNSUPPORTED;
-  GemmArgs g{d_a, d_b, d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0};
+  GemmArgs g{d_a, d_b, d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0, 0, nullptr, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tile == 0) tile = choose_tile(M, N, mode);
   if (tile == 1) return launch<128, 128>(g, st);
@@ -398,11 +548,37 @@ extern "C" int vitta_gemm_nt_bf16w_f32(const float* d_a, const uint16_t* d_b_bf1
                                        float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t tile, void* stream) {
   if (!d_a || !d_b_bf16 || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux)) return VITTA_ERR_INVALID_ARG;
   if (!vitta_gemm_nt_supported(M, N, K) || K % BKH) return VITTA_ERR_UNSUPPORTED;
-  GemmArgs g{d_a, reinterpret_cast<const float*>(d_b_bf16), d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0};
+  GemmArgs g{d_a, reinterpret_cast<const float*>(d_b_bf16), d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0, 0, nullptr, nullptr};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (tile == 0) tile = choose_tile_bf16(M, N, mode);
   if (tile == 1) return launch_bf16<128, 128>(g, st);
   if (tile == 2) return launch_bf16<64, 128>(g, st);
   if (tile == 3) return launch_bf16<64, 64>(g, st);
   return VITTA_ERR_INVALID_ARG;
+}
+
+// stream-K form (64 x 64 tiles): workspace = [65536 arrival counters, ZERO when first used -- the kernel leaves them zero][2 * grid
+// partial tiles of 16 KB], one per stream (launches that share it must not overlap).
+constexpr int64_t SK_CNT_BYTES = 65536 * 4;
+extern "C" int64_t vitta_gemm_nt_sk_workspace_bytes(int32_t grid) { return grid > 0 ? SK_CNT_BYTES + (int64_t)grid * 2 * 64 * 64 * 4 : 0; }
+
+extern "C" int vitta_gemm_nt_sk_f32(const float* d_a, const float* d_b, const float* d_bias, const float* d_aux, float* d_y,
+                                    float* d_pre, int64_t M, int32_t N, int32_t K, int32_t mode, int32_t grid, void* d_workspace,
+                                    int64_t workspace_bytes, void* stream) {
+  if (!d_a || !d_b || !d_y || mode < 0 || mode > 2 || (mode == 2 && !d_aux) || grid <= 0 || !d_workspace) return VITTA_ERR_INVALID_ARG;
+  if (!vitta_gemm_nt_supported(M, N, K)) return VITTA_ERR_UNSUPPORTED;
+  if (workspace_bytes < vitta_gemm_nt_sk_workspace_bytes(grid) || (reinterpret_cast<uintptr_t>(d_workspace) & 15u)) return VITTA_ERR_INVALID_ARG;
+  GemmArgs g{d_a, d_b, d_bias, d_aux, d_y, d_pre, (int)M, N, K, mode, 0, 0, 0, nullptr, nullptr};
+  g.nMt = (int)((M + 63) / 64);
+  g.nNt = (N + 63) / 64;
+  const int64_t tiles = (int64_t)g.nMt * g.nNt, total = tiles * (K / BK);
+  if (tiles > 65536 || (int64_t)grid * 2 * 64 * 64 * 4 >= (1ll << 31)) return VITTA_ERR_UNSUPPORTED;
+  g.sk_per = (int)((total + grid - 1) / grid);
+  g.sk_cnt = static_cast<unsigned*>(d_workspace);
+  g.sk_ws = reinterpret_cast<float*>(static_cast<char*>(d_workspace) + SK_CNT_BYTES);
+  const size_t lds = sizeof(float) * 2 * (64 + 64) * LS;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mode == 2) VITTA_LAUNCH((gemm_nt_sk_kernel<true>), dim3((unsigned)grid), dim3(NTH), lds, st, g);
+  else VITTA_LAUNCH((gemm_nt_sk_kernel<false>), dim3((unsigned)grid), dim3(NTH), lds, st, g);
+  return VITTA_OK;
 }

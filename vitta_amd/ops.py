@@ -1133,6 +1133,29 @@ def gemm_bf16x(a, b, bias=None, mode=0, aux=None, pre=None, out_bf16=False):
     return y
 
 
+# stream-K form of the fp32 product (vitta_gemm_nt_sk_f32) where the 64 x 64 tile count quantises badly on the 256 CUs: grid =
+# GEMM_SK_GRID workgroups (0: never).  One workspace per stream, created on first use (before any capture: a step runs eagerly first).
+GEMM_SK_GRID = int(os.environ.get("VITTA_GEMM_SK", "512"))
+_SK_WS = {}
+
+
+def gemm_sk_pays(m, n, k):
+    """Fewer than 1024 tiles that leave >= 15 % of the CUs' last round idle, and a reduction long enough to cut: measured
+    (tools/bench_gemm_sk.py, profiles/r5_gemm_stream_k.txt) -5..-14 % for K >= 1024, slower for K = 512 (a partial tile's trip
+    through the workspace costs what a quarter of such a tile's slabs do)."""
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    if GEMM_SK_GRID <= 0 or tiles < 128 or tiles >= 1024 or k < 1024:
+        return False
+    rounds = -(-tiles // 256)
+    return tiles / (256.0 * rounds) <= 0.85
+
+
+def _sk_workspace(device):
+    from . import conv
+    nbytes = int(lib().vitta_gemm_nt_sk_workspace_bytes(GEMM_SK_GRID))
+    return conv.zeroed_per_stream(_SK_WS, device, nbytes, spares=3)  # (zero once, eagerly; spares for the streams a capture brings)
+
+
 def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     """y[m][n] = epi(sum_k a[m][k] b[n][k]) (mode 0: + bias, 1: bias + GELU (pre-activation kept in `pre`), 2: times
     gelu'(aux)).  b float32: vitta_gemm_nt_f32 (exact fp32 MFMA); b bfloat16: vitta_gemm_nt_bf16w_f32 (a is rounded to
@@ -1147,7 +1170,12 @@ def gemm_nt(a, b, bias=None, mode=0, aux=None, pre=None, out=None):
     fn, name = (lib().vitta_gemm_nt_f32, "vitta_gemm_nt_f32") if b.dtype == torch.float32 else \
         (lib().vitta_gemm_nt_bf16w_f32, "vitta_gemm_nt_bf16w_f32")
     tm = KTIMING("gemm_bf16" if b.dtype == torch.bfloat16 else "gemm_f32", 2.0 * m * n * k) if KTIMING is not None else None
-    check(fn(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()), name)
+    if b.dtype == torch.float32 and GEMM_TILE == 0 and gemm_sk_pays(m, n, k):
+        ws = _sk_workspace(a.device)
+        check(lib().vitta_gemm_nt_sk_f32(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_SK_GRID, _p(ws),
+                                         ws.numel(), _stream()), "vitta_gemm_nt_sk_f32")
+    else:
+        check(fn(_p(a), _p(b), _p(bias), _p(aux), _p(y), _p(pre), m, n, k, mode, GEMM_TILE, _stream()), name)
     if tm is not None:
         tm.stop()
     return y
