@@ -406,6 +406,12 @@ int vitta_sgd_step_f32(float* d_param, const float* d_grad, float* d_momentum_bu
  * -------------------------------------------------------------------------- */
 int vitta_scale_add_f32(const float* d_x, const float* d_branch, const float* d_scale, int64_t samples,
                         int64_t per_sample, float* d_out, void* stream);
+/* PatchMerging's gather (swin_transformer.py:281-286: cat of x[:, :, 0::2, 0::2], [1::2, 0::2], [0::2, 1::2], [1::2, 1::2] along the
+ * channels) on channels-last planes: merged[p][i][j][k C + c] = x[p][2 i + (k & 1)][2 j + (k >> 1)][c]; x [planes][2 H2][2 W2][C],
+ * merged [planes][H2][W2][4 C].  inverse = 0: d_src = x, d_dst = merged;  1: d_src = merged, d_dst = x (the gradient).  One launch
+ * (torch: four strided copies each way).  C % 4 == 0, 16-byte aligned. */
+int vitta_patch_gather_f32(const float* d_src, float* d_dst, int64_t planes, int32_t H2, int32_t W2, int32_t C, int32_t inverse,
+                           void* stream);
 
 /* --------------------------------------------------------------------------
  * A8 -- the 2D convolutions of the TANet trunk (torchvision ResNet-50 Bottleneck under models/tanet_models/tanet.py:125-150,

@@ -849,6 +849,24 @@ def test_batchnorm_backward_on_channel_major_planes(c, nb, t, hw, relu, mask, ro
     assert (gm.cpu().double() - mref).abs().max().item() <= 1e-6 * mref.abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 56, 56, 128), (1, 4, 28, 28, 256), (2, 2, 14, 14, 512), (1, 3, 6, 10, 4)])
+def test_patch_gather_equals_the_cat_of_strided_slices_both_ways(shape, abi_calls):
+    """swin.PatchGather on vitta_patch_gather_f32 (one launch each way) == torch.cat of the four strided slices of PatchMerging
+    (swin_transformer.py:281-286) and its autograd gradient, bit for bit (pure data movement)."""
+    from vitta_amd import swin
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(_dev()).requires_grad_(True)
+    out = swin.PatchGather.apply(x)
+    ref_in = x.detach().clone().requires_grad_(True)
+    ref = torch.cat([ref_in[:, :, 0::2, 0::2], ref_in[:, :, 1::2, 0::2], ref_in[:, :, 0::2, 1::2], ref_in[:, :, 1::2, 1::2]], -1)
+    assert torch.equal(out, ref)
+    go = torch.randn(ref.shape, generator=g).to(_dev())
+    out.backward(go)
+    ref.backward(go)
+    assert torch.equal(x.grad, ref_in.grad)
+    assert abi_calls.abi.get("vitta_patch_gather_f32", 0) == 2
+
+
 def test_batched_column_sums_equal_the_per_site_launches():
     """vitta_colsum2_multi_f32 (the deferred column sums of a pass's LayerNorm sites: one launch per 32 items) == one
     vitta_colsum2_f32 per item: 40 items (two launches), ragged partial counts, every supported width, outputs that already hold

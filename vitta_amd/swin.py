@@ -346,8 +346,22 @@ class PatchGather(torch.autograd.Function):
     stage's whole output -- 2.1 GB of traffic behind the first PatchMerging of the 4 x 32-frame step, 0.8 ms per video over the three;
     the gradient is simply the four channel groups written back to their pixel parities: four strided copies, every byte once."""
 
+    HIP = __import__("os").environ.get("VITTA_PATCH_GATHER", "1") != "0"  # 0: the strided copies of torch (A/B)
+
+    @staticmethod
+    def _hip(t):
+        return PatchGather.HIP and t.is_cuda and t.dtype == torch.float32 and t.shape[-1] % 4 == 0
+
     @staticmethod
     def forward(ctx, x):
+        if PatchGather._hip(x) and x.shape[-1] % 4 == 0:  # ONE launch (cat of four strided slices: four copy kernels)
+            from . import ops
+            x = x.contiguous()
+            B, D, H, W, C = x.shape
+            out = torch.empty(B, D, H // 2, W // 2, 4 * C, dtype=x.dtype, device=x.device)
+            ops.check(ops.lib().vitta_patch_gather_f32(ops._p(x), ops._p(out), B * D, H // 2, W // 2, C, 0, ops._stream()),
+                      "vitta_patch_gather_f32")
+            return out
         return torch.cat([x[:, :, 0::2, 0::2], x[:, :, 1::2, 0::2], x[:, :, 0::2, 1::2], x[:, :, 1::2, 1::2]], -1)
 
     @staticmethod
@@ -355,6 +369,11 @@ class PatchGather(torch.autograd.Function):
         B, D, H2, W2, C4 = g.shape
         C = C4 // 4
         gx = torch.empty(B, D, 2 * H2, 2 * W2, C, dtype=g.dtype, device=g.device)
+        if PatchGather._hip(g) and C % 4 == 0:
+            from . import ops
+            g = g.contiguous()
+            ops.check(ops.lib().vitta_patch_gather_f32(ops._p(g), ops._p(gx), B * D, H2, W2, C, 1, ops._stream()), "vitta_patch_gather_f32")
+            return gx
         gx[:, :, 0::2, 0::2] = g[..., 0:C]
         gx[:, :, 1::2, 0::2] = g[..., C:2 * C]
         gx[:, :, 0::2, 1::2] = g[..., 2 * C:3 * C]
