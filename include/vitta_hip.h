@@ -385,9 +385,10 @@ int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_
  * A7 -- optimizer update on the flat parameter arena, one launch.
  * Replaces optimizer.step() of corpus/basics.py:671 for the optimizers built at corpus/basics.py:547-560 (torch.optim.Adam over the affine tensors /
  * torch.optim.SGD over every parameter), same element-wise arithmetic as torch's single-tensor formulation.
- *   vitta_adam_step_f32: t = d_step[0] + 1 (device scalar, incremented by the call, so a captured graph advances it; d_step is TWO
- *                        words: d_step[1] is the launch's arrival counter, zero when first used and left zero -- the last
- *                        workgroup to arrive writes the new step, ONE launch);
+ *   vitta_adam_step_f32: t = d_step[0] + 1 (device scalar, incremented by the call, so a captured graph advances it: ONE
+ *                        float); d_ticket: ONE uint32 of the caller's, zero when first used and left zero -- the launch's arrival
+ *                        counter: the last workgroup to arrive writes the new step (one launch; a separate word so that a 1-float step
+ *                        tensor -- a loaded or replaced optimizer state -- is never written out of bounds; NULL = invalid argument);
  *                        g' = g + wd p; m = lerp(m, g', 1-b1); v = b2 v + (1-b2) g'^2;
  *                        p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  m, v, *d_step start at 0.
  *   vitta_sgd_step_f32:  d = g + wd p; buf = momentum buf + d (buf starts at 0); p -= lr buf.
@@ -395,7 +396,7 @@ int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_
  * All arrays n floats, 16-byte aligned.
  * -------------------------------------------------------------------------- */
 int vitta_adam_step_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_step,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t n, void* stream);
+                        uint32_t* d_ticket, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t n, void* stream);
 int vitta_sgd_step_f32(float* d_param, const float* d_grad, float* d_momentum_buf, float lr, float momentum,
                        float weight_decay, int64_t n, void* stream);
 

@@ -311,3 +311,93 @@ def test_swin_bucketed_gradient_exchange_equals_the_monolithic_all_reduce(tmp_pa
         np.testing.assert_array_equal(res[4][r]["step0_ema"], res[1][r]["step0_ema"])
         assert float(res[4][r]["step0_param_sum"]) == float(res[1][r]["step0_param_sum"])
     np.testing.assert_array_equal(res[4][0]["step0_grad"], res[4][1]["step0_grad"])
+
+
+def _rank4_main(rank, world, port, tmp):
+    """One of FOUR ranks: six videos -> step 0 gives every rank a video (0..3), step 1 only ranks 0 and 1 (4, 5): ranks 2 and 3 run dry."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.oracle_backend import OracleBackend
+    from vitta_amd import tta
+    adapter, tta_set = _ws4_adapter(os.path.join(tmp, f"r{rank}"), 1, OracleBackend, tta)
+    assert adapter.world == 4 and adapter.bucket is not None and adapter.engine.distributed
+    out = {}
+    for step in range(2):
+        vid = 4 * step + rank
+        has_video = vid < 6
+        adapter.set_adapt_mode()
+        x = adapter.shape_tta_input(tta_set[vid][0].unsqueeze(0)) if has_video else None
+        _, loss_reg, loss_consis = adapter.adapt_step(x, has_video)
+        named = dict(adapter.model.named_parameters())
+        out[f"step{step}_loss_reg"] = float(loss_reg)
+        out[f"step{step}_loss_consis"] = float(loss_consis) if loss_consis is not None else 0.0
+        out[f"step{step}_ema"] = adapter.engine.ema_mean.detach().cpu().numpy().copy()
+        out[f"step{step}_params"] = np.concatenate([p.detach().cpu().numpy().ravel() for _, p in sorted(named.items()) if p.requires_grad])
+        out[f"step{step}_grads"] = np.concatenate([p.grad.detach().cpu().numpy().ravel() for _, p in sorted(named.items()) if p.requires_grad])
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), **out)
+    torch.distributed.destroy_process_group()
+
+
+def _ws4_adapter(rdir, batch_size, backend, tta):
+    from vitta_amd import data
+    g = H.golden("tta3_bz2.npz")
+    cfg = json.loads(str(g["config"]))
+    Tn, size = cfg["T"], cfg["size"]
+    os.makedirs(rdir, exist_ok=True)
+    ch = g["src_channels"]
+    offs = np.concatenate([[0], np.cumsum(ch)])
+    mp_, vp_ = H.write_stat_files(rdir, [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
+                                  [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    args = H.tanet_args(rdir, clip_length=Tn, input_size=size, batch_size=batch_size, spatiotemp_mean_clean_file=mp_,
+                        spatiotemp_var_clean_file=vp_, update_only_bn_affine=True, lr=1e-5)
+    model = H.build_tanet(101, Tn, 0)
+    model.base_model.fc = torch.nn.Identity()  # no dropout: the four ranks and the one process see the same forward
+    tta.BACKEND_FACTORY = backend
+    try:
+        adapter = tta.ViTTAAdapter(tta.SingleDeviceParallel(model), args)
+    finally:
+        tta.BACKEND_FACTORY = None
+    return adapter, data.SyntheticVideoDataset(6, 2, Tn, size, 101, "tanet", seed0=cfg["seed0"])
+
+
+def test_four_ranks_with_two_dry_ranks_in_the_tail_equal_one_process_batches(tmp_path):
+    """World size 4 (round 6): six videos on four ranks.  Step 0: every rank adapts to one video; step 1: ranks 0 / 1
+    hold videos 4 / 5, ranks 2 and 3 run DRY -- they contribute n = 0 to the packed-moments all-reduce and zeros to the gradient
+    all-reduce.  All four replicas end every step with bit-identical EMA state, gradients and parameters, and those equal ONE process
+    adapting the batch of four and then the batch of two (the reference's semantics with batch_size = R, pinned against the reference
+    at R = 2 by test_two_ranks_equal_reference_batch_of_two): norm_stats_utils.py:193,202-204,242-243 pool every clip of the batch,
+    pred_consistency_utils.py:8,28-30 sums over it."""
+    from oracle.oracle_backend import OracleBackend
+    from vitta_amd import tta
+    mp.spawn(_rank4_main, args=(4, _free_port(), str(tmp_path)), nprocs=4, join=True)
+    r = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(4)]
+    for step in range(2):
+        for k in range(1, 4):
+            np.testing.assert_array_equal(r[0][f"step{step}_ema"], r[k][f"step{step}_ema"])
+            np.testing.assert_array_equal(r[0][f"step{step}_grads"], r[k][f"step{step}_grads"])
+            np.testing.assert_array_equal(r[0][f"step{step}_params"], r[k][f"step{step}_params"])
+            assert float(r[0][f"step{step}_loss_reg"]) == pytest.approx(float(r[k][f"step{step}_loss_reg"]), rel=1e-7)
+    assert float(r[2]["step1_loss_consis"]) == 0.0 and float(r[3]["step1_loss_consis"]) == 0.0
+    # one process: batch of four, then batch of two
+    torch.set_num_threads(8)
+    adapter, tta_set = _ws4_adapter(str(tmp_path / "one"), 4, OracleBackend, tta)
+    for step, vids in enumerate(([0, 1, 2, 3], [4, 5])):
+        adapter.set_adapt_mode()
+        x = torch.stack([tta_set[v][0] for v in vids])
+        _, loss_reg, loss_consis = adapter.adapt_step(adapter.shape_tta_input(x))
+        named = dict(adapter.model.named_parameters())
+        grads = np.concatenate([p.grad.detach().numpy().ravel() for _, p in sorted(named.items()) if p.requires_grad])
+        params = np.concatenate([p.detach().numpy().ravel() for _, p in sorted(named.items()) if p.requires_grad])
+        assert float(r[0][f"step{step}_loss_reg"]) == pytest.approx(float(loss_reg), rel=2e-5 if step == 0 else 1e-4)
+        assert sum(float(r[k][f"step{step}_loss_consis"]) for k in range(4)) == pytest.approx(float(loss_consis), rel=1e-4 if step == 0 else 2e-3, abs=1e-7)
+        # step 1 runs on weights that Adam's FIRST update moved by lr * g / (|g| + eps): an element whose gradient sits at round-off
+        # takes either sign, so the two runs' weights differ by up to 2 lr = 2e-5 there (hence the small lr) and the second step's statistics follow
+        np.testing.assert_allclose(r[0][f"step{step}_ema"], adapter.engine.ema_mean.detach().numpy(), rtol=1e-4, atol=1e-6 if step == 0 else 2e-5)
+        ga, gb = r[0][f"step{step}_grads"].astype(np.float64), grads.astype(np.float64)
+        cos = float(np.dot(ga, gb) / (np.linalg.norm(ga) * np.linalg.norm(gb)))
+        assert cos >= 0.9999, (step, cos)
+        if step == 0:  # (Adam's first update is lr * sign-like: the parameters agree wherever the gradients do)
+            assert np.abs(r[0]["step0_params"] - params).max() <= 2.5e-5

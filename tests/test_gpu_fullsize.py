@@ -170,6 +170,66 @@ def test_config3_swin_full_size_step_matches_cpu_oracle(tmp_path, abi_calls):
     _compare(res, [k for k in sampled if k in res["cpu"]["grads"]], loss_reg_rel=1e-4, grad_frac=5e-3, max_outliers=32)
 
 
+@pytest.mark.parametrize("mode", ["adam", "sgd"])
+def test_config3_swin_full_size_step_matches_the_reference_itself(tmp_path, mode, abi_calls):
+    """BASELINE config 3 at its REAL size against the REFERENCE (round 6; rounds 2-5 compared with the product's own CPU path, kept
+    above as an A/B): tests/golden/tta1_224_swin.npz holds one online step of the reference's own `tta_standard`
+    (corpus/basics.py:516-738) on Video Swin-B, 2 views x 16 frames x 224^2, window (8, 7, 7) UNCLAMPED on the 14 x 14 / 7 x 7 planes of
+    stages 2 / 3 (swin_transformer.py:138-169, 215-274, 316-329: shifted windows + mask in a BACKWARD step, where 20 of the 24 blocks
+    and all 42 hooked LayerNorms live) -- Adam on the LN affine parameters and SGD over everything --, with its DropPath / dropout
+    masks, losses, sampled gradients / updated parameters, EVERY LayerNorm affine gradient whole, the evaluation logits after the
+    update and the noise floors of eight perturbed reference re-runs (tools/refgen/gen_golden.py tta224_swin).  The HIP path (exact
+    fp32 MFMA kernels: wmsa.hip, gemm.hip, layernorm.hip) replays it under the bounds of the small-size golden tests, floors
+    weighted 2x; at most two of the 106 affine tensors may sit over their bound by an L1 sign quantum (counted, capped, printed)."""
+    from test_host_cpu import check_tta_records
+    from test_swin_cpu import check_affine_gradients, run_product_tta_swin
+    g = H.golden("tta1_224_swin.npz")
+    recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, all_affine=True)
+    base = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.1)
+    for row in check_tta_records(g, mode, recs, base, floor_mult=2.0):
+        print("step %d %-70s err %.3e bound %.3e" % row)
+    check_affine_gradients(g, mode, recs[0], grad_frac=5e-3, floor_mult=2.0, max_over=2, cap=0.30)
+    abi_calls.assert_swin_kernels()
+
+
+@pytest.mark.parametrize("mode,recipe", [("adam", "fp32"), ("sgd", "fp32"), ("adam", "bf16"), ("sgd", "bf16")])
+def test_config5_shape_swin_step_matches_the_reference_itself(tmp_path, mode, recipe, abi_calls):
+    """BASELINE config 5's shape against the REFERENCE (round 6): tests/golden/tta1_c5_swin.npz = one step of the reference's own
+    `tta_standard` on Video Swin-B with the SSv2 recipe's window (16, 7, 7) (recognizer3d.py:36-40), K = 174, 4 views x 32 frames x
+    112^2 -- 784-token windows at stages 0-2, shift masks, both optimizers, masks / losses / gradients / logits / noise floors as in
+    the config-3 fixture (tools/refgen/gen_golden.py tta_c5).  fp32: the exact-fp32 kernels under the golden bounds.  bf16: the
+    recipe the bench line times (`--wmsa_bf16 --dense_bf16`: 2-byte activations between LayerNorm, dense layers and window attention)
+    against the fp32 REFERENCE at what 8-bit operand mantissas allow through 24 blocks: statistics loss rel 1e-4, consistency loss rel
+    5e-3, every sampled / affine gradient tensor within 5e-2 of its maximum (cosine of the whole affine gradient >= 0.999), logits
+    within 1e-2 of their maximum."""
+    from test_host_cpu import check_tta_records
+    from test_swin_cpu import check_affine_gradients, run_product_tta_swin
+    from vitta_amd import ops
+    g = H.golden("tta1_c5_swin.npz")
+    old = (ops.WMSA_BF16, ops.DENSE_BF16)
+    ops.WMSA_BF16 = ops.DENSE_BF16 = recipe == "bf16"
+    try:
+        recs = run_product_tta_swin(g, mode, tmp_path, _dev(), None, all_affine=True)
+    finally:
+        ops.WMSA_BF16, ops.DENSE_BF16 = old
+    if recipe == "fp32":
+        base = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.1)
+        for row in check_tta_records(g, mode, recs, base, floor_mult=2.0):
+            print("step %d %-70s err %.3e bound %.3e" % row)
+        check_affine_gradients(g, mode, recs[0], grad_frac=5e-3, floor_mult=2.0, max_over=2, cap=0.30)
+        abi_calls.assert_swin_kernels()
+    else:
+        base = dict(loss_rel=1e-4, logit_frac=1e-2, grad_frac=5e-2, param_lr_mult=0.5)
+        # (the consistency loss is the one quantity bf16 operands move beyond the generic loss bound: checked on its own)
+        k = f"{mode}_step0_"
+        assert recs[0]["loss_consis"] == pytest.approx(float(g[k + "loss_consis"]), rel=5e-3, abs=1e-6)
+        rec = dict(recs[0], loss_consis=float(g[k + "loss_consis"]))
+        for row in check_tta_records(g, mode, [rec], base, floor_mult=2.0):
+            print("step %d %-70s err %.3e bound %.3e" % row)
+        check_affine_gradients(g, mode, recs[0], grad_frac=5e-2, floor_mult=2.0, max_over=4, cap=0.5, cos_min=0.999)
+        assert abi_calls.abi.get("vitta_gemm_nt_bf16x", 0) > 0 and abi_calls.abi.get("vitta_wmsa_rel_fwd_bf16", 0) > 0, abi_calls.abi
+
+
 def _dp_rank(rank, world, port, tmp, classes):
     """One rank of the 2-rank full-size run below (gloo; both ranks share the box's GPU)."""
     import os

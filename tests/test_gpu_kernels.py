@@ -680,7 +680,13 @@ def test_flat_optimizers_match_torch_optim(kind):
         mu, wd = (0.9, 5e-4) if kind == "sgd" else (0.0, 0.0)
         opt = optim.FlatSGD(arena, lr=1e-2, momentum=mu, weight_decay=wd)
         ropt = torch.optim.SGD(ref, lr=1e-2, momentum=mu, weight_decay=wd)
+    guard = None
     for step in range(5):
+        if kind == "adam" and step == 2:
+            #  a replaced / loaded one-element step tensor: the launch's arrival counter is a word of the optimizer's own,
+            # nothing is written behind the step (the word after it keeps its sentinel)
+            guard = torch.tensor([float(opt.state["step"]), 777.0], device=_dev())
+            opt.state["step"] = guard[:1]
         opt.zero_grad()
         for p, r in zip(mine, ref):
             gr = torch.randn(p.shape, device=_dev())
@@ -696,7 +702,7 @@ def test_flat_optimizers_match_torch_optim(kind):
         used[off:off + p.numel()] = True
     assert float(arena.flat_param.detach()[~used].abs().max()) == 0.0
     if kind == "adam":
-        assert float(opt.state["step"]) == 5.0
+        assert float(opt.state["step"]) == 5.0 and float(guard[1]) == 777.0 and int(opt._ticket) == 0
 
 
 def test_fused_bn_act_forked_output_sums_both_gradients():

@@ -593,10 +593,10 @@ def gen_opts():
 
 
 # --------------------------------------------------------------------------------------------
-def ref_swin(num_class, seed, **kw):
+def ref_swin(num_class, seed, window_size=(8, 7, 7), **kw):
     from models.videoswintransformer_models.recognizer3d import Recognizer3D
-    mine = H.build_swin(num_class, seed, **kw)
-    ref = Recognizer3D(num_classes=num_class, patch_size=(2, 4, 4), window_size=(8, 7, 7), drop_path_rate=0.2)
+    mine = H.build_swin(num_class, seed, window_size=tuple(window_size), **kw)
+    ref = Recognizer3D(num_classes=num_class, patch_size=(2, 4, 4), window_size=tuple(window_size), drop_path_rate=0.2)
     ref.load_state_dict(mine.state_dict(), strict=True)
     ref.eval()
     return ref, mine
@@ -644,6 +644,11 @@ def run_reference_tta_swin(args, model_origin, n_videos, capture, perturb=0.0, p
         c = real_deepcopy(obj, *a, **k)
         if isinstance(obj, nn.Module) and capture.model is None:
             capture.model = c
+            eps_p = getattr(capture, "perturb_params", 0.0)
+            if eps_p:  # (as run_reference_tta: another fp32 implementation rounds differently in EVERY layer)
+                with torch.no_grad():
+                    for j, p_ in enumerate(c.parameters()):
+                        p_.mul_(1 + eps_p * H.seeded_randn(tuple(p_.shape), perturb_seed + 7919 * (j + 1)))
             for m in c.modules():
                 if isinstance(m, nn.Dropout) and m.p > 0:
                     m.register_forward_hook(lambda mod, i, o: capture.drop_masks.append(t2n(o != 0)) if mod.training else None)
@@ -677,6 +682,13 @@ def run_reference_tta_swin(args, model_origin, n_videos, capture, perturb=0.0, p
             named = dict(capture.model.named_parameters())
             for key in SWIN_SAMPLED:
                 rec[f"grad::{key}"] = t2n(named[key].grad[:SAMPLE_ROWS]) if named[key].grad is not None else None
+            if getattr(capture, "all_affine", False):  # EVERY LayerNorm weight / bias gradient, whole tensors, in named_parameters order
+                ln_names = [f"{mn}.{pn}" for mn, mod in capture.model.named_modules() if isinstance(mod, nn.LayerNorm)
+                            for pn in ("weight", "bias")]
+                rec["affine_names"] = np.array(ln_names)
+                rec["affine_sizes"] = np.array([named[n].numel() for n in ln_names])
+                rec["affine_grads"] = np.concatenate([t2n(named[n].grad).ravel() if named[n].grad is not None
+                                                      else np.zeros(named[n].numel(), np.float32) for n in ln_names])
             r = _real(self, *a, **k)
             for key in SWIN_SAMPLED:
                 rec[f"param::{key}"] = t2n(named[key][:SAMPLE_ROWS])
@@ -690,7 +702,8 @@ def run_reference_tta_swin(args, model_origin, n_videos, capture, perturb=0.0, p
 
     def fake_dataset(args, split="val", dataset_type=None):
         views = args.n_augmented_views if dataset_type == "tta" else 1
-        ds = SyntheticVideoDataset(n_videos, views, args.clip_length, args.input_size, args.num_classes, "swin", seed0=800)
+        ds = SyntheticVideoDataset(n_videos, views, args.clip_length, args.input_size, args.num_classes, "swin",
+                                   seed0=getattr(capture, "seed0", 800))
         return _Perturbed(ds, perturb, perturb_seed) if perturb else ds
 
     B.get_dataset_videoswin = fake_dataset
@@ -706,15 +719,21 @@ def run_reference_tta_swin(args, model_origin, n_videos, capture, perturb=0.0, p
     return res
 
 
-def gen_tta_swin():
-    """A11/A7 for Video Swin-B: three online steps through the reference's tta_standard, both optimizers."""
+def gen_tta_swin(tag="tta3_swin", T=16, size=64, n_videos=3, views=2, window=(8, 7, 7), K=101, dataset="ucf101", trials=3,
+                 all_affine=False, seed0=800):
+    """A11/A7 for Video Swin-B: online steps through the reference's tta_standard, both optimizers.
+    tta3_swin: three steps at 64^2 (stage-2 / 3 windows clamp to 4 x 4 / 2 x 2).  Round 6: tta1_224_swin = ONE step at BASELINE
+    config 3's real size (2 views x 16 frames x 224^2: window (8, 7, 7) unclamped on the 14 x 14 / 7 x 7 planes of stages 2 / 3, where
+    the 42 hooked LayerNorms live, shift mask in the backward) and tta1_c5_swin = ONE step at config 5's shape (4 views x 32 frames x
+    112^2, K = 174, window (16, 7, 7): recognizer3d.py:36-40); both also record EVERY LayerNorm affine gradient whole (all_affine)
+    with per-tensor noise floors, trials perturbed re-runs (odd ones also perturb every parameter by 1e-7 relative)."""
     from utils.opts import get_opts
     from utils.norm_stats_utils import ComputeNormStatsHook
     from utils.BNS_utils import choose_layers
-    T, size, n_videos = 16, 64, 3
+    n_steps = n_videos
     out = {}
     for mode in ("sgd", "adam"):
-        ref, _ = ref_swin(101, 0)
+        ref, _ = ref_swin(K, 0, window_size=window)
         lns = [m for _, m in choose_layers(ref, [nn.LayerNorm])][1:]
         hooks = [ComputeNormStatsHook(m, clip_len=T, stat_type="spatiotemp", before_norm=False, batch_size=1) for m in lns]
         with torch.no_grad():
@@ -727,27 +746,34 @@ def gen_tta_swin():
         with tempfile.TemporaryDirectory() as tmp:
             mp, vp = H.write_stat_files(tmp, means, vars_)
             args = get_opts()
-            args.arch, args.dataset, args.clip_length, args.workers = "videoswintransformer", "ucf101", T, 0
+            args.arch, args.dataset, args.clip_length, args.workers = "videoswintransformer", dataset, T, 0
             args.input_size, args.scale_size, args.verbose, args.batch_size = size, size, False, 1
             args.num_clips, args.test_crops, args.frame_uniform, args.frame_interval = 1, 1, True, 2
-            args.patch_size, args.window_size = (2, 4, 4), (8, 7, 7)
+            args.patch_size, args.window_size = (2, 4, 4), tuple(window)
+            args.n_augmented_views = views
             args.lambda_pred_consis, args.momentum_mvg, args.chosen_blocks = 0.05, 0.05, SWIN_BLOCKS
             args.spatiotemp_mean_clean_file, args.spatiotemp_var_clean_file = mp, vp
-            args.num_classes, args.gpus, args.result_dir = 101, [0], tmp
+            args.num_classes, args.gpus, args.result_dir = K, [0], tmp
             args.update_only_bn_affine = mode == "adam"
             args.lr = 1e-5 if mode == "sgd" else 1e-3
             cap = _Capture()
+            cap.all_affine, cap.seed0 = all_affine, seed0
             torch.manual_seed(4321)
+            import time as _time
+            t0 = _time.time()
             res = run_reference_tta_swin(args, ref, n_videos, cap)
+            print(f"  {tag} {mode}: reference run {_time.time() - t0:.1f} s", flush=True)
             caps = []
-            for trial in range(3):
+            for trial in range(trials):
                 c2 = _Capture()
+                c2.all_affine, c2.seed0 = all_affine, seed0
+                c2.perturb_params = 1e-7 if (all_affine and trial % 2) else 0.0
                 torch.manual_seed(4321)
                 run_reference_tta_swin(args, ref, n_videos, c2, perturb=1e-7, perturb_seed=90000 + 1000 * trial)
                 caps.append(c2)
-        assert len(cap.steps) == 3 and len(cap.drop_masks) == 3, (len(cap.steps), len(cap.drop_masks))
-        per = len(cap.droppath) // 3
-        for i in range(3):
+        assert len(cap.steps) == n_steps and len(cap.drop_masks) == n_steps, (len(cap.steps), len(cap.drop_masks))
+        per = len(cap.droppath) // n_steps
+        for i in range(n_steps):
             a = cap.steps[i]
             noise = {}
 
@@ -764,6 +790,13 @@ def gen_tta_swin():
                     if a.get(f"grad::{key}") is not None:
                         bump(f"grad::{key}", np.abs(a[f"grad::{key}"] - b[f"grad::{key}"]).max())
                     bump(f"param::{key}", np.abs(a[f"param::{key}"] - b[f"param::{key}"]).max())
+            if all_affine:  # per-tensor floor of every LayerNorm affine gradient: worst |difference| over the perturbed re-runs
+                offs = np.concatenate([[0], np.cumsum(a["affine_sizes"])])
+                fl = np.zeros(len(a["affine_sizes"]))
+                for c2 in caps:
+                    dlt = np.abs(a["affine_grads"] - c2.steps[i]["affine_grads"])
+                    fl = np.maximum(fl, np.array([dlt[offs[j]:offs[j + 1]].max() for j in range(len(fl))]))
+                out[f"{mode}_step{i}_affine_noise"] = fl
             for key, val in noise.items():
                 out[f"{mode}_step{i}_noise_{key}"] = np.array(val)
             for k, v in a.items():
@@ -779,9 +812,20 @@ def gen_tta_swin():
             out["src_channels"] = np.array([len(m) for m in means])
     out["sampled_params"] = np.array(SWIN_SAMPLED)
     out["sample_rows"] = np.array(SAMPLE_ROWS)
-    out["config"] = np.array(json.dumps(dict(T=T, size=size, n_videos=n_videos, batch_size=1, seed0=800, lr_sgd=1e-5,
-                                             lr_adam=1e-3, momentum_mvg=0.05, lambda_pred_consis=0.05)))
-    save("tta3_swin.npz", **out)
+    out["config"] = np.array(json.dumps(dict(T=T, size=size, n_videos=n_videos, batch_size=1, seed0=seed0, lr_sgd=1e-5,
+                                             lr_adam=1e-3, momentum_mvg=0.05, lambda_pred_consis=0.05, views=views,
+                                             window=list(window), K=K, dataset=dataset, n_steps=n_steps)))
+    save(f"{tag}.npz", **out)
+
+
+def gen_tta224_swin():
+    gen_tta_swin(tag="tta1_224_swin", T=16, size=224, n_videos=1, views=2, window=(8, 7, 7), K=101, trials=NOISE_TRIALS,
+                 all_affine=True, seed0=810)
+
+
+def gen_tta_c5():
+    gen_tta_swin(tag="tta1_c5_swin", T=32, size=112, n_videos=1, views=4, window=(16, 7, 7), K=174, dataset="somethingv2",
+                 trials=NOISE_TRIALS, all_affine=True, seed0=820)
 
 
 def gen_bns():
@@ -810,7 +854,7 @@ def gen_bns():
 
 
 SECTIONS = dict(tta224=gen_tta224, l2ops=gen_l2ops, layers=gen_layers, tam=gen_tam, tanet=gen_tanet, tta=gen_tta, sampler=gen_sampler,
-                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, bns=gen_bns, episodic=gen_episodic, data=gen_data, epoch=gen_epoch)
+                opts=gen_opts, dp=gen_dp, swin=gen_swin, tta_swin=gen_tta_swin, tta224_swin=gen_tta224_swin, tta_c5=gen_tta_c5, bns=gen_bns, episodic=gen_episodic, data=gen_data, epoch=gen_epoch)
 
 if __name__ == "__main__":
     for n in (ARGV or list(SECTIONS)):

@@ -197,7 +197,7 @@ SIGNATURES = {
     "vitta_frames_cv2_resize": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _i32, _i32, _p, _p, _i32, _p, _p, _p]),
     "vitta_scale_add_f32": (C.c_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "vitta_patch_gather_f32": (C.c_int, [_p, _p, _i64, _i32, _i32, _i32, _i32, _p]),
-    "vitta_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
+    "vitta_adam_step_f32": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
     "vitta_sgd_step_f32": (C.c_int, [_p, _p, _p, _f32, _f32, _f32, _i64, _p]),
 }
 

@@ -15,7 +15,7 @@ namespace {
 //   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 __global__ __launch_bounds__(VITTA_BLOCK) void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                 float* __restrict__ m, float* __restrict__ v,
-                                                                float* step, float lr, float b1,
+                                                                float* step, unsigned* ticket, float lr, float b1,
                                                                 float b2, float eps, float wd, int64_t n) {
   const double t = (double)*step + 1.0;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
@@ -48,11 +48,10 @@ __global__ __launch_bounds__(VITTA_BLOCK) void adam_step_kernel(float* __restric
       p[i] = p[i] - step_size * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
     }
   }
-  // step += 1 once every workgroup has read it: the last one to arrive (step[1]: arrival counter, zero at rest) writes it.
-  // (Rounds 1-4: a second one-thread launch.)
+  // step += 1 once every workgroup has read it: the last one to arrive (*ticket: arrival counter of the caller's, zero at rest)
+  // writes it.  (Rounds 1-4: a second one-thread launch; round 5: the counter sat in step[1].)
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned* ticket = reinterpret_cast<unsigned*>(step + 1);
     const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -106,13 +105,13 @@ inline bool misaligned(const void* a, const void* b, const void* c, const void* 
 extern "C" {
 
 int vitta_adam_step_f32(float* d_param, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_step,
-                        float lr, float beta1, float beta2, float eps, float weight_decay, int64_t n, void* stream) {
-  if (!d_param || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_step || n <= 0) return VITTA_ERR_INVALID_ARG;
+                        uint32_t* d_ticket, float lr, float beta1, float beta2, float eps, float weight_decay, int64_t n, void* stream) {
+  if (!d_param || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_step || !d_ticket || n <= 0) return VITTA_ERR_INVALID_ARG;
   if (misaligned(d_param, d_grad, d_exp_avg, d_exp_avg_sq)) return VITTA_ERR_INVALID_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t grid = (n + 4 * VITTA_BLOCK - 1) / (4 * VITTA_BLOCK);
   VITTA_LAUNCH(adam_step_kernel, dim3((unsigned)grid), dim3(VITTA_BLOCK), 0, st, d_param, d_grad, d_exp_avg, d_exp_avg_sq,
-               d_step, lr, beta1, beta2, eps, weight_decay, n);
+               d_step, d_ticket, lr, beta1, beta2, eps, weight_decay, n);
   return VITTA_OK;
 }
 

@@ -976,6 +976,8 @@ class TanetHead(torch.autograd.Function):
             raise VittaHipError(f"TanetHead: {f} frame rows are not B x {V} views x {T} segments")
         mask = None
         y = feat
+        if train and p >= 1.0:
+            raise VittaHipError("TanetHead: dropout p must be < 1 (tanet.TSN.fused_head_ok sends p = 1 to the module chain)")
         if train and p > 0.0:
             y, mask = torch.native_dropout(feat, float(p), True)
         dev = feat.device

@@ -38,15 +38,18 @@ class FlatAdam(_FlatOptimizer):
     def __init__(self, arena, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(arena, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         flat = arena.flat_param
-        self._step2 = torch.zeros(2, dtype=torch.float32, device=flat.device)  # [step, arrival counter of the launch (zero at rest)]
-        self.state = {"step": self._step2[:1],
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=flat.device)  # arrival counter of the launch (zero at rest)
+        self.state = {"step": torch.zeros(1, dtype=torch.float32, device=flat.device),
                       "exp_avg": torch.zeros_like(flat), "exp_avg_sq": torch.zeros_like(flat)}
 
     @torch.no_grad()
     def step(self):
         g, st, flat = self.param_groups[0], self.state, self.arena.flat_param
+        step = st["step"]  # (may have been replaced by a loaded state: any one-element fp32 device tensor)
+        if step.numel() != 1 or step.dtype != torch.float32 or step.device != flat.device:
+            raise _lib.VittaHipError("FlatAdam.state['step'] must be a one-element float32 tensor on the arena's device")
         check(lib().vitta_adam_step_f32(_p(flat), _p(self.arena.grad), _p(st["exp_avg"]), _p(st["exp_avg_sq"]),
-                                        _p(st["step"]), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                                        _p(step), _p(self._ticket), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                         float(g["eps"]), float(g["weight_decay"]), flat.numel(), _stream()),
               "vitta_adam_step_f32")
 

@@ -199,9 +199,10 @@ class TSN(nn.Module):
 
     def fused_head_ok(self):
         """The adaptation head can run as ops.TanetHead (dropout -> new_fc -> consensus -> view consistency -> view mean in two
-        launches): the stock modules, no hooks on them."""
+        launches): the stock modules, no hooks on them, 0 < p < 1 (p = 1: nn.Dropout gives zeros and a zero gradient where the fused
+        node's 1 / (1 - p) scale would give inf * 0 -- the module chain keeps that case)."""
         fc, lin = self.base_model.fc, self.new_fc
-        return (self.tam and self.dropout > 0 and type(fc) is nn.Dropout and type(lin) is nn.Linear and self.consensus_type == "avg"
+        return (self.tam and 0.0 < self.dropout < 1.0 and type(fc) is nn.Dropout and type(lin) is nn.Linear and self.consensus_type == "avg"
                 and self.before_softmax and not fc._forward_hooks and not fc._forward_pre_hooks and not lin._forward_hooks
                 and not lin._forward_pre_hooks and not self.consensus._forward_hooks and not self._forward_hooks
                 and not self._forward_pre_hooks and not self.base_model._forward_hooks)

@@ -28,7 +28,9 @@ kernel does not bump tensor versions), the backward adds their gradients with `v
 stem pass does not cover).
 """
 import ctypes as C
+import logging
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -241,20 +243,21 @@ class TrunkRunner:
                 mods.append(b.net.downsample[1])
         return mods
 
-    def eligible(self, x):
+    def why_not(self, x):
+        """None when the hand-written trunk takes this pass, else the reason it declines (logged by trunk.run)."""
         from . import fused_bn, ops
         from .tanet import TemporalBottleneck
         net = self.net
         if not (ENABLED and fused_bn.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
-            return False
+            return "trunk / fused BN passes disabled, or the clip is not a CUDA float32 [N, 3, H, W] tensor"
         if x.requires_grad:  # the node hands no gradient back to the clip
-            return False
+            return "the input clip requires a gradient (the trunk node hands none back)"
         # pixel counts of every stage must be multiples of four (16-byte epilogue accesses): frames x H x W after the stem,
         # after each stride-2 stage
         hh, ww = CV.out_size(CV.out_size(x.shape[2], 7, 2, 3), 3, 2, 1), CV.out_size(CV.out_size(x.shape[3], 7, 2, 3), 3, 2, 1)
         for _ in range(4):
             if (x.shape[0] * hh * ww) % 4:
-                return False
+                return "frames x H x W of a stage is not a multiple of four (16-byte epilogue accesses)"
             hh, ww = CV.out_size(hh, 3, 2, 1), CV.out_size(ww, 3, 2, 1)
         grad = torch.is_grad_enabled()
         mp, c1 = net.maxpool, net.conv1
@@ -265,17 +268,17 @@ class TrunkRunner:
                 or x.shape[3] % 4 \
                 or not isinstance(net.bn1, nn.BatchNorm2d) or net.bn1.training or not net.bn1.affine \
                 or x.shape[0] * 64 > 65535:
-            return False
+            return "the stem is not the stock hook-free 7x7/2 convolution + eval-mode affine BatchNorm2d + 3/2/1 max-pool (or the width is not a multiple of four / too many frames)"
         blocks = self.blocks()
         if not blocks:
-            return False
+            return "no residual blocks"
         t = blocks[0].n_segment if isinstance(blocks[0], TemporalBottleneck) else 0
         if t <= 0 or x.shape[0] % t:
-            return False
+            return "the blocks are not TemporalBottlenecks or the frame count is not a multiple of the segment count"
         engines = set()
         for b in blocks:
             if not isinstance(b, TemporalBottleneck) or b.n_segment != t or b._forward_hooks or b.net._forward_hooks or b.tam._forward_hooks:
-                return False
+                return "a block is not a hook-free TemporalBottleneck with the common segment count"
             n = b.net
             convs = [n.conv1, n.conv2, n.conv3]
             bns = [n.bn1, n.bn2, n.bn3]
@@ -284,41 +287,44 @@ class TrunkRunner:
                 if not (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d)
                         and isinstance(ds[1], nn.BatchNorm2d) and not ds._forward_hooks
                         and ds[0].kernel_size == (1, 1) and ds[0].padding == (0, 0) and ds[0].stride == n.conv2.stride):
-                    return False
+                    return "a downsample branch is not Conv2d 1x1 + BatchNorm2d with conv2's stride"
                 convs.append(ds[0])
                 bns.append(ds[1])
             for cv in convs:
                 if cv.bias is not None or cv._forward_hooks or cv._forward_pre_hooks \
                         or cv.groups != 1 or cv.dilation != (1, 1):
-                    return False
+                    return "a convolution has a bias, a hook, groups or dilation"
             if n.conv1.padding != (0, 0) or n.conv3.padding != (0, 0) or n.conv1.in_channels % 16 or n.conv1.out_channels % 32 \
                     or (n.conv1.kernel_size, n.conv1.stride) != ((1, 1), (1, 1)) or (n.conv3.kernel_size, n.conv3.stride) != ((1, 1), (1, 1)) \
                     or n.conv2.kernel_size != (3, 3) or n.conv2.padding != (1, 1) or n.conv2.stride[0] != n.conv2.stride[1] \
                     or n.conv2.stride[0] not in (1, 2) or n.relu._forward_hooks:
-                return False
+                return "a bottleneck's convolution geometry is not 1x1 / 3x3 (stride 1 | 2) / 1x1 with 16- / 32-aligned channels"
             for bn in bns:
                 if not isinstance(bn, nn.BatchNorm2d) or bn.training or not bn.affine:
-                    return False
+                    return "a BatchNorm2d is in TRAIN mode (--fix_BNS False) or has no affine parameters"
                 ok, hook = _engine_hook(bn)
                 if not ok or (hook is not None and not grad):
-                    return False
+                    return "a BatchNorm2d carries a foreign forward hook (e.g. stat_reg='BNS' BNFeatureHook), or an engine hook under no_grad"
                 if hook is not None:
                     engines.add(id(hook.engine))
             tam = b.tam
             bg, bl = tam.G[1], tam.L[1]
             if bg.training or bl.training or not _noop_hooks_only(bg) or not _noop_hooks_only(bl) \
                     or not ops.tam_branch_supported(n.conv1.out_channels, t) or x.shape[0] // t > 32:
-                return False
+                return "a TAM BatchNorm1d is in train mode or hooked, the TAM width / segment count is unsupported, or more than 32 clips per pass"
             for m in (tam.G[0], tam.G[3], tam.L[0], tam.L[3]):
                 if m._forward_hooks:
-                    return False
+                    return "a TAM convolution / linear layer carries a hook"
         ok, hook = _engine_hook(net.bn1)
         if not ok or hook is not None:  # an ENGINE hook on the stem BN takes the module path (the shipped configuration hooks
-            return False                # layer3/4); producer hooks get the stem's moments from its raw output
+            return "the stem BatchNorm2d carries a foreign or engine hook"                # layer3/4); producer hooks get the stem's moments from its raw output
         for bn in [net.bn1] + [m for b in blocks for m in ([b.net.bn1, b.net.bn2, b.net.bn3] + ([b.net.downsample[1]] if b.net.downsample is not None else []))]:
             if len({bool(h.before_norm) for h in _producer_hooks(bn)}) > 1:
-                return False  # one statistics site per BatchNorm2d: its input OR its output
-        return len(engines) <= 1
+                return "a BatchNorm2d carries statistics-producer hooks on both its input and its output"  # one statistics site per BatchNorm2d: its input OR its output
+        return None if len(engines) <= 1 else "the hooked layers belong to more than one statistics engine"
+
+    def eligible(self, x):
+        return self.why_not(x) is None
 
     # -- caches ------------------------------------------------------------------------------------------------
     def packed(self, conv, kind, adapt=None):
@@ -911,6 +917,26 @@ class TrunkFunction(torch.autograd.Function):
         return (None, None, gpooled) + tuple(grads)
 
 
+_DECLINED = set()
+
+
+def _declined(x, why):
+    """The module-by-module path (vendor-library convolutions + the fused BN passes) takes over: say so ONCE per reason, loudly --
+    a production run must not lose the hand-written kernels silently.  VITTA_REQUIRE_TRUNK=1 raises instead.
+    CPU tensors (BASELINE config 0, the host-logic tests) are not a decline of the HIP path: silent."""
+    if not x.is_cuda:
+        return
+    if os.environ.get("VITTA_REQUIRE_TRUNK", "0") == "1":
+        from ._lib import VittaHipError
+        raise VittaHipError("the hand-written TANet trunk declined this pass: " + why)
+    if why not in _DECLINED:
+        _DECLINED.add(why)
+        msg = "[vitta_amd] WARNING: the hand-written TANet trunk (trunk.py / conv_b3.hip) DECLINED this pass -> module-by-module " \
+              "path with vendor-library convolutions: " + why
+        logging.getLogger("vitta_amd").warning(msg)
+        print(msg, file=sys.stderr, flush=True)
+
+
 def runner_of(resnet):
     runner = getattr(resnet, "_vitta_trunk", None)
     if runner is None:
@@ -922,7 +948,9 @@ def runner_of(resnet):
 def run(resnet, x):
     """features [N, 2048] of the trunk on the hand-written path, or None if the configuration needs the module path."""
     runner = runner_of(resnet)
-    if not runner.eligible(x):
+    why = runner.why_not(x)
+    if why is not None:
+        _declined(x, why)
         return None
     params = [p for m in runner.bn2d_modules() for p in (m.weight, m.bias)]
     for b in runner.blocks():

@@ -168,7 +168,7 @@ class FlatArena:
     ZERO_SLACK = 1 << 18
 
     class Zeroed:
-        """A slice of the arena's zeroed tail.  fresh(): True once after every fill of the arena (zero_grad) -- the slice may then be
+        """A slice of the arena's zeroed tail.  fresh(): True once after every fill of the arena (zero_step) -- the slice may then be
         used as zeroed; False: no fill since the last use, the user zeroes it itself."""
 
         def __init__(self, arena, tensor):
@@ -208,11 +208,19 @@ class FlatArena:
         self.flat_param.grad = self.grad
 
     def zero_grad(self):
-        self._grad_all.zero_()  # gradients + everything reserved behind them: ONE fill per step
+        """Gradients ONLY (what optimizer.zero_grad() means, corpus/basics.py:669-671: forward, optimizer.zero_grad(), backward): the
+        tail behind them holds FORWARD state of the running step -- the trunk's pooled sums its TAM backward reads, the engine's
+        [cnt | s1 | s2] -- and must survive a zero_grad() issued between a forward and its backward."""
+        self.grad.zero_()
+
+    def zero_step(self):
+        """The START of a step: gradients + everything reserved behind them in ONE fill (the adapter's own step and its captures call
+        this before the forward; nobody else does)."""
+        self._grad_all.zero_()
         self._fills += 1
 
     def reserve_zeroed(self, nbytes):
-        """A FlatArena.Zeroed over `nbytes` (256-byte aligned) of the tail that zero_grad() fills, or None when the tail is full."""
+        """A FlatArena.Zeroed over `nbytes` (256-byte aligned) of the tail that zero_step() fills, or None when the tail is full."""
         k = -(-int(nbytes) // 256) * 64
         if self._tail + k > self._grad_all.numel():
             return None
@@ -802,7 +810,7 @@ class ViTTAAdapter:
 
     def _adapt_step_eager(self, input, has_video=True, join=None):
         a = self.args
-        self.arena.zero_grad()
+        self.arena.zero_step()
         output = loss_reg = loss_consis = None
         if has_video:
             actual_bz = input.shape[0] // self.n_views if a.arch == "tanet" else input.shape[0]
@@ -846,7 +854,7 @@ class ViTTAAdapter:
             with self._prepacked() if overlap_eval else contextlib.nullcontext():
                 if overlap_eval:  # the evaluation of the previous video runs beside the adaptation forward
                     g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
-                self.arena.zero_grad()
+                self.arena.zero_step()
                 output, loss_consis = self.forward_local(x, actual_bz)
             if overlap_eval:
                 torch.cuda.current_stream().wait_stream(side)
@@ -1064,7 +1072,8 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
         else:
             for _ in range(args.n_gradient_steps):
                 output, loss_reg, loss_consis = adapter.adapt_step(input, has_video)
-        ahead(tta_iter)  # the step is issued: the next video's upload goes out beside it
+        if overlap:
+            ahead(tta_iter)  # the step is issued: the next video's upload goes out beside it
         if has_video:
             row[0] = loss_reg.detach()
             if loss_consis is not None:
@@ -1088,9 +1097,14 @@ def tta_standard(model_origin, criterion, args=None, logger=None, writer=None):
             ev_input = adapter.shape_eval_input(ev_input.to(device, non_blocking=True))
             ev_target = ev_target.to(device, non_blocking=True)
             output = adapter.evaluate(ev_input)
+            # sequential schedule: the host pulls the next video (loader decode, pinning: both block the host) only now, with this
+            # video's adaptation AND evaluation already issued -- a loader-bound run keeps the GPU busy meanwhile
+            ahead(tta_iter)
             ahead(eval_iter)
             prec1, prec5 = accuracy(output.data, ev_target, topk=(1, 5))
             row[3], row[4] = prec1, prec5
+        else:
+            ahead(tta_iter)
         if args.if_tta_standard == "tta_online":
             adapter.add_hooks_back()
         now = time.time()
