@@ -91,6 +91,8 @@ def parse():
     p.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (PCIe-inclusive) repetition of the timed steps")
     p.add_argument("--no-sgd-all", action="store_true", help="skip the second (SGD over all parameters) timing")
     p.add_argument("--no-swin", action="store_true", help="skip the Video Swin-B legs (configs 3 and 5)")
+    p.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32 convolution leg (VITTA_CONV_ARITH=f32)")
+    p.add_argument("--no-forced-exchange-leg", action="store_true", help="skip the one-rank RCCL leg (child process)")
     p.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been timed")
     p.add_argument("--timed-only", action="store_true",
                    help="profiling aid: stop after the timed region (no eager repeat / adapt-only / streaming legs), so "
@@ -200,7 +202,7 @@ def make_swin_args(tmp, size, clip_length, optimizer, device, n_videos):
 def run_gpu(opt, rank, world, device):
     from vitta_amd import data, tta
     tmp = tempfile.mkdtemp(prefix="vitta_bench_")
-    n_videos = max(16, min(64, opt.steps + opt.warmup))
+    n_videos = 64  # a stream of >= 64 distinct videos per GPU (14.5 MB each, resident in HBM before the timed region)
     if opt.arch == "swin":
         n_videos = min(n_videos, 16)  # 77 MB per clip pair
         model, mp, vp = build_swin_and_stats(tmp, opt.size, opt.clip_length, device)
@@ -292,15 +294,21 @@ def run_gpu(opt, rank, world, device):
             one_step(opt.warmup + b * opt.steps + i)
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:  # the block's time is the slowest rank's
-            t = torch.tensor([dt], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            dt = float(t.item())
+        if world > 1:  # the block's time is the slowest rank's (and the line says which rank that was)
+            mine = torch.tensor([dt], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            per_rank = [float(t.item()) for t in every]
+            dt = max(per_rank)
+            run_gpu.per_rank_blocks.append(per_rank)
         return dt
+
+    run_gpu.per_rank_blocks = []
 
     blocks = [timed_block(0)]
     # every rank derives the same block count from the same (reduced) first block
-    n_blocks = 1 if opt.timed_only else max(1, min(40, int(np.ceil(opt.min_seconds / max(blocks[0], 1e-6)))))
+    # (the secondary legs -- timed_only -- take the median of up to five blocks, the headline of up to forty)
+    n_blocks = max(1, min(5 if opt.timed_only else 40, int(np.ceil((0.5 if opt.timed_only else opt.min_seconds) / max(blocks[0], 1e-6)))))
     for b in range(1, n_blocks):
         blocks.append(timed_block(b))
     elapsed = float(np.median(blocks))
@@ -310,6 +318,43 @@ def run_gpu(opt, rank, world, device):
     eager_elapsed = float("nan")
     run_gpu.conv = None
     run_gpu.host_fed = None
+    run_gpu.exchange = None
+    if world > 1 or opt.force_exchanges:
+        # where a data-parallel step's time goes: the two exchanges bracketed by stream events on every rank, a few steps behind the
+        # timed region (vitta_amd/exchange_timing.py; collectives captured INSIDE a graph cannot carry events: the three-segment and
+        # eager forms launch them eagerly)
+        from vitta_amd import exchange_timing as XT
+        n_x = min(opt.steps, 10)
+        XT.RECORDS = []
+        barrier()
+        tx = time.perf_counter()
+        for i in range(n_x):
+            one_step(opt.warmup + i)
+        barrier()
+        tx = (time.perf_counter() - tx) / n_x
+        mine = dict(rank=rank, ms_per_step_while_timing=1e3 * tx, **{k: v for k, v in XT.summary(n_x).items()})
+        XT.RECORDS = None
+        every = [mine]
+        if world > 1:
+            try:
+                every = [None] * world
+                torch.distributed.all_gather_object(every, mine)
+            except Exception as e:  # noqa: BLE001
+                log(f"exchange report not gathered: {e!r}")
+                every = [mine]
+        res = {"steps": n_x, "per_rank": every,
+               "note": "stream-event time of each eagerly launched exchange on its launching stream (the gradient buckets issued blocking, one "
+                       "event pair each, while this is measured: an upper bound of what the overlapped bucketed form exposes); empty where "
+                       "the collectives are captured inside the step's graph"}
+        for kind in ("moments", "gradients"):
+            vals = [r[kind] for r in every if isinstance(r, dict) and kind in r]
+            if vals:
+                res[kind] = {"bytes_per_step": vals[0]["bytes_per_step"], "calls_per_step": vals[0]["calls_per_step"],
+                             "ms_per_step_mean_over_ranks": float(np.mean([v["ms_per_step"] for v in vals])),
+                             "ms_per_step_max_over_ranks": float(np.max([v["ms_per_step"] for v in vals])),
+                             "slowest_rank": int(np.argmax([v["ms_per_step"] for v in vals]))}
+        run_gpu.exchange = res
+        log(f"exchange decomposition: { {k: v for k, v in res.items() if k in ('moments', 'gradients')} }")
     if rank == 0 and world == 1 and not opt.timed_only and not opt.sequential and not opt.no_host_fed:
         # the same K steps with every video coming from (pinned) HOST memory: `value` above has its inputs resident in HBM; this is the
         # PCIe-inclusive rate -- (a) vitta_amd/prefetch.py, the next video's copies on a copy stream beside the current step (what
@@ -640,6 +685,16 @@ def run_cpu_baseline(opt):
                        f"{cores} threads")
 
 
+def _rocprof_moments():
+    """The moments kernel's bandwidth as rocprofv3 measured it (profiles/r6_moments_rocprof.json, written by tools/prof_summary.py from the
+    kernel trace of this very command; bench.py cannot run the profiler on itself): the bench's own figure above is from stream events."""
+    f = os.path.join(ROOT, "profiles", "r6_moments_rocprof.json")
+    try:
+        return dict(json.load(open(f)), source=os.path.relpath(f, ROOT))
+    except (OSError, ValueError):
+        return None
+
+
 def _trunk_pool_fold():
     from vitta_amd import conv as _cv, trunk as _tr
     return _tr.POOL_FOLD and _cv.ARITH == "b3"
@@ -808,7 +863,7 @@ def main():
         moments = {"kernel": "moments_nchw_partial_kernel (29 layers, 1 launch; stand-alone: in the TANet step the "
                              "hooked moments ride in the convolution epilogues)",
                    "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "one_video": one_video, "streaming": streaming,
-                   "traffic_one_video": traffic,
+                   "traffic_one_video": traffic, "rocprof": _rocprof_moments(),
                    "traffic_source": "profiles/r1_moments_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 per "
                                      "the gfx950 note)"}
         if conv:
@@ -892,6 +947,17 @@ def main():
         "adapt_only_ms": (1e3 * adapt_only if adapt_only == adapt_only else None), "host_fed": getattr(run_gpu, "host_fed", None), "launch_mode": mode, "eager_ms_per_step": eager_ms,
         "roofline": roofline, "ranks": ranks, "dp_graph": dp_graph,
     }
+    # first-contact diagnostics of a data-parallel run: how many distinct devices the ranks really sit on, which
+    # rank was the slowest in how many of the timed blocks, and the two exchanges timed separately
+    line["rccl_ranks_seen"] = len({(r.get("pci_bus_id"), r.get("uuid"), r.get("device_index")) for r in ranks if isinstance(r, dict)}) \
+        if (world > 1 and opt.dist_backend == "nccl") else (1 if opt.force_exchanges else None)
+    prb = getattr(run_gpu, "per_rank_blocks", [])
+    if prb:
+        slow = [int(np.argmax(b)) for b in prb]
+        line["slowest_rank"] = {"per_block": slow, "most_often": int(np.bincount(slow).argmax()),
+                                "spread_ms_per_step": 1e3 * float(np.median([max(b) - min(b) for b in prb])) / opt.steps}
+    if getattr(run_gpu, "exchange", None):
+        line["exchange"] = run_gpu.exchange
     if opt.arch == "swin":
         n_ln = len(adapter.engine.hooks)
         line["metric"] = f"videos/sec TTA step (Video Swin-B, 2x{opt.clip_length}x{opt.size}^2), whole job"
@@ -923,6 +989,53 @@ def main():
                            "optimizer": "SGD all parameters (reference default, corpus/basics.py:547-560)",
                            "launch_mode": run_gpu.mode}
         torch.cuda.empty_cache()
+    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_exact_fp32 and not opt.timed_only and world == 1 \
+            and not opt.force_exchanges and os.environ.get("VITTA_CONV_ARITH", "b3") == "b3":
+        # the strictly exact-fp32 figure in the SAME run: every convolution on v_mfma_f32_32x32x2_f32 (conv_sk / conv_pw /
+        # conv.hip, VITTA_CONV_ARITH=f32) -- no split operands anywhere
+        import copy
+        from vitta_amd import conv as _cv
+        o3 = copy.copy(opt)
+        o3.timed_only = True
+        old_arith, _cv.ARITH = _cv.ARITH, "f32"
+        try:
+            log("third timing: exact-fp32 convolutions (VITTA_CONV_ARITH=f32) ...")
+            e3 = run_gpu(o3, rank, world, device)[0]
+            line["exact_fp32"] = {"value": videos / e3, "unit": "videos/s", "ms_per_step": 1e3 * e3 / opt.steps, "steps": opt.steps,
+                                  "dtype": "f32 (v_mfma_f32_32x32x2_f32 in every convolution; no split-bf16 operands)",
+                                  "launch_mode": run_gpu.mode}
+        except Exception as e:  # noqa: BLE001  (a leg must never cost the headline line)
+            log(f"exact-fp32 leg failed: {e!r}")
+            line["exact_fp32"] = {"error": repr(e)}
+        finally:
+            _cv.ARITH = old_arith
+        torch.cuda.empty_cache()
+    if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_forced_exchange_leg and not opt.timed_only and world == 1 \
+            and not opt.force_exchanges and opt.size == 224:
+        # N = 1 WITH both exchanges live (a one-rank RCCL group): what a SCALE run's N = 1 point pays beyond this line's headline; its own
+        # process (a process-group watchdog abort cannot be caught in-process and must not cost the line)
+        import subprocess
+        try:
+            log("one-rank RCCL leg (--gpus 1 --force-exchanges) in a child process ...")
+            cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-exchanges", "--timed-only", "--no-cpu-baseline",
+                   "--steps", str(opt.steps), "--warmup", str(opt.warmup)]
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_PORT="29547")
+            pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            sub = None
+            for ln in pr.stdout.decode(errors="replace").splitlines():
+                if ln.strip().startswith("{"):
+                    sub = json.loads(ln)
+            if pr.returncode == 0 and sub:
+                line["forced_exchanges_n1"] = {"value": sub["value"], "unit": "videos/s", "ms_per_step": sub["ms_per_step"],
+                                               "dp_graph": sub.get("dp_graph"), "exchange": sub.get("exchange"),
+                                               "launch_mode": sub.get("launch_mode"),
+                                               "note": "the same step with the moments and gradient all-reduces live on a one-rank RCCL group "
+                                                       "(--gpus 1 --force-exchanges): the N = 1 point of the data-parallel form"}
+            else:
+                line["forced_exchanges_n1"] = {"error": f"rc={pr.returncode}"}
+        except Exception as e:  # noqa: BLE001
+            log(f"one-rank RCCL leg failed: {e!r}")
+            line["forced_exchanges_n1"] = {"error": repr(e)}
     if opt.arch == "tanet" and opt.optimizer == "adam_affine" and not opt.no_swin and not opt.timed_only and world == 1 \
             and opt.size == 224:
         # the other half of north_star: Video Swin-B at BASELINE config 3's and config 5's shapes, in the same run

@@ -356,7 +356,9 @@ class StatAlignEngine:
     def exchange(self):
         """The moments all-reduce (data-parallel only): one SUM over the packed [cnt | s1 | s2] buffer."""
         if self.distributed:
-            torch.distributed.all_reduce(self.plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+            from . import exchange_timing as XT
+            with XT.timed("moments", self.plan.stats.numel() * 4):
+                torch.distributed.all_reduce(self.plan.stats, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
 
     def finish_global(self, tie=None):
         """EMA update + loss + backward coefficients from the (reduced) statistics.  `tie`: the model output of this

@@ -266,9 +266,11 @@ class TrunkRunner:
                 or net.relu._forward_hooks or c1._forward_hooks or c1.bias is not None \
                 or (tuple(c1.weight.shape), c1.stride, c1.padding, c1.dilation, c1.groups) != ((64, 3, 7, 7), (2, 2), (3, 3), (1, 1), 1) \
                 or x.shape[3] % 4 \
-                or not isinstance(net.bn1, nn.BatchNorm2d) or net.bn1.training or not net.bn1.affine \
+                or not isinstance(net.bn1, nn.BatchNorm2d) or not net.bn1.affine \
                 or x.shape[0] * 64 > 65535:
             return "the stem is not the stock hook-free 7x7/2 convolution + eval-mode affine BatchNorm2d + 3/2/1 max-pool (or the width is not a multiple of four / too many frames)"
+        if net.bn1.training:
+            return "a BatchNorm2d is in TRAIN mode (--fix_BNS False, or a calibration pass) or has no affine parameters"
         blocks = self.blocks()
         if not blocks:
             return "no residual blocks"
@@ -301,7 +303,7 @@ class TrunkRunner:
                 return "a bottleneck's convolution geometry is not 1x1 / 3x3 (stride 1 | 2) / 1x1 with 16- / 32-aligned channels"
             for bn in bns:
                 if not isinstance(bn, nn.BatchNorm2d) or bn.training or not bn.affine:
-                    return "a BatchNorm2d is in TRAIN mode (--fix_BNS False) or has no affine parameters"
+                    return "a BatchNorm2d is in TRAIN mode (--fix_BNS False, or a calibration pass) or has no affine parameters"
                 ok, hook = _engine_hook(bn)
                 if not ok or (hook is not None and not grad):
                     return "a BatchNorm2d carries a foreign forward hook (e.g. stat_reg='BNS' BNFeatureHook), or an engine hook under no_grad"

@@ -255,7 +255,9 @@ class FlatArena:
             torch._foreach_copy_(dst, src)
 
     def all_reduce(self):
-        torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+        from . import exchange_timing as XT
+        with XT.timed("gradients", self.grad.numel() * 4):
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
 
     # -- bucketed exchange: slices of the arena reduced as soon as their gradients are final ----------------------------
     def span(self, params):
@@ -275,6 +277,11 @@ class FlatArena:
 
     def reduce_range(self, lo, hi, async_op=True):
         if hi <= lo:
+            return
+        from . import exchange_timing as XT
+        if XT.active():  # (bench.py's decomposition steps: one blocking call per bucket, an event pair around it)
+            with XT.timed("gradients", (hi - lo) * 4):
+                torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM)
             return
         w = torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM, async_op=async_op)
         if async_op and w is not None:
