@@ -507,7 +507,8 @@ def run_gpu(opt, rank, world, device):
         log("streaming-size moments done")
     one_graph = use_graph and adapter._graph is not None and ("step" in adapter._graph and adapter._graph["step"] is not None
                                                               or "adapt" in adapter._graph)
-    run_gpu.mode = ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if (one_graph and adapter.bucket is not None) else
+    split = use_graph and adapter._graph is not None and adapter._graph.get("step") == "split"
+    run_gpu.mode = "hipGraph replay (adaptation and evaluation as separate graphs on two streams)" if split else ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if (one_graph and adapter.bucket is not None) else
                                          " (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph or adapter.bucket is not None) else "")) \
         if use_graph else "eager launches"
     run_gpu.eager_ms = (1e3 * eager_elapsed / opt.steps) if use_graph else None

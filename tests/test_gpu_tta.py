@@ -336,11 +336,13 @@ def test_swin_config5_shape_gpu_equals_cpu_oracle_path(tmp_path, bf16, sgd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("capture", [None, "single", "segmented"])
+@pytest.mark.parametrize("capture", [None, "single", "segmented", "split", "split_sgd", "single_sgd"])
 def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture):
     """ViTTAAdapter.step (video i adapted while video i-1 is evaluated on a second stream, the optimizer update waiting for both)
     == adapt(i-1); eval(i-1); adapt(i): same losses and the same evaluation logits, eager and as one hipGraph (with a
-    forked branch) and as the data-parallel segments."""
+    forked branch), as the data-parallel segments, and (round 6) as SEPARATE graphs on two streams -- forward + backward |
+    optimizer on the step's stream, the evaluation graph captured on and replayed from the side stream; *_sgd: SGD over all
+    parameters (split: the trunk's trainable convolutions are re-packed once per step by a graph of its own that both passes wait for)."""
     import json
     import numpy as np
     from vitta_amd import data, tta
@@ -351,8 +353,9 @@ def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture)
     offs = np.concatenate([[0], np.cumsum(ch)])
     mp, vp = H.write_stat_files(str(tmp_path), [g["src_means"][offs[i]:offs[i + 1]] for i in range(len(ch))],
                                 [g["src_vars"][offs[i]:offs[i + 1]] for i in range(len(ch))])
+    sgd = capture is not None and capture.endswith("_sgd")
     args = H.tanet_args(tmp_path, clip_length=T, input_size=size, spatiotemp_mean_clean_file=mp,
-                        spatiotemp_var_clean_file=vp, update_only_bn_affine=True, lr=1e-4)
+                        spatiotemp_var_clean_file=vp, update_only_bn_affine=not sgd, lr=5e-5 if sgd else 1e-4)
     n = 6
     tta_set = data.SyntheticVideoDataset(n, 2, T, size, 101, "tanet", seed0=700)
     eval_set = data.SyntheticVideoDataset(n, 1, T, size, 101, "tanet", seed0=700)
@@ -386,7 +389,7 @@ def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture)
         for i in range(n):
             x, ev = clips(adapter, i)
             if capture is not None and i == 2:
-                adapter.capture_graphs(x, ev, segmented=capture == "segmented", overlap_eval=True)
+                adapter.capture_graphs(x, ev, segmented=capture == "segmented", overlap_eval=True, split=capture.startswith("split"))
             adapter.set_adapt_mode()
             (_, lr_, lc_), ev_out = adapter.step(x, prev)
             losses.append((lr_.item(), lc_.item()))
@@ -395,6 +398,8 @@ def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture)
             prev = ev
         if capture is not None:
             assert "step" in adapter._graph and (adapter._graph["step"] is None) == (capture == "segmented")
+            assert (adapter._graph["step"] == "split") == capture.startswith("split")
+            assert ("pre" in adapter._graph) == (capture == "split_sgd")
         adapter.close_hooks()
         logits.append(adapter.evaluate(prev).clone().cpu())
         torch.cuda.synchronize()
@@ -403,8 +408,11 @@ def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture)
     seq, seq2, ovl = sequential(), sequential(), overlapped()
     floor = max((c - c2).abs().max().item() for (_, _, c), (_, _, c2) in zip(seq, seq2))
     assert len(ovl) == n
-    for (a, b, c), (d, e, f) in zip(seq, ovl):
-        assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
+    # per-step floors = two SEQUENTIAL runs against each other (atomic arrival order differs between any two runs; under SGD over all
+    # parameters every weight moves each step and two runs drift apart ~30x per step: measured 0, 0, 1e-6, 3e-6, 9e-5, 7e-4)
+    for (a, b, c), (d, e, f), (a2, b2, _) in zip(seq, ovl, seq2):
+        fa, fb = abs(a - a2) / abs(a), abs(b - b2) / max(abs(b), 1e-12)
+        assert a == pytest.approx(d, rel=max(1e-4, 8 * fa)) and b == pytest.approx(e, rel=max(5e-3, 8 * fb)), (sgd, fa, fb)
         assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
 
 

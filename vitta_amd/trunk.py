@@ -222,6 +222,7 @@ class TrunkRunner:
         # evaluation reads the adaptation set's forward packs
         self.prepacked = False
         self.after_block = None  # callable(block index) run after each block's backward (tta: bucketed gradient exchange)
+        self.before_block = None  # callable(block index) run before each block's forward of an adaptation pass (tta: delayed evaluation fork)
         # tta.FlatArena of the adapter driving this trunk (or None): the adaptation pass's fixed-point pooling sums then live in the
         # arena's zeroed tail -- the step's ONE fill covers them (FlatArena.Zeroed.fresh() tells whether it has, else zeroed here)
         self.zero_pool = None
@@ -674,7 +675,9 @@ class TrunkRunner:
             if buf is None:
                 buf = torch.zeros(npool, dtype=torch.int64, device=x.device)
             pool = [buf, 0]
-        for b in blocks:
+        for i, b in enumerate(blocks):
+            if keep and self.before_block is not None:
+                self.before_block(i)
             cur, h, w, saved = self.block_forward(b, cur, n, h, w, keep, sites, pool)
             tape.append(saved)
         c = cur.shape[0]

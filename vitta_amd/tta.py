@@ -44,6 +44,14 @@ CAPTURE_MODE = "thread_local"
 FUSED_HEAD = os.environ.get("VITTA_FUSED_HEAD", "1") != "0"
 # overlapped step with trainable convolution weights: pack them once per step, not once per pass (ViTTAAdapter._prepacked)
 PREPACK = os.environ.get("VITTA_PREPACK", "1") != "0"
+# Round 6: the overlapped schedule of ONE process as SEPARATE graphs on two streams -- [re-pack] | forward + backward | optimizer on the
+# step's stream, the evaluation forward as a graph of its own on the side stream -- instead of one graph with a forked branch
+# (VITTA_SPLIT_GRAPHS=0).  Measured (tools/debug/view_split_probe.py): the evaluation graph beside the adaptation graph costs the
+# adaptation nothing (4.68 vs 4.67 ms), the forked single graph ~0.4 ms per step.
+SPLIT_GRAPHS = os.environ.get("VITTA_SPLIT_GRAPHS", "1") != "0"
+# forked forms (one graph / eager): the evaluation forks in front of trunk block EVAL_FORK_BLOCK of the adaptation forward instead of
+# in front of the whole step (0) -- beside the latency-bound layer-3 / 4 launches rather than the bandwidth-bound layer-1 ones
+EVAL_FORK_BLOCK = int(os.environ.get("VITTA_EVAL_FORK_BLOCK", "0"))
 
 NUM_CLASSES = {"ucf101": 101, "hmdb51": 51, "kinetics": 400, "somethingv2": 174, "kth": 6, "u2h": 12, "h2u": 12}
 
@@ -602,7 +610,17 @@ class ViTTAAdapter:
             g["tta_in"].copy_(tta_input)
             g["eval_in"].copy_(eval_input)
             self.engine.plan = g["plan"]  # the buffers the captured launches (and the eager exchanges between them) use
-            if g["step"] is not None:
+            if g["step"] == "split":
+                cur, side = torch.cuda.current_stream(), self._side_stream
+                if "pre" in g:
+                    g["pre"].replay()  # trainable convolutions: ONE re-pack that both passes read
+                side.wait_stream(cur)  # the previous optimizer step, the clips' copies, the re-pack
+                with torch.cuda.stream(side):
+                    g["eval_side"].replay()
+                g["fb"].replay()
+                cur.wait_stream(side)  # the evaluation still reads the weights the update overwrites
+                g["opt"].replay()
+            elif g["step"] is not None:
                 g["step"].replay()
             else:
                 g["seg_fwd"].replay()
@@ -654,6 +672,32 @@ class ViTTAAdapter:
         self.set_adapt_mode()
         return out, side
 
+    def _forked_step(self, tta_input, eval_input, has_video=True):
+        """(eval logits, adaptation outputs) with the evaluation forked on the side stream -- in front of the step, or (EVAL_FORK_BLOCK >
+        0, TANet trunk) in front of that block of the adaptation forward."""
+        runner = None
+        if EVAL_FORK_BLOCK > 0 and has_video and self.args.arch == "tanet":
+            from . import trunk
+            net = self.model.module if isinstance(self.model, SingleDeviceParallel) else self.model
+            base = getattr(net, "base_model", None)
+            if base is not None and trunk.ENABLED and EVAL_FORK_BLOCK < len(trunk.runner_of(base).blocks()):
+                runner = trunk.runner_of(base)
+        if runner is None:
+            ev, side = self._fork_eval(eval_input)
+            return ev, self._adapt_step_eager(tta_input, has_video, join=side)
+        box = {}
+
+        def fork(i):
+            if i == EVAL_FORK_BLOCK and "side" not in box:
+                box["ev"], box["side"] = self._fork_eval(eval_input)
+
+        runner.before_block = fork
+        try:
+            out = self._adapt_step_eager(tta_input, has_video, join=lambda: box["side"])
+        finally:
+            runner.before_block = None
+        return box["ev"], out
+
     def _step_eager(self, tta_input, eval_input, has_video=True):
         if self.device.type != "cuda":  # one queue: the sequential order with the evaluation first
             self.close_hooks()
@@ -662,8 +706,7 @@ class ViTTAAdapter:
             self.set_adapt_mode()
             return self._adapt_step_eager(tta_input, has_video), ev
         with self._prepacked():
-            ev, side = self._fork_eval(eval_input)
-            out = self._adapt_step_eager(tta_input, has_video, join=side)
+            ev, out = self._forked_step(tta_input, eval_input, has_video)
         return out, ev
 
     # -- gradient exchange --------------------------------------------------------------------------------------------
@@ -815,7 +858,7 @@ class ViTTAAdapter:
             return g["adapt_out"]
         return self._adapt_step_eager(input, has_video)
 
-    def _adapt_step_eager(self, input, has_video=True, join=None):
+    def _adapt_step_eager(self, input, has_video=True, join=None, optimizer=True):
         a = self.args
         self.arena.zero_step()
         output = loss_reg = loss_consis = None
@@ -833,8 +876,9 @@ class ViTTAAdapter:
             self._disarm()
         self._exchange_end(ran_backward=has_video)
         if join is not None:  # an evaluation on a side stream still reads the weights this update overwrites
-            torch.cuda.current_stream().wait_stream(join)
-        self.optimizer.step()
+            torch.cuda.current_stream().wait_stream(join() if callable(join) else join)
+        if optimizer:  # (False: the split-graph capture steps in a graph of its own, behind the join with the evaluation stream)
+            self.optimizer.step()
         # detached: nothing the caller holds may keep this step's autograd graph (and its AccumulateGrad
         # nodes, which remember the stream they were created on) alive into a later graph capture
         det = lambda t: None if t is None else t.detach()
@@ -876,7 +920,7 @@ class ViTTAAdapter:
             self.optimizer.step()
         g["adapt_out"] = (output.detach(), loss_reg.detach(), None if loss_consis is None else loss_consis.detach())
 
-    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False, collectives_in_graph=None):
+    def capture_graphs(self, tta_input, eval_input, segmented=False, overlap_eval=False, collectives_in_graph=None, split=None):
         """Capture the adaptation step (forward, hooks, both losses, backward, optimizer) and the
         evaluation forward into two hipGraphs.  The per-video iteration is ~1500 short kernels; eagerly
         the host launch rate, not the GPU, sets the pace (r1a profile: 16 ms of kernels in a 29 ms
@@ -903,15 +947,15 @@ class ViTTAAdapter:
         if collectives_in_graph:
             self._quiesce_collectives()
             try:
-                self._capture(tta_input, eval_input, segmented, overlap_eval, True)
+                self._capture(tta_input, eval_input, segmented, overlap_eval, True, split=False)
                 self.dp_graph = "one"
                 return
             except Exception as e:  # noqa: BLE001  (a capture the collectives library refuses must not cost the run)
                 import warnings
                 warnings.warn(f"data-parallel step not captured as one graph ({e!r}); using three segments")
                 torch.cuda.synchronize()
-        self._capture(tta_input, eval_input, segmented, overlap_eval, False)
-        self.dp_graph = "segments" if "seg_fwd" in self._graph else "one"
+        self._capture(tta_input, eval_input, segmented, overlap_eval, False, split=split)
+        self.dp_graph = "segments" if "seg_fwd" in self._graph else ("split" if self._graph.get("step") == "split" else "one")
 
     def _quiesce_collectives(self):
         """Before a capture that the collectives' own stream joins: nothing of the eager steps may still be listed by the
@@ -934,7 +978,55 @@ class ViTTAAdapter:
         self.arena._pending = []
         self._graph = None
 
-    def _capture(self, tta_input, eval_input, segmented, overlap_eval, collectives_in_graph):
+    def _capture_split(self, g):
+        """The overlapped step of one process as separate graphs (SPLIT_GRAPHS): g["pre"] (only with trainable trunk convolutions: their
+        re-pack, once for both passes), g["fb"] = fill + forward + both losses + backward, g["opt"] = the optimizer update, on the step's
+        stream; g["eval_side"] = the evaluation forward, CAPTURED ON THE SIDE STREAM (everything keyed per stream -- split-K workspaces,
+        arrival tickets, on-demand weight packs -- is then the side stream's own, as in the forked single graph) and replayed there.
+        step() orders them: pre -> {eval_side || fb} -> join -> opt.  Same launches, same results as the forked graph; the two passes
+        are independent graph launches instead of branches the graph executor schedules."""
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        pre_cm = None
+        runner = None
+        if PREPACK and self.args.arch == "tanet":
+            from . import trunk
+            net = self.model.module if isinstance(self.model, SingleDeviceParallel) else self.model
+            base = getattr(net, "base_model", None)
+            if base is not None and trunk.ENABLED:
+                runner = trunk.runner_of(base)
+        try:
+            if runner is not None and any(p.requires_grad for p in base.parameters() if p.dim() == 4):
+                g["pre"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g["pre"], capture_error_mode=CAPTURE_MODE):
+                    pre_cm = self._prepacked()
+                    pre_cm.__enter__()  # (the re-pack launches land in g["pre"]; runner.prepacked stays set for the captures below)
+                if not runner.prepacked:  # nothing was rebuilt (stem only): no such graph
+                    del g["pre"]
+            g["fb"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["fb"], capture_error_mode=CAPTURE_MODE):
+                g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, optimizer=False)
+            g["opt"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["opt"], capture_error_mode=CAPTURE_MODE):
+                self.optimizer.step()
+            self.close_hooks()
+            with torch.cuda.stream(side):
+                self._evaluate_eager(g["eval_in"])  # (eagerly once on the side stream: its per-stream tables exist before the capture)
+            torch.cuda.synchronize()
+            g["eval_side"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["eval_side"], stream=side, capture_error_mode=CAPTURE_MODE):
+                g["eval_out_overlapped"] = self._evaluate_eager(g["eval_in"])
+            self.add_hooks_back()
+            self.set_adapt_mode()
+        finally:
+            if pre_cm is not None:
+                pre_cm.__exit__(None, None, None)
+        g["step"] = "split"
+
+    def _capture(self, tta_input, eval_input, segmented, overlap_eval, collectives_in_graph, split=None):
+        if split is None:
+            split = SPLIT_GRAPHS
         self._abandon_step()
         g = {"tta_in": tta_input.clone(), "eval_in": eval_input.clone()}
         torch.cuda.synchronize()
@@ -946,12 +1038,13 @@ class ViTTAAdapter:
             self._capture_segments(g, overlap_eval)
             if overlap_eval:
                 g["step"] = None  # step() replays the three segments
+        elif overlap_eval and split:
+            self._capture_split(g)
         elif overlap_eval:
             g["step"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["step"], capture_error_mode=CAPTURE_MODE):
                 with self._prepacked():
-                    g["eval_out_overlapped"], side = self._fork_eval(g["eval_in"])
-                    g["adapt_out"] = self._adapt_step_eager(g["tta_in"], True, join=side)
+                    g["eval_out_overlapped"], g["adapt_out"] = self._forked_step(g["tta_in"], g["eval_in"], True)
         else:
             g["adapt"] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g["adapt"], capture_error_mode=CAPTURE_MODE):
