@@ -208,6 +208,22 @@ class VittaHipError(RuntimeError):
     pass
 
 
+_SAID = set()
+
+
+def loud_once(key, msg):
+    """A vendor-library / ATen path is about to run where a hand-written kernel exists (an A/B switch, or a shape a kernel declines): say
+    so ONCE per cause on stderr and through logging -- tests guard the default, this guards a production run."""
+    if key in _SAID:
+        return
+    _SAID.add(key)
+    import logging
+    import sys
+    text = "[vitta_amd] WARNING: " + msg
+    logging.getLogger("vitta_amd").warning(text)
+    print(text, file=sys.stderr, flush=True)
+
+
 def lib():
     """Load (once) and return the bound library; raise loudly if it is absent."""
     global _LIB

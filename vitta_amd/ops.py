@@ -1247,11 +1247,20 @@ def _weight_grad(weight, needed, g2, x2):
     sink, ret = _grad_sink(weight, True, zero=False)
     if ret is None:
         if not (DENSE_WGRAD and _weight_grad_conv(g2, x2, sink.view(weight.shape[0], -1), True)):
+            _said_library_wgrad(weight, g2)
             sink.view(weight.shape[0], -1).addmm_(g2.t(), x2)
         return None
     if DENSE_WGRAD and _weight_grad_conv(g2, x2, ret.view(weight.shape[0], -1), False):
         return ret.view_as(weight)
+    _said_library_wgrad(weight, g2)
     return torch.mm(g2.t(), x2, out=ret.view(weight.shape[0], -1)).view_as(weight)
+
+
+def _said_library_wgrad(weight, g2):
+    if g2.is_cuda:
+        from ._lib import loud_once
+        loud_once(("dense_wgrad", tuple(weight.shape), DENSE_WGRAD), f"dense weight gradient {tuple(weight.shape)} over {g2.shape[0]} rows runs "
+                  "on the vendor library's TN product, not on vitta_conv_f32" + ("" if DENSE_WGRAD else ": VITTA_DENSE_WGRAD=library (an A/B switch)"))
 
 
 def _bias_grad(bias, needed, g2):

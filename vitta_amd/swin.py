@@ -231,6 +231,10 @@ def window_attention(qkv, bias, mask, scale, num_heads):
             return ops.WindowAttention.apply(qkv, bias, mask, scale, num_heads)
         # window sizes the fused kernel does not cover (N > 400, e.g. (16,7,7)) take the composed form
         # below: still GPU library kernels, no host fallback
+    if qkv.is_cuda:
+        from ._lib import loud_once
+        loud_once(("wmsa_composed", N), f"window attention with a dense bias on {N} tokens runs as composed library products (matmul / "
+                  f"softmax), not on wmsa.hip" + ("" if FUSED_ATTENTION else ": swin.FUSED_ATTENTION is off (an A/B switch)"))
     q, k, v = qkv.view(B_, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4)
     attn = (q * scale) @ k.transpose(-2, -1) + bias.unsqueeze(0)
     if mask is not None:
@@ -269,6 +273,10 @@ class WindowAttention3D(nn.Module):
                                                    self.relative_position_code[:N], self.code_offset, region, self.scale,
                                                    self.num_heads)
                 return self.proj_drop(linear(self.proj, out))
+        if x.is_cuda:
+            from ._lib import loud_once
+            loud_once(("wmsa_rel_declined", N), f"relative-position window attention on {N} tokens takes the gathered dense-bias form"
+                      + ("" if FUSED_ATTENTION else ": swin.FUSED_ATTENTION is off (an A/B switch)"))
         idx = self.relative_position_index[:N, :N].reshape(-1)
         bias = self.relative_position_bias_table[idx].view(N, N, self.num_heads).permute(2, 0, 1).contiguous()
         out = window_attention(linear(self.qkv, x), bias, mask, self.scale, self.num_heads)

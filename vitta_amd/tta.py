@@ -530,6 +530,9 @@ class ViTTAAdapter:
         """(video logits, loss_consis) through ops.TanetHead when the model is our TSN on the hand-written trunk with its stock head
         (tanet.TSN.fused_head_ok): the head of the adaptation pass as dropout + ONE launch forward and ONE backward instead of
         fourteen (VITTA_FUSED_HEAD=0: the module chain).  None: not applicable, the caller takes the module chain."""
+        if not FUSED_HEAD and self.device.type == "cuda":
+            from ._lib import loud_once
+            loud_once("fused_head_off", "VITTA_FUSED_HEAD=0 (an A/B switch): the adaptation head runs as the module chain (ATen / library launches)")
         if not FUSED_HEAD or self.device.type != "cuda" or not torch.is_grad_enabled():
             return None
         net = self._net()
