@@ -398,9 +398,10 @@ def test_config5_swin_at_full_size_bf16_recipe_agrees_with_fp32(tmp_path, abi_ca
             rem = (e - nq * q).abs().max().item()
             flips = int((nq != 0).sum())
             report.append((k, round(r, 3), "flips", flips, "remainder / max|g|", rem / gmax))
-            assert rem <= 5e-2 * gmax and 0 < flips <= 16 and nq.abs().max().item() <= 1, (k, rem / gmax, flips, nq.abs().max().item())
+            # measured (round 6): 1-2 flipped channels per tensor, remainders 3.4e-3 .. 7.7e-3 of the maximum
+            assert rem <= 1.5e-2 * gmax and 0 < flips <= 8 and nq.abs().max().item() <= 1, (k, rem / gmax, flips, nq.abs().max().item())
         else:
             over = int((e.abs() > 5e-2 * gmax).sum())
             report.append((k, round(r, 3), "elements over 5e-2", over))
-            assert over <= 16, (k, over)
+            assert over <= 4, (k, over)  # measured: 1-2 elements (the channels whose statistics flipped)
     print("tensors beyond 5e-2 of their maximum:", report)
