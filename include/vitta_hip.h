@@ -375,10 +375,14 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv, const float* d_table, int32_t 
                                const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                                float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                                const void* d_out, const void* d_dout, const float* d_lse, float* d_delta, void* d_dqkv,
-                               float* d_dtable, int32_t io_bf16, void* stream);
+                               float* d_dtable, float* d_dtable_ws, int64_t dtable_ws_bytes, int32_t io_bf16, void* stream);
 /* d_dtable [T, nH] fp32 or NULL: the gradient of the relative-position table is ADDED to it (swin_transformer.py:110-151 under
- * SGD over all parameters) -- by the one-pass backward only (binned in LDS per (window, head), one global atomic per entry);
- * VITTA_ERR_UNSUPPORTED where that form does not apply (vitta_wmsa_bf16_dtable_supported says so beforehand). */
+ * SGD over all parameters) -- by the one-pass backward only: d bias = dS summed along the score tile's diagonals in registers, binned
+ * in LDS per (window, head); VITTA_ERR_UNSUPPORTED where that form does not apply (vitta_wmsa_bf16_dtable_supported says so
+ * beforehand).  d_dtable_ws: caller-owned scratch of vitta_wmsa_bf16_dtable_workspace_bytes(B_, nH, T) bytes (contents undefined before
+ * and after) -- the pairs' columns leave as plain stores and one reduce launch adds the windows; NULL / too small: one global atomic per
+ * (pair, entry), ~6x slower at 256 windows per head. */
+size_t vitta_wmsa_bf16_dtable_workspace_bytes(int64_t B_, int32_t nH, int32_t table_rows);
 int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_rows);
 
 /* --------------------------------------------------------------------------

@@ -535,14 +535,84 @@ __device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, in
   return c;
 }
 
+// d bias of ONE 16 x 16 score tile into the pair's LDS column.  The table row of (query q, key k) is code[q] - code[k] + off, so the tile's
+// 256 scores fall on its ~31 DIAGONALS: (q + 1, k + 1) shares the row of (q, k) unless exactly one of the two tokens wraps to the next
+// line of the window.  Round 5 issued one ds_add_f32 per score -- 256 per tile, the four query groups of an instruction landing on the
+// same ~28 words (up to four lanes per address: 614 K atomics per pair at ~4 clocks a lane, 4.3 of the 4.9 ms of a stage-0 launch).
+// Here the diagonal is summed in registers first: along the lane's four queries r = 0..3 against keys i..i + 3 (DPP row shifts inside the
+// 16-lane key row), then along the four query groups g (lane + 20 = the next group's key + 4: ds_bpermute), each link only where the
+// rows really agree; the leader of a chain adds once, a score whose chain is broken adds on its own.
+__device__ __forceinline__ int dpp_shl(int v, int n, int fill) {  // lane i of a 16-lane row receives lane i + n's value (else `fill`)
+  switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(fill, v, 0x102, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(fill, v, 0x103, 0xf, 0xf, false);
+  }
+}
+__device__ __forceinline__ int dpp_shr(int v, int n, int fill) {  // ... lane i - n's
+  switch (n) {
+    case 1: return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
+    case 2: return __builtin_amdgcn_update_dpp(fill, v, 0x112, 0xf, 0xf, false);
+    default: return __builtin_amdgcn_update_dpp(fill, v, 0x113, 0xf, 0xf, false);
+  }
+}
+__device__ __forceinline__ void dtab_add(float* dtab, const float (&ds)[4], const int (&bin)[4], int i, int g) {
+  const int lane = (g << 4) | i;
+  // ---- the r-chain: (r, key i + r), r = 0..3, led by the lane's r = 0 score ----
+  int full = bin[0] >= 0 ? 1 : 0;
+  float s = ds[0];
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const int br = dpp_shl(bin[r], r, -2);
+    const float vr = __int_as_float(dpp_shl(__float_as_int(ds[r]), r, 0));
+    full &= (br == bin[0]) ? 1 : 0;
+    s += vr;
+  }
+  // a score (r >= 1) is absorbed iff the leader r lanes below it closed its whole chain
+  const int ab1 = dpp_shr(full, 1, 0), ab2 = dpp_shr(full, 2, 0), ab3 = dpp_shr(full, 3, 0);
+  // ---- the g-chain over complete r-chains: lane + 20 continues the diagonal (queries + 4, keys + 4) ----
+  const float lead_v = full ? s : ds[0];
+  int pb[3], pf[3];
+  float pv[3];
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    const int src = (lane + 20 * j) << 2;
+    pb[j - 1] = __builtin_amdgcn_ds_bpermute(src, bin[0]);
+    pf[j - 1] = __builtin_amdgcn_ds_bpermute(src, full);
+    pv[j - 1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(lead_v)));
+  }
+  const int prev = (lane - 20) << 2;
+  const int qb = __builtin_amdgcn_ds_bpermute(prev, bin[0]), qf = __builtin_amdgcn_ds_bpermute(prev, full);
+  const bool has_prev = g >= 1 && i >= 4;
+  const bool absorbed0 = full && has_prev && qf && qb == bin[0];  // an earlier group's leader carries this chain
+  float tot = lead_v;
+  bool link = full != 0;
+#pragma unroll
+  for (int j = 1; j < 4; ++j) {
+    link = link && (g + j < 4) && (i + 4 * j < 16) && pf[j - 1] && pb[j - 1] == bin[0];
+    tot += link ? pv[j - 1] : 0.f;
+  }
+  if (bin[0] >= 0 && !absorbed0) atomicAdd(dtab + bin[0], tot);
+  if (bin[1] >= 0 && !ab1) atomicAdd(dtab + bin[1], ds[1]);
+  if (bin[2] >= 0 && !ab2) atomicAdd(dtab + bin[2], ds[2]);
+  if (bin[3] >= 0 && !ab3) atomicAdd(dtab + bin[3], ds[3]);
+}
+
 // DTAB: the gradient of the relative-position table (swin_transformer.py:110-151, trainable under SGD over all parameters): d bias =
 // dS, binned by code[q] - code[k] + off into an LDS column of T floats (ds_add_f32; different waves hold different key tiles, i.e.
 // mostly different relative positions), added to dtable [T, nH] with one global atomic per non-zero entry at the end
+constexpr bool DTAB_SEPARATE = false;
 template <bool REG, bool TAIL, bool DTAB>
 __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args a, const float* __restrict__ out,
                                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                                       float* __restrict__ delta, float* __restrict__ dqkv, int qc, int nchunks,
-                                                                      float* __restrict__ dtable) {
+                                                                      float* __restrict__ dtable, float* __restrict__ dtable_ws) {
+  // DTAB: the pair's table gradient rides in this launch (GRADS on), or -- DTAB_SEPARATE -- is a pass of its own behind the plain launch:
+  // S, P, dP, dS and the binning only, no dK / dV / dQ products, no accumulator registers
+  // (measured in round 6, 1024 pairs of 784 tokens: ONE kernel with gradients and binning 3.2 ms; the gradients first and the binning as a
+  // pass of its own -- 120 registers, no scratch -- 0.65 + 3.06 ms: the binning is bound by the LDS atomic pipe, ~256 clocks per ds_add_f32
+  // instruction and eight waves per CU issuing them, not by the spills.  DTAB_SEPARATE keeps the two-pass form compilable.)
+  constexpr bool GRADS = !(DTAB && DTAB_SEPARATE);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
   const Carve1 cv = carve1(smem, nt, qc, a.T, DTAB);
@@ -610,10 +680,11 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       if (c4 == 0) {
         cv.dl[row] = in ? dsum : 0.f;
         cv.l[row] = in ? lse[(b * nH + h) * N + q] : INFINITY;  // exp(s - inf) = 0 for padded queries
-        if (in && delta) delta[(b * nH + h) * N + q] = dsum;
+        if (GRADS && in && delta) delta[(b * nH + h) * N + q] = dsum;
       }
     }
-    for (int it = threadIdx.x; it < qrows * DQP; it += TH_BWD1) cv.dq[it] = 0.f;
+    if (GRADS)
+      for (int it = threadIdx.x; it < qrows * DQP; it += TH_BWD1) cv.dq[it] = 0.f;
     __syncthreads();
     // ---- step s: wave w on query tile (s + w) mod qtn (qtn >= 8: eight distinct tiles), against all of its key tiles ----
     for (int st = 0; st < qtn; ++st) {
@@ -645,40 +716,46 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
           const int pkey = cv.cr[min(16 * kt + i, N - 1)];
           const int ckey_j = REG ? pk_code(pkey) : pkey, rkey_j = pk_region(pkey);
           float p[4], ds[4];
+          int bin[4];  // table row of the lane's four scores; -1: padded query / key (TAIL)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float term = cv.tab[qcd[r] - ckey_j + a.off];
+            bin[r] = qcd[r] - ckey_j + a.off;
+            float term = cv.tab[bin[r]];
             if (REG && qrg[r] != rkey_j) term -= 100.f;
-            const float sv = (!TAIL || (q0 + r < N && kvalid)) ? sacc[r] + term : -INFINITY;
+            const bool live = !TAIL || (q0 + r < N && kvalid);
+            const float sv = live ? sacc[r] + term : -INFINITY;
             p[r] = __expf(sv - lv[r]);
             ds[r] = p[r] * (dp[r] - dv[r]);
-            if (DTAB) {
-              if (!TAIL || (q0 + r < N && kvalid)) atomicAdd(cv.dtab + (qcd[r] - ckey_j + a.off), ds[r]);
-            }
+            if (DTAB && !live) bin[r] = -1;
           }
-          const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
-          dv0[j] = mfma(pa, gq0, dv0[j]);
-          dv1[j] = mfma(pa, gq1, dv1[j]);
-          dk0[j] = mfma(da, qq0, dk0[j]);
-          dk1[j] = mfma(da, qq1, dk1[j]);
-          // dQ share of this key tile: dS with the query on the operand's row = the tile written key-major and read transposed
-          *reinterpret_cast<bf16x4*>(tscr + i * TSP + 4 * g) = da;  // M[key i][queries 4 g ..]
-          const bf16x4 dst = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) bf16x4*)(tscr + (4 * g + (i >> 2)) * TSP + 4 * (i & 3)));  // M[keys 4 g ..][query i]
-          dqa = mfma(dst, gather4(cv.kb, kt, g, i, 0), dqa);
-          dqb = mfma(dst, gather4(cv.kb, kt, g, i, 1), dqb);
+          if (DTAB) dtab_add(cv.dtab, ds, bin, i, g);
+          if (GRADS) {
+            const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
+            dv0[j] = mfma(pa, gq0, dv0[j]);
+            dv1[j] = mfma(pa, gq1, dv1[j]);
+            dk0[j] = mfma(da, qq0, dk0[j]);
+            dk1[j] = mfma(da, qq1, dk1[j]);
+            // dQ share of this key tile: dS with the query on the operand's row = the tile written key-major and read transposed
+            *reinterpret_cast<bf16x4*>(tscr + i * TSP + 4 * g) = da;  // M[key i][queries 4 g ..]
+            const bf16x4 dst = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) bf16x4*)(tscr + (4 * g + (i >> 2)) * TSP + 4 * (i & 3)));  // M[keys 4 g ..][query i]
+            dqa = mfma(dst, gather4(cv.kb, kt, g, i, 0), dqa);
+            dqb = mfma(dst, gather4(cv.kb, kt, g, i, 1), dqb);
+          }
         }
       }
       // this wave is the only one on query tile qt in this step: plain read-modify-write of its rows of the dQ tile
+      if (GRADS) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cv.dq[(ql + r) * DQP + i] += dqa[r];
-        cv.dq[(ql + r) * DQP + 16 + i] += dqb[r];
+        for (int r = 0; r < 4; ++r) {
+          cv.dq[(ql + r) * DQP + i] += dqa[r];
+          cv.dq[(ql + r) * DQP + 16 + i] += dqb[r];
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
     // ---- the chunk's dQ ----
-    for (int it = threadIdx.x; it < qrows * 8; it += TH_BWD1) {
+    for (int it = threadIdx.x; GRADS && it < qrows * 8; it += TH_BWD1) {
       const int row = it >> 3, c4 = it & 7, q = 16 * qt0 + row;
       if (q >= N) continue;
       const float4 v = *reinterpret_cast<const float4*>(cv.dq + row * DQP + 4 * c4);
@@ -690,15 +767,24 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       }
     }
   }
-  if (DTAB) {  // (the last step's barrier is behind every ds_add)
-    for (int t = threadIdx.x; t < a.T; t += TH_BWD1) {
-      const float v = cv.dtab[t];
-      if (v != 0.f) atomicAdd(dtable + (int64_t)t * nH + h, v);
+  if (DTAB) {
+    __syncthreads();  // every wave's ds_add of the last chunk (the table pass has no per-step barrier)
+    if (dtable_ws) {
+      // round 6: the pair's column leaves as PLAIN stores into the caller's workspace [window][head][T]; dtable_reduce_kernel adds the
+      // windows.  (One global atomic per entry and pair was 5.4 M device-scope atomics onto 21 K addresses per stage-0 launch -- every
+      // window of a head adds to the same T words --: 3.8 of the launch's 4.5 ms once the LDS binning was pre-reduced.)
+      float* col = dtable_ws + ((int64_t)b * nH + h) * a.T;
+      for (int t = threadIdx.x; t < a.T; t += TH_BWD1) col[t] = cv.dtab[t];
+    } else {
+      for (int t = threadIdx.x; t < a.T; t += TH_BWD1) {
+        const float v = cv.dtab[t];
+        if (v != 0.f) atomicAdd(dtable + (int64_t)t * nH + h, v);
+      }
     }
   }
   // ---- dK, dV of the wave's key tiles ----
 #pragma unroll
-  for (int j = 0; j < KT_MAX; ++j) {
+  for (int j = 0; GRADS && j < KT_MAX; ++j) {
     const int kt = wave + 8 * j;
     if (kt >= nt) break;
 #pragma unroll
@@ -713,6 +799,30 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       }
     }
   }
+}
+
+// dtable[t][h] += sum over the windows of a segment of ws[window][h][t]; grid (ceil(nH T / 256), segments): consecutive threads walk
+// consecutive t of one head (coalesced), a thread sums its segment's windows in window order and adds once
+__global__ __launch_bounds__(256) void dtable_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dtable, int64_t B_, int nH, int T,
+                                                            int seg) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;  // h * T + t
+  if (e >= (int64_t)nH * T) return;
+  const int h = (int)(e / T), t = (int)(e - (int64_t)h * T);
+  const int64_t b0 = (int64_t)blockIdx.y * seg, b1 = b0 + seg < B_ ? b0 + seg : B_;
+  float acc = 0.f;
+  const int64_t stride = (int64_t)nH * T;
+  const float* p = ws + b0 * stride + e;
+  int64_t b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+    p += 8 * stride;
+  }
+  for (; b < b1; ++b, p += stride) acc += *p;
+  if (acc != 0.f) atomicAdd(dtable + (int64_t)t * nH + h, acc);
 }
 
 inline int pick_split(int64_t pairs, int nt, int waves) {
@@ -748,6 +858,11 @@ int vitta_wmsa_bf16_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
   const size_t f = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows), b1 = lds_bytes(nt, (size_t)16 * nt * RP, 0, table_rows),
                b2 = lds_bytes(nt, (size_t)16 * nt * RP, 2 * 16 * nt, table_rows);
   return (f <= 160 * 1024 && b1 <= 160 * 1024 && b2 <= 160 * 1024) ? 1 : 0;
+}
+
+size_t vitta_wmsa_bf16_dtable_workspace_bytes(int64_t B_, int32_t nH, int32_t table_rows) {
+  if (B_ <= 0 || nH <= 0 || table_rows <= 0) return 0;
+  return (size_t)B_ * (size_t)nH * (size_t)table_rows * sizeof(float);
 }
 
 int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_rows) {
@@ -804,14 +919,14 @@ int vitta_wmsa_rel_bwd_bf16(const float* d_qkv, const float* d_table, int32_t T,
                             const float* d_out, const float* d_dout, const float* d_lse, float* d_delta, float* d_dqkv,
                             void* stream) {
   return vitta_wmsa_rel_bwd_bf16_io(d_qkv, d_table, T, d_code, code_off, d_region, nW, B_, N, nH, head_dim, scale, d_rowmap, map_windows,
-                                    tokens_per_sample, d_out, d_dout, d_lse, d_delta, d_dqkv, nullptr, 0, stream);
+                                    tokens_per_sample, d_out, d_dout, d_lse, d_delta, d_dqkv, nullptr, nullptr, 0, 0, stream);
 }
 
 int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
                                const int32_t* d_region, int32_t nW, int64_t B_, int32_t N, int32_t nH, int32_t head_dim,
                                float scale, const int32_t* d_rowmap, int32_t map_windows, int64_t tokens_per_sample,
                                const void* d_out_, const void* d_dout_, const float* d_lse, float* d_delta, void* d_dqkv_,
-                               float* d_dtable, int32_t io_bf16, void* stream) {
+                               float* d_dtable, float* d_dtable_ws, int64_t dtable_ws_bytes, int32_t io_bf16, void* stream) {
   const float* d_qkv = static_cast<const float*>(d_qkv_);
   const float* d_out = static_cast<const float*>(d_out_);
   const float* d_dout = static_cast<const float*>(d_dout_);
@@ -831,6 +946,8 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const bool force_one = form && form[0] == 'o', force_two = form && form[0] == 't';
   int nchunks1 = 0;
   const bool dtab = d_dtable != nullptr;  // the table gradient exists in the one-pass kernel only
+  // with a workspace of B_ x nH x T floats the pairs' columns leave as plain stores and ONE reduce launch adds them (else: global atomics)
+  float* const ws = (dtab && d_dtable_ws && dtable_ws_bytes >= (int64_t)vitta_wmsa_bf16_dtable_workspace_bytes(B_, nH, T)) ? d_dtable_ws : nullptr;
   const int qc1 = bwd1_chunks(nt, T, dtab, &nchunks1);
   const size_t lf = qc1 ? bwd1_lds_bytes(nt, qc1, T, dtab) : 0;
   if (dtab && (qc1 <= 0 || nt > 8 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
@@ -839,16 +956,35 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   do {                                                                                                                                \
     if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT>, lf)) return VITTA_ERR_LAUNCH;                                                   \
     VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf, st, a, d_out, d_dout, d_lse,    \
-                 d_delta, d_dqkv, qc1, nchunks1, d_dtable);                                                                           \
+                 d_delta, d_dqkv, qc1, nchunks1, d_dtable, ws);                                                                       \
   } while (0)
-    if (dtab) {
+    if (!dtab || DTAB_SEPARATE) {  // the gradients: chunking and LDS of the plain form (no table column)
+      int nchunks0 = 0;
+      const int qc0 = bwd1_chunks(nt, T, false, &nchunks0);
+      const size_t lf0 = bwd1_lds_bytes(nt, qc0, T, false);
+      const int qc_keep = qc1, nc_keep = nchunks1;
+      const size_t lf_keep = lf;
+#define WMSA_BWD0(R, TL)                                                                                                              \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, false>, lf0)) return VITTA_ERR_LAUNCH;                                               \
+    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, false>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf0, st, a, d_out, d_dout, d_lse, \
+                 d_delta, d_dqkv, qc0, nchunks0, nullptr, nullptr);                                                                  \
+  } while (0)
+      if (reg) { if (tail) WMSA_BWD0(true, true); else WMSA_BWD0(true, false); }
+      else { if (tail) WMSA_BWD0(false, true); else WMSA_BWD0(false, false); }
+#undef WMSA_BWD0
+      (void)qc_keep; (void)nc_keep; (void)lf_keep;
+    }
+    if (dtab) {  // the launch that bins the table gradient (with the gradients, or -- DTAB_SEPARATE -- behind the plain launch)
       if (reg) { if (tail) WMSA_BWD1(true, true, true); else WMSA_BWD1(true, false, true); }
       else { if (tail) WMSA_BWD1(false, true, true); else WMSA_BWD1(false, false, true); }
-    } else {
-      if (reg) { if (tail) WMSA_BWD1(true, true, false); else WMSA_BWD1(true, false, false); }
-      else { if (tail) WMSA_BWD1(false, true, false); else WMSA_BWD1(false, false, false); }
     }
 #undef WMSA_BWD1
+    if (ws) {
+      const int segs = (int)(B_ >= 64 ? 8 : B_ >= 8 ? 2 : 1), seg = (int)((B_ + segs - 1) / segs);
+      VITTA_LAUNCH(dtable_reduce_kernel, dim3((unsigned)(((int64_t)nH * T + 255) / 256), (unsigned)segs), dim3(256), 0, st, ws, d_dtable, B_,
+                   nH, T, seg);
+    }
     return VITTA_OK;
   }
 #define WMSA_BWD(R, TL)                                                                                                               \

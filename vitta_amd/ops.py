@@ -520,9 +520,14 @@ class WindowAttentionRel(torch.autograd.Function):
         tm = KTIMING("wmsa_bf16" if bf16 else "wmsa_f32", 10.0 * n * n * hd * b_ * nh, 10.0 * n * n * b_ * nh) if KTIMING is not None else None
         dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         if bf16:
+            ws = None
+            if dtable is not None:  # scratch for the pairs' table-gradient columns (plain stores + one reduce launch instead of atomics)
+                ws = torch.empty(int(lib().vitta_wmsa_bf16_dtable_workspace_bytes(b_, nh, table.shape[0])) // 4, dtype=torch.float32,
+                                 device=qkv.device)
             check(lib().vitta_wmsa_rel_bwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                                    hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
-                                                   _p(dqkv), _p(dtable), int(qkv.dtype == torch.bfloat16), _stream()), "vitta_wmsa_rel_bwd_bf16")
+                                                   _p(dqkv), _p(dtable), _p(ws), ws.numel() * 4 if ws is not None else 0,
+                                                   int(qkv.dtype == torch.bfloat16), _stream()), "vitta_wmsa_rel_bwd_bf16")
             if tm is not None:
                 tm.stop()
             return dqkv, r_table, None, None, None, None, None, None
