@@ -20,6 +20,8 @@
 // (col = lane&15 = query, row = 4*(lane>>4)+r = key) is exactly the A-operand layout the second GEMM
 // needs (A[i = lane&15][k = lane>>4] with key = 16t + 4*(lane>>4) + r at k-step r), so P feeds P.V
 // straight from the accumulators: no LDS round trip, no shuffles.
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace vitta;
@@ -552,6 +554,236 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dkv_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward in ONE pass (round 6; relative-position form with a frozen table: the LN-affine adaptation of BASELINE config 3).
+// The two kernels above evaluate every score tile twice -- S and dP once query-major for dQ, once key-major for dK / dV: 56
+// v_mfma_f32_16x16x4_f32 per (query tile, key tile) and the exp / bias / mask arithmetic twice.  Here a tile is evaluated ONCE (40):
+// a wave owns key tiles (K and V fragments in registers, dK / dV in accumulators, as wmsa_bwd_dkv_kernel), the queries are walked in
+// chunks whose raw Q and dO rows sit in LDS.  S [query][key] has the query on the accumulator's ROW index, which is the index the next
+// product contracts over: dV = P^T dO and dK = dS^T Q take P and dS straight from the accumulators.  dQ = dS K contracts over KEYS: the
+// dS tile goes through a wave-private 16 x 20 float LDS turn-around (four ds_write_b32, one ds_read_b128 with the roles of the
+// indices exchanged) and meets K rows from LDS.  dQ sums over the waves' key tiles in an fp32 LDS tile: in step s of a chunk wave w
+// works on query tile (s + w) mod chunk -- eight waves on eight different tiles --, adds its key tiles' shares in registers and writes
+// them with plain read-modify-writes; one barrier per step (the structure of wmsa_bf16.hip's one-pass kernel).
+// Reference: swin_transformer.py:138-169 (autograd of the attention).
+// ------------------------------------------------------------------------------------------------
+constexpr int KT1 = 4;     // key tiles per wave: 8 waves x 4 = 32 tiles = 512 tokens (the (8,7,7) window: 25)
+constexpr int TSP1 = 20;   // pitch of the turn-around tile in floats (16-byte aligned rows, quad-bank spread)
+struct Carve1 {
+  float *k, *q, *g, *dq, *l, *dl, *tab, *scr;
+  int *cr, *rows;
+};
+__host__ __device__ inline size_t bwd1_floats(int nt, int qc, int T) {
+  const size_t qrows = 16 * (size_t)qc;
+  return (size_t)16 * nt * KPAD + 3 * qrows * KPAD + 2 * qrows + ((T + 3) & ~3) + (size_t)WMSA_WAVES * 16 * TSP1 + 2 * 16 * (size_t)nt;
+}
+// balanced chunks of >= 8 query tiles that fit LDS; returns the largest chunk (0: none)
+inline int bwd1_chunks(int nt, int T, int* nchunks) {
+  for (int nc = 1; nc <= nt; ++nc) {
+    if (nt / nc < WMSA_WAVES) break;
+    const int qc = (nt + nc - 1) / nc;
+    if (sizeof(float) * bwd1_floats(nt, qc, T) > 160 * 1024) continue;
+    *nchunks = nc;
+    return qc;
+  }
+  return 0;
+}
+__device__ __forceinline__ Carve1 carve1(float* smem, int nt, int qc, int T) {
+  Carve1 c;
+  const int qrows = 16 * qc;
+  c.k = smem;
+  c.q = c.k + 16 * nt * KPAD;
+  c.g = c.q + qrows * KPAD;
+  c.dq = c.g + qrows * KPAD;
+  c.l = c.dq + qrows * KPAD;
+  c.dl = c.l + qrows;
+  c.tab = c.dl + qrows;
+  c.scr = c.tab + ((T + 3) & ~3);
+  c.cr = reinterpret_cast<int*>(c.scr + WMSA_WAVES * 16 * TSP1);
+  c.rows = c.cr + 16 * nt;
+  return c;
+}
+
+// the q rows of dqkv [tokens][3][nH][32] to zero (ksplit = 2: both workgroups of a pair add their dQ share)
+__global__ __launch_bounds__(256) void wmsa_zero_q_kernel(float* __restrict__ dqkv, int64_t tokens, int C) {
+  const int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;  // over tokens x C floats
+  if (e >= tokens * C) return;
+  const int64_t tok = e / C;
+  *reinterpret_cast<float4*>(dqkv + tok * 3 * C + (e - tok * C)) = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <bool REG>
+__global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_fused_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ table, const int* __restrict__ code_g, const int* __restrict__ region_g,
+    int T, int off, int nW, int N, int nH, float scale, RowMap rm, const float* __restrict__ out, const float* __restrict__ dout,
+    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, int qc, int nchunks, int ksplit) {
+  // ksplit (gridDim.x) = 2: the pair's key tiles are dealt to two workgroups (tile kt belongs to workgroup kt mod 2) where a workgroup
+  // per pair would leave half of the CUs idle (stage 2 of Swin-B: 128 (window, head) pairs, 18 of the 24 blocks).  Each workgroup owns
+  // dK / dV of its tiles; both ADD their dQ share into the q rows of dqkv, which the launch wrapper zeroed (two addends onto zero:
+  // the sum does not depend on who arrives first).
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nt = (N + 15) / 16;
+  const int kx = blockIdx.x;
+  const Carve1 cv = carve1(smem, nt, qc, T);
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t rs = 3 * (int64_t)nH * HD;
+  const int C = nH * HD;
+  fill_rows(cv.rows, rm, b, N, nt);
+  stage_rows(cv.k, qkv, h, 1, N, nH, nt, cv.rows);  // K rows of the whole window: the B operand of dQ
+  {  // table column of the head, packed code | region of the window's tokens
+    Carve tmp;
+    tmp.tab = cv.tab; tmp.code = cv.cr;
+    (void)setup_terms<true>(tmp, table, nullptr, code_g, region_g, T, off, nW, N, nH, h, b, nt);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+  float* const scr = cv.scr + wave * 16 * TSP1;
+  // the wave's key tiles: K / V fragments (B operands of S and dP), the key's packed code, dK / dV accumulators
+  float kf[KT1][8], vf[KT1][8];
+  int pkey[KT1];
+  bool kval[KT1];
+  f32x4 dk0[KT1], dk1[KT1], dv0[KT1], dv1[KT1];
+  __syncthreads();  // rows / codes in place
+#pragma unroll
+  for (int j = 0; j < KT1; ++j) {
+    dk0[j] = dk1[j] = dv0[j] = dv1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kt = min(kx + ksplit * (wave + WMSA_WAVES * j), nt - 1), key = min(16 * kt + i, N - 1);
+    kval[j] = kx + ksplit * (wave + WMSA_WAVES * j) < nt && 16 * kt + i < N;
+    pkey[j] = cv.cr[key];
+    load8(kf[j], qkv + (int64_t)cv.rows[key] * rs + (int64_t)(nH + h) * HD + 8 * kk);
+    load8(vf[j], qkv + (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * kk);
+  }
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int qt0 = ch * nt / nchunks, qtn = (ch + 1) * nt / nchunks - qt0, qrows = 16 * qtn;
+    __syncthreads();  // (the previous chunk's readers are done)
+    // ---- stage the chunk: raw Q rows, dO rows, lse (+inf for padded queries: p = 0), delta = sum_d dO O (also stored), zero dQ ----
+    for (int it = threadIdx.x; it < qrows * 8; it += WMSA_THREADS) {
+      const int row = it >> 3, c4 = it & 7, q = 16 * qt0 + row;
+      const bool in = q < N;
+      const int tok = cv.rows[in ? q : N - 1];
+      float4 q4 = *reinterpret_cast<const float4*>(qkv + (int64_t)tok * rs + h * HD + 4 * c4);
+      float4 g4 = *reinterpret_cast<const float4*>(dout + (int64_t)tok * C + h * HD + 4 * c4);
+      const float4 o4 = *reinterpret_cast<const float4*>(out + (int64_t)tok * C + h * HD + 4 * c4);
+      if (!in) q4 = g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(cv.q + row * KPAD + 4 * c4) = q4;
+      *reinterpret_cast<float4*>(cv.g + row * KPAD + 4 * c4) = g4;
+      *reinterpret_cast<float4*>(cv.dq + row * KPAD + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      float dsum = g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+      dsum += __shfl_xor(dsum, 1, 64);
+      dsum += __shfl_xor(dsum, 2, 64);
+      dsum += __shfl_xor(dsum, 4, 64);
+      if (c4 == 0) {
+        cv.dl[row] = in ? dsum : 0.f;
+        cv.l[row] = in ? lse[(b * nH + h) * N + q] : INFINITY;
+        if (in) delta[(b * nH + h) * N + q] = dsum;
+      }
+    }
+    __syncthreads();
+    // ---- step st: wave w on query tile (st + w) mod qtn (qtn >= 8: eight distinct tiles) against all of its key tiles ----
+    for (int st = 0; st < qtn; ++st) {
+      int qt = st + wave;
+      qt = qt >= qtn ? qt - qtn : qt;
+      float qf[8], gf[8];
+      load8(qf, cv.q + (16 * qt + i) * KPAD + 8 * kk);
+      load8(gf, cv.g + (16 * qt + i) * KPAD + 8 * kk);
+      const int ql = 16 * qt + 4 * kk;                       // the lane's four queries (accumulator rows), chunk-local
+      const int4 cq4 = *reinterpret_cast<const int4*>(cv.cr + 16 * qt0 + ql);
+      const float4 l4 = *reinterpret_cast<const float4*>(cv.l + ql), d4 = *reinterpret_cast<const float4*>(cv.dl + ql);
+      const int cq[4] = {cq4.x, cq4.y, cq4.z, cq4.w};
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+      f32x4 dqa = {0.f, 0.f, 0.f, 0.f}, dqb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KT1; ++j) {
+        const int kt = kx + ksplit * (wave + WMSA_WAVES * j);
+        if (kt < nt) {
+          // S [query][key] and dP [query][key]: A = Q / dO rows (LDS), B = K^T / V^T (registers); row = query 4 kk + r, col = key i
+          f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            s = mfma(qf[u], kf[j][u], s);
+            dp = mfma(gf[u], vf[j][u], dp);
+          }
+          const int ck = (REG ? pk_code(pkey[j]) : pkey[j]) - off, rk = pk_region(pkey[j]);
+          float tv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tv[r] = cv.tab[(REG ? pk_code(cq[r]) : cq[r]) - ck];
+          f32x4 p, ds;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float term = (REG && pk_region(cq[r]) != rk) ? tv[r] - 100.f : tv[r];
+            // a padded query has lse = +inf (p = 0); a padded KEY lane must not reach dQ, which sums over keys
+            p[r] = kval[j] ? __expf(fmaf(s[r], scale, term) - lq[r]) : 0.f;
+            ds[r] = p[r] * (dp[r] - dq_[r]);
+          }
+          // dV[key][d] += P^T dO ; dK[key][d] += dS^T Q   (A = accumulator-layout values, B rows = queries 16 qt + 4 kk + r)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* grow = cv.g + (ql + r) * KPAD;
+            const float* qrow = cv.q + (ql + r) * KPAD;
+            dv0[j] = mfma(p[r], grow[i], dv0[j]);
+            dv1[j] = mfma(p[r], grow[16 + i], dv1[j]);
+            dk0[j] = mfma(ds[r], qrow[i], dk0[j]);
+            dk1[j] = mfma(ds[r], qrow[16 + i], dk1[j]);
+          }
+          // dQ share of this key tile: dS with the QUERY on the operand's row = the tile through the wave's turn-around
+#pragma unroll
+          for (int r = 0; r < 4; ++r) scr[(4 * kk + r) * TSP1 + i] = ds[r];         // M[query 4 kk + r][key i]
+          const float4 x4 = *reinterpret_cast<const float4*>(scr + i * TSP1 + 4 * kk);  // M[query i][keys 4 kk ..]
+          const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float* krow = cv.k + (16 * kt + 4 * kk + r) * KPAD;
+            dqa = mfma(xs[r], krow[i], dqa);
+            dqb = mfma(xs[r], krow[16 + i], dqb);
+          }
+        }
+      }
+      // this wave is the only one on query tile qt in this step: plain read-modify-write of its rows of the dQ tile
+      // (accumulator rows of dqa / dqb = queries 4 kk + r of the tile, column = d = i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cv.dq[(ql + r) * KPAD + i] += dqa[r];
+        cv.dq[(ql + r) * KPAD + 16 + i] += dqb[r];
+      }
+      __syncthreads();
+    }
+    // ---- the chunk's dQ ----
+    for (int it = threadIdx.x; it < qrows * 8; it += WMSA_THREADS) {
+      const int row = it >> 3, c4 = it & 7, q = 16 * qt0 + row;
+      if (q >= N) continue;
+      const float4 v = *reinterpret_cast<const float4*>(cv.dq + row * KPAD + 4 * c4);
+      float* o = dqkv + (int64_t)cv.rows[q] * rs + (int64_t)h * HD + 4 * c4;
+      if (ksplit == 1) {
+        *reinterpret_cast<float4*>(o) = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+      } else {
+        atomicAdd(o, v.x * scale);
+        atomicAdd(o + 1, v.y * scale);
+        atomicAdd(o + 2, v.z * scale);
+        atomicAdd(o + 3, v.w * scale);
+      }
+    }
+  }
+  // ---- dK, dV of the wave's key tiles ----
+#pragma unroll
+  for (int j = 0; j < KT1; ++j) {
+    const int kt = kx + ksplit * (wave + WMSA_WAVES * j);
+    if (kt >= nt) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = 16 * kt + 4 * kk + r;
+      if (krow < N) {
+        float* ok = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(nH + h) * HD;
+        float* ov = dqkv + (int64_t)cv.rows[krow] * rs + (int64_t)(2 * nH + h) * HD;
+        ok[i] = dk0[j][r] * scale;
+        ok[16 + i] = dk1[j][r] * scale;
+        ov[i] = dv0[j][r];
+        ov[16 + i] = dv1[j][r];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Windows of 401 .. 800 tokens (the (16,7,7) window of the 32-frame SSv2 recipe: N = 784).  K and V of one (window, head)
 // no longer fit LDS together (226 KB), so keys (forward, dQ) / queries (dK dV) are walked in CHUNKS of 25 tiles that are
@@ -1015,6 +1247,37 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
   const int nt = (a.N + 15) / 16;
   const int qs = pick_qsplit(a.B_ * a.nH, nt);
   const int T = REL ? a.T : 0;
+  if constexpr (REL) {
+    // one pass (frozen table, a workgroup per (window, head) fills the chip): VITTA_WMSA_F32_BWD=two keeps the two-kernel form (A/B)
+    const char* form = std::getenv("VITTA_WMSA_F32_BWD");
+    int nchunks = 0;
+    // a workgroup per pair from 256 pairs on; two workgroups per pair (key tiles dealt out, dQ added) from 128; below: two kernels
+    const int64_t pairs = a.B_ * a.nH;
+    const bool forced = form && form[0] == 'o';
+    const int ksplit = pairs >= 256 ? 1 : 2;
+    const int qc = (!dbias && nt <= WMSA_WAVES * KT1 && !(form && form[0] == 't') && (pairs >= 128 || forced))
+                       ? bwd1_chunks(nt, T, &nchunks) : 0;
+    if (qc > 0) {
+      const size_t lf = sizeof(float) * bwd1_floats(nt, qc, T);
+      if (ksplit > 1) {
+        const int64_t tokens = a.rm.map ? (a.B_ / a.rm.nWm) * a.rm.L : a.B_ * (int64_t)a.N;
+        const int Cc = a.nH * HD;
+        VITTA_LAUNCH(wmsa_zero_q_kernel, dim3((unsigned)((tokens * Cc / 4 + 255) / 256)), dim3(256), 0, st, dqkv, tokens, Cc);
+      }
+#define WMSA_BWD1(REG)                                                                                                  \
+  do {                                                                                                                 \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_fused_kernel<REG>),                                 \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf) != hipSuccess)                        \
+      return VITTA_ERR_LAUNCH;                                                                                         \
+    VITTA_LAUNCH((wmsa_bwd_fused_kernel<REG>), dim3(ksplit, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lf, st, a.qkv, a.bias, a.code, \
+                 a.region, T, a.off, a.nW, a.N, a.nH, a.scale, a.rm, out, dout, lse, delta, dqkv, qc, nchunks, ksplit);  \
+  } while (0)
+      if (a.region) WMSA_BWD1(true);
+      else WMSA_BWD1(false);
+#undef WMSA_BWD1
+      return VITTA_OK;
+    }
+  }
   const size_t lds1 = lds_bytes(a.N, (REL && dbias) ? ((T + 3) & ~3) : 0, T), lds2 = lds_bytes(a.N, 2 * 16 * nt, T);
 #define WMSA_BWD(REG)                                                                                                   \
   do {                                                                                                                 \
