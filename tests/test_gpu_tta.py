@@ -259,7 +259,7 @@ def test_segmented_graph_capture_equals_single_graph_on_gpu(tmp_path):
     floor = max((c - c2).abs().max().item() for (_, _, c), (_, _, c2) in zip(single, single2))
     for (a, b, c), (d, e, f) in zip(single, seg):
         assert a == pytest.approx(d, rel=1e-4) and b == pytest.approx(e, rel=5e-3)
-        assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
+        assert (f - c).abs().max().item() <= max(6 * floor, 2e-3 * c.abs().max().item())
 
 
 @pytest.mark.parametrize("bf16,sgd", [(False, False), (True, False), ("dense", False), (True, True)])
@@ -421,7 +421,7 @@ def test_overlapped_evaluation_equals_sequential_order_on_gpu(tmp_path, capture)
     for (a, b, c), (d, e, f), (a2, b2, _) in zip(seq, ovl, seq2):
         fa, fb = abs(a - a2) / abs(a), abs(b - b2) / max(abs(b), 1e-12)
         assert a == pytest.approx(d, rel=max(1e-4, 8 * fa)) and b == pytest.approx(e, rel=max(5e-3, 8 * fb)), (sgd, fa, fb)
-        assert (f - c).abs().max().item() <= max(4 * floor, 2e-3 * c.abs().max().item())
+        assert (f - c).abs().max().item() <= max(6 * floor, 2e-3 * c.abs().max().item())
 
 
 def test_tta_loop_overlapped_schedule_logs_the_same_run_on_gpu(tmp_path):
