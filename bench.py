@@ -264,6 +264,7 @@ def run_gpu(opt, rank, world, device):
             log("first warm-up step done")
     torch.cuda.synchronize()
     use_graph = not opt.no_graph and opt.warmup >= 2
+    run_gpu.split_graphs = False
     if use_graph:
         x, _ = tta_set[0]
         ev, _ = eval_set[0]
@@ -273,6 +274,7 @@ def run_gpu(opt, rank, world, device):
                                    collectives_in_graph=True if opt.graph_collectives else (False if opt.segmented_graph else None))
             one_step(opt.warmup)  # first replay outside the timed region
             torch.cuda.synchronize()
+            run_gpu.split_graphs = adapter._graph is not None and adapter._graph.get("step") == "split"
             log("hipGraphs captured")
         except Exception as e:  # noqa: BLE001
             if world == 1 and not opt.force_exchanges:
@@ -507,7 +509,7 @@ def run_gpu(opt, rank, world, device):
         log("streaming-size moments done")
     one_graph = use_graph and adapter._graph is not None and ("step" in adapter._graph and adapter._graph["step"] is not None
                                                               or "adapt" in adapter._graph)
-    split = use_graph and adapter._graph is not None and adapter._graph.get("step") == "split"
+    split = use_graph and getattr(run_gpu, "split_graphs", False)  # (the form the TIMED steps ran in; the adapt-only graphs above replaced it)
     run_gpu.mode = "hipGraph replay (adaptation and evaluation as separate graphs on two streams)" if split else ("hipGraph replay" + (" (one graph, RCCL all-reduces captured)" if (one_graph and adapter.bucket is not None) else
                                          " (3 segments, exchanges eager)" if (world > 1 or opt.segmented_graph or adapter.bucket is not None) else "")) \
         if use_graph else "eager launches"
