@@ -523,3 +523,24 @@ def test_device_prefetcher_uploads_one_batch_ahead_on_its_own_stream():
         assert pf.uploads == 5
         want = [float(a.double().sum() + b.sum()) for a, b in host]
         assert [float(s) for s in sums] == want
+
+
+def test_role_streams_stay_distinct_when_the_stream_pool_wraps():
+    """vitta_amd/streams.py (round 6): torch.cuda.Stream() hands out a per-device pool of 32 streams round-robin, so late in a long-lived
+    process two requests share a handle -- and with it everything this package keys per stream (split-K workspaces, arrival tickets).
+    The evaluation side stream, the trunk's helper streams, the copy stream and torch's graph-capture stream must be pairwise distinct
+    whatever was created in between (the full GPU suite once put the side stream ON the capture stream: NaN losses in video 7)."""
+    from vitta_amd import streams
+    d = _dev()
+    burn = [torch.cuda.Stream(d) for _ in range(45)]  # wrap the pool
+    got = [streams.role(d, "eval"), streams.role(d, "copy")] + streams.roles(d, "trunk_helper", 8)
+    burn += [torch.cuda.Stream(d) for _ in range(45)]
+    again = [streams.role(d, "eval"), streams.role(d, "copy")] + streams.roles(d, "trunk_helper", 8)
+    assert [s.cuda_stream for s in got] == [s.cuda_stream for s in again]  # a role keeps its stream
+    handles = [s.cuda_stream for s in got] + [torch.cuda.graphs.graph.default_capture_stream.cuda_stream,
+                                              torch.cuda.default_stream(d).cuda_stream, torch.cuda.current_stream(d).cuda_stream]
+    assert len(set(handles[:11])) == 11 and len(set(handles)) >= 12, handles
+    x = torch.ones(8, device=d)
+    with torch.cuda.graph(torch.cuda.CUDAGraph()):  # a capture after the fact still finds its stream off every role's
+        y = x * 2
+    assert torch.cuda.graphs.graph.default_capture_stream.cuda_stream not in {s.cuda_stream for s in got}

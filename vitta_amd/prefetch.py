@@ -29,7 +29,11 @@ class DevicePrefetcher:
         self.depth = max(1, int(depth))
         self.queue = []  # [(batch on the device, copy event, pinned host tensors kept alive until the event)]
         self.done = False
-        self.stream = torch.cuda.Stream(self.device) if self.on else None
+        if self.on:  # (one copy stream per device for every prefetcher: a role stream, distinct from the compute-side roles)
+            from . import streams
+            self.stream = streams.role(self.device, "copy")
+        else:
+            self.stream = None
         self.uploads = 0  # batches whose copy ran on the copy stream (tests)
 
     def _upload(self, batch):

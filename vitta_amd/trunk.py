@@ -83,7 +83,8 @@ class _Fork:
             if pool is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("vitta_amd.trunk: run one eager step before capturing (helper streams are created eagerly)")
-                pool = _side_pool[device.index] = [torch.cuda.Stream(device) for _ in range(8)]
+                from . import streams
+                pool = _side_pool[device.index] = streams.roles(device, "trunk_helper", 8)  # distinct from every other role's
             used = sum(1 for k in _side_streams if k[0] == device.index)
             self.side = _side_streams[key] = pool[used % len(pool)]
         ev = torch.cuda.Event()

@@ -661,7 +661,8 @@ class ViTTAAdapter:
         """Issue the evaluation forward on the side stream (hooks closed, model.eval()); the caller joins."""
         cur = torch.cuda.current_stream()
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            from . import streams
+            self._side_stream = streams.role(self.device, "eval")
         side = self._side_stream
         capturing = torch.cuda.is_current_stream_capturing()
         side.wait_stream(cur)  # the previous optimizer step and the copy of the clip
@@ -989,8 +990,12 @@ class ViTTAAdapter:
         step() orders them: pre -> {eval_side || fb} -> join -> opt.  Same launches, same results as the forked graph; the two passes
         are independent graph launches instead of branches the graph executor schedules."""
         if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
+            from . import streams
+            self._side_stream = streams.role(self.device, "eval")
         side = self._side_stream
+        # (the adaptation graphs are captured on torch's default capture stream -- one pool stream for every capture of the process, whose
+        # per-stream buffers therefore exist after the first capture --; vitta_amd/streams.py keeps the side stream off it)
+        assert side.cuda_stream != torch.cuda.graphs.graph.default_capture_stream.cuda_stream
         pre_cm = None
         runner = None
         if PREPACK and self.args.arch == "tanet":
