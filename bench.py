@@ -1022,7 +1022,13 @@ def main():
             log("one-rank RCCL leg (--gpus 1 --force-exchanges) in a child process ...")
             cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-exchanges", "--timed-only", "--no-cpu-baseline",
                    "--steps", str(opt.steps), "--warmup", str(opt.warmup)]
-            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_PORT="29547")
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+            sk.close()
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port))
             pr = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
             sub = None
             for ln in pr.stdout.decode(errors="replace").splitlines():
