@@ -502,122 +502,68 @@ struct Carve1 {
   int *cr, *rows;
 };
 // qc = query tiles of the largest chunk; dtab: room for the table gradient of the (window, head) pair (T floats)
-__host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T, bool dtab) {
+// grads = false: the table-gradient pass of its own (no dQ tile, no turn-around scratch)
+__host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T, bool dtab, bool grads = true) {
   const size_t qrows = 16 * (size_t)qc, tp = (size_t)((T + 3) & ~3);
-  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + 8 * 16 * TSP) + 4 * (qrows * DQP + 2 * qrows + tp * (dtab ? 2 : 1) + 2 * 16 * (size_t)nt) + 64;
+  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + (grads ? 8 * 16 * TSP : 0)) +
+         4 * ((grads ? qrows * DQP : 0) + 2 * qrows + tp * (dtab ? 3 : 1) + 2 * 16 * (size_t)nt) + 64;
 }
 // chunks of query tiles: the fewest that fit LDS, BALANCED (chunk c = tiles [c nt / nc, (c + 1) nt / nc)), every chunk >= 8 tiles (the
 // step-synchronous rotation puts the eight waves on eight distinct tiles); returns the largest chunk, 0: no admissible chunking
-inline int bwd1_chunks(int nt, int T, bool dtab, int* nchunks) {
+inline int bwd1_chunks(int nt, int T, bool dtab, int* nchunks, bool grads = true) {
   for (int nc = (nt + 12) / 13; nc <= nt; ++nc) {
     if (nt / nc < 8) break;
     const int qc = (nt + nc - 1) / nc;
-    if (bwd1_lds_bytes(nt, qc, T, dtab) > 160 * 1024) continue;
+    if (bwd1_lds_bytes(nt, qc, T, dtab, grads) > 160 * 1024) continue;
     *nchunks = nc;
     return qc;
   }
   return 0;
 }
-__device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, int T, bool dtab) {
+__device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, int T, bool dtab, bool grads = true) {
   Carve1 c;
   const int qrows = 16 * qc, tp = (T + 3) & ~3;
   c.kb = reinterpret_cast<unsigned short*>(smem);
   c.qb = c.kb + 16 * nt * RP;
   c.gb = c.qb + qrows * RP;
   c.tscr = c.gb + qrows * RP;
-  c.dq = reinterpret_cast<float*>(c.tscr + 8 * 16 * TSP);
-  c.l = c.dq + qrows * DQP;
+  c.dq = reinterpret_cast<float*>(c.tscr + (grads ? 8 * 16 * TSP : 0));
+  c.l = c.dq + (grads ? qrows * DQP : 0);
   c.dl = c.l + qrows;
   c.tab = c.dl + qrows;
   c.dtab = c.tab + tp;
-  c.cr = reinterpret_cast<int*>(c.dtab + (dtab ? tp : 0));
+  c.cr = reinterpret_cast<int*>(c.dtab + (dtab ? 2 * tp : 0));  // (the table-gradient column holds 64-bit fixed-point words)
   c.rows = c.cr + 16 * nt;
   return c;
 }
 
-// d bias of ONE 16 x 16 score tile into the pair's LDS column.  The table row of (query q, key k) is code[q] - code[k] + off, so the tile's
-// 256 scores fall on its ~31 DIAGONALS: (q + 1, k + 1) shares the row of (q, k) unless exactly one of the two tokens wraps to the next
-// line of the window.  Round 5 issued one ds_add_f32 per score -- 256 per tile, the four query groups of an instruction landing on the
-// same ~28 words (up to four lanes per address: 614 K atomics per pair at ~4 clocks a lane, 4.3 of the 4.9 ms of a stage-0 launch).
-// Here the diagonal is summed in registers first: along the lane's four queries r = 0..3 against keys i..i + 3 (DPP row shifts inside the
-// 16-lane key row), then along the four query groups g (lane + 20 = the next group's key + 4: ds_bpermute), each link only where the
-// rows really agree; the leader of a chain adds once, a score whose chain is broken adds on its own.
-__device__ __forceinline__ int dpp_shl(int v, int n, int fill) {  // lane i of a 16-lane row receives lane i + n's value (else `fill`)
-  switch (n) {
-    case 1: return __builtin_amdgcn_update_dpp(fill, v, 0x101, 0xf, 0xf, false);
-    case 2: return __builtin_amdgcn_update_dpp(fill, v, 0x102, 0xf, 0xf, false);
-    default: return __builtin_amdgcn_update_dpp(fill, v, 0x103, 0xf, 0xf, false);
-  }
-}
-__device__ __forceinline__ int dpp_shr(int v, int n, int fill) {  // ... lane i - n's
-  switch (n) {
-    case 1: return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
-    case 2: return __builtin_amdgcn_update_dpp(fill, v, 0x112, 0xf, 0xf, false);
-    default: return __builtin_amdgcn_update_dpp(fill, v, 0x113, 0xf, 0xf, false);
-  }
-}
-__device__ __forceinline__ void dtab_add(float* dtab, const float (&ds)[4], const int (&bin)[4], int i, int g) {
-  const int lane = (g << 4) | i;
-  // ---- the r-chain: (r, key i + r), r = 0..3, led by the lane's r = 0 score ----
-  int full = bin[0] >= 0 ? 1 : 0;
-  float s = ds[0];
-#pragma unroll
-  for (int r = 1; r < 4; ++r) {
-    const int br = dpp_shl(bin[r], r, -2);
-    const float vr = __int_as_float(dpp_shl(__float_as_int(ds[r]), r, 0));
-    full &= (br == bin[0]) ? 1 : 0;
-    s += vr;
-  }
-  // a score (r >= 1) is absorbed iff the leader r lanes below it closed its whole chain
-  const int ab1 = dpp_shr(full, 1, 0), ab2 = dpp_shr(full, 2, 0), ab3 = dpp_shr(full, 3, 0);
-  // ---- the g-chain over complete r-chains: lane + 20 continues the diagonal (queries + 4, keys + 4) ----
-  const float lead_v = full ? s : ds[0];
-  int pb[3], pf[3];
-  float pv[3];
-#pragma unroll
-  for (int j = 1; j < 4; ++j) {
-    const int src = (lane + 20 * j) << 2;
-    pb[j - 1] = __builtin_amdgcn_ds_bpermute(src, bin[0]);
-    pf[j - 1] = __builtin_amdgcn_ds_bpermute(src, full);
-    pv[j - 1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(lead_v)));
-  }
-  const int prev = (lane - 20) << 2;
-  const int qb = __builtin_amdgcn_ds_bpermute(prev, bin[0]), qf = __builtin_amdgcn_ds_bpermute(prev, full);
-  const bool has_prev = g >= 1 && i >= 4;
-  const bool absorbed0 = full && has_prev && qf && qb == bin[0];  // an earlier group's leader carries this chain
-  float tot = lead_v;
-  bool link = full != 0;
-#pragma unroll
-  for (int j = 1; j < 4; ++j) {
-    link = link && (g + j < 4) && (i + 4 * j < 16) && pf[j - 1] && pb[j - 1] == bin[0];
-    tot += link ? pv[j - 1] : 0.f;
-  }
-  if (bin[0] >= 0 && !absorbed0) atomicAdd(dtab + bin[0], tot);
-  if (bin[1] >= 0 && !ab1) atomicAdd(dtab + bin[1], ds[1]);
-  if (bin[2] >= 0 && !ab2) atomicAdd(dtab + bin[2], ds[2]);
-  if (bin[3] >= 0 && !ab3) atomicAdd(dtab + bin[3], ds[3]);
-}
-
 // DTAB: the gradient of the relative-position table (swin_transformer.py:110-151, trainable under SGD over all parameters): d bias =
-// dS, binned by code[q] - code[k] + off into an LDS column of T floats (ds_add_f32; different waves hold different key tiles, i.e.
-// mostly different relative positions), added to dtable [T, nH] with one global atomic per non-zero entry at the end
-constexpr bool DTAB_SEPARATE = false;
-template <bool REG, bool TAIL, bool DTAB>
+// dS, binned by code[q] - code[k] + off into an LDS column of the (window, head) pair.
+// Round 6: the column is 64-bit FIXED POINT and the binning is ds_add_u64.  tools/ubench/lds_atomic_probe.hip, eight waves on one
+// column: a ds_add_f32 instruction occupies the CU's LDS for 192 clocks, a ds_add_u32 for 7.5, a ds_add_u64 for 8.0 (a plain
+// read-modify-write for 10.6) -- float atomics in LDS run at a twenty-fifth of the integer rate, which was 4.3 of a stage-0 launch's
+// 4.9 ms in round 5 (and what a pre-reduction of dS along the score diagonals, DPP + ds_bpermute, could only shave: 4.9 -> 4.5 ms).
+// The scale is a power of two per pair, chosen so that no sum can overflow: |dS| = p |dP - delta| <= |dO_q . V_k| + |dO_q . O_q| <=
+// 64 max|dO| max|V| = B (O is a convex combination of V rows), at most N scores per table row, so 2^e B N < 2^62; ldexpf(dS, e) is then
+// an integer of <= 24 significant bits that the conversion represents exactly: the column is the EXACT sum of the fp32 dS values
+// (integer addition is associative: the table gradient of a pair no longer depends on the order in which the waves arrive).  A
+// non-finite dO / V (B not finite) marks the whole column NaN.
+template <bool REG, bool TAIL, bool DTAB, bool GRADS = true>
 __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args a, const float* __restrict__ out,
                                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                                       float* __restrict__ delta, float* __restrict__ dqkv, int qc, int nchunks,
                                                                       float* __restrict__ dtable, float* __restrict__ dtable_ws) {
-  // DTAB: the pair's table gradient rides in this launch (GRADS on), or -- DTAB_SEPARATE -- is a pass of its own behind the plain launch:
-  // S, P, dP, dS and the binning only, no dK / dV / dQ products, no accumulator registers
-  // (measured in round 6, 1024 pairs of 784 tokens: ONE kernel with gradients and binning 3.2 ms; the gradients first and the binning as a
-  // pass of its own -- 120 registers, no scratch -- 0.65 + 3.06 ms: the binning is bound by the LDS atomic pipe, ~256 clocks per ds_add_f32
-  // instruction and eight waves per CU issuing them, not by the spills.  DTAB_SEPARATE keeps the two-pass form compilable.)
-  constexpr bool GRADS = !(DTAB && DTAB_SEPARATE);
+  // DTAB + GRADS: the pair's table gradient rides in the launch that produces dQ / dK / dV (windows whose 64-bit column still fits LDS
+  // beside the dQ tile: N <= 400).  DTAB alone: a pass of its own behind the plain launch -- S, P, dP, dS and the binning only, no dK /
+  // dV / dQ products, no accumulator registers, no dQ tile -- for the 784-token windows, where the 42 KB column does not fit otherwise
+  // (with float atomics that pass measured 3.06 ms on 1024 pairs and lost to the single kernel; with ds_add_u64 it is the score
+  // arithmetic of a forward).
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = a.N, nH = a.nH, nt = (N + 15) / 16;
-  const Carve1 cv = carve1(smem, nt, qc, a.T, DTAB);
+  const Carve1 cv = carve1(smem, nt, qc, a.T, DTAB, GRADS);
+  unsigned long long* const dcol = reinterpret_cast<unsigned long long*>(cv.dtab);
   if (DTAB)
-    for (int t = threadIdx.x; t < a.T; t += TH_BWD1) cv.dtab[t] = 0.f;
+    for (int t = threadIdx.x; t < a.T; t += TH_BWD1) dcol[t] = 0ull;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int64_t rs = 3 * (int64_t)nH * HD;
@@ -634,6 +580,7 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
   // key tiles of this wave: wave, wave + 8, ...: V fragments, code / region of the lane's key, dK / dV accumulators -- in registers
   bf16x4 va[KT_MAX], vb[KT_MAX];
   f32x4 dk0[KT_MAX], dk1[KT_MAX], dv0[KT_MAX], dv1[KT_MAX];
+  float vmax = 0.f;
   __syncthreads();  // rows / code table in place
 #pragma unroll
   for (int j = 0; j < KT_MAX; ++j) {
@@ -641,6 +588,46 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
     const int kt = min(wave + 8 * j, nt - 1), key = min(16 * kt + i, N - 1);
     float vf_[8];
     load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va[j], vb[j], vf_);
+    if (DTAB) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vmax = fmaxf(vmax, fabsf(vf_[u]) + (vf_[u] != vf_[u] ? INFINITY : 0.f));
+    }
+  }
+  int dexp = 0;        // fixed-point exponent of the pair's table-gradient column
+  bool dbad = false;   // non-finite operands: the column leaves as NaN
+  if (DTAB) {
+    float gmax = 0.f;  // max |dO| over the pair's rows (one pass over 16 nt x 32 values)
+    for (int it = threadIdx.x; it < N * 4; it += TH_BWD1) {
+      const int row = it >> 2, c8 = it & 3;
+      const int64_t e = (int64_t)cv.rows[row] * C + h * HD + 8 * c8;
+      bf16x4 lo_, hi_;
+      float f[8];
+      load_frag(dout, e, a.io16, 1.f, lo_, hi_, f);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gmax = fmaxf(gmax, fabsf(f[u]) + (f[u] != f[u] ? INFINITY : 0.f));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    float* const red = cv.l;   // (free until the first chunk is staged)
+    if (lane == 0) {
+      red[wave] = gmax;
+      red[8 + wave] = vmax;
+    }
+    __syncthreads();
+    gmax = vmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < TH_BWD1 / 64; ++w) {
+      gmax = fmaxf(gmax, red[w]);
+      vmax = fmaxf(vmax, red[8 + w]);
+    }
+    const float B = 64.f * gmax * vmax * (float)N;
+    dbad = !(B < INFINITY);
+    int ex = 0;
+    if (!dbad && B > 0.f) (void)frexpf(B, &ex);  // B < 2^ex
+    dexp = dbad ? 0 : min(100, 60 - ex);         // 2^dexp B < 2^60 (B holds the factor N; one bit of slack for the bf16 roundings); dexp <= 100
   }
   const bool kvalid_all = !TAIL;
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -728,7 +715,11 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
             ds[r] = p[r] * (dp[r] - dv[r]);
             if (DTAB && !live) bin[r] = -1;
           }
-          if (DTAB) dtab_add(cv.dtab, ds, bin, i, g);
+          if (DTAB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (bin[r] >= 0) atomicAdd(dcol + bin[r], dbad ? 1ull : (unsigned long long)__float2ll_rn(ldexpf(ds[r], dexp)));
+          }
           if (GRADS) {
             const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]), da = pack4(ds[0], ds[1], ds[2], ds[3]);
             dv0[j] = mfma(pa, gq0, dv0[j]);
@@ -774,10 +765,14 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       // windows.  (One global atomic per entry and pair was 5.4 M device-scope atomics onto 21 K addresses per stage-0 launch -- every
       // window of a head adds to the same T words --: 3.8 of the launch's 4.5 ms once the LDS binning was pre-reduced.)
       float* col = dtable_ws + ((int64_t)b * nH + h) * a.T;
-      for (int t = threadIdx.x; t < a.T; t += TH_BWD1) col[t] = cv.dtab[t];
+      for (int t = threadIdx.x; t < a.T; t += TH_BWD1) {
+        const long long w = (long long)dcol[t];
+        col[t] = dbad ? (w != 0 ? NAN : 0.f) : (float)ldexp((double)w, -dexp);
+      }
     } else {
       for (int t = threadIdx.x; t < a.T; t += TH_BWD1) {
-        const float v = cv.dtab[t];
+        const long long w = (long long)dcol[t];
+        const float v = dbad ? (w != 0 ? NAN : 0.f) : (float)ldexp((double)w, -dexp);
         if (v != 0.f) atomicAdd(dtable + (int64_t)t * nH + h, v);
       }
     }
@@ -869,7 +864,9 @@ int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_
   if (!vitta_wmsa_bf16_supported(N, head_dim, table_rows)) return 0;
   const int nt = (N + 15) / 16;
   int nc = 0;
-  return (nt <= 8 * KT_MAX && bwd1_chunks(nt, table_rows, true, &nc) > 0) ? 1 : 0;
+  if (nt > 8 * KT_MAX) return 0;
+  if (bwd1_chunks(nt, table_rows, true, &nc) > 0) return 1;                                                     // in the gradients' launch
+  return (bwd1_chunks(nt, table_rows, false, &nc) > 0 && bwd1_chunks(nt, table_rows, true, &nc, false) > 0) ? 1 : 0;  // as a pass of its own
 }
 
 int vitta_wmsa_rel_fwd_bf16(const float* d_qkv, const float* d_table, int32_t T, const int32_t* d_code, int32_t code_off,
@@ -948,37 +945,37 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const bool dtab = d_dtable != nullptr;  // the table gradient exists in the one-pass kernel only
   // with a workspace of B_ x nH x T floats the pairs' columns leave as plain stores and ONE reduce launch adds them (else: global atomics)
   float* const ws = (dtab && d_dtable_ws && dtable_ws_bytes >= (int64_t)vitta_wmsa_bf16_dtable_workspace_bytes(B_, nH, T)) ? d_dtable_ws : nullptr;
-  const int qc1 = bwd1_chunks(nt, T, dtab, &nchunks1);
-  const size_t lf = qc1 ? bwd1_lds_bytes(nt, qc1, T, dtab) : 0;
-  if (dtab && (qc1 <= 0 || nt > 8 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
-  if ((dtab || (!force_two && (qs == 1 || force_one))) && qc1 > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
-#define WMSA_BWD1(R, TL, DT)                                                                                                          \
+  // chunkings: plain (gradients only), fused (gradients + the 64-bit table column in one launch), table pass alone (no dQ tile)
+  int nc_plain = 0, nc_fused = 0, nc_tab = 0;
+  const int qc_plain = bwd1_chunks(nt, T, false, &nc_plain);
+  const int qc_fused = dtab ? bwd1_chunks(nt, T, true, &nc_fused) : 0;
+  const int qc_tab = (dtab && qc_fused <= 0) ? bwd1_chunks(nt, T, true, &nc_tab, false) : 0;
+  (void)nchunks1;
+  if (dtab && ((qc_fused <= 0 && (qc_tab <= 0 || qc_plain <= 0)) || nt > 8 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
+  if ((dtab || (!force_two && (qs == 1 || force_one))) && qc_plain > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
+#define WMSA_BWD1(R, TL, DT, GR, QC, NC, LF, DTP, WSP)                                                                                \
   do {                                                                                                                                \
-    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT>, lf)) return VITTA_ERR_LAUNCH;                                                   \
-    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf, st, a, d_out, d_dout, d_lse,    \
-                 d_delta, d_dqkv, qc1, nchunks1, d_dtable, ws);                                                                       \
+    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR>, LF)) return VITTA_ERR_LAUNCH;                                               \
+    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), LF, st, a, d_out, d_dout, d_lse, \
+                 d_delta, d_dqkv, QC, NC, DTP, WSP);                                                                                  \
   } while (0)
-    if (!dtab || DTAB_SEPARATE) {  // the gradients: chunking and LDS of the plain form (no table column)
-      int nchunks0 = 0;
-      const int qc0 = bwd1_chunks(nt, T, false, &nchunks0);
-      const size_t lf0 = bwd1_lds_bytes(nt, qc0, T, false);
-      const int qc_keep = qc1, nc_keep = nchunks1;
-      const size_t lf_keep = lf;
-#define WMSA_BWD0(R, TL)                                                                                                              \
+#define WMSA_BWD1_ALL(DT, GR, QC, NC, LF, DTP, WSP)                                                                                   \
   do {                                                                                                                                \
-    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, false>, lf0)) return VITTA_ERR_LAUNCH;                                               \
-    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, false>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), lf0, st, a, d_out, d_dout, d_lse, \
-                 d_delta, d_dqkv, qc0, nchunks0, nullptr, nullptr);                                                                  \
+    if (reg) { if (tail) WMSA_BWD1(true, true, DT, GR, QC, NC, LF, DTP, WSP); else WMSA_BWD1(true, false, DT, GR, QC, NC, LF, DTP, WSP); } \
+    else { if (tail) WMSA_BWD1(false, true, DT, GR, QC, NC, LF, DTP, WSP); else WMSA_BWD1(false, false, DT, GR, QC, NC, LF, DTP, WSP); } \
   } while (0)
-      if (reg) { if (tail) WMSA_BWD0(true, true); else WMSA_BWD0(true, false); }
-      else { if (tail) WMSA_BWD0(false, true); else WMSA_BWD0(false, false); }
-#undef WMSA_BWD0
-      (void)qc_keep; (void)nc_keep; (void)lf_keep;
+    if (dtab && qc_fused > 0) {  // gradients and table column in one launch
+      const size_t lf = bwd1_lds_bytes(nt, qc_fused, T, true);
+      WMSA_BWD1_ALL(true, true, qc_fused, nc_fused, lf, d_dtable, ws);
+    } else {
+      const size_t lf0 = bwd1_lds_bytes(nt, qc_plain, T, false);
+      WMSA_BWD1_ALL(false, true, qc_plain, nc_plain, lf0, nullptr, nullptr);
+      if (dtab) {  // ... and the table pass of every pair behind it (784-token windows)
+        const size_t lft = bwd1_lds_bytes(nt, qc_tab, T, true, false);
+        WMSA_BWD1_ALL(true, false, qc_tab, nc_tab, lft, d_dtable, ws);
+      }
     }
-    if (dtab) {  // the launch that bins the table gradient (with the gradients, or -- DTAB_SEPARATE -- behind the plain launch)
-      if (reg) { if (tail) WMSA_BWD1(true, true, true); else WMSA_BWD1(true, false, true); }
-      else { if (tail) WMSA_BWD1(false, true, true); else WMSA_BWD1(false, false, true); }
-    }
+#undef WMSA_BWD1_ALL
 #undef WMSA_BWD1
     if (ws) {
       const int segs = (int)(B_ >= 64 ? 8 : B_ >= 8 ? 2 : 1), seg = (int)((B_ + segs - 1) / segs);

@@ -454,6 +454,9 @@ class WindowAttention(torch.autograd.Function):
 WMSA_BF16 = False
 
 
+_dtable_ws = {}  # (device index, stream) -> scratch of the bf16 attention's table-gradient columns
+
+
 class WindowAttentionRel(torch.autograd.Function):
     """WindowAttention with the relative-position bias looked up from the [T, nH] table and the shift
     mask derived from region ids inside the kernel (nothing of size N x N in memory).
@@ -521,9 +524,14 @@ class WindowAttentionRel(torch.autograd.Function):
         dtable, r_table = _grad_sink(table, ctx.needs_input_grad[1])
         if bf16:
             ws = None
-            if dtable is not None:  # scratch for the pairs' table-gradient columns (plain stores + one reduce launch instead of atomics)
-                ws = torch.empty(int(lib().vitta_wmsa_bf16_dtable_workspace_bytes(b_, nh, table.shape[0])) // 4, dtype=torch.float32,
-                                 device=qkv.device)
+            if dtable is not None and os.environ.get("VITTA_DTABLE_WS", "1") != "0":
+                # scratch for the pairs' table-gradient columns (plain stores + one reduce launch instead of atomics): one grow-only
+                # buffer per stream, made outside any capture the first time (contents are undefined before and after a call)
+                need = int(lib().vitta_wmsa_bf16_dtable_workspace_bytes(b_, nh, table.shape[0])) // 4
+                key = (qkv.device.index, torch.cuda.current_stream(qkv.device).cuda_stream)
+                ws = _dtable_ws.get(key)
+                if ws is None or ws.numel() < need:
+                    ws = _dtable_ws[key] = torch.empty(need, dtype=torch.float32, device=qkv.device)
             check(lib().vitta_wmsa_rel_bwd_bf16_io(_p(qkv), _p(table), table.shape[0], _p(code), off, _p(region), nw, b_, n, nh,
                                                    hd, scale, _p(rowmap), nwm, tokens, _p(out), _p(dout), _p(lse), _p(delta),
                                                    _p(dqkv), _p(dtable), _p(ws), ws.numel() * 4 if ws is not None else 0,
