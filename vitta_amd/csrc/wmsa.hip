@@ -343,15 +343,20 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
     const float* __restrict__ qkv, const float* __restrict__ bias, const float* __restrict__ mask,
     const int* __restrict__ code_g, const int* __restrict__ region_g, int T, int off, int nW, int N, int nH,
     float scale, int qsplit, RowMap rm, const float* __restrict__ out, const float* __restrict__ dout,
-    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias) {
+    const float* __restrict__ lse, float* __restrict__ delta, float* __restrict__ dqkv, float* __restrict__ dbias, int dfix) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt = (N + 15) / 16;
-  // REL + dbias: the table gradient of this workgroup accumulates in LDS (ds_add_f32), one global
-  // atomic per table entry at the end
-  const Carve cv = carve(smem, nt, (REL && dbias) ? ((T + 3) & ~3) : 0, T);
+  // REL + dbias: the table gradient of this workgroup accumulates in LDS, one global atomic per table entry at the end.  Round 6: the
+  // column is 64-bit FIXED POINT and the binning ds_add_u64 -- a ds_add_f32 instruction occupies the CU's LDS for 192 clocks, a
+  // ds_add_u64 for 8 (tools/ubench/lds_atomic_probe.hip).  The power-of-two scale of the workgroup comes from a bound no sum can
+  // exceed: |dS| = p |dP - delta| <= 64 max|dO| max|V|, at most N scores per table row (as wmsa_bf16.hip); ldexpf(dS, e) is an integer
+  // the conversion represents exactly, so the column is the exact sum of the fp32 dS values, whatever the order of the waves.
+  // (dfix = 0: the 64-bit column does not fit LDS beside K and V -- the (16,7,7) table on a clamped window --, float column as before)
+  const Carve cv = carve(smem, nt, (REL && dbias) ? (dfix ? 2 : 1) * ((T + 3) & ~3) : 0, T);
   float* k_lds = cv.buf0;
   float* v_lds = cv.buf1;
-  float* dtab = cv.extra;
+  unsigned long long* dtab = reinterpret_cast<unsigned long long*>(cv.extra);
+  float* dtabf = cv.extra;
   const int* rows = cv.rows;
   const int h = blockIdx.y;
   const int64_t b = blockIdx.z;
@@ -360,7 +365,10 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   stage_rows(v_lds, qkv, h, 2, N, nH, nt, rows);
   const AddTerms terms = setup_terms<REL>(cv, bias, mask, code_g, region_g, T, off, nW, N, nH, h, b, nt);
   if (REL && dbias)
-    for (int i = threadIdx.x; i < T; i += WMSA_THREADS) dtab[i] = 0.f;
+    for (int i = threadIdx.x; i < T; i += WMSA_THREADS) {
+      if (dfix) dtab[i] = 0ull;
+      else dtabf[i] = 0.f;
+    }
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -370,6 +378,44 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   const float* q_base = qkv + (int64_t)h * HD;
   const int per = (nt + qsplit - 1) / qsplit;
   const int rt0 = blockIdx.x * per, rt1 = min(nt, rt0 + per);
+  int dexp = 0;
+  bool dbad = false;
+  if (REL && dbias && dfix) {  // the fixed-point exponent: max |V| from the staged rows, max |dO| over the window's rows (one pass)
+    float vmax = 0.f, gmax = 0.f;
+    for (int it = threadIdx.x; it < N * 8; it += WMSA_THREADS) {
+      const int row = it >> 3, c4 = it & 7;
+      const float4 v4 = *reinterpret_cast<const float4*>(v_lds + row * KPAD + 4 * c4);
+      const float4 g4 = *reinterpret_cast<const float4*>(dout + (int64_t)rows[row] * C + h * HD + 4 * c4);
+      const float vv[8] = {v4.x, v4.y, v4.z, v4.w, g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vmax = fmaxf(vmax, fabsf(vv[u]) + (vv[u] != vv[u] ? INFINITY : 0.f));
+        gmax = fmaxf(gmax, fabsf(vv[4 + u]) + (vv[4 + u] != vv[4 + u] ? INFINITY : 0.f));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    }
+    __shared__ float red_max[2 * WMSA_WAVES];
+    if (lane == 0) {
+      red_max[wave] = gmax;
+      red_max[WMSA_WAVES + wave] = vmax;
+    }
+    __syncthreads();
+    gmax = vmax = 0.f;
+#pragma unroll
+    for (int w = 0; w < WMSA_WAVES; ++w) {
+      gmax = fmaxf(gmax, red_max[w]);
+      vmax = fmaxf(vmax, red_max[WMSA_WAVES + w]);
+    }
+    const float B = 64.f * gmax * vmax * (float)N;
+    dbad = !(B < INFINITY);
+    int ex = 0;
+    if (!dbad && B > 0.f) (void)frexpf(B, &ex);
+    dexp = dbad ? 0 : min(100, 60 - ex);
+  }
   for (int rt = rt0 + wave; rt < rt1; rt += WMSA_WAVES) {
     const bool qvalid = 16 * rt + i < N;
     const int q = min(16 * rt + i, N - 1);
@@ -410,8 +456,13 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * t + 4 * kk + r;
           if (key < N) {
-            if constexpr (REL) atomicAdd(dtab + (pk_code(terms.cr[q]) - pk_code(terms.cr[key]) + terms.off), ds[r]);
-            else atomicAdd(dbias_row + key, ds[r]);
+            if constexpr (REL) {
+              const int bin = pk_code(terms.cr[q]) - pk_code(terms.cr[key]) + terms.off;
+              if (dfix) atomicAdd(dtab + bin, dbad ? 1ull : (unsigned long long)__float2ll_rn(ldexpf(ds[r], dexp)));
+              else atomicAdd(dtabf + bin, ds[r]);
+            } else {
+              atomicAdd(dbias_row + key, ds[r]);
+            }
           }
         }
       }
@@ -435,7 +486,13 @@ __global__ __launch_bounds__(WMSA_THREADS) void wmsa_bwd_dq_kernel(
   if (REL && dbias) {
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += WMSA_THREADS) {
-      const float v = dtab[t];
+      float v;
+      if (dfix) {
+        const long long w = (long long)dtab[t];
+        v = dbad ? (w != 0 ? NAN : 0.f) : (float)ldexp((double)w, -dexp);
+      } else {
+        v = dtabf[t];
+      }
       if (v != 0.f) atomicAdd(dbias + (int64_t)t * nH + h, v);  // REL: dbias is the table gradient [T, nH]
     }
   }
@@ -1278,7 +1335,8 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
       return VITTA_OK;
     }
   }
-  const size_t lds1 = lds_bytes(a.N, (REL && dbias) ? ((T + 3) & ~3) : 0, T), lds2 = lds_bytes(a.N, 2 * 16 * nt, T);
+  const int dfix = (REL && dbias && lds_bytes(a.N, 2 * ((T + 3) & ~3), T) <= 160 * 1024) ? 1 : 0;  // the 64-bit table column fits
+  const size_t lds1 = lds_bytes(a.N, (REL && dbias) ? (dfix ? 2 : 1) * ((T + 3) & ~3) : 0, T), lds2 = lds_bytes(a.N, 2 * 16 * nt, T);
 #define WMSA_BWD(REG)                                                                                                   \
   do {                                                                                                                 \
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wmsa_bwd_dq_kernel<REL, REG>),                               \
@@ -1287,7 +1345,7 @@ int launch_bwd(const WmsaArgs& a, const float* out, const float* dout, const flo
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)                      \
       return VITTA_ERR_LAUNCH;                                                                                         \
     VITTA_LAUNCH((wmsa_bwd_dq_kernel<REL, REG>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds1, st, a.qkv, a.bias, \
-                 a.mask, a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dbias); \
+                 a.mask, a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, out, dout, lse, delta, dqkv, dbias, dfix); \
     VITTA_LAUNCH((wmsa_bwd_dkv_kernel<REL, REG>), dim3(qs, a.nH, (unsigned)a.B_), dim3(WMSA_THREADS), lds2, st, a.qkv, a.bias, \
                  a.mask, a.code, a.region, T, a.off, a.nW, a.N, a.nH, a.scale, qs, a.rm, dout, lse, delta, dqkv);       \
   } while (0)
