@@ -386,6 +386,20 @@ size_t vitta_wmsa_bf16_dtable_workspace_bytes(int64_t B_, int32_t nH, int32_t ta
 int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_rows);
 
 /* --------------------------------------------------------------------------
+ * A10, SGD over all parameters on the bf16 recipe -- dense WEIGHT gradients with 2-byte operands (round 6).
+ * Replaces autograd's d weight (and d bias) of the nn.Linear products of swin_transformer.py:30-35, 144, 165, 304-311 where both the
+ * layer input x [M, K] and the output gradient g [M, N] are bfloat16 in memory (ops.bf16_flow): out [N, K] fp32 (+)= g^T x on
+ * v_mfma_f32_16x16x16_bf16, both fragments by the LDS transpose read (the contraction runs over the tokens, the slow axis of both
+ * operands), fp32 accumulation; d_bias_grad [N] fp32 or NULL: += column sums of g.  M % 32 == 0, N % 128 == 0, K % 128 == 0.
+ * The token axis is cut into splits; d_ws: caller-owned scratch of vitta_gemm_tn_bf16_workspace_bytes(M, N, K) bytes (16-byte aligned,
+ * contents undefined before and after) for the splits' partial tiles, which one reduce launch adds in split order.
+ * -------------------------------------------------------------------------- */
+int vitta_gemm_tn_bf16_supported(int64_t M, int32_t N, int32_t K);
+size_t vitta_gemm_tn_bf16_workspace_bytes(int64_t M, int32_t N, int32_t K);
+int vitta_gemm_tn_bf16(const void* d_g, const void* d_x, float* d_out, int64_t M, int32_t N, int32_t K, int32_t accumulate,
+                       float* d_bias_grad, void* d_ws, size_t ws_bytes, void* stream);
+
+/* --------------------------------------------------------------------------
  * A7 -- optimizer update on the flat parameter arena, one launch.
  * Replaces optimizer.step() of corpus/basics.py:671 for the optimizers built at corpus/basics.py:547-560 (torch.optim.Adam over the affine tensors /
  * torch.optim.SGD over every parameter), same element-wise arithmetic as torch's single-tensor formulation.

@@ -355,3 +355,41 @@ def test_bf16_data_flow_mlp_and_linear_match_the_fp32_path(train_weights):
         if a_ is None:
             continue
         assert (a_ - b_).abs().max().item() <= 3e-2 * b_.abs().max().item(), (i, (a_ - b_).abs().max().item(), b_.abs().max().item())
+
+
+@pytest.mark.parametrize("m,n,k,acc,bias", [(3136, 1024, 1024, False, True), (12544, 2048, 512, True, True), (50176, 256, 768, False, False),
+                                            (200704, 384, 128, True, True), (128, 128, 128, False, True), (6272, 512, 2048, True, False)])
+def test_gemm_tn_bf16_weight_gradient_against_fp64(m, n, k, acc, bias):
+    """gemm_tn_bf16.hip (round 6): out [N, K] (+)= g^T x with g [M, N], x [M, K] bfloat16 in memory -- the dense weight gradients of the
+    bf16 recipe under SGD over all parameters (autograd's d weight / d bias of swin_transformer.py:30-35, 144, 165) -- against the
+    fp64 product of the SAME bf16 values: only the fp32 accumulation order is left (4e-5 of the maximum, the bound of the other
+    bf16-operand products), with and without accumulation into a live gradient, with the bias gradient (column sums of g) riding in
+    the launch; every shape of Swin-B's stages incl. the 256-way token split of stage 0."""
+    from vitta_amd import _lib
+    from vitta_amd.ops import _p, _stream, check
+    L = _lib.lib()
+    assert L.vitta_gemm_tn_bf16_supported(m, n, k) == 1
+    d = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(m + n + k)
+    g = (torch.randn(m, n, generator=gen) * 0.5).to(d).to(torch.bfloat16)
+    x = torch.randn(m, k, generator=gen).to(d).to(torch.bfloat16)
+    out0 = torch.randn(n, k, generator=gen).to(d)
+    out = out0.clone()
+    db0 = torch.randn(n, generator=gen).to(d)
+    db = db0.clone()
+    need = int(L.vitta_gemm_tn_bf16_workspace_bytes(m, n, k))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=d)
+    check(L.vitta_gemm_tn_bf16(_p(g), _p(x), _p(out), m, n, k, 1 if acc else 0, _p(db) if bias else None, _p(ws), need, _stream()), "vitta_gemm_tn_bf16")
+    torch.cuda.synchronize()
+    ref = g.double().t() @ x.double()
+    want = ref + (out0.double() if acc else 0)
+    err = (out.double() - want).abs().max().item()
+    assert err <= 4e-5 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+    if bias:
+        bref = g.double().sum(0) + db0.double()
+        berr = (db.double() - bref).abs().max().item()
+        assert berr <= 1e-5 * max(1.0, bref.abs().max().item()) * (1 + m ** 0.5 / 64), (berr, bref.abs().max().item())
+    else:
+        assert torch.equal(db, db0)
+    # shapes it declines say so
+    assert L.vitta_gemm_tn_bf16_supported(m, 174, k) == 0 and L.vitta_gemm_tn_bf16_supported(m + 8, n, k) == 0

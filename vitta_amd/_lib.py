@@ -135,6 +135,9 @@ SIGNATURES = {
     "vitta_wmsa_rel_fwd_bf16_io": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _i32, _i64, _p, _p, _i32, _p]),
     "vitta_wmsa_rel_bwd_bf16_io": (C.c_int, [_p, _p, _i32, _p, _i32, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "vitta_wmsa_bf16_dtable_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
+    "vitta_gemm_tn_bf16_supported": (C.c_int, [_i64, _i32, _i32]),
+    "vitta_gemm_tn_bf16_workspace_bytes": (C.c_size_t, [_i64, _i32, _i32]),
+    "vitta_gemm_tn_bf16": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _sz, _p]),
     "vitta_wmsa_bf16_dtable_supported": (C.c_int, [_i32, _i32, _i32]),
     "vitta_wmsa_bwd_f32": (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, _i32, _f32, _p, _p, _p, _p, _p, _p, _p]),
     "vitta_moments_partials_timed_f32": (C.c_int, [_p, C.POINTER(_p), _p, _sz, _p, _p, _p]),

@@ -1276,6 +1276,36 @@ def _said_library_wgrad(weight, g2):
                   "on the vendor library's TN product, not on vitta_conv_f32" + ("" if DENSE_WGRAD else ": VITTA_DENSE_WGRAD=library (an A/B switch)"))
 
 
+TN_WGRAD_BF16 = os.environ.get("VITTA_TN_WGRAD_BF16", "1") != "0"  # 0: the fp32 convolution-kernel product behind .float() copies (A/B)
+_tn_ws = {}  # (device index, stream) -> grow-only scratch of the splits' partial tiles
+
+
+def _wgrad_bf16(weight, w_needed, bias, b_needed, g2, x2):
+    """d weight (+ d bias) of one nn.Linear from 2-byte operands: g2 [M, N], x2 [M, K] bfloat16 as the bf16 data flow leaves them
+    (no .float() copies), on gemm_tn_bf16.hip.  Returns (handled, dw, db); handled False: the caller takes the fp32 path."""
+    if not (TN_WGRAD_BF16 and w_needed and g2.dtype == torch.bfloat16 and x2 is not None and x2.dtype == torch.bfloat16
+            and g2.is_contiguous() and x2.is_contiguous() and weight.dim() == 2):
+        return False, None, None
+    m, n = g2.shape
+    k = x2.shape[1]
+    if not lib().vitta_gemm_tn_bf16_supported(m, n, k):
+        return False, None, None
+    sink, ret = _grad_sink(weight, True, zero=False)
+    bsink = bret = None
+    if b_needed and bias is not None:
+        bsink, bret = _grad_sink(bias, True, zero=True)
+    need = int(lib().vitta_gemm_tn_bf16_workspace_bytes(m, n, k))
+    ws = None
+    if need:
+        key = (g2.device.index, torch.cuda.current_stream(g2.device).cuda_stream)
+        ws = _tn_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _tn_ws[key] = torch.empty(need, dtype=torch.uint8, device=g2.device)
+    check(lib().vitta_gemm_tn_bf16(_p(g2), _p(x2), _p(sink), m, n, k, 1 if ret is None else 0, _p(bsink), _p(ws), ws.numel() if ws is not None else 0,
+                                   _stream()), "vitta_gemm_tn_bf16")
+    return True, (None if ret is None else ret.view_as(weight)), bret
+
+
 def _bias_grad(bias, needed, g2):
     """Column sums of the output gradient added into the bias gradient's sink by vitta_colsum2_f32 (rows taken in pairs:
     both of its outputs point at the sink); torch's column reduce ran at ~1.2 TB/s on these shapes."""
@@ -1343,10 +1373,12 @@ class DenseLinear(torch.autograd.Function):
                 dx = _x_dtype_grad(gemm_nt(g2.float() if g2.dtype != torch.float32 else g2, _operand(weight, True, g2.shape[0])), ctx.x16)
             dx = dx.view(ctx.xshape)
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
-            g32 = g2 if g2.dtype == torch.float32 else g2.float()
-            x32 = x2 if (x2 is None or x2.dtype == torch.float32) else x2.float()
-            dw = _weight_grad(weight, ctx.needs_input_grad[1], g32, x32)
-            db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g32)
+            handled, dw, db = _wgrad_bf16(weight, ctx.needs_input_grad[1], bias, bias is not None and ctx.needs_input_grad[2], g2, x2)
+            if not handled:
+                g32 = g2 if g2.dtype == torch.float32 else g2.float()
+                x32 = x2 if (x2 is None or x2.dtype == torch.float32) else x2.float()
+                dw = _weight_grad(weight, ctx.needs_input_grad[1], g32, x32)
+                db = _bias_grad(bias, bias is not None and ctx.needs_input_grad[2], g32)
         else:
             dw = db = None
         return dx, dw, db, None
@@ -1391,8 +1423,18 @@ class FusedMlp(torch.autograd.Function):
                 g2 = g2.to(torch.bfloat16)
             gh = gemm_bf16x(g2, _bf16_weight(w2, True), mode=2, aux=h, out_bf16=True)
             dx = gemm_bf16x(gh, _bf16_weight(w1, True), out_bf16=True).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-            if any(ctx.needs_input_grad[1:]):  # SGD over all parameters: the weight-gradient products take fp32 operands
-                g2, gh, x2, a = g2.float(), gh.float(), (x2.float() if x2 is not None else None), (a.float() if a is not None else None)
+            if any(ctx.needs_input_grad[1:]):  # SGD over all parameters: the weight-gradient products on the 2-byte operands as they are
+                ok1, dw1, db1 = _wgrad_bf16(w1, ctx.needs_input_grad[1], b1, b1 is not None and ctx.needs_input_grad[2], gh, x2)
+                ok2, dw2, db2 = _wgrad_bf16(w2, ctx.needs_input_grad[3], b2, b2 is not None and ctx.needs_input_grad[4], g2, a)
+                if not ok1:  # (a shape gemm_tn_bf16.hip declines, or VITTA_TN_WGRAD_BF16=0: fp32 copies for the convolution-kernel product)
+                    gh32, x32 = gh.float(), (x2.float() if x2 is not None else None)
+                    dw1 = _weight_grad(w1, ctx.needs_input_grad[1], gh32, x32)
+                    db1 = _bias_grad(b1, b1 is not None and ctx.needs_input_grad[2], gh32)
+                if not ok2:
+                    g32, a32 = g2.float(), (a.float() if a is not None else None)
+                    dw2 = _weight_grad(w2, ctx.needs_input_grad[3], g32, a32)
+                    db2 = _bias_grad(b2, b2 is not None and ctx.needs_input_grad[4], g32)
+                return dx, dw1, db1, dw2, db2, None
         else:
             gh = gemm_nt(g2, _operand(w2, True, g2.shape[0]), mode=2, aux=h)
             dx = gemm_nt(gh, _operand(w1, True, g2.shape[0])).view(ctx.xshape) if ctx.needs_input_grad[0] else None
