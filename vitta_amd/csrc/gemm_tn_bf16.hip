@@ -15,6 +15,8 @@
 // registers (the padded pitch rules out one LDS-DMA instruction per four rows), one barrier per 32 tokens.  The token axis is cut into
 // `splits` contiguous ranges so that tiles x splits ~ 3 workgroups per CU; a split writes its fp32 partial tile to the caller's
 // workspace and ONE reduce launch adds the splits in split order into out (deterministic; splits = 1 writes out directly).
+#include <cstdlib>
+
 #include "common.h"
 
 using namespace vitta;
@@ -182,7 +184,12 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const TnArgs a) {
 inline int pick_splits(int64_t M, int tiles) {
   // ~3 workgroups per CU over the launch, at least four stages (128 tokens) per split, at most 512 splits
   const int64_t stages = M / MS;
-  int64_t s = (768 + tiles - 1) / tiles;
+  static const int target = [] {
+    const char* e = std::getenv("VITTA_TN_WGRAD_WGS");
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : 768;
+  }();
+  int64_t s = (target + tiles - 1) / tiles;
   if (s > stages / 4) s = stages / 4;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
