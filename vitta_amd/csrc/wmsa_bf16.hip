@@ -51,6 +51,18 @@ __device__ __forceinline__ f32x4 mfma(bf16x4 a, bf16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x32_bf16 (gfx950): the contraction of a head's 32 channels -- or of TWO 16-key tiles -- in one instruction; lane
+// (i, g) holds elements 8 g .. 8 g + 7 of the contraction on both operands, the C layout is that of the 16x16x16 form
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hbf16x8, a), __builtin_bit_cast(hbf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+constexpr float LOG2E = 1.4426950408889634f;
+// exp(x - m) as ONE multiply-add and the hardware's 2^x (v_exp_f32), mL = m log2(e): __expf(x - m) is a subtraction, a multiplication
+// and the exponential -- a quarter of the score tile's vector arithmetic sits on this line
+__device__ __forceinline__ float exp_sub(float x, float mL) { return __builtin_amdgcn_exp2f(__builtin_fmaf(x, LOG2E, -mL)); }
+
 struct RowMap {
   const int* map;
   int nWm;
@@ -102,6 +114,8 @@ __device__ __forceinline__ void fill_rows(int* rows, const RowMap& rm, int64_t b
 }
 
 // table column of head h + packed code | region of the window's tokens
+// SH: the codes are stored << SH (2: byte offsets into the table column -- the forward's table reads need no address arithmetic)
+template <int SH = 0>
 __device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h, int64_t b, int nt) {
   const int TH = blockDim.x;
   for (int i0 = threadIdx.x; i0 < a.T; i0 += 8 * TH) {
@@ -115,7 +129,7 @@ __device__ __forceinline__ void setup_terms(const Carve& c, const Args& a, int h
   for (int i = threadIdx.x; i < 16 * nt; i += TH) {
     const int n = i < a.N ? i : a.N - 1;
     const int reg = a.region ? a.region[(b % a.nW) * (int64_t)a.N + n] : 0;
-    c.cr[i] = a.code[n] | (reg << 16);
+    c.cr[i] = (a.code[n] << SH) | (reg << 16);
   }
 }
 
@@ -214,6 +228,24 @@ __device__ __forceinline__ void add_terms_t(f32x4& acc, const float* tab, const 
   }
 }
 
+// The same on codes stored as BYTE offsets (setup_terms<2>): cqb = LDS address of the table column + 4 (code[q] + off) (+ the region of
+// q in the high half), so a table read is one subtraction and the load (the index form: subtraction, shift-add, load).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+template <bool REG, bool TAIL>
+__device__ __forceinline__ void add_terms_b(f32x4& acc, unsigned cqb, int rq, const int* cr, int t, int g, int N) {
+  const int key0 = 16 * t + 4 * g;
+  const int4 ck = *reinterpret_cast<const int4*>(cr + key0);
+  const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
+  float tv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tv[r] = *(lds_cfloat*)(cqb - (unsigned)(REG ? pk_code(kc[r]) : kc[r]));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = (REG && pk_region(kc[r]) != rq) ? tv[r] - 100.f : tv[r];
+    acc[r] = (!TAIL || key0 + r < N) ? acc[r] + v : -INFINITY;
+  }
+}
+
 // B operand of a contraction over tokens from a ROW-major tile: the four tokens 16 t + 4 g + e of column d = 16 half + i, by the
 // LDS transpose read of gfx950 (ds_read_b64_tr_b16): lane k of a 16-lane group hands in the address of a quarter row -- token
 // 4 g + k / 4, columns 4 (k % 4) .. + 3 of the [4 tokens][16 columns] block -- and receives column k of the block (verified element
@@ -242,10 +274,11 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
   fill_rows(cv.rows, a.rm, b, N, nt);
   stage_rows(cv.a0, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);
   stage_rows(cv.a1, qkv_at(a, (int64_t)(2 * nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);  // V row-major: the PV operand comes by transpose read
-  setup_terms(cv, a, h, b, nt);
+  setup_terms<2>(cv, a, h, b, nt);
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
+  const unsigned tab_b = (unsigned)(size_t)(lds_cfloat*)cv.tab + 4u * (unsigned)a.off;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
@@ -254,6 +287,9 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
     float qf_[8];
     load_frag(a.qkv, (int64_t)h * HD + (int64_t)cv.rows[q] * rs + 8 * g, a.io16, a.scale, qa, qb, qf_);
     const int pq = cv.cr[q];
+    const unsigned cqb = tab_b + (unsigned)(REG ? pk_code(pq) : pq);
+    const int rq = pk_region(pq);
+    const bf16x8 q8 = cat8(qa, qb);
     float m = -INFINITY, l = 0.f;  // of query i (this lane's column of the S^T tiles); l: the lane's share (keys 4 g + r)
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // rows = queries 4 g + r, column d = i (| 16 + i)
 #pragma unroll
@@ -267,11 +303,12 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
         if (tb + t < nt) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * (tb + t) + i) * RP + 8 * g);
           f32x4 s = {0.f, 0.f, 0.f, 0.f};
-          s = mfma(__builtin_shufflevector(kf, kf, 0, 1, 2, 3), qa, s);
-          s = mfma(__builtin_shufflevector(kf, kf, 4, 5, 6, 7), qb, s);
-          add_terms_t<REG, TAIL>(s, cv.tab, cv.cr, a.off, tb + t, g, pq, N);
+          s = mfma32(kf, q8, s);  // the head's 32 channels in one product
+          add_terms_b<REG, TAIL>(s, cqb, rq, cv.cr, tb + t, g, N);
           acc[t] = s;
           mc = fmaxf(mc, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
+        } else {
+          acc[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // past the window: probability zero in the paired product below
         }
       }
       mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
@@ -288,20 +325,25 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
         }
       }
       m = mn;
+      const float mL = m * LOG2E;
+      // P V over PAIRS of key tiles: contraction element 8 g + j of the 32-wide product = key 4 g + j of tile t (j < 4) | of tile t + 1;
+      // a chunk's odd last tile pairs with zero probabilities
 #pragma unroll
-      for (int t = 0; t < NTM; ++t) {
+      for (int t = 0; t < NTM; t += 2) {
         if (tb + t < nt) {
-          float p[4];
+          const int t1 = (t + 1 < NTM && tb + t + 1 < nt) ? t + 1 : t;  // the V rows read for a missing partner: any tile of the window
+          float p[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            p[r] = __expf(acc[t][r] - m);
-            l += p[r];
+            p[r] = exp_sub(acc[t][r], mL);
+            p[4 + r] = t + 1 < NTM ? exp_sub(acc[t + 1 < NTM ? t + 1 : t][r], mL) : 0.f;  // (-inf scores past the window: 0)
+            l += p[r] + p[4 + r];
           }
-          const bf16x4 pa = pack4(p[0], p[1], p[2], p[3]);
-          const bf16x4 v0 = gather4(vrow, tb + t, g, i, 0);
-          const bf16x4 v1 = gather4(vrow, tb + t, g, i, 1);
-          o0 = mfma(pa, v0, o0);
-          o1 = mfma(pa, v1, o1);
+          const bf16x8 pa = cat8(pack4(p[0], p[1], p[2], p[3]), pack4(p[4], p[5], p[6], p[7]));
+          const bf16x8 v0 = cat8(gather4(vrow, tb + t, g, i, 0), gather4(vrow, tb + t1, g, i, 0));
+          const bf16x8 v1 = cat8(gather4(vrow, tb + t, g, i, 1), gather4(vrow, tb + t1, g, i, 1));
+          o0 = mfma32(pa, v0, o0);
+          o1 = mfma32(pa, v1, o1);
         }
       }
     }
@@ -491,8 +533,9 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
 // workgroup = one (window, head) pair (launches with fewer pairs than CUs keep the two kernels above, which split a pair over several
 // workgroups).  Chunks are balanced and must hold >= 8 tiles each (bwd1_chunks; otherwise the two kernels above).
 // ------------------------------------------------------------------------------------------------
-constexpr int TH_BWD1 = 512;
-constexpr int KT_MAX = 7;      // key tiles a wave can own: 8 waves x 7 >= 50
+constexpr int NW1 = 8;  // waves of the one-pass backward (twelve -- 168 registers, 45 of them spilled, chunks of >= 12 tiles -- measured 757 vs 652 us)
+constexpr int TH_BWD1 = 64 * NW1;
+constexpr int KT_MAX = (NTB + NW1 - 1) / NW1;  // key tiles a wave can own: NW1 x KT_MAX >= 50
 constexpr int DQP = 36;        // pitch of the fp32 dQ tile in floats: the four row groups of a tile land 16 banks apart
 constexpr int TSP = 20;        // pitch of the per-wave turn-around tile in bf16 elements
 
@@ -505,14 +548,14 @@ struct Carve1 {
 // grads = false: the table-gradient pass of its own (no dQ tile, no turn-around scratch)
 __host__ __device__ inline size_t bwd1_lds_bytes(int nt, int qc, int T, bool dtab, bool grads = true) {
   const size_t qrows = 16 * (size_t)qc, tp = (size_t)((T + 3) & ~3);
-  return 2 * ((size_t)16 * nt * RP + 2 * qrows * RP + (grads ? 8 * 16 * TSP : 0)) +
+  return 2 * ((size_t)16 * (nt + 1) * RP + 2 * qrows * RP + (grads ? NW1 * 16 * TSP : 0)) +   // (K: the window + one tile of zeros)
          4 * ((grads ? qrows * DQP : 0) + 2 * qrows + tp * (dtab ? 3 : 1) + 2 * 16 * (size_t)nt) + 64;
 }
 // chunks of query tiles: the fewest that fit LDS, BALANCED (chunk c = tiles [c nt / nc, (c + 1) nt / nc)), every chunk >= 8 tiles (the
 // step-synchronous rotation puts the eight waves on eight distinct tiles); returns the largest chunk, 0: no admissible chunking
 inline int bwd1_chunks(int nt, int T, bool dtab, int* nchunks, bool grads = true) {
   for (int nc = (nt + 12) / 13; nc <= nt; ++nc) {
-    if (nt / nc < 8) break;
+    if (nt / nc < NW1) break;
     const int qc = (nt + nc - 1) / nc;
     if (bwd1_lds_bytes(nt, qc, T, dtab, grads) > 160 * 1024) continue;
     *nchunks = nc;
@@ -524,10 +567,10 @@ __device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, in
   Carve1 c;
   const int qrows = 16 * qc, tp = (T + 3) & ~3;
   c.kb = reinterpret_cast<unsigned short*>(smem);
-  c.qb = c.kb + 16 * nt * RP;
+  c.qb = c.kb + 16 * (nt + 1) * RP;
   c.gb = c.qb + qrows * RP;
   c.tscr = c.gb + qrows * RP;
-  c.dq = reinterpret_cast<float*>(c.tscr + (grads ? 8 * 16 * TSP : 0));
+  c.dq = reinterpret_cast<float*>(c.tscr + (grads ? NW1 * 16 * TSP : 0));
   c.l = c.dq + (grads ? qrows * DQP : 0);
   c.dl = c.l + qrows;
   c.tab = c.dl + qrows;
@@ -548,7 +591,7 @@ __device__ __forceinline__ Carve1 carve1(unsigned char* smem, int nt, int qc, in
 // an integer of <= 24 significant bits that the conversion represents exactly: the column is the EXACT sum of the fp32 dS values
 // (integer addition is associative: the table gradient of a pair no longer depends on the order in which the waves arrive).  A
 // non-finite dO / V (B not finite) marks the whole column NaN.
-template <bool REG, bool TAIL, bool DTAB, bool GRADS = true>
+template <bool REG, bool TAIL, bool DTAB, bool GRADS = true, int KT = KT_MAX>
 __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args a, const float* __restrict__ out,
                                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                                       float* __restrict__ delta, float* __restrict__ dqkv, int qc, int nchunks,
@@ -569,7 +612,7 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
   const int64_t rs = 3 * (int64_t)nH * HD;
   const int C = nH * HD;
   fill_rows(cv.rows, a.rm, b, N, nt);
-  stage_rows(cv.kb, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt, cv.rows, 1.f, a.io16);  // K, row-major, the whole window
+  stage_rows(cv.kb, qkv_at(a, (int64_t)(nH + h) * HD), rs, N, nt + 1, cv.rows, 1.f, a.io16);  // K, row-major, the whole window + one tile of zeros
   {  // table column of the head + packed code | region of the window's tokens (setup_terms on this carve)
     Carve tmp;
     tmp.tab = cv.tab; tmp.cr = cv.cr;
@@ -578,14 +621,14 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
   unsigned short* const tscr = cv.tscr + wave * 16 * TSP;
   // key tiles of this wave: wave, wave + 8, ...: V fragments, code / region of the lane's key, dK / dV accumulators -- in registers
-  bf16x4 va[KT_MAX], vb[KT_MAX];
-  f32x4 dk0[KT_MAX], dk1[KT_MAX], dv0[KT_MAX], dv1[KT_MAX];
+  bf16x4 va[KT], vb[KT];
+  f32x4 dk0[KT], dk1[KT], dv0[KT], dv1[KT];
   float vmax = 0.f;
   __syncthreads();  // rows / code table in place
 #pragma unroll
-  for (int j = 0; j < KT_MAX; ++j) {
+  for (int j = 0; j < KT; ++j) {
     dk0[j] = dk1[j] = dv0[j] = dv1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kt = min(wave + 8 * j, nt - 1), key = min(16 * kt + i, N - 1);
+    const int kt = min(wave + NW1 * j, nt - 1), key = min(16 * kt + i, N - 1);
     float vf_[8];
     load_frag(a.qkv, (int64_t)cv.rows[key] * rs + (int64_t)(2 * nH + h) * HD + 8 * g, a.io16, 1.f, va[j], vb[j], vf_);
     if (DTAB) {
@@ -614,14 +657,14 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
     float* const red = cv.l;   // (free until the first chunk is staged)
     if (lane == 0) {
       red[wave] = gmax;
-      red[8 + wave] = vmax;
+      red[16 + wave] = vmax;
     }
     __syncthreads();
     gmax = vmax = 0.f;
 #pragma unroll
     for (int w = 0; w < TH_BWD1 / 64; ++w) {
       gmax = fmaxf(gmax, red[w]);
-      vmax = fmaxf(vmax, red[8 + w]);
+      vmax = fmaxf(vmax, red[16 + w]);
     }
     const float B = 64.f * gmax * vmax * (float)N;
     dbad = !(B < INFINITY);
@@ -687,18 +730,16 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
       const float4 dq4 = *reinterpret_cast<const float4*>(cv.dl + ql);
       const int qcd[4] = {REG ? pk_code(cq.x) : cq.x, REG ? pk_code(cq.y) : cq.y, REG ? pk_code(cq.z) : cq.z, REG ? pk_code(cq.w) : cq.w};
       const int qrg[4] = {pk_region(cq.x), pk_region(cq.y), pk_region(cq.z), pk_region(cq.w)};
-      const float lv[4] = {lq.x, lq.y, lq.z, lq.w}, dv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
+      const float lvL[4] = {lq.x * LOG2E, lq.y * LOG2E, lq.z * LOG2E, lq.w * LOG2E}, dv[4] = {dq4.x, dq4.y, dq4.z, dq4.w};
       f32x4 dqa = {0.f, 0.f, 0.f, 0.f}, dqb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < KT_MAX; ++j) {
-        const int kt = wave + 8 * j;
-        if (kt < nt) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cv.kb + (16 * kt + i) * RP + 8 * g);
+      auto tile = [&](const int j) {
+        const int kt = wave + NW1 * j;
+        {
+          const int kte = min(kt, nt);  // (a tile past the window reads the zero tile: S = bias only, and its dS meets K = 0 in the dQ product)
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cv.kb + (16 * kte + i) * RP + 8 * g);
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sacc = mfma(__builtin_shufflevector(qf, qf, 0, 1, 2, 3), __builtin_shufflevector(kf, kf, 0, 1, 2, 3), sacc);
-          sacc = mfma(__builtin_shufflevector(qf, qf, 4, 5, 6, 7), __builtin_shufflevector(kf, kf, 4, 5, 6, 7), sacc);
-          dp = mfma(__builtin_shufflevector(gf, gf, 0, 1, 2, 3), va[j], dp);
-          dp = mfma(__builtin_shufflevector(gf, gf, 4, 5, 6, 7), vb[j], dp);
+          sacc = mfma32(qf, kf, sacc);                // S = Q K^T and dP = dO V^T: the head's 32 channels in one product each
+          dp = mfma32(gf, cat8(va[j], vb[j]), dp);
           const bool kvalid = kvalid_all || 16 * kt + i < N;
           const int pkey = cv.cr[min(16 * kt + i, N - 1)];
           const int ckey_j = REG ? pk_code(pkey) : pkey, rkey_j = pk_region(pkey);
@@ -711,9 +752,9 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
             if (REG && qrg[r] != rkey_j) term -= 100.f;
             const bool live = !TAIL || (q0 + r < N && kvalid);
             const float sv = live ? sacc[r] + term : -INFINITY;
-            p[r] = __expf(sv - lv[r]);
+            p[r] = exp_sub(sv, lvL[r]);
             ds[r] = p[r] * (dp[r] - dv[r]);
-            if (DTAB && !live) bin[r] = -1;
+            if (DTAB && !(live && kt < nt)) bin[r] = -1;
           }
           if (DTAB) {
 #pragma unroll
@@ -730,11 +771,19 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
             *reinterpret_cast<bf16x4*>(tscr + i * TSP + 4 * g) = da;  // M[key i][queries 4 g ..]
             const bf16x4 dst = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) bf16x4*)(tscr + (4 * g + (i >> 2)) * TSP + 4 * (i & 3)));  // M[keys 4 g ..][query i]
-            dqa = mfma(dst, gather4(cv.kb, kt, g, i, 0), dqa);
-            dqb = mfma(dst, gather4(cv.kb, kt, g, i, 1), dqb);
+            dqa = mfma(dst, gather4(cv.kb, kte, g, i, 0), dqa);
+            dqb = mfma(dst, gather4(cv.kb, kte, g, i, 1), dqb);
           }
         }
-      }
+      };
+      // The first KT - 1 tiles of a wave run as ONE straight-line block, valid or not (a tile past the window works on the zero tile
+      // and its dK / dV are never stored), the last one behind a branch: with every tile behind its own branch (round 5) the compiler
+      // could not interleave them, and a tile is a chain of LDS reads, matrix products, a table read, exp, conversions, an LDS
+      // turn-around and more products -- ~1300 clocks per tile and wave at two waves per SIMD.  KT is picked per window size on the host
+      // (784 tokens: seven -- six for every wave and the 49th tile for wave 0).
+#pragma unroll
+      for (int j = 0; j < KT - 1; ++j) tile(j);
+      if (wave + NW1 * (KT - 1) < nt) tile(KT - 1);
       // this wave is the only one on query tile qt in this step: plain read-modify-write of its rows of the dQ tile
       if (GRADS) {
 #pragma unroll
@@ -779,8 +828,8 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
   }
   // ---- dK, dV of the wave's key tiles ----
 #pragma unroll
-  for (int j = 0; GRADS && j < KT_MAX; ++j) {
-    const int kt = wave + 8 * j;
+  for (int j = 0; GRADS && j < KT; ++j) {
+    const int kt = wave + NW1 * j;
     if (kt >= nt) break;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -864,7 +913,7 @@ int vitta_wmsa_bf16_dtable_supported(int32_t N, int32_t head_dim, int32_t table_
   if (!vitta_wmsa_bf16_supported(N, head_dim, table_rows)) return 0;
   const int nt = (N + 15) / 16;
   int nc = 0;
-  if (nt > 8 * KT_MAX) return 0;
+  if (nt > NW1 * KT_MAX) return 0;
   if (bwd1_chunks(nt, table_rows, true, &nc) > 0) return 1;                                                     // in the gradients' launch
   return (bwd1_chunks(nt, table_rows, false, &nc) > 0 && bwd1_chunks(nt, table_rows, true, &nc, false) > 0) ? 1 : 0;  // as a pass of its own
 }
@@ -899,6 +948,22 @@ int vitta_wmsa_rel_fwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
     VITTA_LAUNCH((wmsa_bf16_fwd_kernel<25, TH_FWD_S, CHV, R, TL>), dim3(qs, nH, (unsigned)B_), dim3(TH_FWD_S), lds, st, a, d_out, d_lse); \
   } while (0)
   // <= 400 tokens: one key chunk; 401 .. 800: two chunks of 25 tiles, online softmax; eight waves either way
+  // round 6: 401 .. 800 tokens run SIXTEEN waves on four chunks of 13 tiles (128 registers, four waves per SIMD): with the score
+  // products on the 32-wide MFMA, exp on one multiply-add + v_exp_f32 and the table reads on byte offsets the kernel is latency bound
+  // (vector ALU busy 34 % of a wave's lifetime at two waves per SIMD), and the second pair of waves buys 398 -> 339 us on 1024 shifted
+  // pairs (round 4 measured no gain from the same split, before those cuts).  VITTA_WMSA_FWD16=0: the eight-wave form.
+  static const bool fwd16 = [] { const char* e = std::getenv("VITTA_WMSA_FWD16"); return !(e && e[0] == '0'); }();
+  if (fwd16 && nt > 25) {
+#define WMSA_FWD16(R, TL)                                                                                                             \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_fwd_kernel<13, 1024, 4, R, TL>, lds)) return VITTA_ERR_LAUNCH;                                               \
+    VITTA_LAUNCH((wmsa_bf16_fwd_kernel<13, 1024, 4, R, TL>), dim3(qs, nH, (unsigned)B_), dim3(1024), lds, st, a, d_out, d_lse);         \
+  } while (0)
+    if (reg) { if (tail) WMSA_FWD16(true, true); else WMSA_FWD16(true, false); }
+    else { if (tail) WMSA_FWD16(false, true); else WMSA_FWD16(false, false); }
+#undef WMSA_FWD16
+    return VITTA_OK;
+  }
   if (nt <= 25) {
     if (reg) { if (tail) WMSA_FWD(1, true, true); else WMSA_FWD(1, true, false); }
     else { if (tail) WMSA_FWD(1, false, true); else WMSA_FWD(1, false, false); }
@@ -951,13 +1016,19 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
   const int qc_fused = dtab ? bwd1_chunks(nt, T, true, &nc_fused) : 0;
   const int qc_tab = (dtab && qc_fused <= 0) ? bwd1_chunks(nt, T, true, &nc_tab, false) : 0;
   (void)nchunks1;
-  if (dtab && ((qc_fused <= 0 && (qc_tab <= 0 || qc_plain <= 0)) || nt > 8 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
-  if ((dtab || (!force_two && (qs == 1 || force_one))) && qc_plain > 0 && nt <= 8 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
+  if (dtab && ((qc_fused <= 0 && (qc_tab <= 0 || qc_plain <= 0)) || nt > NW1 * KT_MAX)) return VITTA_ERR_UNSUPPORTED;  // (vitta_wmsa_bf16_dtable_supported)
+  if ((dtab || (!force_two && (qs == 1 || force_one))) && qc_plain > 0 && nt <= NW1 * KT_MAX) {  // one workgroup per (window, head): the one-pass kernel
+#define WMSA_BWD1_KT(R, TL, DT, GR, KTV, QC, NC, LF, DTP, WSP)                                                                        \
+  do {                                                                                                                                \
+    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR, KTV>, LF)) return VITTA_ERR_LAUNCH;                                          \
+    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR, KTV>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), LF, st, a, d_out, d_dout,  \
+                 d_lse, d_delta, d_dqkv, QC, NC, DTP, WSP);                                                                           \
+  } while (0)
+  // key tiles per wave (compile time: the first KT - 1 run unconditionally): <= 32 tiles four, else seven
 #define WMSA_BWD1(R, TL, DT, GR, QC, NC, LF, DTP, WSP)                                                                                \
   do {                                                                                                                                \
-    if (!set_lds(wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR>, LF)) return VITTA_ERR_LAUNCH;                                               \
-    VITTA_LAUNCH((wmsa_bf16_bwd_fused_kernel<R, TL, DT, GR>), dim3(1, nH, (unsigned)B_), dim3(TH_BWD1), LF, st, a, d_out, d_dout, d_lse, \
-                 d_delta, d_dqkv, QC, NC, DTP, WSP);                                                                                  \
+    if (nt <= NW1 * 4) WMSA_BWD1_KT(R, TL, DT, GR, 4, QC, NC, LF, DTP, WSP);                                                            \
+    else WMSA_BWD1_KT(R, TL, DT, GR, KT_MAX, QC, NC, LF, DTP, WSP);                                                                     \
   } while (0)
 #define WMSA_BWD1_ALL(DT, GR, QC, NC, LF, DTP, WSP)                                                                                   \
   do {                                                                                                                                \
@@ -977,6 +1048,7 @@ int vitta_wmsa_rel_bwd_bf16_io(const void* d_qkv_, const float* d_table, int32_t
     }
 #undef WMSA_BWD1_ALL
 #undef WMSA_BWD1
+#undef WMSA_BWD1_KT
     if (ws) {
       const int segs = (int)(B_ >= 64 ? 8 : B_ >= 8 ? 2 : 1), seg = (int)((B_ + segs - 1) / segs);
       VITTA_LAUNCH(dtable_reduce_kernel, dim3((unsigned)(((int64_t)nH * T + 255) / 256), (unsigned)segs), dim3(256), 0, st, ws, d_dtable, B_,
