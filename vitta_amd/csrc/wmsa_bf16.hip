@@ -231,19 +231,25 @@ __device__ __forceinline__ void add_terms_t(f32x4& acc, const float* tab, const 
 // The same on codes stored as BYTE offsets (setup_terms<2>): cqb = LDS address of the table column + 4 (code[q] + off) (+ the region of
 // q in the high half), so a table read is one subtraction and the load (the index form: subtraction, shift-add, load).
 typedef __attribute__((address_space(3))) const float lds_cfloat;
-template <bool REG, bool TAIL>
-__device__ __forceinline__ void add_terms_b(f32x4& acc, unsigned cqb, int rq, const int* cr, int t, int g, int N) {
+// The terms are returned as the score product's INITIAL accumulator (S = bias + K Q^T costs no addition); TAIL: mask_tail afterwards.
+template <bool REG>
+__device__ __forceinline__ f32x4 terms_b(unsigned cqb, int rq, const int* cr, int t, int g) {
   const int key0 = 16 * t + 4 * g;
   const int4 ck = *reinterpret_cast<const int4*>(cr + key0);
   const int kc[4] = {ck.x, ck.y, ck.z, ck.w};
-  float tv[4];
+  f32x4 tv;
 #pragma unroll
   for (int r = 0; r < 4; ++r) tv[r] = *(lds_cfloat*)(cqb - (unsigned)(REG ? pk_code(kc[r]) : kc[r]));
+  if (REG) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float v = (REG && pk_region(kc[r]) != rq) ? tv[r] - 100.f : tv[r];
-    acc[r] = (!TAIL || key0 + r < N) ? acc[r] + v : -INFINITY;
+    for (int r = 0; r < 4; ++r) tv[r] = pk_region(kc[r]) != rq ? tv[r] - 100.f : tv[r];
   }
+  return tv;
+}
+__device__ __forceinline__ void mask_tail(f32x4& acc, int t, int g, int N) {
+  const int key0 = 16 * t + 4 * g;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = key0 + r < N ? acc[r] : -INFINITY;
 }
 
 // B operand of a contraction over tokens from a ROW-major tile: the four tokens 16 t + 4 g + e of column d = 16 half + i, by the
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
   const unsigned tab_b = (unsigned)(size_t)(lds_cfloat*)cv.tab + 4u * (unsigned)a.off;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
     const int q = min(16 * rt + i, N - 1);
@@ -290,8 +296,12 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
     const unsigned cqb = tab_b + (unsigned)(REG ? pk_code(pq) : pq);
     const int rq = pk_region(pq);
     const bf16x8 q8 = cat8(qa, qb);
-    float m = -INFINITY, l = 0.f;  // of query i (this lane's column of the S^T tiles); l: the lane's share (keys 4 g + r)
+    float m = -INFINITY;  // of query i (this lane's column of the S^T tiles)
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};  // rows = queries 4 g + r, column d = i (| 16 + i)
+    // the softmax denominators as a THIRD product against a column of ones (the matrix pipe is a tenth busy, the vector ALU is the
+    // bound): l[r] = sum over the keys of the bf16 probabilities the numerator uses, in the rows' layout the normalisation needs
+    f32x4 ol = {0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int tb = c * NTM;
@@ -302,9 +312,9 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
       for (int t = 0; t < NTM; ++t) {
         if (tb + t < nt) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (16 * (tb + t) + i) * RP + 8 * g);
-          f32x4 s = {0.f, 0.f, 0.f, 0.f};
-          s = mfma32(kf, q8, s);  // the head's 32 channels in one product
-          add_terms_b<REG, TAIL>(s, cqb, rq, cv.cr, tb + t, g, N);
+          f32x4 s = terms_b<REG>(cqb, rq, cv.cr, tb + t, g);  // bias (+ shift mask): the accumulator's initial value
+          s = mfma32(kf, q8, s);                              // the head's 32 channels in one product
+          if (TAIL) mask_tail(s, tb + t, g, N);
           acc[t] = s;
           mc = fmaxf(mc, fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
         } else {
@@ -316,12 +326,12 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
       const float mn = fmaxf(m, mc);
       if (CH > 1) {
         const float corr = __expf(m - mn);  // (first chunk: exp(-inf) = 0 on zero sums)
-        l *= corr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float cr_ = __shfl(corr, 4 * g + r, 64);  // the factor of query 4 g + r lives in the lanes whose column it is
           o0[r] *= cr_;
           o1[r] *= cr_;
+          ol[r] *= cr_;
         }
       }
       m = mn;
@@ -337,31 +347,29 @@ __global__ __launch_bounds__(THREADS) void wmsa_bf16_fwd_kernel(const Args a, fl
           for (int r = 0; r < 4; ++r) {
             p[r] = exp_sub(acc[t][r], mL);
             p[4 + r] = t + 1 < NTM ? exp_sub(acc[t + 1 < NTM ? t + 1 : t][r], mL) : 0.f;  // (-inf scores past the window: 0)
-            l += p[r] + p[4 + r];
           }
           const bf16x8 pa = cat8(pack4(p[0], p[1], p[2], p[3]), pack4(p[4], p[5], p[6], p[7]));
           const bf16x8 v0 = cat8(gather4(vrow, tb + t, g, i, 0), gather4(vrow, tb + t1, g, i, 0));
           const bf16x8 v1 = cat8(gather4(vrow, tb + t, g, i, 1), gather4(vrow, tb + t1, g, i, 1));
           o0 = mfma32(pa, v0, o0);
           o1 = mfma32(pa, v1, o1);
+          ol = mfma32(pa, ones, ol);
         }
       }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv_l = 1.f / l;
-    // C layout: row = query 4 g + r, column = d = i; the row's 1 / l lives in lane 4 g + r
+    // C layout: row = query 4 g + r, column = d = i (every column of ol holds the row's denominator)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qrow = 16 * rt + 4 * g + r;
-      const float il = __shfl(inv_l, 4 * g + r, 64);
+      const float il = 1.f / ol[r];
+      const float mr = __shfl(m, 4 * g + r, 64);  // the maximum of query 4 g + r lives in the lanes whose column it is
       if (qrow < N) {
         const int64_t o = (int64_t)cv.rows[qrow] * C + h * HD;
         store_el(out, o + i, a.io16, o0[r] * il);
         store_el(out, o + 16 + i, a.io16, o1[r] * il);
+        if (i == 0) lse[(b * nH + h) * N + qrow] = mr + __logf(ol[r]);
       }
     }
-    if (g == 0 && 16 * rt + i < N) lse[(b * nH + h) * N + 16 * rt + i] = m + __logf(l);
   }
 }
 
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dq_kernel(const Args a, 
   __syncthreads();
   const unsigned short* krow = cv.a0;
   const unsigned short* vrow = cv.a1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   const int C = nH * HD;
   for (int rt = blockIdx.x * WV + wave; rt < nt; rt += gridDim.x * WV) {
     const bool qvalid = 16 * rt + i < N;
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(TH_BWD) void wmsa_bf16_bwd_dkv_kernel(const Args a,
   __syncthreads();
   const unsigned short* qrow_l = cv.a0;
   const unsigned short* grow_l = cv.a1;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4, WV = blockDim.x >> 6;
   for (int kt = blockIdx.x * WV + wave; kt < nt; kt += gridDim.x * WV) {
     const int key = min(16 * kt + i, N - 1);
     const bool kvalid = 16 * kt + i < N;
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
     tmp.tab = cv.tab; tmp.cr = cv.cr;
     setup_terms(tmp, a, h, b, nt);
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;  // (scalar: the tiles' offsets are SALU work)
   unsigned short* const tscr = cv.tscr + wave * 16 * TSP;
   // key tiles of this wave: wave, wave + 8, ...: V fragments, code / region of the lane's key, dK / dV accumulators -- in registers
   bf16x4 va[KT], vb[KT];
@@ -737,23 +745,28 @@ __global__ __launch_bounds__(TH_BWD1) void wmsa_bf16_bwd_fused_kernel(const Args
         {
           const int kte = min(kt, nt);  // (a tile past the window reads the zero tile: S = bias only, and its dS meets K = 0 in the dQ product)
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cv.kb + (16 * kte + i) * RP + 8 * g);
-          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          sacc = mfma32(qf, kf, sacc);                // S = Q K^T and dP = dO V^T: the head's 32 channels in one product each
-          dp = mfma32(gf, cat8(va[j], vb[j]), dp);
           const bool kvalid = kvalid_all || 16 * kt + i < N;
           const int pkey = cv.cr[min(16 * kt + i, N - 1)];
           const int ckey_j = REG ? pk_code(pkey) : pkey, rkey_j = pk_region(pkey);
           float p[4], ds[4];
           int bin[4];  // table row of the lane's four scores; -1: padded query / key (TAIL)
+          // the additive terms are the products' INITIAL accumulators: S = (bias + mask) + Q K^T, dP - delta = -delta + dO V^T
+          f32x4 sacc, dp = {-dv[0], -dv[1], -dv[2], -dv[3]};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             bin[r] = qcd[r] - ckey_j + a.off;
             float term = cv.tab[bin[r]];
             if (REG && qrg[r] != rkey_j) term -= 100.f;
+            sacc[r] = term;
+          }
+          sacc = mfma32(qf, kf, sacc);  // the head's 32 channels in one product each
+          dp = mfma32(gf, cat8(va[j], vb[j]), dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
             const bool live = !TAIL || (q0 + r < N && kvalid);
-            const float sv = live ? sacc[r] + term : -INFINITY;
+            const float sv = live ? sacc[r] : -INFINITY;
             p[r] = exp_sub(sv, lvL[r]);
-            ds[r] = p[r] * (dp[r] - dv[r]);
+            ds[r] = p[r] * dp[r];
             if (DTAB && !(live && kt < nt)) bin[r] = -1;
           }
           if (DTAB) {
