@@ -17,6 +17,8 @@ BASE_GPU = dict(loss_rel=5e-5, logit_frac=2e-3, grad_frac=5e-3, param_lr_mult=0.
 # (one sign(ema - source) flip of an L1 term among the sampled channels: tests/test_host_cpu.py::check_tta_records); the
 # exact-fp32 convolution arithmetic runs without the allowance (strict per-tensor floors everywhere) so that a path bug
 # cannot hide behind what the split arithmetic's other summation order needs.
+# Calibration, round 6: with NO allowance the fourteen step tests of this file pass in three of four consecutive runs on one box; the fourth
+# draws one flip (test_batch_of_two_matches_reference_on_gpu[b3]) -- the allowance covers a run-to-run event, not a standing error.
 OUTLIERS = (1, 0.30)
 
 
