@@ -816,6 +816,14 @@ def main():
         _tta.FORCE_EXCHANGES = True  # (the data-parallel default: one graph with the RCCL calls captured; --segmented-graph: three)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if opt.dist_backend == "nccl" and world > torch.cuda.device_count():
+            # more ranks than devices (e.g. `--gpus 2` typed on a one-GPU box): RCCL refuses two ranks on one device ("Duplicate GPU
+            # detected").  Say so and rehearse the data-parallel path over gloo -- the line is marked, it is NOT a scaling figure.
+            if rank == 0:
+                print(f"[bench] WARNING: {world} ranks on {torch.cuda.device_count()} device(s): RCCL refuses duplicate devices -> the "
+                      "exchanges run over gloo and the ranks time-share the device; this line is a rehearsal, not a scaling figure",
+                      file=sys.stderr, flush=True)
+            opt.dist_backend = "gloo"
         if opt.dist_backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)
         else:  # rehearsal of the data-parallel path with several ranks on ONE GPU (RCCL refuses duplicate devices)
@@ -954,6 +962,8 @@ def main():
     # rank was the slowest in how many of the timed blocks, and the two exchanges timed separately
     line["rccl_ranks_seen"] = len({(r.get("pci_bus_id"), r.get("uuid"), r.get("device_index")) for r in ranks if isinstance(r, dict)}) \
         if (world > 1 and opt.dist_backend == "nccl") else (1 if opt.force_exchanges else None)
+    if world > 1:
+        line["ranks_per_device"] = -(-world // max(1, torch.cuda.device_count()))  # > 1: time-shared devices (a rehearsal)
     prb = getattr(run_gpu, "per_rank_blocks", [])
     if prb:
         slow = [int(np.argmax(b)) for b in prb]
